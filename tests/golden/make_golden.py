@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory from the REAL reference.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+The reference MPPI controller is the extension-less rospy script
+``/root/reference/control/src/mppi``.  ROS is not installed here, so the
+ROS modules it imports are replaced by empty stand-in *modules* (they are only
+touched by ``Controller``/``main``, which we drive by hand below); the numeric
+code (``dd_dynamics``, ``rk4``, ``MPPI``) runs unmodified.  Nothing of the
+reference is copied: the fixtures hold inputs and expected outputs only.
+
+Noise convention: the reference draws
+``np.random.normal(0, sig[0,0], size=(2, K))`` once per timestep from numpy's
+legacy global MT19937.  For an even draw count per call that stream equals
+``np.random.RandomState(seed).normal(0, sigma, (n_ticks, T, 2, K))`` -- asserted
+below -- so fixtures store only the seed; tests regenerate the noise.
+"""
+import importlib.machinery
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference/control/src/mppi"
+
+
+# --------------------------------------------------------------------------
+# import recipe
+# --------------------------------------------------------------------------
+class _Rec(object):
+    """Attribute bag standing in for a ROS message."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class _Pub(object):
+    def __init__(self, *a, **k):
+        self.sent = []
+
+    def publish(self, msg):
+        self.sent.append((msg.linear.x, msg.angular.z))
+
+
+def _twist():
+    return _Rec(linear=_Rec(x=0.0, y=0.0, z=0.0), angular=_Rec(x=0.0, y=0.0, z=0.0))
+
+
+def _euler_from_quaternion(q):
+    # yaw-only stand-in for tf.transformations.euler_from_quaternion (external
+    # ROS library); the harness below only ever feeds pure-yaw quaternions.
+    x, y, z, w = q
+    yaw = np.arctan2(2.0 * (w * z + x * y), 1.0 - 2.0 * (y * y + z * z))
+    return (0.0, 0.0, yaw)
+
+
+def load_reference(params):
+    import matplotlib
+    matplotlib.use("Agg")
+    rospy = types.ModuleType("rospy")
+    rospy.Subscriber = lambda *a, **k: None
+    rospy.Publisher = _Pub
+    rospy.get_param = lambda name: params[name]
+    rospy.loginfo = lambda *a, **k: None
+    rospy.ROSInterruptException = type("ROSInterruptException", (Exception,), {})
+    tf = types.ModuleType("tf")
+    tft = types.ModuleType("tf.transformations")
+    tft.euler_from_quaternion = _euler_from_quaternion
+    tf.transformations = tft
+    nav = types.ModuleType("nav_msgs")
+    navm = types.ModuleType("nav_msgs.msg")
+    navm.Odometry = _Rec
+    nav.msg = navm
+    geo = types.ModuleType("geometry_msgs")
+    geom = types.ModuleType("geometry_msgs.msg")
+    geom.Twist = _twist
+    geom.Quaternion = _Rec
+    geom.Vector3 = _Rec
+    geo.msg = geom
+    for name, mod in [("rospy", rospy), ("tf", tf), ("tf.transformations", tft),
+                      ("nav_msgs", nav), ("nav_msgs.msg", navm),
+                      ("geometry_msgs", geo), ("geometry_msgs.msg", geom)]:
+        sys.modules[name] = mod
+    loader = importlib.machinery.SourceFileLoader("ref_mppi", REF)
+    spec = importlib.util.spec_from_loader("ref_mppi", loader)
+    mod = importlib.util.module_from_spec(spec)
+    loader.exec_module(mod)
+    return mod
+
+
+def nominal_warm(T):
+    return np.array([np.linspace(-2.0, 1.0, T), np.linspace(1.5, -1.0, T)])
+
+
+def nominal_hot(T):
+    # drives the sampled controls into the +-6.35492 clip
+    return np.array([np.linspace(5.5, 6.3, T), np.linspace(-6.3, -5.0, T)])
+
+
+SIG = 0.9
+LAM = 0.001
+
+
+def main():
+    params = {"waypoints": []}
+    ref = load_reference(params)
+    out = {}
+    kat = {}
+
+    # ---------------------------------------------------------------- A: KATs
+    np.random.seed(0)
+    m = ref.MPPI()
+    s1 = m.get_path(np.array([0.0, 0.0, 0.0]), np.array([0.0, -1.0, 0.0]))
+    u1 = m.uvec[-1].copy()
+    kat["default_tick1_state"] = s1.tolist()
+    kat["default_tick1_u"] = u1.tolist()
+    kat["default_tick1_sum_latest_uvec"] = float(m.latest_uvec.sum())
+    s2 = m.get_path(s1, np.array([0.0, -1.0, 0.0]))
+    kat["default_tick2_state"] = s2.tolist()
+    kat["default_tick2_u"] = m.uvec[-1].tolist()
+    np.random.seed(0)
+    m = ref.MPPI(horizon=50, samples=64)
+    s = m.get_path(np.array([0.0, 0.0, 0.0]), np.array([1.0, 0.0, 0.0]))
+    kat["h50k64_tick1_state"] = s.tolist()
+    kat["h50k64_tick1_u"] = m.uvec[-1].tolist()
+    kat["rk4_wrap"] = ref.rk4(np.array([[0.0], [0.0], [3.1]]),
+                              np.array([[-6.35492], [6.35492]]), 0.02)[:, 0].tolist()
+    kat["rk4_plain"] = ref.rk4(np.array([[0.3], [-0.2], [0.7]]),
+                               np.array([[1.25], [-0.5]]), 0.01)[:, 0].tolist()
+    kat["dd_dynamics"] = ref.dd_dynamics(np.array([[0.3], [-0.2], [0.7]]),
+                                         np.array([[1.25], [-0.5]]))[:, 0].tolist()
+    ctl = ref.Controller()
+    kat["wheelsToTwist_1_2"] = list(ctl.wheelsToTwist([1.0, 2.0]))
+    kat["constants"] = {"WHEEL_VEL_MAX": ref.WHEEL_VEL_MAX, "WHEEL_RADIUS": ref.WHEEL_RADIUS,
+                        "WHEEL_BASE": ref.WHEEL_BASE}
+
+    # ------------------------------------------- B: get_cost2go / update_action
+    cases = [
+        # name, K, T, seed, state, goal, nominal
+        ("c2g_zero", 16, 50, 0, [0.0, 0.0, 0.0], [0.0, -1.0, 0.0], "zero"),
+        ("c2g_warm", 32, 50, 1, [0.1, -0.2, 0.3], [1.0, 0.0, 0.0], "warm"),
+        ("c2g_wrap", 8, 100, 2, [0.0, 0.0, 3.1], [-1.0, 0.5, -3.0], "warm"),
+        ("c2g_clip", 64, 20, 3, [-0.5, 0.25, -1.0], [0.5, 0.5, 1.0], "hot"),
+        ("c2g_tiny", 2, 6, 4, [0.0, 0.0, 0.0], [0.2, 0.1, 0.0], "warm"),
+    ]
+    for name, K, T, seed, state, goal, nom in cases:
+        mp = ref.MPPI(horizon=T, samples=K)
+        u0 = {"zero": np.zeros((2, T)), "warm": nominal_warm(T), "hot": nominal_hot(T)}[nom]
+        sig = np.array([[SIG, 0.0], [0.0, SIG]])
+        np.random.seed(seed)
+        V, eps = mp.get_cost2go(np.array(state), u0.copy(), np.array(goal), LAM, sig)
+        eps = np.array(eps)
+        chk = np.random.RandomState(seed).normal(0.0, SIG, (T, 2, K))
+        assert np.array_equal(eps, chk), name
+        V_in = V.copy()
+        unew = mp.update_action(u0.copy(), list(eps), V.copy(), sig, LAM)
+        out[name + "_V"] = V_in
+        out[name + "_unew"] = unew
+        out[name + "_meta"] = np.array([K, T, seed], dtype=np.int64)
+        out[name + "_state"] = np.array(state)
+        out[name + "_goal"] = np.array(goal)
+        out[name + "_u0"] = u0
+
+    # ---------------------------------------------- C: closed-loop tick sequences
+    seqs = [
+        ("seq_park", 32, 50, 5, 12, [0.0, 0.0, 0.0], [0.0, -1.0, 0.0]),
+        ("seq_wp", 16, 100, 6, 8, [0.0, 0.0, 0.0], [1.0, 0.0, 0.0]),
+    ]
+    for name, K, T, seed, nt, state, goal in seqs:
+        mp = ref.MPPI(horizon=T, samples=K)
+        np.random.seed(seed)
+        st = np.array(state)
+        states, us, lat = [], [], []
+        for _ in range(nt):
+            st = mp.get_path(st, np.array(goal))
+            states.append(st.copy())
+            us.append(mp.uvec[-1].copy())
+            lat.append(mp.latest_uvec.copy())
+        # stream identity across ticks
+        allnoise = np.random.RandomState(seed).normal(0.0, SIG, (nt, T, 2, K))
+        nxt = np.random.normal(0.0, SIG, size=(2, K))
+        rs = np.random.RandomState(seed)
+        rs.normal(0.0, SIG, (nt, T, 2, K))
+        assert np.array_equal(nxt, rs.normal(0.0, SIG, (2, K)))
+        del allnoise
+        out[name + "_states"] = np.array(states)
+        out[name + "_u"] = np.array(us)
+        out[name + "_latest_uvec"] = np.array(lat)
+        out[name + "_meta"] = np.array([K, T, seed, nt], dtype=np.int64)
+        out[name + "_state0"] = np.array(state)
+        out[name + "_goal"] = np.array(goal)
+
+    # ------------------------------------------------- D: Savitzky-Golay operator
+    from scipy.signal import savgol_filter
+    for T in (6, 10, 20, 50, 100, 200):
+        # row i = response to the unit impulse e_i  =>  u_f = u @ S
+        out["savgol_S_%d" % T] = savgol_filter(np.eye(T), T - 1, 3, axis=1)
+    rs = np.random.RandomState(7)
+    u = rs.uniform(-6.0, 6.0, (2, 50))
+    out["savgol_in_50"] = u
+    out["savgol_out_50"] = savgol_filter(u, 49, 3, axis=1)
+
+    # ----------------------------------- E: BASELINE config 1 (K=1000, T=50) summary
+    K, T, seed = 1000, 50, 0
+    for nom in ("zero", "warm"):
+        mp = ref.MPPI(horizon=T, samples=K)
+        u0 = np.zeros((2, T)) if nom == "zero" else nominal_warm(T)
+        mp.latest_uvec = u0.copy()
+        np.random.seed(seed)
+        sig = np.array([[SIG, 0.0], [0.0, SIG]])
+        V, eps = mp.get_cost2go(np.array([0.0, 0.0, 0.0]), u0.copy(),
+                                np.array([0.0, -1.0, 0.0]), LAM, sig)
+        out["c1_%s_Vsum_t" % nom] = V.sum(axis=1)
+        out["c1_%s_Vmin_t" % nom] = V.min(axis=1)
+        out["c1_%s_Vcols" % nom] = V[:, ::100].copy()
+        unew = mp.update_action(u0.copy(), eps, V.copy(), sig, LAM)
+        out["c1_%s_unew" % nom] = unew
+        # full tick
+        mp = ref.MPPI(horizon=T, samples=K)
+        mp.latest_uvec = u0.copy()
+        np.random.seed(seed)
+        nxt = mp.get_path(np.array([0.0, 0.0, 0.0]), np.array([0.0, -1.0, 0.0]))
+        out["c1_%s_next_state" % nom] = nxt
+        out["c1_%s_u_applied" % nom] = mp.uvec[-1].copy()
+
+    # --------------------------------- F: Controller state machine (model in the loop)
+    def run_controller(waypoints, seed, n_cb, K=None, T=None, thresh=None):
+        params["waypoints"] = waypoints
+        np.random.seed(seed)
+        c = ref.Controller()
+        if K is not None:
+            c.mppi = ref.MPPI(horizon=T, samples=K, thresh=thresh)
+        plant = np.array([0.0, 0.0, 0.0])
+        rows = []
+        for _ in range(n_cb):
+            q = (0.0, 0.0, np.sin(plant[2] / 2.0), np.cos(plant[2] / 2.0))
+            odom = _Rec(pose=_Rec(pose=_Rec(
+                position=_Rec(x=plant[0], y=plant[1], z=0.0),
+                orientation=_Rec(x=q[0], y=q[1], z=q[2], w=q[3]))))
+            n0 = len(c.tw_pub.sent)
+            c.pos_cb(odom)
+            assert len(c.tw_pub.sent) == n0 + 1
+            vx, wz = c.tw_pub.sent[-1]
+            seen = c.mppi.start.copy()
+            u = np.array([0.0, 0.0]) if c.done else c.mppi.uvec[-1, :].copy()
+            rows.append(np.concatenate([seen, c.mppi.goal, u, [vx, wz, float(c.idx),
+                                                                  float(c.done), float(c.init)]]))
+            # plant: the reference's own integrator driven by the applied wheel speeds
+            plant = ref.rk4(plant.reshape(3, 1), u.reshape(2, 1), c.mppi.dt)[:, 0]
+        return np.array(rows)
+
+    out["ctl_park"] = run_controller([], 11, 40, K=16, T=20, thresh=0.05)
+    out["ctl_park_meta"] = np.array([16, 20, 11, 40], dtype=np.int64)
+    # pentagon with a generous threshold so several waypoint switches happen quickly
+    out["ctl_wp"] = run_controller([[1, 0], [2, 1], [1, 2], [0, 2], [0, 0]], 12, 60,
+                                   K=16, T=20, thresh=0.97)
+    out["ctl_wp_meta"] = np.array([16, 20, 12, 60], dtype=np.int64)
+
+    np.savez_compressed(os.path.join(HERE, "mppi_golden.npz"), **out)
+    with open(os.path.join(HERE, "mppi_kat.json"), "w") as f:
+        json.dump(kat, f, indent=1, sort_keys=True)
+    print("wrote", len(out), "arrays;",
+          os.path.getsize(os.path.join(HERE, "mppi_golden.npz")), "bytes")
+    for k in sorted(kat):
+        print(k, kat[k])
+
+
+if __name__ == "__main__":
+    main()

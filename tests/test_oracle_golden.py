@@ -1,0 +1,150 @@
+"""Pins the CPU oracle (oracle/mppi_oracle.c) to golden vectors produced by the REAL
+reference (tests/golden/make_golden.py, run in the build container).  CPU only."""
+import numpy as np
+import pytest
+
+SIG, LAM = 0.9, 0.001
+C2G = ["c2g_zero", "c2g_warm", "c2g_wrap", "c2g_clip", "c2g_tiny"]
+
+
+def test_kat_kinematics(orc, kat):
+    assert np.allclose(orc.dd_dynamics([0.3, -0.2, 0.7], [1.25, -0.5]), kat["dd_dynamics"], rtol=0, atol=1e-17)
+    assert np.allclose(orc.rk4([0.3, -0.2, 0.7], [1.25, -0.5], 0.01), kat["rk4_plain"], rtol=0, atol=1e-16)
+    # theta wrap branch of rk4 (control/src/mppi:52-53)
+    assert np.allclose(orc.rk4([0, 0, 3.1], [-6.35492, 6.35492], 0.02), kat["rk4_wrap"], rtol=0, atol=1e-15)
+    assert np.allclose(orc.wheels_to_twist([1.0, 2.0]), kat["wheelsToTwist_1_2"], rtol=0, atol=1e-17)
+    p = orc.default_params()
+    assert p.u_max == kat["constants"]["WHEEL_VEL_MAX"]
+    assert p.wheel_radius == kat["constants"]["WHEEL_RADIUS"]
+    assert p.wheel_base == kat["constants"]["WHEEL_BASE"]
+
+
+@pytest.mark.parametrize("T", [6, 10, 20, 50, 100, 200])
+def test_savgol_operator_matches_scipy(orc, golden, T):
+    S = orc.savgol_matrix(T)
+    ref = golden["savgol_S_%d" % T]
+    assert np.abs(S - ref).max() < 2e-12
+    # rank-6 operator, rows of an interpolating filter sum to 1 column-wise
+    assert np.linalg.matrix_rank(S, tol=1e-9) <= 8
+    assert np.allclose(S.sum(axis=0), 1.0, atol=1e-12)
+
+
+def test_savgol_apply(orc, golden):
+    S = orc.savgol_matrix(50)
+    assert np.abs(golden["savgol_in_50"] @ S - golden["savgol_out_50"]).max() < 1e-12
+
+
+def test_savgol_even_window_rejected(orc):
+    with pytest.raises(ValueError):
+        orc.savgol_matrix(51)
+
+
+@pytest.mark.parametrize("name", C2G)
+def test_get_cost2go(orc, golden, name):
+    K, T, seed = golden[name + "_meta"]
+    eps = orc.reference_noise(int(seed), SIG, int(T), int(K))
+    V = orc.get_cost2go(golden[name + "_state"], golden[name + "_u0"], golden[name + "_goal"], LAM, SIG, eps)
+    ref = golden[name + "_V"]
+    assert V.shape == ref.shape
+    assert np.abs(V - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+    assert np.abs(V - ref).max() < 1e-9
+
+
+@pytest.mark.parametrize("name", C2G)
+def test_update_action(orc, golden, name):
+    K, T, seed = golden[name + "_meta"]
+    eps = orc.reference_noise(int(seed), SIG, int(T), int(K))
+    # from the reference's own V (isolates update_action) ...
+    u = orc.update_action(golden[name + "_u0"], eps, golden[name + "_V"], LAM, S=golden["savgol_S_%d" % T]
+                          if "savgol_S_%d" % T in golden.files else None)
+    assert np.abs(u - golden[name + "_unew"]).max() < 1e-10
+    # ... and end to end through the oracle's V and its own savgol operator
+    V = orc.get_cost2go(golden[name + "_state"], golden[name + "_u0"], golden[name + "_goal"], LAM, SIG, eps)
+    u2 = orc.update_action(golden[name + "_u0"], eps, V, LAM)
+    assert np.abs(u2 - golden[name + "_unew"]).max() < 1e-9
+
+
+@pytest.mark.parametrize("name", ["seq_park", "seq_wp"])
+def test_closed_loop_ticks(orc, golden, name):
+    K, T, seed, nt = [int(x) for x in golden[name + "_meta"]]
+    noise = orc.reference_noise(seed, SIG, T, K, n_ticks=nt)
+    st = golden[name + "_state0"].copy()
+    lat = np.zeros((2, T))
+    for i in range(nt):
+        st, ua, lat = orc.get_path(st, golden[name + "_goal"], lat, noise[i], LAM, SIG)
+        assert np.abs(st - golden[name + "_states"][i]).max() < 1e-10, i
+        assert np.abs(ua - golden[name + "_u"][i]).max() < 1e-9, i
+        assert np.abs(lat - golden[name + "_latest_uvec"][i]).max() < 1e-9, i
+
+
+def test_default_node_ticks(orc, kat):
+    """MPPI() as shipped (K=10, T=100; control/src/mppi:62) two ticks, SURVEY 8c known answers."""
+    noise = orc.reference_noise(0, SIG, 100, 10, n_ticks=2)
+    lat = np.zeros((2, 100))
+    st, ua, lat = orc.get_path([0, 0, 0], [0, -1, 0], lat, noise[0], LAM, SIG)
+    assert np.allclose(st, kat["default_tick1_state"], rtol=0, atol=1e-13)
+    assert np.allclose(ua, kat["default_tick1_u"], rtol=0, atol=1e-10)
+    assert abs(lat.sum() - kat["default_tick1_sum_latest_uvec"]) < 1e-8
+    st, ua, lat = orc.get_path(st, [0, -1, 0], lat, noise[1], LAM, SIG)
+    assert np.allclose(st, kat["default_tick2_state"], rtol=0, atol=1e-13)
+    assert np.allclose(ua, kat["default_tick2_u"], rtol=0, atol=1e-10)
+
+
+def test_h50k64_tick(orc, kat):
+    noise = orc.reference_noise(0, SIG, 50, 64)
+    st, ua, _ = orc.get_path([0, 0, 0], [1, 0, 0], np.zeros((2, 50)), noise, LAM, SIG)
+    assert np.allclose(st, kat["h50k64_tick1_state"], rtol=0, atol=1e-13)
+    assert np.allclose(ua, kat["h50k64_tick1_u"], rtol=0, atol=1e-10)
+
+
+@pytest.mark.parametrize("nom", ["zero", "warm"])
+def test_config1_k1000(orc, golden, nom):
+    """BASELINE config 1: K=1000, T=50 parallel park, seed 0."""
+    K, T = 1000, 50
+    eps = orc.reference_noise(0, SIG, T, K)
+    u0 = np.zeros((2, T)) if nom == "zero" else np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
+    V = orc.get_cost2go([0, 0, 0], u0, [0, -1, 0], LAM, SIG, eps)
+    assert np.abs(V[:, ::100] - golden["c1_%s_Vcols" % nom]).max() < 1e-9
+    assert np.abs(V.min(axis=1) - golden["c1_%s_Vmin_t" % nom]).max() < 1e-9
+    assert np.abs(V.sum(axis=1) - golden["c1_%s_Vsum_t" % nom]).max() < 1e-6
+    assert np.abs(orc.update_action(u0, eps, V, LAM) - golden["c1_%s_unew" % nom]).max() < 1e-9
+    st, ua, _ = orc.get_path([0, 0, 0], [0, -1, 0], u0, eps, LAM, SIG)
+    assert np.abs(st - golden["c1_%s_next_state" % nom]).max() < 1e-12
+    assert np.abs(ua - golden["c1_%s_u_applied" % nom]).max() < 1e-9
+
+
+def test_shard_merge_equals_update(orc, golden):
+    """splitting K over G shards + merge == update_action's increment (incl. the 1e-8 floor)."""
+    name = "c2g_clip"
+    K, T, seed = [int(x) for x in golden[name + "_meta"]]
+    eps = orc.reference_noise(seed, SIG, T, K)
+    V = golden[name + "_V"]
+    full = orc.merge_partials(orc.shard_partials(eps, V, 0, K, LAM)[None], [K], LAM)
+    for G in (2, 4, 8):
+        b = np.linspace(0, K, G + 1).astype(int)
+        parts = np.stack([orc.shard_partials(eps, V, b[g], b[g + 1], LAM) for g in range(G)])
+        du = orc.merge_partials(parts, np.diff(b), LAM)
+        assert np.abs(du - full).max() < 1e-13
+    # and the increment is what update_action adds before clip/filter
+    Vc = V - V.min(axis=1, keepdims=True)
+    w = np.exp(-Vc / LAM) + 1e-8
+    w /= w.sum(axis=1, keepdims=True)
+    du_ref = np.einsum("tck,tk->ct", eps, w)
+    assert np.abs(full - du_ref).max() < 1e-13
+
+
+def test_philox_known_answers(orc):
+    """Random123 known-answer vectors for Philox4x32-10 (Salmon et al., SC'11 distribution kat_vectors)."""
+    assert orc.philox4x32_10([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert orc.philox4x32_10([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert orc.philox4x32_10([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344],
+                             [0xa4093822, 0x299f31d0]) == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_philox_noise_statistics(orc):
+    e = orc.philox_noise(seed=0, agent=0, tick=0, k_off=0, K_local=20000, T=6, sigma=0.9)
+    assert abs(e.mean()) < 0.01 and abs(e.std() - 0.9) < 0.01
+    # shard-count invariance: sample ids are global
+    a = orc.philox_noise(3, 1, 2, 0, 64, 7, 0.9)
+    b = orc.philox_noise(3, 1, 2, 32, 32, 7, 0.9)
+    assert np.array_equal(a[:, :, 32:], b)
