@@ -1,0 +1,195 @@
+/*
+ * mppi_hip.h -- C ABI of the MI355X-native MPPI rollout engine (libmppi_hip.so).
+ *
+ * Drop-in seam: the three hot methods of the reference controller's `MPPI` class
+ * (moribots/motion_planning, control/src/mppi) plus its tick driver:
+ *
+ *     MPPI.__init__/initialize   control/src/mppi:62-83     -> mppi_create / mppi_reset
+ *     MPPI.get_cost2go           control/src/mppi:127-178   -> mppi_rollout (+ mppi_download_value/_noise)
+ *     MPPI.get_cost              control/src/mppi:180-184   -> inside the rollout kernel
+ *     MPPI.update_action         control/src/mppi:186-208   -> mppi_update
+ *     MPPI.perform_action        control/src/mppi:210-213   -> mppi_plant_step
+ *     MPPI.get_path              control/src/mppi:85-102    -> mppi_tick (= tick_begin + tick_finish)
+ *
+ * The reference has no FFI of its own (the node is one Python script); the binding a
+ * maintainer adds is the ctypes shim shown in INTEGRATION.md (shipped as
+ * motion_planning_amd/mppi.py).
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; opaque handle owns every device buffer;
+ *   - host arrays are caller-owned, row-major float64, laid out exactly like the
+ *     reference's numpy arrays, with a leading agent axis A (A = 1 for the stock node):
+ *         state, goal [A][3]   uvec [A][2][T]   eps [A][T][2][K]   V [A][T][K];
+ *   - every function returns 0 on success or a negative MPPI_E_* code, never throws or
+ *     aborts across the ABI; mppi_last_error() gives the message;
+ *   - one handle is not re-entrant; it may be driven from any single thread;
+ *   - all work is enqueued on the handle's HIP stream (mppi_set_stream; default: the
+ *     null stream).  Calls that return host data synchronise that stream, the rest are
+ *     asynchronous.
+ *   - K is the number of samples owned by THIS handle (one GPU's shard); sample_offset is
+ *     the global index of its first sample (device-RNG streams are keyed by global index,
+ *     so results do not depend on the shard count).
+ */
+#ifndef MPPI_HIP_H
+#define MPPI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPPI_ABI_VERSION 1
+
+/* error codes */
+#define MPPI_OK 0
+#define MPPI_E_INVALID (-1)   /* bad argument / bad handle */
+#define MPPI_E_HIP (-2)       /* a HIP runtime call failed (no device, OOM, launch error) */
+#define MPPI_E_STATE (-3)     /* call order violated (e.g. update before rollout) */
+#define MPPI_E_INTERNAL (-4)
+
+/* storage type of the per-(t,k) intermediates eps and V kept in HBM */
+#define MPPI_STORE_F32 0 /* eps fp32, V as fp32 offset from the nominal cost-to-go */
+#define MPPI_STORE_F64 1 /* eps fp64, V fp64 (offset form as well)                 */
+
+/* noise source for a rollout */
+#define MPPI_NOISE_INJECTED 0 /* use the buffer filled by mppi_upload_noise (reference-RNG parity) */
+#define MPPI_NOISE_PHILOX 1   /* device Philox4x32-10 + Box-Muller keyed by (seed, tick, agent, sample) */
+
+/* kernels, for mppi_kernel_timing */
+#define MPPI_KERNEL_NOMINAL 0
+#define MPPI_KERNEL_ROLLOUT 1
+#define MPPI_KERNEL_UPDATE 2
+#define MPPI_KERNEL_MERGE 3
+#define MPPI_KERNEL_FINALIZE 4
+#define MPPI_KERNEL_COUNT 5
+
+typedef struct mppi_engine mppi_engine;
+
+typedef struct mppi_config {
+    int32_t n_agents;      /* A >= 1 independent controllers batched in one engine           */
+    int32_t samples;       /* K >= 1 rollouts per agent owned by this engine (MPPI samples=)  */
+    int32_t horizon;       /* T >= 5, T-1 odd (Savitzky-Golay window, control/src/mppi:202)   */
+    int32_t storage;       /* MPPI_STORE_F32 | MPPI_STORE_F64                                 */
+    int32_t device;        /* HIP device ordinal                                              */
+    uint32_t sample_offset;/* global index of local sample 0                                  */
+    double dt;             /* <= 0: 1/T  (control/src/mppi:67)                                */
+    double sigma;          /* noise std-dev = sig[0,0] (control/src/mppi:145); default 0.9    */
+    double lambda;         /* temperature; default 0.001 (control/src/mppi:89)                */
+    double q[3];           /* diag Q  (control/src/mppi:69)                                   */
+    double r[2];           /* diag R  (control/src/mppi:71)                                   */
+    double p1[3];          /* diag P1 (control/src/mppi:73)                                   */
+    double u_max;          /* WHEEL_VEL_MAX  (control/src/mppi:18)                            */
+    double wheel_radius;   /* WHEEL_RADIUS   (control/src/mppi:19)                            */
+    double wheel_base;     /* WHEEL_BASE     (control/src/mppi:20)                            */
+    double floor_w;        /* weight floor 1e-8 (control/src/mppi:193)                        */
+} mppi_config;
+
+/* Fill *cfg with the reference defaults (K=10, T=100, constants above). */
+int mppi_default_config(mppi_config *cfg);
+
+int mppi_abi_version(void);
+
+/* Message of the most recent failure on this handle (or, with h == NULL, of the last
+ * failed mppi_create on this thread).  Never NULL. */
+const char *mppi_last_error(const mppi_engine *h);
+
+/* MPPI.__init__, control/src/mppi:62-77: allocates device buffers, zero nominal controls. */
+int mppi_create(const mppi_config *cfg, mppi_engine **out);
+int mppi_destroy(mppi_engine *h);
+
+/* Use an existing hipStream_t (e.g. torch's current stream) for all later work. */
+int mppi_set_stream(mppi_engine *h, void *hip_stream);
+
+/* Per-call sig / lam of get_path (control/src/mppi:88-89). */
+int mppi_set_sigma_lambda(mppi_engine *h, double sigma, double lambda);
+
+/* MPPI.initialize, control/src/mppi:79-83: zero the nominal controls of one agent (-1: all). */
+int mppi_reset(mppi_engine *h, int agent);
+
+/* latest_uvec [2][T] of one agent (control/src/mppi:81, :100-101). */
+int mppi_set_nominal(mppi_engine *h, int agent, const double *uvec);
+int mppi_get_nominal(mppi_engine *h, int agent, double *uvec);
+
+/* Injected noise, eps [A][T][2][K] float64 (the list `eps` of control/src/mppi:143-146). */
+int mppi_upload_noise(mppi_engine *h, const double *eps);
+/* The noise of the last rollout as the kernels used it (after rounding to the storage type). */
+int mppi_download_noise(mppi_engine *h, double *eps);
+
+/*
+ * MPPI.get_cost2go, control/src/mppi:127-178.  state, goal [A][3] (NULL: keep the
+ * device-resident values; for state that is the state predicted by the last tick).
+ * Leaves eps and V resident in HBM for mppi_update.  tick_id feeds the RNG counter.
+ */
+int mppi_rollout(mppi_engine *h, const double *state, const double *goal, int noise_mode,
+                 uint64_t seed, uint32_t tick_id);
+
+/* value_fcn [A][T][K] of the last rollout (absolute cost-to-go, float64). */
+int mppi_download_value(mppi_engine *h, double *V);
+/* Replace the resident V (update_action called with a caller-made value_fcn). */
+int mppi_upload_value(mppi_engine *h, const double *V);
+
+/*
+ * MPPI.update_action, control/src/mppi:186-208: per-timestep softmax weights over this
+ * engine's K samples, weighted-noise update, clip, Savitzky-Golay, clip.  The result
+ * becomes the engine's nominal sequence (get_path assigns it to latest_uvec, :90) and is
+ * copied to uvec_out [A][2][T] when non-NULL.
+ */
+int mppi_update(mppi_engine *h, double *uvec_out);
+
+/* MPPI.perform_action, control/src/mppi:210-213: one rk4 step with the nominal u[:,0].
+ * state [A][3] (NULL: resident), next_state [A][3]. */
+int mppi_plant_step(mppi_engine *h, const double *state, double *next_state);
+
+/* Receding-horizon shift, control/src/mppi:100-101. */
+int mppi_shift(mppi_engine *h);
+
+/*
+ * MPPI.get_path, control/src/mppi:85-102, split at the only cross-GPU exchange:
+ *   tick_begin : nominal baseline -> rollout+cost -> softmax partials -> per-(agent,t)
+ *                merged partials of THIS shard, left in a device buffer of
+ *                mppi_partials_bytes() bytes, float64 [A][T][8] =
+ *                {min V, sum e, sum e*eps0, sum e*eps1, sum eps0, sum eps1, K_shard, 0};
+ *   (host side all-gathers those buffers over RCCL when K is sharded over GPUs)
+ *   tick_finish: merges n_shards such buffers (device pointer, [n_shards][A][T][8];
+ *                NULL = this engine's own), control update, clip, filter, clip, plant
+ *                step, shift.  Asynchronous; results stay on the device.
+ * mppi_tick = tick_begin + tick_finish(own partials) + mppi_get_outputs.
+ */
+int mppi_tick_begin(mppi_engine *h, const double *state, const double *goal, int noise_mode,
+                    uint64_t seed, uint32_t tick_id);
+int mppi_partials_ptr(mppi_engine *h, void **dev_ptr, size_t *bytes);
+int mppi_tick_finish(mppi_engine *h, const void *gathered_dev, int n_shards);
+/* Synchronises; next_state [A][3], u_applied [A][2] (either may be NULL). */
+int mppi_get_outputs(mppi_engine *h, double *next_state, double *u_applied);
+int mppi_tick(mppi_engine *h, const double *state, const double *goal, int noise_mode,
+              uint64_t seed, uint32_t tick_id, double *next_state, double *u_applied);
+
+/* Capture begin+finish (device RNG, resident state/goal) into a hipGraph and replay it:
+ * one launch per tick for the launch-bound small-K case.  tick_id advances per replay. */
+int mppi_tick_graph(mppi_engine *h, uint64_t seed);
+
+int mppi_synchronize(mppi_engine *h);
+
+/* Savitzky-Golay operator S [T][T] with u_f = u @ S, as savgol_filter(u, T-1, 3, axis=1)
+ * (mode='interp') applies it at control/src/mppi:202.  Host only. */
+int mppi_savgol_matrix(int horizon, double *S);
+
+/*
+ * Kernel timing with HIP events on the engine's stream.  mask = OR of (1 << MPPI_KERNEL_*)
+ * to bracket, 0 = off.  mppi_kernel_times synchronises and returns, per kernel, the summed
+ * duration (ms) and the number of launches since timing was (re)enabled.
+ */
+int mppi_kernel_timing(mppi_engine *h, uint32_t mask);
+int mppi_kernel_times(mppi_engine *h, double *ms /*[MPPI_KERNEL_COUNT]*/,
+                      int64_t *launches /*[MPPI_KERNEL_COUNT]*/);
+
+/* Bytes of HBM held by the engine, and launch geometry (blocks) of rollout / update kernels. */
+int mppi_engine_info(mppi_engine *h, size_t *hbm_bytes, int32_t *rollout_blocks,
+                     int32_t *update_blocks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPPI_HIP_H */

@@ -1,0 +1,693 @@
+// mppi_engine.hip -- host side of libmppi_hip.so: the engine object behind the C ABI of
+// include/mppi_hip.h.  Owns the HBM buffers, picks launch geometry for gfx950 and enqueues
+// the kernels of mppi_kernels.hpp on one HIP stream.  Mirrors the reference's `MPPI` object
+// (moribots/motion_planning control/src/mppi:61-213): the nominal control sequence
+// `latest_uvec` lives on the device between ticks exactly like the Python attribute does.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/mppi_hip.h"
+#include "mppi_kernels.hpp"
+#include "savgol.hpp"
+
+namespace {
+
+struct EngineError {
+    int code;
+    std::string msg;
+};
+
+[[noreturn]] void fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    throw EngineError{code, buf};
+}
+
+#define HIPCHK(expr)                                                                             \
+    do {                                                                                         \
+        hipError_t e__ = (expr);                                                                 \
+        if (e__ != hipSuccess)                                                                   \
+            fail(MPPI_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+
+thread_local std::string g_create_error = "";
+
+template <typename T>
+T* dev_alloc(size_t n, size_t& tally) {
+    void* p = nullptr;
+    const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    HIPCHK(hipMalloc(&p, bytes));
+    tally += bytes;
+    return static_cast<T*>(p);
+}
+
+}  // namespace
+
+struct mppi_engine {
+    mppi_config cfg{};
+    mppi::DevParams P{};
+    std::string err = "";
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    size_t hbm_bytes = 0;
+
+    // launch geometry
+    int roll_bs = 256, roll_blocks = 0, nterm = 4;
+    size_t roll_lds = 0;
+    int NCH = 1, CH = 1024;
+
+    // device buffers
+    void* d_eps = nullptr;   // S [A][T][2][Ks]
+    void* d_dV = nullptr;    // S [A][T][Ks]
+    double* d_tc = nullptr;  // [A][T][8]
+    double* d_base = nullptr;
+    double* d_unom = nullptr;
+    double* d_ufilt = nullptr;
+    double* d_state = nullptr;
+    double* d_goal = nullptr;
+    double* d_part = nullptr;
+    double* d_merged = nullptr;
+    double* d_S = nullptr;
+    double* d_out = nullptr;
+    uint32_t* d_tick = nullptr;
+    double* d_tmp = nullptr;
+    size_t tmp_elems = 0;
+
+    // pinned staging ring for state/goal uploads
+    static constexpr int kRing = 16;
+    double* h_stage = nullptr;  // [kRing][A*6]
+    hipEvent_t ring_ev[kRing]{};
+    bool ring_used[kRing]{};
+    int ring_pos = 0;
+
+    bool noise_ready = false, value_ready = false, partials_ready = false, have_state = false, have_goal = false;
+
+    // kernel timing
+    uint32_t time_mask = 0;
+    struct Pending { int kid; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> ev_pool;
+    double t_ms[MPPI_KERNEL_COUNT]{};
+    int64_t t_n[MPPI_KERNEL_COUNT]{};
+
+    // hipGraph of a whole tick
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    uint64_t graph_seed = 0;
+
+    bool f64() const { return cfg.storage == MPPI_STORE_F64; }
+    size_t esz() const { return f64() ? 8 : 4; }
+
+    hipEvent_t get_event() {
+        if (!ev_pool.empty()) { hipEvent_t e = ev_pool.back(); ev_pool.pop_back(); return e; }
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        return e;
+    }
+    void drain_timing() {
+        if (pending.empty()) return;
+        HIPCHK(hipStreamSynchronize(stream));
+        for (auto& p : pending) {
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, p.a, p.b));
+            t_ms[p.kid] += ms; t_n[p.kid] += 1;
+            ev_pool.push_back(p.a); ev_pool.push_back(p.b);
+        }
+        pending.clear();
+    }
+    struct Scope {  // brackets one kernel launch with events when its bit is set
+        mppi_engine* e; int kid; hipEvent_t a = nullptr;
+        Scope(mppi_engine* e_, int kid_) : e(e_), kid(kid_) {
+            if (e->time_mask & (1u << kid)) { a = e->get_event(); HIPCHK(hipEventRecord(a, e->stream)); }
+        }
+        ~Scope() noexcept(false) {
+            if (a) {
+                hipEvent_t b = e->get_event();
+                HIPCHK(hipEventRecord(b, e->stream));
+                e->pending.push_back({kid, a, b});
+                if (e->pending.size() >= 4096) e->drain_timing();
+            }
+        }
+    };
+
+    void ensure_tmp(size_t elems) {
+        if (elems <= tmp_elems) return;
+        if (d_tmp) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(d_tmp)); hbm_bytes -= tmp_elems * 8; d_tmp = nullptr; tmp_elems = 0; }
+        d_tmp = dev_alloc<double>(elems, hbm_bytes);
+        tmp_elems = elems;
+    }
+
+    void stage_upload(const double* src, double* dst, size_t n) {
+        const int slot = ring_pos;
+        ring_pos = (ring_pos + 1) % kRing;
+        if (ring_used[slot]) HIPCHK(hipEventSynchronize(ring_ev[slot]));
+        double* h = h_stage + (size_t)slot * cfg.n_agents * 6;
+        std::memcpy(h, src, n * sizeof(double));
+        HIPCHK(hipMemcpyAsync(dst, h, n * sizeof(double), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipEventRecord(ring_ev[slot], stream));
+        ring_used[slot] = true;
+    }
+
+    void set_inputs(const double* state, const double* goal) {
+        const size_t n = (size_t)cfg.n_agents * 3;
+        if (state) { stage_upload(state, d_state, n); have_state = true; }
+        if (goal) { stage_upload(goal, d_goal, n); have_goal = true; }
+        if (!have_state || !have_goal) fail(MPPI_E_STATE, "state/goal passed as NULL before ever being set");
+    }
+
+    template <typename S, int NT, bool PH>
+    void launch_rollout_t(uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
+        auto kern = mppi::rollout_kernel<S, NT, PH>;
+        static thread_local const void* configured = nullptr;
+        if (configured != (const void*)kern) {
+            HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            configured = (const void*)kern;
+        }
+        dim3 grid(roll_blocks, cfg.n_agents);
+        hipLaunchKernelGGL(kern, grid, dim3(roll_bs), roll_lds, stream, P, d_state, d_goal, d_tc,
+                           static_cast<S*>(d_eps), static_cast<S*>(d_dV), seed, tick, tick_ptr);
+        HIPCHK(hipGetLastError());
+    }
+    template <typename S, bool PH>
+    void launch_rollout_s(uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
+        if (nterm == 4) launch_rollout_t<S, 4, PH>(seed, tick, tick_ptr);
+        else if (nterm == 7) launch_rollout_t<S, 7, PH>(seed, tick, tick_ptr);
+        else launch_rollout_t<S, 0, PH>(seed, tick, tick_ptr);
+    }
+
+    void run_nominal() {
+        Scope sc(this, MPPI_KERNEL_NOMINAL);
+        hipLaunchKernelGGL(mppi::nominal_kernel, dim3(cfg.n_agents), dim3(mppi::kNomThreads),
+                           (size_t)cfg.horizon * sizeof(double), stream, P, d_state, d_goal, d_unom, d_tc, d_base);
+        HIPCHK(hipGetLastError());
+    }
+    void run_rollout(int noise_mode, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
+        if (noise_mode == MPPI_NOISE_INJECTED && !noise_ready)
+            fail(MPPI_E_STATE, "MPPI_NOISE_INJECTED but mppi_upload_noise was never called");
+        if (noise_mode != MPPI_NOISE_INJECTED && noise_mode != MPPI_NOISE_PHILOX)
+            fail(MPPI_E_INVALID, "unknown noise_mode %d", noise_mode);
+        Scope sc(this, MPPI_KERNEL_ROLLOUT);
+        const bool ph = noise_mode == MPPI_NOISE_PHILOX;
+        if (f64()) { if (ph) launch_rollout_s<double, true>(seed, tick, tick_ptr); else launch_rollout_s<double, false>(seed, tick, tick_ptr); }
+        else { if (ph) launch_rollout_s<float, true>(seed, tick, tick_ptr); else launch_rollout_s<float, false>(seed, tick, tick_ptr); }
+        noise_ready = true; value_ready = true; partials_ready = false;
+    }
+    void run_update() {
+        if (!noise_ready || !value_ready) fail(MPPI_E_STATE, "update needs a rollout (or uploaded V and eps) first");
+        {
+            Scope sc(this, MPPI_KERNEL_UPDATE);
+            dim3 grid(NCH, cfg.horizon, cfg.n_agents);
+            if (f64())
+                hipLaunchKernelGGL(mppi::update_kernel<double>, grid, dim3(256), 0, stream, P,
+                                   static_cast<const double*>(d_eps), static_cast<const double*>(d_dV), d_part, NCH, CH);
+            else
+                hipLaunchKernelGGL(mppi::update_kernel<float>, grid, dim3(256), 0, stream, P,
+                                   static_cast<const float*>(d_eps), static_cast<const float*>(d_dV), d_part, NCH, CH);
+            HIPCHK(hipGetLastError());
+        }
+        {
+            Scope sc(this, MPPI_KERNEL_MERGE);
+            hipLaunchKernelGGL(mppi::merge_kernel, dim3(cfg.horizon, cfg.n_agents), dim3(64), 0, stream, P, d_part, NCH, d_merged);
+            HIPCHK(hipGetLastError());
+        }
+        partials_ready = true;
+    }
+    void run_finalize(const double* gathered, int G, int flags) {
+        if (!gathered) {
+            if (!partials_ready) fail(MPPI_E_STATE, "no partials: call mppi_tick_begin first");
+            gathered = d_merged; G = 1;
+        }
+        if (G < 1) fail(MPPI_E_INVALID, "n_shards must be >= 1");
+        Scope sc(this, MPPI_KERNEL_FINALIZE);
+        hipLaunchKernelGGL(mppi::finalize_kernel, dim3(cfg.n_agents), dim3(256), (size_t)4 * cfg.horizon * sizeof(double),
+                           stream, P, gathered, G, d_S, d_unom, d_ufilt, d_state, d_out, d_tick, flags);
+        HIPCHK(hipGetLastError());
+        partials_ready = false;
+    }
+
+    void refresh_params() {
+        P.sigma = cfg.sigma; P.lambda = cfg.lambda; P.inv_lambda = 1.0 / cfg.lambda;
+    }
+
+    void init(const mppi_config& c) {
+        cfg = c;
+        if (cfg.n_agents < 1 || cfg.samples < 1) fail(MPPI_E_INVALID, "n_agents and samples must be >= 1");
+        if (cfg.horizon < 5 || ((cfg.horizon - 1) % 2) == 0)
+            fail(MPPI_E_INVALID, "horizon=%d: the Savitzky-Golay window horizon-1 must be odd and > 3 "
+                 "(scipy.signal.savgol_filter at control/src/mppi:202)", cfg.horizon);
+        if (cfg.storage != MPPI_STORE_F32 && cfg.storage != MPPI_STORE_F64) fail(MPPI_E_INVALID, "bad storage %d", cfg.storage);
+        if (!(cfg.lambda > 0.0) || !(cfg.sigma >= 0.0)) fail(MPPI_E_INVALID, "lambda must be > 0 and sigma >= 0");
+        if (!(cfg.dt > 0.0)) cfg.dt = 1.0 / (double)cfg.horizon;  // control/src/mppi:67
+        int ndev = 0;
+        HIPCHK(hipGetDeviceCount(&ndev));
+        if (ndev < 1) fail(MPPI_E_HIP, "no HIP device visible: libmppi_hip has no CPU fallback");
+        if (cfg.device < 0 || cfg.device >= ndev) fail(MPPI_E_INVALID, "device %d out of range (%d visible)", cfg.device, ndev);
+        device = cfg.device;
+        HIPCHK(hipSetDevice(device));
+        HIPCHK(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
+        stream = own_stream;
+
+        const int A = cfg.n_agents, K = cfg.samples, T = cfg.horizon;
+        P.A = A; P.K = K; P.T = T; P.Ks = (K + 63) / 64 * 64;
+        P.sample_offset = cfg.sample_offset;
+        P.dt = cfg.dt;
+        P.q0 = cfg.q[0]; P.q1 = cfg.q[1]; P.q2 = cfg.q[2];
+        P.r0 = cfg.r[0]; P.r1 = cfg.r[1];
+        P.p0 = cfg.p1[0]; P.p1 = cfg.p1[1]; P.p2 = cfg.p1[2];
+        P.u_max = cfg.u_max;
+        P.kth = cfg.wheel_radius / cfg.wheel_base;
+        P.rhalf = cfg.wheel_radius / 2.0;
+        P.floor_w = cfg.floor_w;
+        refresh_params();
+
+        // rollout geometry: LDS column of T stage costs per lane; keep >= 3 blocks/CU if possible
+        const size_t per_lane = (size_t)T * esz();
+        roll_bs = 0;
+        for (int bs : {256, 128, 64})
+            if (per_lane * bs <= 53 * 1024) { roll_bs = bs; break; }
+        if (!roll_bs) {
+            if (per_lane * 64 <= 160 * 1024) roll_bs = 64;
+            else fail(MPPI_E_INVALID, "horizon %d too long for the LDS-resident stage costs (max %d)", T,
+                      (int)(160 * 1024 / (64 * esz())));
+        }
+        roll_lds = per_lane * roll_bs;
+        roll_blocks = (K + roll_bs - 1) / roll_bs;
+        const double phi_max = P.kth * P.dt * P.u_max;  // |h/2| <= kth*dt*(2 u_max)/2
+        nterm = phi_max <= 0.03 ? 4 : (phi_max <= 0.25 ? 7 : 0);
+
+        // update geometry: ~4096 blocks on 256 CUs, chunks are multiples of 1024 samples
+        {
+            const long rows = (long)T * A;
+            long nch = (4096 + rows - 1) / rows;
+            const long max_ch = ((long)K + 1023) / 1024;
+            nch = std::max(1L, std::min(nch, max_ch));
+            long ch = ((long)K + nch - 1) / nch;
+            ch = (ch + 1023) / 1024 * 1024;
+            CH = (int)ch;
+            NCH = (int)(((long)K + ch - 1) / ch);
+        }
+
+        const size_t Ks = (size_t)P.Ks;
+        {
+            void* p = nullptr;
+            size_t bytes = (size_t)A * T * 2 * Ks * esz();
+            HIPCHK(hipMalloc(&p, bytes)); hbm_bytes += bytes; d_eps = p;
+            bytes = (size_t)A * T * Ks * esz();
+            HIPCHK(hipMalloc(&p, bytes)); hbm_bytes += bytes; d_dV = p;
+        }
+        d_tc = dev_alloc<double>((size_t)A * T * mppi::kTcW, hbm_bytes);
+        d_base = dev_alloc<double>((size_t)A * T, hbm_bytes);
+        d_unom = dev_alloc<double>((size_t)A * 2 * T, hbm_bytes);
+        d_ufilt = dev_alloc<double>((size_t)A * 2 * T, hbm_bytes);
+        d_state = dev_alloc<double>((size_t)A * 3, hbm_bytes);
+        d_goal = dev_alloc<double>((size_t)A * 3, hbm_bytes);
+        d_part = dev_alloc<double>((size_t)A * T * NCH * mppi::kTupleW, hbm_bytes);
+        d_merged = dev_alloc<double>((size_t)A * T * mppi::kTupleW, hbm_bytes);
+        d_S = dev_alloc<double>((size_t)T * T, hbm_bytes);
+        d_out = dev_alloc<double>((size_t)A * 8, hbm_bytes);
+        d_tick = dev_alloc<uint32_t>(1, hbm_bytes);
+        HIPCHK(hipMemsetAsync(d_unom, 0, (size_t)A * 2 * T * sizeof(double), stream));  // uvec_init, :65
+        HIPCHK(hipMemsetAsync(d_ufilt, 0, (size_t)A * 2 * T * sizeof(double), stream));
+        HIPCHK(hipMemsetAsync(d_out, 0, (size_t)A * 8 * sizeof(double), stream));
+        HIPCHK(hipMemsetAsync(d_tick, 0, sizeof(uint32_t), stream));
+        HIPCHK(hipMemsetAsync(d_eps, 0, (size_t)A * T * 2 * Ks * esz(), stream));
+        HIPCHK(hipMemsetAsync(d_dV, 0, (size_t)A * T * Ks * esz(), stream));
+
+        std::vector<double> S;
+        if (!mppi::savgol_operator(T, S)) fail(MPPI_E_INVALID, "cannot build the Savitzky-Golay operator for horizon %d", T);
+        HIPCHK(hipMemcpyAsync(d_S, S.data(), S.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_stage), (size_t)kRing * A * 6 * sizeof(double), hipHostMallocDefault));
+        for (int i = 0; i < kRing; ++i) HIPCHK(hipEventCreateWithFlags(&ring_ev[i], hipEventDisableTiming));
+    }
+
+    void destroy_graph() {
+        if (graph_exec) { hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+        if (graph) { hipGraphDestroy(graph); graph = nullptr; }
+    }
+
+    ~mppi_engine() {
+        hipSetDevice(device);
+        if (stream) hipStreamSynchronize(stream);
+        destroy_graph();
+        for (auto& p : pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+        for (auto e : ev_pool) hipEventDestroy(e);
+        for (int i = 0; i < kRing; ++i) if (ring_ev[i]) hipEventDestroy(ring_ev[i]);
+        if (h_stage) hipHostFree(h_stage);
+        void* bufs[] = {d_eps, d_dV, d_tc, d_base, d_unom, d_ufilt, d_state, d_goal, d_part, d_merged, d_S, d_out, d_tick, d_tmp};
+        for (void* b : bufs) if (b) hipFree(b);
+        if (own_stream) hipStreamDestroy(own_stream);
+    }
+};
+
+// --------------------------------------------------------------------------------------------
+// C ABI
+// --------------------------------------------------------------------------------------------
+#define API_BEGIN(h)                                   \
+    if (!(h)) return MPPI_E_INVALID;                   \
+    try {                                              \
+        hipError_t sd__ = hipSetDevice((h)->device);   \
+        if (sd__ != hipSuccess) fail(MPPI_E_HIP, "hipSetDevice(%d): %s", (h)->device, hipGetErrorString(sd__));
+#define API_END(h)                                                                  \
+        return MPPI_OK;                                                             \
+    } catch (const EngineError& e) { (h)->err = e.msg; return e.code; }             \
+    catch (const std::bad_alloc&) { (h)->err = "host allocation failed"; return MPPI_E_INTERNAL; } \
+    catch (const std::exception& e) { (h)->err = e.what(); return MPPI_E_INTERNAL; } \
+    catch (...) { (h)->err = "unknown error"; return MPPI_E_INTERNAL; }
+
+extern "C" {
+
+int mppi_abi_version(void) { return MPPI_ABI_VERSION; }
+
+int mppi_default_config(mppi_config* cfg) {
+    if (!cfg) return MPPI_E_INVALID;
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->n_agents = 1;
+    cfg->samples = 10;   // control/src/mppi:62
+    cfg->horizon = 100;  // control/src/mppi:62
+    cfg->storage = MPPI_STORE_F32;
+    cfg->device = 0;
+    cfg->sample_offset = 0;
+    cfg->dt = 0.0;
+    cfg->sigma = 0.9;     // control/src/mppi:88
+    cfg->lambda = 0.001;  // control/src/mppi:89
+    cfg->q[0] = 1e3; cfg->q[1] = 1e3; cfg->q[2] = 0.0;       // :69
+    cfg->r[0] = 1.0; cfg->r[1] = 1.0;                        // :71
+    cfg->p1[0] = 1e3; cfg->p1[1] = 1e3; cfg->p1[2] = 1e3;    // :73
+    cfg->u_max = 6.35492;       // :18
+    cfg->wheel_radius = 0.033;  // :19
+    cfg->wheel_base = 0.16;     // :20
+    cfg->floor_w = 1e-8;        // :193
+    return MPPI_OK;
+}
+
+const char* mppi_last_error(const mppi_engine* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int mppi_create(const mppi_config* cfg, mppi_engine** out) {
+    if (!cfg || !out) { g_create_error = "mppi_create: NULL argument"; return MPPI_E_INVALID; }
+    *out = nullptr;
+    mppi_engine* e = nullptr;
+    try {
+        e = new mppi_engine();
+        e->init(*cfg);
+        *out = e;
+        return MPPI_OK;
+    } catch (const EngineError& er) { g_create_error = er.msg; delete e; return er.code; }
+    catch (const std::exception& ex) { g_create_error = ex.what(); delete e; return MPPI_E_INTERNAL; }
+    catch (...) { g_create_error = "unknown error"; delete e; return MPPI_E_INTERNAL; }
+}
+
+int mppi_destroy(mppi_engine* h) {
+    if (!h) return MPPI_E_INVALID;
+    delete h;
+    return MPPI_OK;
+}
+
+int mppi_set_stream(mppi_engine* h, void* hip_stream) {
+    API_BEGIN(h)
+    h->drain_timing();
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->destroy_graph();
+    h->stream = static_cast<hipStream_t>(hip_stream);
+    API_END(h)
+}
+
+int mppi_set_sigma_lambda(mppi_engine* h, double sigma, double lambda) {
+    API_BEGIN(h)
+    if (!(lambda > 0.0) || !(sigma >= 0.0)) fail(MPPI_E_INVALID, "lambda must be > 0 and sigma >= 0");
+    h->cfg.sigma = sigma; h->cfg.lambda = lambda;
+    h->refresh_params();
+    h->destroy_graph();
+    API_END(h)
+}
+
+int mppi_reset(mppi_engine* h, int agent) {
+    API_BEGIN(h)
+    const size_t row = (size_t)2 * h->cfg.horizon * sizeof(double);
+    if (agent < 0) HIPCHK(hipMemsetAsync(h->d_unom, 0, row * h->cfg.n_agents, h->stream));
+    else if (agent < h->cfg.n_agents) HIPCHK(hipMemsetAsync(h->d_unom + (size_t)agent * 2 * h->cfg.horizon, 0, row, h->stream));
+    else fail(MPPI_E_INVALID, "agent %d out of range", agent);
+    API_END(h)
+}
+
+int mppi_set_nominal(mppi_engine* h, int agent, const double* uvec) {
+    API_BEGIN(h)
+    if (!uvec || agent < 0 || agent >= h->cfg.n_agents) fail(MPPI_E_INVALID, "bad agent/uvec");
+    const size_t n = (size_t)2 * h->cfg.horizon;
+    HIPCHK(hipMemcpyAsync(h->d_unom + agent * n, uvec, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    API_END(h)
+}
+
+int mppi_get_nominal(mppi_engine* h, int agent, double* uvec) {
+    API_BEGIN(h)
+    if (!uvec || agent < 0 || agent >= h->cfg.n_agents) fail(MPPI_E_INVALID, "bad agent/uvec");
+    const size_t n = (size_t)2 * h->cfg.horizon;
+    HIPCHK(hipMemcpyAsync(uvec, h->d_unom + agent * n, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    API_END(h)
+}
+
+int mppi_upload_noise(mppi_engine* h, const double* eps) {
+    API_BEGIN(h)
+    if (!eps) fail(MPPI_E_INVALID, "eps is NULL");
+    const int A = h->cfg.n_agents, T = h->cfg.horizon, K = h->cfg.samples;
+    const size_t n = (size_t)A * T * 2 * K;
+    h->ensure_tmp(n);
+    HIPCHK(hipMemcpyAsync(h->d_tmp, eps, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    dim3 grid(std::min((K + 255) / 256, 1024), A * T * 2);
+    if (h->f64()) hipLaunchKernelGGL(mppi::pack_rows_kernel<double>, grid, dim3(256), 0, h->stream, h->d_tmp, static_cast<double*>(h->d_eps), K, h->P.Ks, (const double*)nullptr, 1);
+    else hipLaunchKernelGGL(mppi::pack_rows_kernel<float>, grid, dim3(256), 0, h->stream, h->d_tmp, static_cast<float*>(h->d_eps), K, h->P.Ks, (const double*)nullptr, 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->noise_ready = true;
+    API_END(h)
+}
+
+int mppi_download_noise(mppi_engine* h, double* eps) {
+    API_BEGIN(h)
+    if (!eps) fail(MPPI_E_INVALID, "eps is NULL");
+    if (!h->noise_ready) fail(MPPI_E_STATE, "no noise resident");
+    const int A = h->cfg.n_agents, T = h->cfg.horizon, K = h->cfg.samples;
+    const size_t n = (size_t)A * T * 2 * K;
+    h->ensure_tmp(n);
+    dim3 grid(std::min((K + 255) / 256, 1024), A * T * 2);
+    if (h->f64()) hipLaunchKernelGGL(mppi::unpack_rows_kernel<double>, grid, dim3(256), 0, h->stream, static_cast<const double*>(h->d_eps), h->d_tmp, K, h->P.Ks, (const double*)nullptr, 1);
+    else hipLaunchKernelGGL(mppi::unpack_rows_kernel<float>, grid, dim3(256), 0, h->stream, static_cast<const float*>(h->d_eps), h->d_tmp, K, h->P.Ks, (const double*)nullptr, 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(eps, h->d_tmp, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    API_END(h)
+}
+
+int mppi_rollout(mppi_engine* h, const double* state, const double* goal, int noise_mode, uint64_t seed, uint32_t tick_id) {
+    API_BEGIN(h)
+    h->set_inputs(state, goal);
+    h->run_nominal();
+    h->run_rollout(noise_mode, seed, tick_id, nullptr);
+    API_END(h)
+}
+
+int mppi_download_value(mppi_engine* h, double* V) {
+    API_BEGIN(h)
+    if (!V) fail(MPPI_E_INVALID, "V is NULL");
+    if (!h->value_ready) fail(MPPI_E_STATE, "no value function resident");
+    const int A = h->cfg.n_agents, T = h->cfg.horizon, K = h->cfg.samples;
+    const size_t n = (size_t)A * T * K;
+    h->ensure_tmp(n);
+    dim3 grid(std::min((K + 255) / 256, 1024), A * T);
+    if (h->f64()) hipLaunchKernelGGL(mppi::unpack_rows_kernel<double>, grid, dim3(256), 0, h->stream, static_cast<const double*>(h->d_dV), h->d_tmp, K, h->P.Ks, (const double*)h->d_base, 1);
+    else hipLaunchKernelGGL(mppi::unpack_rows_kernel<float>, grid, dim3(256), 0, h->stream, static_cast<const float*>(h->d_dV), h->d_tmp, K, h->P.Ks, (const double*)h->d_base, 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(V, h->d_tmp, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    API_END(h)
+}
+
+int mppi_upload_value(mppi_engine* h, const double* V) {
+    API_BEGIN(h)
+    if (!V) fail(MPPI_E_INVALID, "V is NULL");
+    const int A = h->cfg.n_agents, T = h->cfg.horizon, K = h->cfg.samples;
+    const size_t n = (size_t)A * T * K;
+    h->ensure_tmp(n);
+    HIPCHK(hipMemcpyAsync(h->d_tmp, V, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    // baseline := per-row minimum, so the stored offsets are >= 0 and small near the minimum
+    hipLaunchKernelGGL(mppi::row_min_kernel, dim3(A * T), dim3(256), 0, h->stream, h->d_tmp, K, h->d_base);
+    HIPCHK(hipGetLastError());
+    dim3 grid(std::min((K + 255) / 256, 1024), A * T);
+    if (h->f64()) hipLaunchKernelGGL(mppi::pack_rows_kernel<double>, grid, dim3(256), 0, h->stream, h->d_tmp, static_cast<double*>(h->d_dV), K, h->P.Ks, (const double*)h->d_base, 1);
+    else hipLaunchKernelGGL(mppi::pack_rows_kernel<float>, grid, dim3(256), 0, h->stream, h->d_tmp, static_cast<float*>(h->d_dV), K, h->P.Ks, (const double*)h->d_base, 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->value_ready = true;
+    API_END(h)
+}
+
+int mppi_update(mppi_engine* h, double* uvec_out) {
+    API_BEGIN(h)
+    h->run_update();
+    h->run_finalize(nullptr, 1, 0);
+    if (uvec_out) {
+        const size_t n = (size_t)h->cfg.n_agents * 2 * h->cfg.horizon;
+        HIPCHK(hipMemcpyAsync(uvec_out, h->d_ufilt, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    API_END(h)
+}
+
+int mppi_plant_step(mppi_engine* h, const double* state, double* next_state) {
+    API_BEGIN(h)
+    const int A = h->cfg.n_agents;
+    if (state) { h->stage_upload(state, h->d_state, (size_t)A * 3); h->have_state = true; }
+    if (!h->have_state) fail(MPPI_E_STATE, "no state resident");
+    hipLaunchKernelGGL(mppi::plant_kernel, dim3((A + 63) / 64), dim3(64), 0, h->stream, h->P, h->d_state, h->d_unom, h->d_out);
+    HIPCHK(hipGetLastError());
+    if (next_state) {
+        std::vector<double> o((size_t)A * 8);
+        HIPCHK(hipMemcpyAsync(o.data(), h->d_out, o.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        for (int a = 0; a < A; ++a) for (int i = 0; i < 3; ++i) next_state[a * 3 + i] = o[(size_t)a * 8 + i];
+    }
+    API_END(h)
+}
+
+int mppi_shift(mppi_engine* h) {
+    API_BEGIN(h)
+    hipLaunchKernelGGL(mppi::shift_kernel, dim3(h->cfg.n_agents * 2), dim3(256), (size_t)h->cfg.horizon * sizeof(double), h->stream, h->P, h->d_unom);
+    HIPCHK(hipGetLastError());
+    API_END(h)
+}
+
+int mppi_tick_begin(mppi_engine* h, const double* state, const double* goal, int noise_mode, uint64_t seed, uint32_t tick_id) {
+    API_BEGIN(h)
+    h->set_inputs(state, goal);
+    h->run_nominal();
+    h->run_rollout(noise_mode, seed, tick_id, nullptr);
+    h->run_update();
+    API_END(h)
+}
+
+int mppi_partials_ptr(mppi_engine* h, void** dev_ptr, size_t* bytes) {
+    API_BEGIN(h)
+    if (dev_ptr) *dev_ptr = h->d_merged;
+    if (bytes) *bytes = (size_t)h->cfg.n_agents * h->cfg.horizon * mppi::kTupleW * sizeof(double);
+    API_END(h)
+}
+
+int mppi_tick_finish(mppi_engine* h, const void* gathered_dev, int n_shards) {
+    API_BEGIN(h)
+    h->run_finalize(static_cast<const double*>(gathered_dev), n_shards, 1 | 2);
+    API_END(h)
+}
+
+int mppi_get_outputs(mppi_engine* h, double* next_state, double* u_applied) {
+    API_BEGIN(h)
+    const int A = h->cfg.n_agents;
+    std::vector<double> o((size_t)A * 8);
+    HIPCHK(hipMemcpyAsync(o.data(), h->d_out, o.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int a = 0; a < A; ++a) {
+        if (next_state) for (int i = 0; i < 3; ++i) next_state[a * 3 + i] = o[(size_t)a * 8 + i];
+        if (u_applied) for (int i = 0; i < 2; ++i) u_applied[a * 2 + i] = o[(size_t)a * 8 + 3 + i];
+    }
+    API_END(h)
+}
+
+int mppi_tick(mppi_engine* h, const double* state, const double* goal, int noise_mode, uint64_t seed, uint32_t tick_id,
+              double* next_state, double* u_applied) {
+    int rc = mppi_tick_begin(h, state, goal, noise_mode, seed, tick_id);
+    if (rc) return rc;
+    rc = mppi_tick_finish(h, nullptr, 1);
+    if (rc) return rc;
+    if (next_state || u_applied) rc = mppi_get_outputs(h, next_state, u_applied);
+    return rc;
+}
+
+int mppi_tick_graph(mppi_engine* h, uint64_t seed) {
+    API_BEGIN(h)
+    if (!h->have_state || !h->have_goal) fail(MPPI_E_STATE, "tick_graph needs a resident state and goal (run one mppi_tick first)");
+    if (h->stream == nullptr) fail(MPPI_E_STATE, "graph capture is not possible on the null stream");
+    if (h->graph_exec && h->graph_seed != seed) h->destroy_graph();
+    if (!h->graph_exec) {
+        const uint32_t saved = h->time_mask;
+        h->time_mask = 0;
+        HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        try {
+            h->run_nominal();
+            h->run_rollout(MPPI_NOISE_PHILOX, seed, 0, h->d_tick);
+            h->run_update();
+            h->run_finalize(nullptr, 1, 1 | 2 | 4);
+        } catch (...) {
+            hipGraph_t g = nullptr;
+            hipStreamEndCapture(h->stream, &g);
+            if (g) hipGraphDestroy(g);
+            h->time_mask = saved;
+            throw;
+        }
+        HIPCHK(hipStreamEndCapture(h->stream, &h->graph));
+        HIPCHK(hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
+        h->graph_seed = seed;
+        h->time_mask = saved;
+    }
+    HIPCHK(hipGraphLaunch(h->graph_exec, h->stream));
+    h->noise_ready = true; h->value_ready = true; h->partials_ready = false;
+    API_END(h)
+}
+
+int mppi_synchronize(mppi_engine* h) {
+    API_BEGIN(h)
+    HIPCHK(hipStreamSynchronize(h->stream));
+    API_END(h)
+}
+
+int mppi_savgol_matrix(int horizon, double* S) {
+    if (!S || horizon < 1) return MPPI_E_INVALID;
+    try {
+        std::vector<double> v;
+        if (!mppi::savgol_operator(horizon, v)) return MPPI_E_INVALID;
+        std::memcpy(S, v.data(), v.size() * sizeof(double));
+        return MPPI_OK;
+    } catch (...) { return MPPI_E_INTERNAL; }
+}
+
+int mppi_kernel_timing(mppi_engine* h, uint32_t mask) {
+    API_BEGIN(h)
+    h->drain_timing();
+    h->time_mask = mask;
+    for (int i = 0; i < MPPI_KERNEL_COUNT; ++i) { h->t_ms[i] = 0.0; h->t_n[i] = 0; }
+    API_END(h)
+}
+
+int mppi_kernel_times(mppi_engine* h, double* ms, int64_t* launches) {
+    API_BEGIN(h)
+    h->drain_timing();
+    for (int i = 0; i < MPPI_KERNEL_COUNT; ++i) {
+        if (ms) ms[i] = h->t_ms[i];
+        if (launches) launches[i] = h->t_n[i];
+    }
+    API_END(h)
+}
+
+int mppi_engine_info(mppi_engine* h, size_t* hbm_bytes, int32_t* rollout_blocks, int32_t* update_blocks) {
+    API_BEGIN(h)
+    if (hbm_bytes) *hbm_bytes = h->hbm_bytes;
+    if (rollout_blocks) *rollout_blocks = h->roll_blocks * h->cfg.n_agents;
+    if (update_blocks) *update_blocks = h->NCH * h->cfg.horizon * h->cfg.n_agents;
+    API_END(h)
+}
+
+}  // extern "C"

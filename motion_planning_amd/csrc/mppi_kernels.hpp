@@ -1,0 +1,597 @@
+// mppi_kernels.hpp -- hand-written gfx950 (CDNA4, wave64) kernels of the MPPI hot path.
+//
+// Reference being replaced (moribots/motion_planning): control/src/mppi
+//   get_cost2go :127-178, get_cost :180-184, rk4 :39-54, dd_dynamics :23-30,
+//   update_action :186-208, perform_action :210-213, get_path :85-102.
+//
+// Pipeline of one control tick (DESIGN.md has the byte accounting):
+//   nominal_kernel   1 block / agent    nominal (eps = 0) rollout by block scans -> per-step table
+//                                       tc[a][t] + baseline cost-to-go base[a][t]
+//   rollout_kernel   1 lane / sample    noise -> clip -> RK4 step -> stage cost (registers),
+//                                       stage costs parked in LDS, reverse cumsum, writes
+//                                       eps[a][t][2][K] and dV = V - base  (HBM-bound, 12 B/step)
+//   update_kernel    1 block / (chunk,t,a)  streaming per-timestep online softmax over K
+//                                       (reads the 12 B/step back) -> partial tuples
+//   merge_kernel     1 wave / (t,a)     merges chunk partials -> shard partial [A][T][8]
+//   finalize_kernel  1 block / agent    merges shard partials (after the RCCL all-gather),
+//                                       control update, clip, Savitzky-Golay, clip, plant step, shift
+//
+// No MFMA: there is no dense contraction on this path.  All state / cost arithmetic is
+// fp64 (lambda = 1e-3 amplifies cost error 1000x inside exp(), fp32 accumulation of V ~ 1e4
+// cannot feed it); only the HBM-resident intermediates are stored narrow (fp32) and V is
+// stored as an offset from the nominal trajectory's cost-to-go so that fp32 keeps ~1e-6
+// absolute accuracy where the softmax weights live.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mppi {
+
+constexpr int kTupleW = 8;  // {min, D, N0, N1, E0, E1, count, pad}
+constexpr int kTcW = 8;     // {un0, un1, w0, w1, cb, 0, 0, 0}
+
+struct DevParams {
+    int A, K, Ks, T;          // Ks: padded row pitch (elements) of eps / dV rows
+    uint32_t sample_offset;
+    double dt, sigma, lambda, inv_lambda;
+    double q0, q1, q2, r0, r1, p0, p1, p2;
+    double u_max, kth, rhalf, floor_w;  // kth = wheel_radius / wheel_base, rhalf = wheel_radius / 2
+};
+
+__device__ __forceinline__ double clampd(double v, double lim) { return fmin(fmax(v, -lim), lim); }
+
+// control/src/mppi:52-53 : theta -> (-pi, pi]
+__device__ __forceinline__ double wrap_theta(double th) {
+    return th - (ceil((th + M_PI) / (2.0 * M_PI)) - 1.0) * 2.0 * M_PI;
+}
+
+// sin / cos of a SMALL angle by Taylor series (|phi| <= 0.03 for NTERM 4, <= 0.25 for NTERM 7:
+// truncation < 1e-17).  The RK4 stages of the diff-drive model evaluate cos/sin at theta,
+// theta + h/2, theta + h with h = dt * kth * (u1 - u0) -- a rotation of the heading vector by
+// phi = h/2, so no range reduction and no full-range sincos is needed per step.
+template <int NTERM>
+__device__ __forceinline__ void small_sincos(double phi, double& s, double& c) {
+    const double z = phi * phi;
+    if (NTERM == 4) {
+        s = phi * fma(z, fma(z, fma(z, -1.0 / 5040.0, 1.0 / 120.0), -1.0 / 6.0), 1.0);
+        c = fma(z, fma(z, fma(z, -1.0 / 720.0, 1.0 / 24.0), -0.5), 1.0);
+    } else {
+        double ps = fma(z, 1.0 / 6227020800.0, -1.0 / 39916800.0);
+        ps = fma(z, ps, 1.0 / 362880.0);
+        ps = fma(z, ps, -1.0 / 5040.0);
+        ps = fma(z, ps, 1.0 / 120.0);
+        ps = fma(z, ps, -1.0 / 6.0);
+        s = phi * fma(z, ps, 1.0);
+        double pc = fma(z, -1.0 / 87178291200.0, 1.0 / 479001600.0);
+        pc = fma(z, pc, -1.0 / 3628800.0);
+        pc = fma(z, pc, 1.0 / 40320.0);
+        pc = fma(z, pc, -1.0 / 720.0);
+        pc = fma(z, pc, 1.0 / 24.0);
+        pc = fma(z, pc, -0.5);
+        c = fma(z, pc, 1.0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// block-wide inclusive scan of one double per thread (Hillis-Steele through LDS); NT = blockDim.x
+// ---------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ double block_scan_incl(double v, double* sh, double& total) {
+    const int tid = threadIdx.x;
+    sh[tid] = v;
+    __syncthreads();
+#pragma unroll
+    for (int off = 1; off < NT; off <<= 1) {
+        const double add = (tid >= off) ? sh[tid - off] : 0.0;
+        __syncthreads();
+        v += add;
+        sh[tid] = v;
+        __syncthreads();
+    }
+    total = sh[NT - 1];
+    __syncthreads();
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// nominal_kernel: the eps = 0 rollout of each agent.  It only provides a BASELINE (any per-t
+// constant cancels in the per-timestep softmax, control/src/mppi:189), so it is free to use
+// parallel prefix sums: for this model RK4 == Simpson's rule on the heading, theta/x/y are
+// prefix sums over t and the cost-to-go is a suffix sum.
+//   tc[a][t]   = {un0, un1, lam*sig*un0, lam*sig*un1, cb}   cb = -1/2 xQx_nom(t) - [t==T-1] xP1x_nom
+//   base[a][t] = nominal cost-to-go  (V = base + dV)
+// grid = A blocks x 256 threads, dynamic LDS = T doubles.
+// ---------------------------------------------------------------------------------------------
+constexpr int kNomThreads = 256;
+
+__global__ __launch_bounds__(kNomThreads) void nominal_kernel(DevParams P, const double* __restrict__ state,
+                                                             const double* __restrict__ goal,
+                                                             const double* __restrict__ unom,
+                                                             double* __restrict__ tc,
+                                                             double* __restrict__ base) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* cstage = reinterpret_cast<double*>(smem_raw);  // [T]
+    __shared__ double sh[kNomThreads];
+    const int a = blockIdx.x, tid = threadIdx.x, T = P.T;
+    const double gx = goal[a * 3 + 0], gy = goal[a * 3 + 1], gth = goal[a * 3 + 2];
+    double car_x = state[a * 3 + 0], car_y = state[a * 3 + 1], car_th = state[a * 3 + 2];
+    const double ls = P.lambda * P.sigma;
+    for (int b0 = 0; b0 < T; b0 += kNomThreads) {
+        const int t = b0 + tid;
+        const bool valid = t < T;
+        const double un0 = valid ? unom[(a * 2 + 0) * T + t] : 0.0;
+        const double un1 = valid ? unom[(a * 2 + 1) * T + t] : 0.0;
+        const double u0 = clampd(un0, P.u_max), u1 = clampd(un1, P.u_max);
+        const double h = valid ? P.kth * P.dt * (u1 - u0) : 0.0;
+        double tot_h, tot_x, tot_y;
+        const double hin = block_scan_incl<kNomThreads>(h, sh, tot_h);
+        const double th = car_th + (hin - h);
+        double s0, c0, s1, c1, s2, c2;
+        sincos(th, &s0, &c0);
+        sincos(th + 0.5 * h, &s1, &c1);
+        sincos(th + h, &s2, &c2);
+        const double aa = P.dt * P.rhalf * (u0 + u1) * (1.0 / 6.0);
+        const double ix = valid ? aa * (c0 + 4.0 * c1 + c2) : 0.0;
+        const double iy = valid ? aa * (s0 + 4.0 * s1 + s2) : 0.0;
+        const double X = car_x + block_scan_incl<kNomThreads>(ix, sh, tot_x);
+        const double Y = car_y + block_scan_incl<kNomThreads>(iy, sh, tot_y);
+        if (valid) {
+            const double thn = wrap_theta(th + h);
+            const double dx = X - gx, dy = Y - gy, dth = thn - gth;
+            const double xqx = P.q0 * dx * dx + P.q1 * dy * dy + P.q2 * dth * dth;
+            const double uru = P.r0 * un0 * un0 + P.r1 * un1 * un1;
+            double cst = 0.5 * (xqx + uru);
+            if (t == T - 1) cst += P.p0 * dx * dx + P.p1 * dy * dy + P.p2 * dth * dth;
+            double* o = tc + ((size_t)a * T + t) * kTcW;
+            o[0] = un0; o[1] = un1; o[2] = ls * un0; o[3] = ls * un1;
+            o[4] = 0.5 * uru - cst; o[5] = 0.0; o[6] = 0.0; o[7] = 0.0;
+            cstage[t] = cst;
+        }
+        car_th += tot_h; car_x += tot_x; car_y += tot_y;
+    }
+    __syncthreads();
+    double carry = 0.0;
+    for (int b0 = ((T - 1) / kNomThreads) * kNomThreads; b0 >= 0; b0 -= kNomThreads) {
+        const int t = b0 + tid;
+        const double v = (t < T) ? cstage[t] : 0.0;
+        double tot;
+        const double inc = block_scan_incl<kNomThreads>(v, sh, tot);
+        if (t < T) base[(size_t)a * T + t] = carry + tot - (inc - v);
+        carry += tot;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11) -- the generator hipRAND exposes as
+// HIPRAND_RNG_PSEUDO_PHILOX4_32_10 -- inlined so that (seed, tick, agent, global sample, t)
+// addresses the stream identically on any shard layout and on the CPU twin (oracle/).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// two N(0, sigma^2) draws from two 32-bit words (Box-Muller on 24-bit uniforms, fp32)
+__device__ __forceinline__ void box_muller(uint32_t w0, uint32_t w1, float sigma, float& e0, float& e1) {
+    const float u1 = ((float)(w0 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = (float)(w1 >> 8) * (1.0f / 16777216.0f);
+    const float r = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincospif(2.0f * u2, &sn, &cs);
+    e0 = sigma * (r * cs);
+    e1 = sigma * (r * sn);
+}
+
+// ---------------------------------------------------------------------------------------------
+// rollout_kernel: MPPI.get_cost2go (control/src/mppi:127-178) for one sample per lane.
+//   S      storage type of eps / dV in HBM (float | double)
+//   NTERM  4 | 7: Taylor terms for the per-step heading rotation; 0: full sincos every step
+//   PHILOX true: draw eps in-kernel and WRITE it; false: READ the injected eps
+// grid = (ceil(K / BS), A), block = BS, dynamic LDS = T * BS * sizeof(S) (stage costs, lane-major
+// columns -> conflict-free).  Per lane and step: 2 eps + 1 dV element through HBM, fully
+// coalesced (consecutive lanes = consecutive k).
+// ---------------------------------------------------------------------------------------------
+template <typename S, int NTERM, bool PHILOX>
+__global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double* __restrict__ state,
+                                                     const double* __restrict__ goal,
+                                                     const double* __restrict__ tc, S* __restrict__ eps,
+                                                     S* __restrict__ dV, uint64_t seed, uint32_t tick_arg,
+                                                     const uint32_t* __restrict__ tick_ptr) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    S* lc = reinterpret_cast<S*>(smem_raw);  // [T][BS]
+    const int BS = blockDim.x, tid = threadIdx.x, a = blockIdx.y, T = P.T;
+    const int k = blockIdx.x * BS + tid;
+    const bool active = k < P.K;
+    const size_t Ks = (size_t)P.Ks;
+    const double gx = goal[a * 3 + 0], gy = goal[a * 3 + 1], gth = goal[a * 3 + 2];
+    double x = state[a * 3 + 0], y = state[a * 3 + 1], th = state[a * 3 + 2];
+    double c, s;
+    sincos(th, &s, &c);
+    S* eps_a = eps + (size_t)a * T * 2 * Ks + k;
+    const double* tca = tc + (size_t)a * T * kTcW;
+    const double half_kd = 0.5 * P.kth * P.dt;             // phi = half_kd * (u1 - u0) = h / 2
+    const double sixth_rd = P.dt * P.rhalf * (1.0 / 6.0);  // Simpson weight of (u0 + u1)
+
+    uint32_t key0 = 0, key1 = 0, ctr0 = 0, tick = 0;
+    float sigf = 0.f;
+    if (PHILOX) {
+        key0 = (uint32_t)seed; key1 = (uint32_t)(seed >> 32);
+        ctr0 = P.sample_offset + (uint32_t)k;
+        tick = tick_ptr ? *tick_ptr : tick_arg;
+        sigf = (float)P.sigma;
+    }
+
+    constexpr int U = 4;  // steps per software-pipelined chunk
+    S cur[U][2], nxt[U][2];
+    auto load_chunk = [&](int t0, S (&buf)[U][2]) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int t = t0 + j;
+            const bool ok = active && t < T;
+            buf[j][0] = ok ? eps_a[(size_t)(t * 2 + 0) * Ks] : (S)0;
+            buf[j][1] = ok ? eps_a[(size_t)(t * 2 + 1) * Ks] : (S)0;
+        }
+    };
+    auto draw_chunk = [&](int t0, S (&buf)[U][2]) {  // U == 4: two Philox calls
+#pragma unroll
+        for (int j = 0; j < U; j += 2) {
+            uint32_t o[4];
+            philox4x32_10(ctr0, (uint32_t)((t0 + j) >> 1), tick, (uint32_t)a, key0, key1, o);
+            float e0, e1, e2, e3;
+            box_muller(o[0], o[1], sigf, e0, e1);
+            box_muller(o[2], o[3], sigf, e2, e3);
+            buf[j][0] = (S)e0; buf[j][1] = (S)e1;
+            buf[j + 1][0] = (S)e2; buf[j + 1][1] = (S)e3;
+        }
+    };
+    if (!PHILOX) load_chunk(0, cur);
+
+    for (int t0 = 0; t0 < T; t0 += U) {
+        if (PHILOX) draw_chunk(t0, cur);
+        else load_chunk(t0 + U, nxt);  // prefetch: HBM latency hides under this chunk's math
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int t = t0 + j;
+            if (t < T) {  // wave-uniform
+                const double* tcp = tca + (size_t)t * kTcW;  // uniform -> scalar loads
+                const double un0 = tcp[0], un1 = tcp[1], w0 = tcp[2], w1 = tcp[3], cb = tcp[4];
+                const double e0 = (double)cur[j][0], e1 = (double)cur[j][1];
+                if (PHILOX && active) {
+                    eps_a[(size_t)(t * 2 + 0) * Ks] = cur[j][0];
+                    eps_a[(size_t)(t * 2 + 1) * Ks] = cur[j][1];
+                }
+                // EXPLORE + CLIP (control/src/mppi:147-152)
+                const double u0 = clampd(un0 + e0, P.u_max), u1 = clampd(un1 + e1, P.u_max);
+                // rk4 (control/src/mppi:39-54) for dd_dynamics (:23-30): theta_dot is constant
+                // over the step, so the four stages sit at theta, theta+h/2 (twice), theta+h.
+                const double phi = half_kd * (u1 - u0);
+                const double aa = sixth_rd * (u0 + u1);
+                double c1, s1, c2, s2;
+                if (NTERM == 0) {
+                    sincos(th + phi, &s1, &c1);
+                    sincos(th + 2.0 * phi, &s2, &c2);
+                } else {
+                    double sp, cp;
+                    small_sincos<NTERM>(phi, sp, cp);
+                    c1 = c * cp - s * sp; s1 = s * cp + c * sp;
+                    c2 = c1 * cp - s1 * sp; s2 = s1 * cp + c1 * sp;
+                }
+                x = fma(aa, c + 4.0 * c1 + c2, x);
+                y = fma(aa, s + 4.0 * s1 + s2, y);
+                th = wrap_theta(th + 2.0 * phi);
+                c = c2; s = s2;
+                // get_cost (control/src/mppi:180-184) minus the nominal stage cost (cb):
+                //   1/2 xQx + 1/2 uRu + lam*sig*(un . eps)  with u = NOMINAL, eps = UNCLIPPED
+                const double dx = x - gx, dy = y - gy, dth = th - gth;
+                double dc = 0.5 * (P.q0 * dx * dx + P.q1 * dy * dy + P.q2 * dth * dth) + cb;
+                dc = fma(w0, e0, dc);
+                dc = fma(w1, e1, dc);
+                if (t == T - 1)  // terminal cost (control/src/mppi:165-173), theta error not wrapped
+                    dc += P.p0 * dx * dx + P.p1 * dy * dy + P.p2 * dth * dth;
+                lc[t * BS + tid] = (S)dc;
+            }
+        }
+        if (!PHILOX) {
+#pragma unroll
+            for (int j = 0; j < U; ++j) { cur[j][0] = nxt[j][0]; cur[j][1] = nxt[j][1]; }
+        }
+    }
+    // value_fcn = reverse cumulative sum over t (control/src/mppi:175), as an offset from base[a][t]
+    double acc = 0.0;
+    S* dv = dV + (size_t)a * T * Ks + k;
+    for (int t = T - 1; t >= 0; --t) {
+        acc += (double)lc[t * BS + tid];
+        if (active) dv[(size_t)t * Ks] = (S)acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// update_kernel: the K-reduction of MPPI.update_action (control/src/mppi:187-196) as a single
+// streaming pass.  Per timestep the reference needs min_k V, sum_k w and sum_k eps*w with
+// w = exp(-(V - min)/lam) + 1e-8.  Each lane keeps an online-softmax tuple (running min m,
+// D = sum e, N = sum e*eps, E = sum eps) so V and eps are read exactly once (12 B/step fp32);
+// the 1e-8 floor is applied at merge time as floor*count / floor*E.
+// grid = (NCH, T, A) x 256 threads; block (ch,t,a) owns samples [ch*CH, min(K,(ch+1)*CH)).
+// part[a][t][ch] = {m, D, N0, N1, E0, E1, count, 0} (float64).
+// ---------------------------------------------------------------------------------------------
+template <typename R> struct Exp2;
+template <> struct Exp2<float> {
+    static __device__ __forceinline__ float f(float v) { return exp2f(v); }
+};
+template <> struct Exp2<double> {
+    static __device__ __forceinline__ double f(double v) { return exp2(v); }
+};
+
+template <typename R>
+__device__ __forceinline__ R wave_min(R v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+    return v;
+}
+template <typename R>
+__device__ __forceinline__ R wave_sum(R v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <typename S>
+__global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __restrict__ eps,
+                                                    const S* __restrict__ dV, double* __restrict__ part,
+                                                    int NCH, int CH) {
+    using R = S;                                        // accumulate in the storage precision
+    constexpr int VEC = 16 / (int)sizeof(S);            // elements per 16-byte lane load
+    const int ch = blockIdx.x, t = blockIdx.y, a = blockIdx.z, tid = threadIdx.x;
+    const size_t Ks = (size_t)P.Ks;
+    const S* v_row = dV + ((size_t)a * P.T + t) * Ks;
+    const S* e0_row = eps + (((size_t)a * P.T + t) * 2 + 0) * Ks;
+    const S* e1_row = e0_row + Ks;
+    const int k_begin = ch * CH;
+    const int k_end = min(P.K, k_begin + CH);
+    const R scale = (R)(P.inv_lambda * 1.4426950408889634);  // log2(e) / lambda
+    R m = (R)INFINITY, D = 0, N0 = 0, N1 = 0, E0 = 0, E1 = 0;
+
+    for (int k = k_begin + tid * VEC; k < k_end; k += 256 * VEC) {
+        S v[VEC], a0[VEC], a1[VEC];
+        if (k + VEC <= k_end) {  // rows are 256-byte aligned, k % VEC == 0 -> 16-byte aligned
+            typedef S vec_t __attribute__((ext_vector_type(VEC)));
+            const vec_t vv = *reinterpret_cast<const vec_t*>(v_row + k);
+            const vec_t x0 = *reinterpret_cast<const vec_t*>(e0_row + k);
+            const vec_t x1 = *reinterpret_cast<const vec_t*>(e1_row + k);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) { v[i] = vv[i]; a0[i] = x0[i]; a1[i] = x1[i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const bool ok = k + i < k_end;
+                v[i] = ok ? v_row[k + i] : (S)INFINITY;  // weight 0, eps 0: no contribution
+                a0[i] = ok ? e0_row[k + i] : (S)0;
+                a1[i] = ok ? e1_row[k + i] : (S)0;
+            }
+        }
+        R vm = v[0];
+#pragma unroll
+        for (int i = 1; i < VEC; ++i) vm = fmin(vm, v[i]);
+        if (vm < m) {  // new running minimum: rescale what has been accumulated
+            const R sc = Exp2<R>::f((vm - m) * scale);  // m = +inf the first time -> 0
+            D *= sc; N0 *= sc; N1 *= sc;
+            m = vm;
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const R e = Exp2<R>::f((m - v[i]) * scale);
+            D += e;
+            N0 = fma(e, (R)a0[i], N0);
+            N1 = fma(e, (R)a1[i], N1);
+            E0 += a0[i];
+            E1 += a1[i];
+        }
+    }
+    // lanes -> wave -> block
+    __shared__ R red[4][6];
+    const R wm = wave_min(m);
+    {
+        const R sc = (m == (R)INFINITY) ? (R)0 : Exp2<R>::f((wm - m) * scale);
+        D *= sc; N0 *= sc; N1 *= sc;
+    }
+    D = wave_sum(D); N0 = wave_sum(N0); N1 = wave_sum(N1); E0 = wave_sum(E0); E1 = wave_sum(E1);
+    const int wid = tid >> 6, lane = tid & 63;
+    if (lane == 0) { red[wid][0] = wm; red[wid][1] = D; red[wid][2] = N0; red[wid][3] = N1; red[wid][4] = E0; red[wid][5] = E1; }
+    __syncthreads();
+    if (tid == 0) {
+        double M = INFINITY;
+        for (int w = 0; w < 4; ++w) M = fmin(M, (double)red[w][0]);
+        double d = 0, n0 = 0, n1 = 0, e0 = 0, e1 = 0;
+        for (int w = 0; w < 4; ++w) {
+            const double mw = (double)red[w][0];
+            const double sc = (mw == INFINITY) ? 0.0 : exp((M - mw) * P.inv_lambda);
+            d += sc * (double)red[w][1]; n0 += sc * (double)red[w][2]; n1 += sc * (double)red[w][3];
+            e0 += (double)red[w][4]; e1 += (double)red[w][5];
+        }
+        double* o = part + (((size_t)a * P.T + t) * NCH + ch) * kTupleW;
+        o[0] = M; o[1] = d; o[2] = n0; o[3] = n1; o[4] = e0; o[5] = e1;
+        o[6] = (double)max(0, k_end - k_begin); o[7] = 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// tuple merge:  M = min m_i;  D = sum exp(-(m_i - M)/lam) D_i  (same for N);
+// E, count add.  Exact algebra of splitting the K-sum of control/src/mppi:189-196.
+// merge_kernel: one wave per (t, a) reduces the NCH chunk tuples of this shard.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void merge_kernel(DevParams P, const double* __restrict__ part, int NCH,
+                                                  double* __restrict__ merged) {
+    const int t = blockIdx.x, a = blockIdx.y, lane = threadIdx.x;
+    const double* src = part + ((size_t)a * P.T + t) * NCH * kTupleW;
+    double m = INFINITY;
+    for (int i = lane; i < NCH; i += 64)
+        if (src[i * kTupleW + 6] > 0.0) m = fmin(m, src[i * kTupleW]);
+    const double M = wave_min(m);
+    double d = 0, n0 = 0, n1 = 0, e0 = 0, e1 = 0, cnt = 0;
+    for (int i = lane; i < NCH; i += 64) {
+        const double* q = src + i * kTupleW;
+        if (q[6] > 0.0) {
+            const double sc = exp((M - q[0]) * P.inv_lambda);
+            d += sc * q[1]; n0 += sc * q[2]; n1 += sc * q[3]; e0 += q[4]; e1 += q[5]; cnt += q[6];
+        }
+    }
+    d = wave_sum(d); n0 = wave_sum(n0); n1 = wave_sum(n1);
+    e0 = wave_sum(e0); e1 = wave_sum(e1); cnt = wave_sum(cnt);
+    if (lane == 0) {
+        double* o = merged + ((size_t)a * P.T + t) * kTupleW;
+        o[0] = M; o[1] = d; o[2] = n0; o[3] = n1; o[4] = e0; o[5] = e1; o[6] = cnt; o[7] = 0.0;
+    }
+}
+
+// exact rk4 step in the reference's operation order (control/src/mppi:39-54), used for the plant
+__device__ __forceinline__ void rk4_exact(const DevParams& P, const double x0[3], double u0, double u1,
+                                          double out[3]) {
+    const double sum = u0 + u1, om = P.kth * (u1 - u0);
+    double k1[3], k2[3], k3[3], k4[3];
+    k1[0] = P.dt * (P.rhalf * cos(x0[2]) * sum); k1[1] = P.dt * (P.rhalf * sin(x0[2]) * sum); k1[2] = P.dt * om;
+    double th = x0[2] + k1[2] / 2;
+    k2[0] = P.dt * (P.rhalf * cos(th) * sum); k2[1] = P.dt * (P.rhalf * sin(th) * sum); k2[2] = P.dt * om;
+    th = x0[2] + k2[2] / 2;
+    k3[0] = P.dt * (P.rhalf * cos(th) * sum); k3[1] = P.dt * (P.rhalf * sin(th) * sum); k3[2] = P.dt * om;
+    th = x0[2] + k3[2];
+    k4[0] = P.dt * (P.rhalf * cos(th) * sum); k4[1] = P.dt * (P.rhalf * sin(th) * sum); k4[2] = P.dt * om;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out[i] = x0[i] + (1.0 / 6.0) * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]);
+    out[2] = wrap_theta(out[2]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// finalize_kernel: the tail of update_action (control/src/mppi:196-208) and of get_path
+// (:91-101) for one agent per block.
+//   gathered [G][A][T][8] shard partials (G = 1: this engine's own)
+//   flags: bit0 plant step (perform_action :210-213), bit1 receding-horizon shift (:100-101),
+//          bit2 bump the device tick counter (graph replay)
+//   ufilt [A][2][T] filtered controls (un-shifted), outv [A][8] = {next_state[3], u_applied[2]}
+// dynamic LDS = 4*T doubles.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void finalize_kernel(DevParams P, const double* __restrict__ gathered, int G,
+                                                      const double* __restrict__ Smat, double* __restrict__ unom,
+                                                      double* __restrict__ ufilt, double* __restrict__ state,
+                                                      double* __restrict__ outv, uint32_t* tick_ptr, int flags) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* un = reinterpret_cast<double*>(smem_raw);  // [2][T] updated + clipped
+    double* uf = un + 2 * P.T;                          // [2][T] filtered + clipped
+    const int a = blockIdx.x, tid = threadIdx.x, T = P.T;
+    for (int t = tid; t < T; t += blockDim.x) {
+        double M = INFINITY;
+        for (int g = 0; g < G; ++g) {
+            const double* q = gathered + (((size_t)g * P.A + a) * T + t) * kTupleW;
+            if (q[6] > 0.0) M = fmin(M, q[0]);
+        }
+        double d = 0, n0 = 0, n1 = 0, e0 = 0, e1 = 0, cnt = 0;
+        for (int g = 0; g < G; ++g) {
+            const double* q = gathered + (((size_t)g * P.A + a) * T + t) * kTupleW;
+            if (q[6] > 0.0) {
+                const double sc = exp((M - q[0]) * P.inv_lambda);
+                d += sc * q[1]; n0 += sc * q[2]; n1 += sc * q[3]; e0 += q[4]; e1 += q[5]; cnt += q[6];
+            }
+        }
+        // omg = exp(-V/lam) + 1e-8, normalised; uvec += eps . omg   (control/src/mppi:193-196)
+        const double den = d + P.floor_w * cnt;
+        const double du0 = (n0 + P.floor_w * e0) / den, du1 = (n1 + P.floor_w * e1) / den;
+        un[t] = clampd(unom[((size_t)a * 2 + 0) * T + t] + du0, P.u_max);      // :198-199
+        un[T + t] = clampd(unom[((size_t)a * 2 + 1) * T + t] + du1, P.u_max);
+    }
+    __syncthreads();
+    for (int j = tid; j < T; j += blockDim.x) {  // savgol_filter as u @ S  (:202), then clip (:205-206)
+        double s0 = 0.0, s1 = 0.0;
+        for (int t = 0; t < T; ++t) {
+            const double w = Smat[(size_t)t * T + j];
+            s0 = fma(un[t], w, s0);
+            s1 = fma(un[T + t], w, s1);
+        }
+        uf[j] = clampd(s0, P.u_max);
+        uf[T + j] = clampd(s1, P.u_max);
+    }
+    __syncthreads();
+    for (int j = tid; j < T; j += blockDim.x) {
+        ufilt[((size_t)a * 2 + 0) * T + j] = uf[j];
+        ufilt[((size_t)a * 2 + 1) * T + j] = uf[T + j];
+        if (flags & 2) {  // shift left, zero the tail (:100-101)
+            unom[((size_t)a * 2 + 0) * T + j] = (j + 1 < T) ? uf[j + 1] : 0.0;
+            unom[((size_t)a * 2 + 1) * T + j] = (j + 1 < T) ? uf[T + j + 1] : 0.0;
+        } else {
+            unom[((size_t)a * 2 + 0) * T + j] = uf[j];
+            unom[((size_t)a * 2 + 1) * T + j] = uf[T + j];
+        }
+    }
+    if (tid == 0) {
+        if (flags & 1) {
+            double x0[3] = {state[a * 3 + 0], state[a * 3 + 1], state[a * 3 + 2]}, xn[3];
+            rk4_exact(P, x0, uf[0], uf[T], xn);
+            double* o = outv + (size_t)a * 8;
+            o[0] = xn[0]; o[1] = xn[1]; o[2] = xn[2]; o[3] = uf[0]; o[4] = uf[T];
+            state[a * 3 + 0] = xn[0]; state[a * 3 + 1] = xn[1]; state[a * 3 + 2] = xn[2];
+        }
+        if ((flags & 4) && a == 0 && tick_ptr) *tick_ptr = *tick_ptr + 1u;
+    }
+}
+
+// perform_action alone (control/src/mppi:210-213): next = rk4(state, unom[:,0])
+__global__ void plant_kernel(DevParams P, const double* __restrict__ state, const double* __restrict__ unom,
+                             double* __restrict__ outv) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= P.A) return;
+    const double x0[3] = {state[a * 3 + 0], state[a * 3 + 1], state[a * 3 + 2]};
+    const double u0 = unom[((size_t)a * 2 + 0) * P.T], u1 = unom[((size_t)a * 2 + 1) * P.T];
+    double xn[3];
+    rk4_exact(P, x0, u0, u1, xn);
+    double* o = outv + (size_t)a * 8;
+    o[0] = xn[0]; o[1] = xn[1]; o[2] = xn[2]; o[3] = u0; o[4] = u1;
+}
+
+// receding-horizon shift alone (control/src/mppi:100-101); one block per (agent,row) so the
+// read of column j+1 and the write of column j cannot race across blocks
+__global__ void shift_kernel(DevParams P, double* __restrict__ unom) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* row = reinterpret_cast<double*>(smem_raw);
+    double* u = unom + (size_t)blockIdx.x * P.T;
+    for (int j = threadIdx.x; j < P.T; j += blockDim.x) row[j] = u[j];
+    __syncthreads();
+    for (int j = threadIdx.x; j < P.T; j += blockDim.x) u[j] = (j + 1 < P.T) ? row[j + 1] : 0.0;
+}
+
+// host <-> storage conversions (parity / compatibility paths, not on the tick path)
+//   rows: n_rows rows of K elements; src pitch K (host layout), dst pitch Ks
+template <typename S>
+__global__ void pack_rows_kernel(const double* __restrict__ src, S* __restrict__ dst, int K, int Ks,
+                                 const double* __restrict__ row_bias, int rows_per_bias) {
+    const size_t row = blockIdx.y;
+    const double b = row_bias ? row_bias[row / rows_per_bias] : 0.0;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x)
+        dst[row * Ks + k] = (S)(src[row * K + k] - b);
+}
+template <typename S>
+__global__ void unpack_rows_kernel(const S* __restrict__ src, double* __restrict__ dst, int K, int Ks,
+                                   const double* __restrict__ row_bias, int rows_per_bias) {
+    const size_t row = blockIdx.y;
+    const double b = row_bias ? row_bias[row / rows_per_bias] : 0.0;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x)
+        dst[row * K + k] = (double)src[row * Ks + k] + b;
+}
+// per-row minimum of a [rows][K] float64 array (mppi_upload_value picks it as the baseline)
+__global__ __launch_bounds__(256) void row_min_kernel(const double* __restrict__ src, int K, double* __restrict__ out) {
+    __shared__ double red[4];
+    const size_t row = blockIdx.x;
+    double m = INFINITY;
+    for (int k = threadIdx.x; k < K; k += 256) m = fmin(m, src[row * K + k]);
+    m = wave_min(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) out[row] = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+}
+
+}  // namespace mppi

@@ -1,0 +1,361 @@
+"""Host-side mirror of the reference's MPPI interface on top of libmppi_hip.so.
+
+``Engine`` is the thin object wrapper over the C ABI (batched over agents, one GPU's
+shard of the samples).  ``MPPI`` mirrors the reference class of the same name
+(moribots/motion_planning ``control/src/mppi:61-213``): same constructor arguments, same
+method names, argument meaning and array layouts, so the reference's ``Controller``
+logic runs against it unmodified -- but every K x T loop runs in the HIP kernels.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import MPPI_NOISE_INJECTED, MPPI_NOISE_PHILOX, MPPI_STORE_F32, MPPI_STORE_F64
+
+# control/src/mppi:18-20
+WHEEL_VEL_MAX = 6.35492
+WHEEL_RADIUS = 0.033
+WHEEL_BASE = 0.16
+
+
+def dd_dynamics(x, u):
+    """Diff-drive kinematics, control/src/mppi:23-30 (x [3,N], u [2,N]).  Host utility for
+    callers that want the model itself (e.g. a simulated plant); the engine never calls it."""
+    x = np.asarray(x, dtype=np.float64)
+    u = np.asarray(u, dtype=np.float64)
+    v = u[0, :] + u[1, :]
+    return np.array([(WHEEL_RADIUS / 2.0) * np.cos(x[2, :]) * v,
+                     (WHEEL_RADIUS / 2.0) * np.sin(x[2, :]) * v,
+                     (WHEEL_RADIUS / WHEEL_BASE) * (u[1, :] - u[0, :])])
+
+
+def rk4(x0, u, dt):
+    """Runge-Kutta 4 step + theta wrap, control/src/mppi:39-54.  Host utility (see dd_dynamics);
+    passing it as ``model=`` selects the engine's built-in RK4 rollout."""
+    x0 = np.asarray(x0, dtype=np.float64)
+    k1 = dt * dd_dynamics(x0, u)
+    k2 = dt * dd_dynamics(x0 + k1 / 2, u)
+    k3 = dt * dd_dynamics(x0 + k2 / 2, u)
+    k4 = dt * dd_dynamics(x0 + k3, u)
+    xnew = x0 + (1.0 / 6.0) * (k1 + 2 * k2 + 2 * k3 + k4)
+    xnew[2, :] = xnew[2, :] - (np.ceil((xnew[2, :] + np.pi) / (2.0 * np.pi)) - 1.0) * 2.0 * np.pi
+    return xnew
+
+
+_STORAGE = {"f32": MPPI_STORE_F32, "f64": MPPI_STORE_F64, MPPI_STORE_F32: MPPI_STORE_F32,
+            MPPI_STORE_F64: MPPI_STORE_F64}
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != tuple(shape):
+        raise ValueError("expected shape %s, got %s" % (tuple(shape), a.shape))
+    return a
+
+
+class Engine(object):
+    """One libmppi_hip engine: A agents x K samples (this GPU's shard) x T horizon."""
+
+    def __init__(self, samples, horizon, n_agents=1, storage="f32", device=0, sample_offset=0,
+                 dt=None, sigma=0.9, lam=0.001, **overrides):
+        self._lib = _capi.load()
+        cfg = _capi.default_config()
+        cfg.n_agents, cfg.samples, cfg.horizon = int(n_agents), int(samples), int(horizon)
+        cfg.storage = _STORAGE[storage]
+        cfg.device = int(device)
+        cfg.sample_offset = int(sample_offset)
+        cfg.dt = 0.0 if dt is None else float(dt)
+        cfg.sigma, cfg.lambda_ = float(sigma), float(lam)
+        for key, val in overrides.items():
+            if key in ("q", "r", "p1"):
+                arr = getattr(cfg, key)
+                for i, v in enumerate(val):
+                    arr[i] = float(v)
+            elif key in ("u_max", "wheel_radius", "wheel_base", "floor_w"):
+                setattr(cfg, key, float(val))
+            else:
+                raise TypeError("unknown engine option %r" % key)
+        self._h = C.c_void_p()
+        rc = self._lib.mppi_create(C.byref(cfg), C.byref(self._h))
+        if rc:
+            self._h = None
+            _capi.check(rc, None)
+        self.A, self.K, self.T = cfg.n_agents, cfg.samples, cfg.horizon
+        self.dt = 1.0 / self.T if dt is None else float(dt)
+        self.storage = "f64" if cfg.storage == MPPI_STORE_F64 else "f32"
+        self.sigma, self.lam = cfg.sigma, cfg.lambda_
+
+    # -- lifetime ------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mppi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _ck(self, rc):
+        _capi.check(rc, self._h)
+
+    # -- configuration -------------------------------------------------------------------
+    def set_stream(self, stream_ptr):
+        self._ck(self._lib.mppi_set_stream(self._h, C.c_void_p(int(stream_ptr))))
+
+    def set_sigma_lambda(self, sigma, lam):
+        if sigma != self.sigma or lam != self.lam:
+            self._ck(self._lib.mppi_set_sigma_lambda(self._h, float(sigma), float(lam)))
+            self.sigma, self.lam = float(sigma), float(lam)
+
+    def reset(self, agent=-1):
+        self._ck(self._lib.mppi_reset(self._h, int(agent)))
+
+    def set_nominal(self, uvec, agent=0):
+        u = _f64(uvec, (2, self.T))
+        self._ck(self._lib.mppi_set_nominal(self._h, int(agent), _capi.dptr(u)))
+
+    def get_nominal(self, agent=0):
+        u = np.empty((2, self.T))
+        self._ck(self._lib.mppi_get_nominal(self._h, int(agent), _capi.dptr(u)))
+        return u
+
+    # -- two-stage path (get_cost2go / update_action) --------------------------------------
+    def upload_noise(self, eps):
+        e = _f64(eps).reshape(self.A, self.T, 2, self.K)
+        self._ck(self._lib.mppi_upload_noise(self._h, _capi.dptr(e)))
+
+    def download_noise(self):
+        e = np.empty((self.A, self.T, 2, self.K))
+        self._ck(self._lib.mppi_download_noise(self._h, _capi.dptr(e)))
+        return e
+
+    def _sg(self, state, goal):
+        s = None if state is None else _f64(state).reshape(self.A, 3)
+        g = None if goal is None else _f64(goal).reshape(self.A, 3)
+        return s, g
+
+    def rollout(self, state, goal, noise="injected", seed=0, tick_id=0):
+        s, g = self._sg(state, goal)
+        mode = MPPI_NOISE_PHILOX if noise == "philox" else MPPI_NOISE_INJECTED
+        self._ck(self._lib.mppi_rollout(self._h, _capi.dptr(s), _capi.dptr(g), mode, int(seed), int(tick_id)))
+
+    def download_value(self):
+        v = np.empty((self.A, self.T, self.K))
+        self._ck(self._lib.mppi_download_value(self._h, _capi.dptr(v)))
+        return v
+
+    def upload_value(self, V):
+        v = _f64(V).reshape(self.A, self.T, self.K)
+        self._ck(self._lib.mppi_upload_value(self._h, _capi.dptr(v)))
+
+    def update(self, want_output=True):
+        u = np.empty((self.A, 2, self.T)) if want_output else None
+        self._ck(self._lib.mppi_update(self._h, _capi.dptr(u)))
+        return u
+
+    def plant_step(self, state=None):
+        s, _ = self._sg(state, None)
+        nxt = np.empty((self.A, 3))
+        self._ck(self._lib.mppi_plant_step(self._h, _capi.dptr(s), _capi.dptr(nxt)))
+        return nxt
+
+    def shift(self):
+        self._ck(self._lib.mppi_shift(self._h))
+
+    # -- tick path -----------------------------------------------------------------------
+    def tick_begin(self, state=None, goal=None, noise="philox", seed=0, tick_id=0):
+        s, g = self._sg(state, goal)
+        mode = MPPI_NOISE_PHILOX if noise == "philox" else MPPI_NOISE_INJECTED
+        self._ck(self._lib.mppi_tick_begin(self._h, _capi.dptr(s), _capi.dptr(g), mode, int(seed), int(tick_id)))
+
+    def partials(self):
+        """(device pointer, bytes) of this shard's merged partials [A][T][8] float64."""
+        p, n = C.c_void_p(), C.c_size_t()
+        self._ck(self._lib.mppi_partials_ptr(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def tick_finish(self, gathered_ptr=None, n_shards=1):
+        self._ck(self._lib.mppi_tick_finish(self._h, C.c_void_p(gathered_ptr) if gathered_ptr else None, int(n_shards)))
+
+    def get_outputs(self):
+        nxt, ua = np.empty((self.A, 3)), np.empty((self.A, 2))
+        self._ck(self._lib.mppi_get_outputs(self._h, _capi.dptr(nxt), _capi.dptr(ua)))
+        return nxt, ua
+
+    def tick(self, state=None, goal=None, noise="philox", seed=0, tick_id=0):
+        self.tick_begin(state, goal, noise, seed, tick_id)
+        self.tick_finish()
+        return self.get_outputs()
+
+    def tick_graph(self, seed=0):
+        self._ck(self._lib.mppi_tick_graph(self._h, int(seed)))
+
+    def synchronize(self):
+        self._ck(self._lib.mppi_synchronize(self._h))
+
+    # -- instrumentation -----------------------------------------------------------------
+    def kernel_timing(self, kernels=()):
+        mask = 0
+        for k in kernels:
+            mask |= 1 << _capi.KERNELS.index(k)
+        self._ck(self._lib.mppi_kernel_timing(self._h, mask))
+
+    def kernel_times(self):
+        ms = (C.c_double * len(_capi.KERNELS))()
+        n = (C.c_int64 * len(_capi.KERNELS))()
+        self._ck(self._lib.mppi_kernel_times(self._h, ms, n))
+        return {k: (ms[i], n[i]) for i, k in enumerate(_capi.KERNELS)}
+
+    def info(self):
+        b, r, u = C.c_size_t(), C.c_int32(), C.c_int32()
+        self._ck(self._lib.mppi_engine_info(self._h, C.byref(b), C.byref(r), C.byref(u)))
+        return {"hbm_bytes": b.value, "rollout_blocks": r.value, "update_blocks": u.value}
+
+
+def savgol_matrix(horizon):
+    """The operator S with savgol_filter(u, T-1, 3, axis=1) == u @ S (control/src/mppi:202)."""
+    S = np.empty((horizon, horizon))
+    rc = _capi.load().mppi_savgol_matrix(int(horizon), _capi.dptr(S))
+    if rc:
+        raise ValueError("horizon %d: Savitzky-Golay window horizon-1 must be odd and > 3" % horizon)
+    return S
+
+
+class MPPI(object):
+    """Drop-in for the reference ``MPPI`` (control/src/mppi:61-213), running on the GPU.
+
+    Extra keyword arguments (not in the reference):
+      rng      "numpy"  -- draw noise exactly like the reference (np.random.normal per
+                           timestep from numpy's global RNG, :143-146) and inject it: same
+                           seed => same trajectory as the reference;
+               "philox" -- device Philox4x32-10 keyed by (seed, tick, sample): nothing
+                           crosses PCIe, the production mode.
+      storage  "f32" (default) | "f64"  HBM storage of eps / V (arithmetic is fp64 either way).
+    Unlike the reference, get_cost2go / update_action do not mutate their arguments.
+    """
+
+    def __init__(self, model=rk4, horizon=100, samples=10, thresh=0.05, rng="numpy", seed=0,
+                 storage="f32", device=0):
+        if model is not rk4 and model != "rk4":
+            raise NotImplementedError("only the reference's default model=rk4 (diff drive) is built in")
+        if rng not in ("numpy", "philox"):
+            raise ValueError("rng must be 'numpy' or 'philox'")
+        self.horizon = int(horizon)
+        self.samples = int(samples)
+        self.uvec_init = np.zeros((2, self.horizon))
+        self.model = model
+        self.dt = 1.0 / float(horizon)
+        self.Q = np.array([[1e3, 0.0, 0.0], [0.0, 1e3, 0.0], [0.0, 0.0, 0.0]])
+        self.R = np.array([[1.0, 0.0], [0.0, 1.0]])
+        self.P1 = np.array([[1e3, 0.0, 0.0], [0.0, 1e3, 0.0], [0.0, 0.0, 1e3]])
+        self.thresh = thresh
+        self.start = np.array([0.0, 0.0, 0.0])
+        self.goal = np.array([0.0, 0.0, 0.0])
+        self.rng = rng
+        self.seed = int(seed)
+        self._tick = 0
+        self._eng = Engine(self.samples, self.horizon, 1, storage=storage, device=device)
+        self.initialize()
+
+    # control/src/mppi:79-83
+    def initialize(self):
+        self.fin_time = [0]
+        self._eng.reset()
+        self.uvec = np.array([self.uvec_init[:, 0]])
+        self.path = np.array([self.start])
+
+    @property
+    def latest_uvec(self):
+        return self._eng.get_nominal()
+
+    @latest_uvec.setter
+    def latest_uvec(self, u):
+        self._eng.set_nominal(u)
+
+    @staticmethod
+    def _sigma(sig):
+        sig = np.asarray(sig, dtype=np.float64)
+        if sig.ndim == 0:
+            return float(sig)
+        if sig.shape != (2, 2) or sig[0, 1] != 0.0 or sig[1, 0] != 0.0 or sig[0, 0] != sig[1, 1]:
+            raise ValueError("sig must be sigma * I (the reference draws N(0, sig[0,0]) for both wheels)")
+        return float(sig[0, 0])
+
+    def _draw(self, sigma):
+        # one legacy-RNG call per timestep, exactly the reference's consumption (:143-146)
+        return np.stack([np.random.normal(0, sigma, size=(2, self.samples)) for _ in range(self.horizon)])
+
+    # control/src/mppi:85-102
+    def get_path(self, state, goal, sig=np.array([[.9, 0.0], [0.0, .9]]), lam=.001):
+        sigma = self._sigma(sig)
+        self._eng.set_sigma_lambda(sigma, lam)
+        if self.rng == "numpy":
+            self._eng.upload_noise(self._draw(sigma))
+            nxt, ua = self._eng.tick(state, goal, noise="injected")
+        else:
+            nxt, ua = self._eng.tick(state, goal, noise="philox", seed=self.seed, tick_id=self._tick)
+        self._tick += 1
+        state = nxt[0]
+        self.path = np.concatenate((self.path, np.array([state])))
+        self.uvec = np.concatenate((self.uvec, np.array([ua[0]])))
+        self.fin_time.append(self.fin_time[-1] + self.dt)
+        return state
+
+    # control/src/mppi:104-125
+    def solve_path(self, start, goal, sig=np.array([[1.0, 0.0], [0.0, 1.0]]), lam=.01, max_iters=100000):
+        self.start = np.asarray(start, dtype=np.float64)
+        self.goal = np.asarray(goal, dtype=np.float64)
+        state = self.start
+        self.path = np.array([state])
+        self._eng.reset()
+        i = 0
+        while np.linalg.norm(state[:2] - self.goal[:2]) > self.thresh and i < max_iters:
+            i += 1
+            state = self.get_path(state, self.goal, sig, lam)
+        return state, i
+
+    # control/src/mppi:127-178
+    def get_cost2go(self, state, uvec, goal, lam, sig):
+        sigma = self._sigma(sig)
+        self._eng.set_sigma_lambda(sigma, lam)
+        self._eng.set_nominal(uvec)
+        if self.rng == "numpy":
+            self._eng.upload_noise(self._draw(sigma))
+            self._eng.rollout(state, goal, noise="injected")
+        else:
+            self._eng.rollout(state, goal, noise="philox", seed=self.seed, tick_id=self._tick)
+            self._tick += 1
+        value_fcn = self._eng.download_value()[0]
+        eps = self._eng.download_noise()[0]
+        return value_fcn, [eps[t] for t in range(self.horizon)]
+
+    # control/src/mppi:180-184 -- scalar form kept for API parity; the kernels fuse it
+    def get_cost(self, state, desired_state, u, lam, sig, eps):
+        d = np.asarray(state, dtype=np.float64) - np.asarray(desired_state, dtype=np.float64)
+        u = np.asarray(u, dtype=np.float64)
+        return 0.5 * (d.dot(self.Q).dot(d) + u.dot(self.R).dot(u)) + lam * u.dot(np.asarray(sig)).dot(eps)
+
+    # control/src/mppi:186-208
+    def update_action(self, uvec, eps, value_fcn, sig, lam):
+        self._eng.set_sigma_lambda(self._sigma(sig), lam)
+        self._eng.set_nominal(uvec)
+        self._eng.upload_noise(np.asarray(eps, dtype=np.float64))
+        self._eng.upload_value(value_fcn)
+        return self._eng.update()[0]
+
+    # control/src/mppi:210-213
+    def perform_action(self, state, uvec):
+        keep = self._eng.get_nominal()  # the reference's perform_action has no side effects
+        self._eng.set_nominal(uvec)
+        nxt = self._eng.plant_step(state)[0]
+        self._eng.set_nominal(keep)
+        return nxt

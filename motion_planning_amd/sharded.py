@@ -1,0 +1,106 @@
+"""K sharded over GPUs: one process per GPU, one tiny RCCL exchange per control tick.
+
+The reference is single-process (control/src/mppi); its only cross-sample coupling is the
+per-timestep softmax of update_action (:187-196).  Splitting K over G ranks therefore needs
+exactly one exchange per tick: each rank reduces its samples to the tuple
+{min V, sum e, sum e*eps, sum eps, count} per (agent, t) -- [A][T][8] float64, 3.2 KB at
+T=50 -- the ranks all-gather those tuples (torch.distributed, backend "nccl" = RCCL over
+xGMI; "gloo" on CPU in the tests) and every rank finishes the tick identically
+(merge, control update, clip, filter, clip, plant step, shift).  The message is
+latency-bound, so it is ONE collective of the whole [A][T][8] block, not one per timestep.
+"""
+import numpy as np
+
+TUPLE_W = 8
+
+
+class _DevBuf(object):
+    """Zero-copy view of a device buffer owned by libmppi_hip for torch.as_tensor."""
+
+    def __init__(self, ptr, n_f64):
+        self.__cuda_array_interface__ = {"shape": (n_f64,), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+class HipShard(object):
+    """Adapter: one libmppi_hip Engine as a shard (partials exposed as a torch CUDA tensor)."""
+
+    def __init__(self, engine, torch_device):
+        import torch
+        self.engine = engine
+        self.device = torch_device
+        ptr, nbytes = engine.partials()
+        self._part = torch.as_tensor(_DevBuf(ptr, nbytes // 8), device=torch_device)
+        assert self._part.data_ptr() == ptr, "torch copied the partials buffer instead of aliasing it"
+        # all work of the engine goes to torch's current stream so that collectives order with it
+        engine.set_stream(torch.cuda.current_stream(torch_device).cuda_stream)
+
+    def tick_begin(self, state, goal, noise, seed, tick_id):
+        self.engine.tick_begin(state, goal, noise=noise, seed=seed, tick_id=tick_id)
+
+    def partials_tensor(self):
+        return self._part
+
+    def tick_finish(self, gathered, n_shards):
+        if gathered is None:
+            self.engine.tick_finish()
+        else:
+            self.engine.tick_finish(gathered.data_ptr(), n_shards)
+
+    def get_outputs(self):
+        return self.engine.get_outputs()
+
+
+def shard_range(samples_total, world_size, rank):
+    """Contiguous, balanced split of the global sample index range (first ranks get the remainder)."""
+    base, rem = divmod(int(samples_total), int(world_size))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class ShardedTicker(object):
+    """Drives one shard per rank through tick_begin -> all-gather -> tick_finish.
+
+    ``shard`` is anything with the HipShard interface (the CPU tests plug the oracle in);
+    ``group`` a torch.distributed process group (None: the default group, or single process).
+    """
+
+    def __init__(self, shard, group=None):
+        import torch
+        import torch.distributed as dist
+        self.shard = shard
+        self.group = group
+        self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
+        self.world = self.dist.get_world_size(group) if self.dist else 1
+        self.rank = self.dist.get_rank(group) if self.dist else 0
+        part = shard.partials_tensor()
+        self._gathered = torch.empty((self.world,) + tuple(part.shape), dtype=part.dtype,
+                                     device=part.device) if self.world > 1 else None
+
+    def tick_async(self, state=None, goal=None, noise="philox", seed=0, tick_id=0):
+        self.shard.tick_begin(state, goal, noise, seed, tick_id)
+        if self.world > 1:
+            # one all-gather of [A][T][8] f64 per tick (RCCL over xGMI on GPUs)
+            self.dist.all_gather_into_tensor(self._gathered, self.shard.partials_tensor(), group=self.group)
+            self.shard.tick_finish(self._gathered, self.world)
+        else:
+            self.shard.tick_finish(None, 1)
+
+    def tick(self, state=None, goal=None, noise="philox", seed=0, tick_id=0):
+        self.tick_async(state, goal, noise, seed, tick_id)
+        return self.shard.get_outputs()
+
+
+def make_hip_ticker(samples_total, horizon, n_agents=1, storage="f32", local_rank=0, group=None, **engine_kw):
+    """Engine for this rank's slice of the samples + the ticker around it."""
+    import torch
+    import torch.distributed as dist
+    from .mppi import Engine
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    lo, hi = shard_range(samples_total, world, rank)
+    torch.cuda.set_device(local_rank)
+    eng = Engine(hi - lo, horizon, n_agents=n_agents, storage=storage, device=local_rank,
+                 sample_offset=lo, **engine_kw)
+    shard = HipShard(eng, torch.device("cuda", local_rank))
+    return ShardedTicker(shard, group), eng

@@ -1,0 +1,438 @@
+"""GPU parity: the HIP engine, driven through the C ABI (ctypes), against
+ (1) golden vectors generated from the real reference (tests/golden/*), and
+ (2) the CPU oracle on the same seeded inputs.
+
+Tolerances (stated here, derived in DESIGN.md "Numerics"):
+  storage f64 : V   |err| <= 1e-9 * max(1, |V|max)     (fp64 arithmetic, different but
+                u   |err| <= 1e-9                        equivalent rounding order)
+  storage f32 : eps is rounded to fp32 once (the oracle is fed the same rounded eps), V is
+                kept as an fp32 offset dV from the nominal cost-to-go =>
+                V   |err| <= 3e-7 * max(1, |dV|max);  u |err| <= 1e-6 when the best/2nd-best
+                cost gap is >> lambda (true for all fixtures here).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SIG, LAM = 0.9, 0.001
+C2G = ["c2g_zero", "c2g_warm", "c2g_wrap", "c2g_clip", "c2g_tiny"]
+
+
+def _engine(K, T, storage, **kw):
+    from motion_planning_amd.mppi import Engine
+    return Engine(K, T, storage=storage, **kw)
+
+
+def _round_eps(eps, storage):
+    return eps.astype(np.float32).astype(np.float64) if storage == "f32" else eps
+
+
+def _vtol(orc, state, u0, goal, V, T, K):
+    """3e-7 * max(1, max |V - V_nominal|): the fp32-offset storage tolerance."""
+    Vn = orc.get_cost2go(state, u0, goal, LAM, SIG, np.zeros((T, 2, 1)))
+    return 3e-7 * max(1.0, np.abs(V - Vn).max())
+
+
+@pytest.mark.parametrize("storage", ["f64", "f32"])
+@pytest.mark.parametrize("name", C2G)
+def test_get_cost2go_golden(orc, golden, name, storage):
+    K, T, seed = [int(x) for x in golden[name + "_meta"]]
+    state, goal, u0 = golden[name + "_state"], golden[name + "_goal"], golden[name + "_u0"]
+    eps = orc.reference_noise(seed, SIG, T, K)
+    with _engine(K, T, storage) as e:
+        e.set_nominal(u0)
+        e.upload_noise(eps)
+        e.rollout(state, goal, noise="injected")
+        V = e.download_value()[0]
+        used = e.download_noise()[0]
+    assert np.array_equal(used, _round_eps(eps, storage))
+    ref = golden[name + "_V"]
+    if storage == "f64":
+        assert np.abs(V - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+    else:
+        Vo = orc.get_cost2go(state, u0, goal, LAM, SIG, used)
+        tol = _vtol(orc, state, u0, goal, Vo, T, K)
+        assert np.abs(V - Vo).max() <= tol
+        # and against the reference itself: only the one-time fp32 rounding of eps on top
+        assert np.abs(V - ref).max() <= tol + 2e-3
+
+
+@pytest.mark.parametrize("storage", ["f64", "f32"])
+@pytest.mark.parametrize("name", C2G)
+def test_update_action_golden(orc, golden, name, storage):
+    K, T, seed = [int(x) for x in golden[name + "_meta"]]
+    eps = orc.reference_noise(seed, SIG, T, K)
+    with _engine(K, T, storage) as e:
+        e.set_nominal(golden[name + "_u0"])
+        e.upload_noise(eps)
+        e.upload_value(golden[name + "_V"])
+        u = e.update()[0]
+        Vback = e.download_value()[0]
+    ref = golden[name + "_unew"]
+    assert np.abs(u - ref).max() <= (1e-9 if storage == "f64" else 1e-6)
+    # upload/download of V round-trips (offset form)
+    V = golden[name + "_V"]
+    rt = 1e-9 if storage == "f64" else 2e-7 * max(1.0, (V - V.min(axis=1, keepdims=True)).max())
+    assert np.abs(Vback - V).max() <= rt
+
+
+@pytest.mark.parametrize("storage", ["f64", "f32"])
+@pytest.mark.parametrize("name", ["seq_park", "seq_wp"])
+def test_closed_loop_ticks_golden(golden, name, storage):
+    """MPPI.get_path driven exactly like the reference (numpy global RNG, same seed)."""
+    from motion_planning_amd import MPPI
+    K, T, seed, nt = [int(x) for x in golden[name + "_meta"]]
+    m = MPPI(horizon=T, samples=K, rng="numpy", storage=storage)
+    np.random.seed(seed)
+    st = golden[name + "_state0"].copy()
+    tol_s, tol_u = (1e-10, 1e-9) if storage == "f64" else (1e-8, 1e-5)
+    for i in range(nt):
+        st = m.get_path(st, golden[name + "_goal"])
+        assert np.abs(st - golden[name + "_states"][i]).max() < tol_s, i
+        assert np.abs(m.uvec[-1] - golden[name + "_u"][i]).max() < tol_u, i
+        assert np.abs(m.latest_uvec - golden[name + "_latest_uvec"][i]).max() < tol_u, i
+    assert m.path.shape == (nt + 1, 3) and len(m.fin_time) == nt + 1
+
+
+def test_default_node_known_answers(kat):
+    """MPPI() as the node constructs it (K=10, T=100), SURVEY 8c known answers."""
+    from motion_planning_amd import MPPI
+    np.random.seed(0)
+    m = MPPI(storage="f64")
+    s1 = m.get_path(np.array([0.0, 0.0, 0.0]), np.array([0.0, -1.0, 0.0]))
+    assert np.allclose(s1, kat["default_tick1_state"], rtol=0, atol=1e-13)
+    assert np.allclose(m.uvec[-1], kat["default_tick1_u"], rtol=0, atol=1e-9)
+    assert abs(m.latest_uvec.sum() - kat["default_tick1_sum_latest_uvec"]) < 1e-7
+    s2 = m.get_path(s1, np.array([0.0, -1.0, 0.0]))
+    assert np.allclose(s2, kat["default_tick2_state"], rtol=0, atol=1e-13)
+    assert np.allclose(m.uvec[-1], kat["default_tick2_u"], rtol=0, atol=1e-9)
+    np.random.seed(0)
+    m = MPPI(horizon=50, samples=64, storage="f64")
+    s = m.get_path(np.array([0.0, 0.0, 0.0]), np.array([1.0, 0.0, 0.0]))
+    assert np.allclose(s, kat["h50k64_tick1_state"], rtol=0, atol=1e-13)
+    assert np.allclose(m.uvec[-1], kat["h50k64_tick1_u"], rtol=0, atol=1e-9)
+
+
+def test_api_methods_match_reference_semantics(orc, golden, kat):
+    from motion_planning_amd import MPPI
+    name = "c2g_warm"
+    K, T, seed = [int(x) for x in golden[name + "_meta"]]
+    m = MPPI(horizon=T, samples=K, storage="f64")
+    sig = np.array([[SIG, 0.0], [0.0, SIG]])
+    np.random.seed(seed)
+    V, eps = m.get_cost2go(golden[name + "_state"], golden[name + "_u0"], golden[name + "_goal"], LAM, sig)
+    assert isinstance(eps, list) and len(eps) == T and eps[0].shape == (2, K)
+    assert np.abs(V - golden[name + "_V"]).max() < 1e-9
+    u = m.update_action(golden[name + "_u0"], eps, V, sig, LAM)
+    assert np.abs(u - golden[name + "_unew"]).max() < 1e-9
+    nxt = m.perform_action(np.array([0.3, -0.2, 0.7]), np.tile(np.array([[1.25], [-0.5]]), (1, T)))
+    assert np.allclose(nxt, orc.rk4([0.3, -0.2, 0.7], [1.25, -0.5], 1.0 / T), rtol=0, atol=1e-15)
+    x = np.array([0.3, -0.2, 0.7])
+    c = m.get_cost(x, np.zeros(3), np.array([1.0, 2.0]), LAM, sig, np.array([0.1, -0.2]))
+    assert abs(c - (0.5 * (1e3 * (0.09 + 0.04) + 5.0) + LAM * SIG * (0.1 - 0.4))) < 1e-12
+    with pytest.raises(ValueError):
+        m.get_path(x, x, sig=np.array([[0.9, 0.1], [0.1, 0.9]]))
+
+
+@pytest.mark.parametrize("nom", ["zero", "warm"])
+@pytest.mark.parametrize("storage", ["f64", "f32"])
+def test_config1_k1000(orc, golden, nom, storage):
+    """BASELINE config 1 (K=1000, T=50, parallel park, seed 0) against the reference's outputs."""
+    K, T = 1000, 50
+    eps = orc.reference_noise(0, SIG, T, K)
+    u0 = np.zeros((2, T)) if nom == "zero" else np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
+    with _engine(K, T, storage) as e:
+        e.set_nominal(u0)
+        e.upload_noise(eps)
+        e.rollout([0, 0, 0], [0, -1, 0], noise="injected")
+        V = e.download_value()[0]
+        u = e.update()[0]
+        e.set_nominal(u0)
+        nxt, ua = e.tick([0, 0, 0], [0, -1, 0], noise="injected")
+    tv = 1e-9 if storage == "f64" else 3e-3   # f32: eps rounded once (see module docstring)
+    assert np.abs(V[:, ::100] - golden["c1_%s_Vcols" % nom]).max() < tv
+    assert np.abs(V.min(axis=1) - golden["c1_%s_Vmin_t" % nom]).max() < tv
+    tu = 1e-9 if storage == "f64" else 1e-5
+    assert np.abs(u - golden["c1_%s_unew" % nom]).max() < tu
+    assert np.abs(nxt[0] - golden["c1_%s_next_state" % nom]).max() < (1e-12 if storage == "f64" else 1e-8)
+    assert np.abs(ua[0] - golden["c1_%s_u_applied" % nom]).max() < tu
+
+
+@pytest.mark.parametrize("storage", ["f64", "f32"])
+def test_config2_k10000_vs_oracle(orc, storage):
+    """BASELINE config 2 (K=10 000, T=50) injected noise, full V and u against the oracle."""
+    K, T = 10000, 50
+    eps = _round_eps(orc.reference_noise(0, SIG, T, K), storage)
+    u0 = np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
+    state, goal = [0.0, 0.0, 0.0], [0.0, -1.0, 0.0]
+    with _engine(K, T, storage) as e:
+        e.set_nominal(u0)
+        e.upload_noise(eps)
+        nxt, ua = e.tick(state, goal, noise="injected")
+        V = e.download_value()[0]
+        lat = e.get_nominal()
+    Vo = orc.get_cost2go(state, u0, goal, LAM, SIG, eps)
+    tol = 1e-9 * np.abs(Vo).max() if storage == "f64" else _vtol(orc, state, u0, goal, Vo, T, K)
+    assert np.abs(V - Vo).max() <= tol
+    so, uo, lo = orc.get_path(state, goal, u0, eps, LAM, SIG)
+    gap = np.sort(Vo, axis=1)
+    assert (gap[:, 1] - gap[:, 0]).min() > 20 * LAM   # weights are decided, u is comparable
+    tu = 1e-9 if storage == "f64" else 1e-6
+    assert np.abs(ua[0] - uo).max() < tu and np.abs(lat - lo).max() < tu
+    assert np.abs(nxt[0] - so).max() < 1e-9
+
+
+def test_odd_sizes_and_ragged_tail(orc):
+    """K not a multiple of the lane/vector/block sizes, T not a multiple of the unroll; K=1."""
+    for K, T in [(1, 6), (3, 8), (65, 10), (257, 12), (1025, 6), (2049, 20)]:
+        eps = orc.reference_noise(K + T, SIG, T, K)
+        u0 = 0.3 * np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
+        state, goal = [0.05, -0.02, 0.4], [0.3, 0.2, -0.1]
+        with _engine(K, T, "f64") as e:
+            e.set_nominal(u0)
+            e.upload_noise(eps)
+            nxt, ua = e.tick(state, goal, noise="injected")
+            V = e.download_value()[0]
+        Vo = orc.get_cost2go(state, u0, goal, LAM, SIG, eps)
+        assert np.abs(V - Vo).max() <= 1e-9 * max(1.0, np.abs(Vo).max()), (K, T)
+        so, uo, _ = orc.get_path(state, goal, u0, eps, LAM, SIG)
+        assert np.abs(ua[0] - uo).max() < 1e-9 and np.abs(nxt[0] - so).max() < 1e-12, (K, T)
+
+
+def test_large_step_uses_full_sincos(orc):
+    """dt so large that |h/2| > 0.25 rad: the rotation falls back to sincos (NTERM=0); also the
+    mid branch (NTERM=7)."""
+    for dt in (2.0, 0.15):
+        K, T = 64, 10
+        eps = orc.reference_noise(9, SIG, T, K)
+        u0 = np.array([np.linspace(-3, 3, T), np.linspace(3, -3, T)])
+        state, goal = [0.0, 0.0, 3.0], [1.0, 1.0, -3.0]
+        with _engine(K, T, "f64", dt=dt) as e:
+            e.set_nominal(u0)
+            e.upload_noise(eps)
+            e.rollout(state, goal, noise="injected")
+            V = e.download_value()[0]
+        Vo = orc.get_cost2go(state, u0, goal, LAM, SIG, eps, dt=dt)
+        assert np.abs(V - Vo).max() <= 1e-9 * np.abs(Vo).max(), dt
+
+
+def test_multi_agent_batch(orc):
+    """A agents in one engine == A independent controllers (config 5 shape, scaled down)."""
+    A, K, T = 3, 200, 50
+    eps = np.stack([orc.reference_noise(a, SIG, T, K) for a in range(A)])
+    states = np.array([[0.05 * a, 0.0, 0.1 * a] for a in range(A)])
+    goals = np.array([[0.05 * a, -1.0, 0.0] for a in range(A)])
+    u0 = [0.2 * (a + 1) * np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)]) for a in range(A)]
+    with _engine(K, T, "f64", n_agents=A) as e:
+        for a in range(A):
+            e.set_nominal(u0[a], agent=a)
+        e.upload_noise(eps)
+        nxt, ua = e.tick(states, goals, noise="injected")
+        V = e.download_value()
+        lat = [e.get_nominal(a) for a in range(A)]
+    for a in range(A):
+        Vo = orc.get_cost2go(states[a], u0[a], goals[a], LAM, SIG, eps[a])
+        assert np.abs(V[a] - Vo).max() <= 1e-9 * np.abs(Vo).max()
+        so, uo, lo = orc.get_path(states[a], goals[a], u0[a], eps[a], LAM, SIG)
+        assert np.abs(nxt[a] - so).max() < 1e-12 and np.abs(ua[a] - uo).max() < 1e-9
+        assert np.abs(lat[a] - lo).max() < 1e-9
+
+
+def test_philox_matches_cpu_twin_and_is_shard_invariant(orc):
+    K, T, seed, tick = 512, 50, 1234567890123, 7
+    with _engine(K, T, "f32") as e:
+        e.rollout([0, 0, 0], [0, -1, 0], noise="philox", seed=seed, tick_id=tick)
+        dev = e.download_noise()[0]
+    twin = orc.philox_noise(seed, 0, tick, 0, K, T, SIG)
+    assert np.abs(dev - twin).max() < 2e-6          # same integer stream, fp32 transform
+    assert abs(dev.std() - SIG) < 0.02
+    with _engine(K // 2, T, "f32", sample_offset=K // 2) as e:  # the second shard alone
+        e.rollout([0, 0, 0], [0, -1, 0], noise="philox", seed=seed, tick_id=tick)
+        half = e.download_noise()[0]
+    assert np.array_equal(half, dev[:, :, K // 2:])
+    with _engine(K, T, "f32", n_agents=2) as e:     # agent index is part of the counter
+        e.rollout(np.zeros((2, 3)), np.zeros((2, 3)), noise="philox", seed=seed, tick_id=tick)
+        two = e.download_noise()
+    assert np.array_equal(two[0], dev) and not np.array_equal(two[1], dev)
+    assert np.abs(two[1] - orc.philox_noise(seed, 1, tick, 0, K, T, SIG)).max() < 2e-6
+
+
+def test_philox_tick_against_oracle_on_device_noise(orc):
+    """Seed parity end to end: run a device-RNG tick, read the noise back, replay on the CPU."""
+    K, T = 4096, 50
+    u0 = np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
+    with _engine(K, T, "f32") as e:
+        e.set_nominal(u0)
+        nxt, ua = e.tick([0, 0, 0], [0, -1, 0], noise="philox", seed=42, tick_id=3)
+        eps = e.download_noise()[0]
+        V = e.download_value()[0]
+    Vo = orc.get_cost2go([0, 0, 0], u0, [0, -1, 0], LAM, SIG, eps)
+    assert np.abs(V - Vo).max() <= _vtol(orc, [0, 0, 0], u0, [0, -1, 0], Vo, T, K)
+    so, uo, _ = orc.get_path([0, 0, 0], [0, -1, 0], u0, eps, LAM, SIG)
+    assert np.abs(ua[0] - uo).max() < 1e-6 and np.abs(nxt[0] - so).max() < 1e-9
+
+
+def test_shard_partials_merge_equals_single_engine(orc):
+    """K split over 2 and 4 engines (= GPUs), partials concatenated as an all-gather would,
+    finished on each shard: identical controls to the unsharded engine."""
+    import ctypes as C
+    from motion_planning_amd import _capi
+    K, T, seed = 4096, 50, 99
+    u0 = np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
+    state, goal = [0, 0, 0], [0, -1, 0]
+    with _engine(K, T, "f32") as e:
+        e.set_nominal(u0)
+        ref_nxt, ref_u = e.tick(state, goal, noise="philox", seed=seed, tick_id=1)
+        ref_lat = e.get_nominal()
+    hip = C.CDLL("libamdhip64.so")
+    for G in (2, 4):
+        engs = [_engine(K // G, T, "f32", sample_offset=g * (K // G)) for g in range(G)]
+        try:
+            bufs = []
+            for e in engs:
+                e.set_nominal(u0)
+                e.tick_begin(state, goal, noise="philox", seed=seed, tick_id=1)
+                e.synchronize()
+                ptr, nbytes = e.partials()
+                host = np.empty(nbytes // 8)
+                assert hip.hipMemcpy(host.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(nbytes), 2) == 0
+                bufs.append(host)
+            gathered = np.concatenate(bufs)
+            dev = C.c_void_p()
+            assert hip.hipMalloc(C.byref(dev), C.c_size_t(gathered.nbytes)) == 0
+            assert hip.hipMemcpy(dev, gathered.ctypes.data_as(C.c_void_p), C.c_size_t(gathered.nbytes), 1) == 0
+            for e in engs:
+                e.tick_finish(dev.value, G)
+                nxt, ua = e.get_outputs()
+                assert np.abs(ua - ref_u).max() < 1e-12 and np.abs(nxt - ref_nxt).max() < 1e-14
+                assert np.abs(e.get_nominal() - ref_lat).max() < 1e-12
+            hip.hipFree(dev)
+        finally:
+            for e in engs:
+                e.close()
+
+
+def test_update_properties(orc):
+    """Size-independent properties of update_action: (a) constant noise => u + c exactly
+    (weights sum to one), (b) lambda -> inf => plain mean of eps (floor and weights uniform)."""
+    K, T = 5000, 50
+    rs = np.random.RandomState(5)
+    V = rs.uniform(0, 50, (T, K))
+    u0 = np.array([np.linspace(-1, 1, T), np.linspace(1, -1, T)])
+    S = orc.savgol_matrix(T)
+    with _engine(K, T, "f64") as e:
+        eps = np.empty((T, 2, K)); eps[:, 0, :] = 0.25; eps[:, 1, :] = -0.5
+        e.set_nominal(u0); e.upload_noise(eps); e.upload_value(V)
+        u = e.update()[0]
+        assert np.abs(u - np.clip((u0 + np.array([[0.25], [-0.5]])) @ S, -6.35492, 6.35492)).max() < 1e-12
+        eps = rs.normal(0, SIG, (T, 2, K))
+        e.set_sigma_lambda(SIG, 1e9)
+        e.set_nominal(u0); e.upload_noise(eps); e.upload_value(V)
+        u = e.update()[0]
+        assert np.abs(u - np.clip((u0 + eps.mean(axis=2).T) @ S, -6.35492, 6.35492)).max() < 1e-9
+
+
+@pytest.mark.parametrize("K,T", [(100000, 100), (1000000, 50)])
+def test_full_size_properties(orc, K, T):
+    """BASELINE configs 3 and 4 at full size (device RNG).  The oracle cannot replay 5e7 steps
+    in seconds, so: (1) a random subset of trajectories is replayed exactly, (2) cost-to-go is
+    a reverse cumulative sum of non-negative-ish stage costs, (3) the softmax-merge of the full
+    K equals the oracle's update on the stored V/eps for a few timesteps."""
+    u0 = np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
+    state, goal = [0.0, 0.0, 0.0], ([1.0, 0.0, 0.0] if T == 100 else [0.0, -1.0, 0.0])
+    with _engine(K, T, "f32") as e:
+        e.set_nominal(u0)
+        nxt, ua = e.tick(state, goal, noise="philox", seed=0, tick_id=0)
+        V = e.download_value()[0]
+        eps = e.download_noise()[0]
+        lat = e.get_nominal()
+    assert np.isfinite(V).all() and np.isfinite(eps).all()
+    assert abs(eps.std() - SIG) < 2e-3 and abs(eps.mean()) < 2e-3
+    idx = np.random.RandomState(1).choice(K, 256, replace=False)
+    Vo = orc.get_cost2go(state, u0, goal, LAM, SIG, eps[:, :, idx])
+    assert np.abs(V[:, idx] - Vo).max() <= _vtol(orc, state, u0, goal, Vo, T, 256)
+    # stage costs recovered from V are >= -(lam*sig*|u||eps|) ~ -1e-2
+    assert (V[:-1] - V[1:]).min() > -0.05
+    # control update from the device's own V/eps, in float64 on the host
+    Vc = V - V.min(axis=1, keepdims=True)
+    w = np.exp(-Vc / LAM) + 1e-8
+    w /= w.sum(axis=1, keepdims=True)
+    du = np.einsum("tck,tk->ct", eps, w)
+    un = np.clip(u0 + du, -6.35492, 6.35492)
+    uf = np.clip(un @ orc.savgol_matrix(T), -6.35492, 6.35492)
+    gap = np.sort(V, axis=1)[:, :2]
+    decided = (gap[:, 1] - gap[:, 0]) > 50 * LAM   # rows whose argmin cannot flip within fp32 dV error
+    assert decided.mean() > 0.5
+    if decided.all():
+        assert np.abs(ua[0] - uf[:, 0]).max() < 1e-5
+        assert np.abs(lat[:, :-1] - uf[:, 1:]).max() < 1e-5
+    assert np.abs(nxt[0] - orc.rk4(state, ua[0], 1.0 / T)).max() < 1e-12
+
+
+def test_tick_graph_equals_eager():
+    K, T, seed = 2048, 50, 17
+    u0 = np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
+    with _engine(K, T, "f32") as a, _engine(K, T, "f32") as b:
+        a.set_nominal(u0); b.set_nominal(u0)
+        sa, _ = a.tick([0, 0, 0], [0, -1, 0], noise="philox", seed=seed, tick_id=0)
+        sb, _ = b.tick([0, 0, 0], [0, -1, 0], noise="philox", seed=seed, tick_id=0)
+        # eager: ticks 0.. with explicit ids; graph: device tick counter starts at 0
+        a.reset(); b.reset(); a.set_nominal(u0); b.set_nominal(u0)
+        a.tick([0, 0, 0], [0, -1, 0], noise="philox", seed=seed, tick_id=0)
+        for i in range(1, 4):
+            a.tick(None, None, noise="philox", seed=seed, tick_id=i)
+        ea = a.get_outputs()
+        # graph path on b: prime state/goal without running a tick
+        b.rollout([0, 0, 0], [0, -1, 0], noise="philox", seed=seed, tick_id=0)
+        for i in range(4):
+            b.tick_graph(seed)
+        eb = b.get_outputs()
+        assert np.array_equal(ea[0], eb[0]) and np.array_equal(ea[1], eb[1])
+        assert np.array_equal(a.get_nominal(), b.get_nominal())
+
+
+def test_error_behaviour():
+    from motion_planning_amd.mppi import Engine
+    from motion_planning_amd._capi import MppiError
+    with pytest.raises(MppiError) as ei:
+        Engine(16, 51)  # window 50 is even: scipy of the reference's era raises too
+    assert ei.value.code == -1
+    with pytest.raises(MppiError):
+        Engine(0, 50)
+    with _engine(16, 10, "f32") as e:
+        with pytest.raises(MppiError) as ei:
+            e.rollout([0, 0, 0], [0, 0, 0], noise="injected")  # no noise uploaded
+        assert ei.value.code == -3
+        with pytest.raises(MppiError):
+            e.tick_begin(None, None)  # state never set
+        with pytest.raises(MppiError):
+            e.update()
+        with pytest.raises(ValueError):
+            e.set_nominal(np.zeros((2, 11)))
+
+
+@pytest.mark.parametrize("name,waypoints", [("ctl_park", []),
+                                            ("ctl_wp", [[1, 0], [2, 1], [1, 2], [0, 2], [0, 0]])])
+def test_controller_state_machine_golden(golden, name, waypoints):
+    """The node shell (control/src/mppi:296-389) replayed against the reference's own
+    Controller with the reference's rk4 as the plant (tests/golden/make_golden.py section F)."""
+    from motion_planning_amd import MPPI, Controller
+    from motion_planning_amd.mppi import rk4
+    K, T, seed, n_cb = [int(x) for x in golden[name + "_meta"]]
+    rows = golden[name]
+    thresh = 0.05 if name == "ctl_park" else 0.97
+    np.random.seed(seed)
+    c = Controller(waypoints, mppi=MPPI(horizon=T, samples=K, thresh=thresh, storage="f64"))
+    plant = np.array([0.0, 0.0, 0.0])
+    for i in range(n_cb):
+        q = (0.0, 0.0, np.sin(plant[2] / 2.0), np.cos(plant[2] / 2.0))
+        vx, wz = c.odom_cb(plant[0], plant[1], *q)
+        u = np.array([0.0, 0.0]) if c.done else c.mppi.uvec[-1, :].copy()
+        r = rows[i]
+        assert np.abs(c.mppi.start - r[0:3]).max() < 1e-9, i
+        assert np.abs(c.mppi.goal - r[3:6]).max() < 1e-9, i
+        assert np.abs(u - r[6:8]).max() < 1e-8, i
+        assert abs(vx - r[8]) < 1e-9 and abs(wz - r[9]) < 1e-8, i
+        assert (c.idx, float(c.done), float(c.init)) == (int(r[10]), r[11], r[12]), i
+        plant = rk4(plant.reshape(3, 1), u.reshape(2, 1), c.mppi.dt)[:, 0]
