@@ -48,7 +48,7 @@ def cpu_baseline(T, goal, budget_s=12.0):
     host cores on a bounded sample of the same workload: K_cpu rollouts of the same T."""
     from oracle import oracle as orc
     orc.build()
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     K_cpu = 100000
     eps = np.random.RandomState(0).normal(0.0, 0.9, (T, 2, K_cpu))
     u0 = nominal_warm(T)

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <stdexcept>
@@ -66,12 +67,13 @@ struct mppi_engine {
 
     // launch geometry
     int roll_bs = 256, roll_blocks = 0, nterm = 4;
-    size_t roll_lds = 0;
     int NCH = 1, CH = 1024;
+    int variant = 0;  // MPPI_VARIANT env: A/B switches for tuning runs (bit0: libm Box-Muller)
 
     // device buffers
     void* d_eps = nullptr;   // S [A][T][2][Ks]
-    void* d_dV = nullptr;    // S [A][T][Ks]
+    void* d_dP = nullptr;    // S [A][T][Ks]  exclusive prefix of (stage cost - nominal stage cost)
+    void* d_stot = nullptr;  // S [A][Ks]     per-sample total of the same
     double* d_tc = nullptr;  // [A][T][8]
     double* d_base = nullptr;
     double* d_unom = nullptr;
@@ -168,18 +170,19 @@ struct mppi_engine {
         if (!have_state || !have_goal) fail(MPPI_E_STATE, "state/goal passed as NULL before ever being set");
     }
 
+    template <typename S, int NT, bool PH, bool FB>
+    void launch_rollout_f(uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
+        auto kern = mppi::rollout_kernel<S, NT, PH, FB>;
+        dim3 grid(roll_blocks, cfg.n_agents);
+        hipLaunchKernelGGL(kern, grid, dim3(roll_bs), 0, stream, P, d_state, d_goal, d_tc, static_cast<S*>(d_eps),
+                           static_cast<S*>(d_dP), static_cast<S*>(d_stot), seed, tick, tick_ptr);
+        HIPCHK(hipGetLastError());
+    }
     template <typename S, int NT, bool PH>
     void launch_rollout_t(uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
-        auto kern = mppi::rollout_kernel<S, NT, PH>;
-        static thread_local const void* configured = nullptr;
-        if (configured != (const void*)kern) {
-            HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            configured = (const void*)kern;
-        }
-        dim3 grid(roll_blocks, cfg.n_agents);
-        hipLaunchKernelGGL(kern, grid, dim3(roll_bs), roll_lds, stream, P, d_state, d_goal, d_tc,
-                           static_cast<S*>(d_eps), static_cast<S*>(d_dV), seed, tick, tick_ptr);
-        HIPCHK(hipGetLastError());
+        if (!PH) launch_rollout_f<S, NT, false, false>(seed, tick, tick_ptr);
+        else if (variant & 1) launch_rollout_f<S, NT, PH, false>(seed, tick, tick_ptr);
+        else launch_rollout_f<S, NT, PH, true>(seed, tick, tick_ptr);
     }
     template <typename S, bool PH>
     void launch_rollout_s(uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
@@ -209,13 +212,18 @@ struct mppi_engine {
         if (!noise_ready || !value_ready) fail(MPPI_E_STATE, "update needs a rollout (or uploaded V and eps) first");
         {
             Scope sc(this, MPPI_KERNEL_UPDATE);
-            dim3 grid(NCH, cfg.horizon, cfg.n_agents);
-            if (f64())
-                hipLaunchKernelGGL(mppi::update_kernel<double>, grid, dim3(256), 0, stream, P,
-                                   static_cast<const double*>(d_eps), static_cast<const double*>(d_dV), d_part, NCH, CH);
-            else
-                hipLaunchKernelGGL(mppi::update_kernel<float>, grid, dim3(256), 0, stream, P,
-                                   static_cast<const float*>(d_eps), static_cast<const float*>(d_dV), d_part, NCH, CH);
+            const int mode = (variant >> 1) & 3;
+            dim3 grid = (mode & 2) ? dim3(NCH, cfg.horizon, cfg.n_agents) : dim3(cfg.horizon, NCH, cfg.n_agents);
+#define LAUNCH_UPD(TYPE, MODE)                                                                              \
+    hipLaunchKernelGGL((mppi::update_kernel<TYPE, MODE>), grid, dim3(256), 0, stream, P,                    \
+                       static_cast<const TYPE*>(d_eps), static_cast<const TYPE*>(d_dP),                     \
+                       static_cast<const TYPE*>(d_stot), d_part, NCH, CH)
+            if (f64()) LAUNCH_UPD(double, 0);
+            else if (mode == 0) LAUNCH_UPD(float, 0);
+            else if (mode == 1) LAUNCH_UPD(float, 1);
+            else if (mode == 2) LAUNCH_UPD(float, 2);
+            else LAUNCH_UPD(float, 3);
+#undef LAUNCH_UPD
             HIPCHK(hipGetLastError());
         }
         {
@@ -244,6 +252,7 @@ struct mppi_engine {
 
     void init(const mppi_config& c) {
         cfg = c;
+        if (const char* v = std::getenv("MPPI_VARIANT")) variant = std::atoi(v);
         if (cfg.n_agents < 1 || cfg.samples < 1) fail(MPPI_E_INVALID, "n_agents and samples must be >= 1");
         if (cfg.horizon < 5 || ((cfg.horizon - 1) % 2) == 0)
             fail(MPPI_E_INVALID, "horizon=%d: the Savitzky-Golay window horizon-1 must be odd and > 3 "
@@ -273,17 +282,7 @@ struct mppi_engine {
         P.floor_w = cfg.floor_w;
         refresh_params();
 
-        // rollout geometry: LDS column of T stage costs per lane; keep >= 3 blocks/CU if possible
-        const size_t per_lane = (size_t)T * esz();
-        roll_bs = 0;
-        for (int bs : {256, 128, 64})
-            if (per_lane * bs <= 53 * 1024) { roll_bs = bs; break; }
-        if (!roll_bs) {
-            if (per_lane * 64 <= 160 * 1024) roll_bs = 64;
-            else fail(MPPI_E_INVALID, "horizon %d too long for the LDS-resident stage costs (max %d)", T,
-                      (int)(160 * 1024 / (64 * esz())));
-        }
-        roll_lds = per_lane * roll_bs;
+        roll_bs = 256;
         roll_blocks = (K + roll_bs - 1) / roll_bs;
         const double phi_max = P.kth * P.dt * P.u_max;  // |h/2| <= kth*dt*(2 u_max)/2
         nterm = phi_max <= 0.03 ? 4 : (phi_max <= 0.25 ? 7 : 0);
@@ -291,7 +290,9 @@ struct mppi_engine {
         // update geometry: ~4096 blocks on 256 CUs, chunks are multiples of 1024 samples
         {
             const long rows = (long)T * A;
-            long nch = (4096 + rows - 1) / rows;
+            long target = 4096;
+            if (const char* v = std::getenv("MPPI_UPD_BLOCKS")) target = std::max(1L, std::atol(v));
+            long nch = (target + rows - 1) / rows;
             const long max_ch = ((long)K + 1023) / 1024;
             nch = std::max(1L, std::min(nch, max_ch));
             long ch = ((long)K + nch - 1) / nch;
@@ -306,7 +307,9 @@ struct mppi_engine {
             size_t bytes = (size_t)A * T * 2 * Ks * esz();
             HIPCHK(hipMalloc(&p, bytes)); hbm_bytes += bytes; d_eps = p;
             bytes = (size_t)A * T * Ks * esz();
-            HIPCHK(hipMalloc(&p, bytes)); hbm_bytes += bytes; d_dV = p;
+            HIPCHK(hipMalloc(&p, bytes)); hbm_bytes += bytes; d_dP = p;
+            bytes = (size_t)A * Ks * esz();
+            HIPCHK(hipMalloc(&p, bytes)); hbm_bytes += bytes; d_stot = p;
         }
         d_tc = dev_alloc<double>((size_t)A * T * mppi::kTcW, hbm_bytes);
         d_base = dev_alloc<double>((size_t)A * T, hbm_bytes);
@@ -324,7 +327,8 @@ struct mppi_engine {
         HIPCHK(hipMemsetAsync(d_out, 0, (size_t)A * 8 * sizeof(double), stream));
         HIPCHK(hipMemsetAsync(d_tick, 0, sizeof(uint32_t), stream));
         HIPCHK(hipMemsetAsync(d_eps, 0, (size_t)A * T * 2 * Ks * esz(), stream));
-        HIPCHK(hipMemsetAsync(d_dV, 0, (size_t)A * T * Ks * esz(), stream));
+        HIPCHK(hipMemsetAsync(d_dP, 0, (size_t)A * T * Ks * esz(), stream));
+        HIPCHK(hipMemsetAsync(d_stot, 0, (size_t)A * Ks * esz(), stream));
 
         std::vector<double> S;
         if (!mppi::savgol_operator(T, S)) fail(MPPI_E_INVALID, "cannot build the Savitzky-Golay operator for horizon %d", T);
@@ -348,7 +352,7 @@ struct mppi_engine {
         for (auto e : ev_pool) hipEventDestroy(e);
         for (int i = 0; i < kRing; ++i) if (ring_ev[i]) hipEventDestroy(ring_ev[i]);
         if (h_stage) hipHostFree(h_stage);
-        void* bufs[] = {d_eps, d_dV, d_tc, d_base, d_unom, d_ufilt, d_state, d_goal, d_part, d_merged, d_S, d_out, d_tick, d_tmp};
+        void* bufs[] = {d_eps, d_dP, d_stot, d_tc, d_base, d_unom, d_ufilt, d_state, d_goal, d_part, d_merged, d_S, d_out, d_tick, d_tmp};
         for (void* b : bufs) if (b) hipFree(b);
         if (own_stream) hipStreamDestroy(own_stream);
     }
@@ -510,8 +514,8 @@ int mppi_download_value(mppi_engine* h, double* V) {
     const size_t n = (size_t)A * T * K;
     h->ensure_tmp(n);
     dim3 grid(std::min((K + 255) / 256, 1024), A * T);
-    if (h->f64()) hipLaunchKernelGGL(mppi::unpack_rows_kernel<double>, grid, dim3(256), 0, h->stream, static_cast<const double*>(h->d_dV), h->d_tmp, K, h->P.Ks, (const double*)h->d_base, 1);
-    else hipLaunchKernelGGL(mppi::unpack_rows_kernel<float>, grid, dim3(256), 0, h->stream, static_cast<const float*>(h->d_dV), h->d_tmp, K, h->P.Ks, (const double*)h->d_base, 1);
+    if (h->f64()) hipLaunchKernelGGL(mppi::value_unpack_kernel<double>, grid, dim3(256), 0, h->stream, static_cast<const double*>(h->d_dP), static_cast<const double*>(h->d_stot), (const double*)h->d_base, h->d_tmp, K, h->P.Ks, T);
+    else hipLaunchKernelGGL(mppi::value_unpack_kernel<float>, grid, dim3(256), 0, h->stream, static_cast<const float*>(h->d_dP), static_cast<const float*>(h->d_stot), (const double*)h->d_base, h->d_tmp, K, h->P.Ks, T);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(V, h->d_tmp, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -529,8 +533,8 @@ int mppi_upload_value(mppi_engine* h, const double* V) {
     hipLaunchKernelGGL(mppi::row_min_kernel, dim3(A * T), dim3(256), 0, h->stream, h->d_tmp, K, h->d_base);
     HIPCHK(hipGetLastError());
     dim3 grid(std::min((K + 255) / 256, 1024), A * T);
-    if (h->f64()) hipLaunchKernelGGL(mppi::pack_rows_kernel<double>, grid, dim3(256), 0, h->stream, h->d_tmp, static_cast<double*>(h->d_dV), K, h->P.Ks, (const double*)h->d_base, 1);
-    else hipLaunchKernelGGL(mppi::pack_rows_kernel<float>, grid, dim3(256), 0, h->stream, h->d_tmp, static_cast<float*>(h->d_dV), K, h->P.Ks, (const double*)h->d_base, 1);
+    if (h->f64()) hipLaunchKernelGGL(mppi::value_pack_kernel<double>, grid, dim3(256), 0, h->stream, (const double*)h->d_tmp, (const double*)h->d_base, static_cast<double*>(h->d_dP), static_cast<double*>(h->d_stot), K, h->P.Ks, T);
+    else hipLaunchKernelGGL(mppi::value_pack_kernel<float>, grid, dim3(256), 0, h->stream, (const double*)h->d_tmp, (const double*)h->d_base, static_cast<float*>(h->d_dP), static_cast<float*>(h->d_stot), K, h->P.Ks, T);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     h->value_ready = true;

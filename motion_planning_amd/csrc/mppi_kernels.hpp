@@ -7,9 +7,9 @@
 // Pipeline of one control tick (DESIGN.md has the byte accounting):
 //   nominal_kernel   1 block / agent    nominal (eps = 0) rollout by block scans -> per-step table
 //                                       tc[a][t] + baseline cost-to-go base[a][t]
-//   rollout_kernel   1 lane / sample    noise -> clip -> RK4 step -> stage cost (registers),
-//                                       stage costs parked in LDS, reverse cumsum, writes
-//                                       eps[a][t][2][K] and dV = V - base  (HBM-bound, 12 B/step)
+//   rollout_kernel   1 lane / sample    noise -> clip -> RK4 step -> stage cost, all in registers;
+//                                       writes eps[a][t][2][K] and the running cost prefix
+//                                       dP[a][t][K] (+ one total per sample): 12 B/step to HBM
 //   update_kernel    1 block / (chunk,t,a)  streaming per-timestep online softmax over K
 //                                       (reads the 12 B/step back) -> partial tuples
 //   merge_kernel     1 wave / (t,a)     merges chunk partials -> shard partial [A][T][8]
@@ -20,7 +20,10 @@
 // fp64 (lambda = 1e-3 amplifies cost error 1000x inside exp(), fp32 accumulation of V ~ 1e4
 // cannot feed it); only the HBM-resident intermediates are stored narrow (fp32) and V is
 // stored as an offset from the nominal trajectory's cost-to-go so that fp32 keeps ~1e-6
-// absolute accuracy where the softmax weights live.
+// absolute accuracy where the softmax weights live:
+//     V[t][k] = base[t] + Stot[k] - dP[t][k],   dP[t][k] = sum_{tau<t} (c[tau][k] - c_nom[tau])
+// (the reverse cumsum of control/src/mppi:175 written as total minus exclusive prefix, so the
+// rollout streams its output step by step and needs no per-lane history -- no LDS, no T limit).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -170,8 +173,9 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
                                               uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;  // v_mad_u64_u32
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -179,36 +183,43 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// two N(0, sigma^2) draws from two 32-bit words (Box-Muller on 24-bit uniforms, fp32)
+// two N(0, sigma^2) draws from two 32-bit words: Box-Muller in fp32 on a 23-bit radius uniform
+// u1 = (w0>>9 + 1/2) / 2^23 in (0,1) and a 24-bit angle uniform u2 = (w1>>8) / 2^24 in [0,1)
+// (both exact in fp32).  FAST: the gfx950 transcendental units directly -- v_log_f32 (log2),
+// v_sqrt_f32, v_sin_f32 / v_cos_f32 (argument in revolutions, exactly what Box-Muller wants).
+template <bool FAST>
 __device__ __forceinline__ void box_muller(uint32_t w0, uint32_t w1, float sigma, float& e0, float& e1) {
-    const float u1 = ((float)(w0 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u1 = ((float)(w0 >> 9) + 0.5f) * (1.0f / 8388608.0f);
     const float u2 = (float)(w1 >> 8) * (1.0f / 16777216.0f);
-    const float r = sqrtf(-2.0f * logf(u1));
-    float sn, cs;
-    sincospif(2.0f * u2, &sn, &cs);
+    float r, sn, cs;
+    if (FAST) {
+        r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // -2 ln2 log2(u1)
+        sn = __builtin_amdgcn_sinf(u2);
+        cs = __builtin_amdgcn_cosf(u2);
+    } else {
+        r = sqrtf(-2.0f * logf(u1));
+        sincospif(2.0f * u2, &sn, &cs);
+    }
     e0 = sigma * (r * cs);
     e1 = sigma * (r * sn);
 }
 
 // ---------------------------------------------------------------------------------------------
 // rollout_kernel: MPPI.get_cost2go (control/src/mppi:127-178) for one sample per lane.
-//   S      storage type of eps / dV in HBM (float | double)
+//   S      storage type of eps / dP / Stot in HBM (float | double)
 //   NTERM  4 | 7: Taylor terms for the per-step heading rotation; 0: full sincos every step
 //   PHILOX true: draw eps in-kernel and WRITE it; false: READ the injected eps
-// grid = (ceil(K / BS), A), block = BS, dynamic LDS = T * BS * sizeof(S) (stage costs, lane-major
-// columns -> conflict-free).  Per lane and step: 2 eps + 1 dV element through HBM, fully
-// coalesced (consecutive lanes = consecutive k).
+// grid = (ceil(K / 256), A), block = 256, no LDS.  Per lane and step: 2 eps + 1 dP element
+// through HBM, fully coalesced (consecutive lanes = consecutive k).
 // ---------------------------------------------------------------------------------------------
-template <typename S, int NTERM, bool PHILOX>
+template <typename S, int NTERM, bool PHILOX, bool FASTBM>
 __global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double* __restrict__ state,
                                                      const double* __restrict__ goal,
                                                      const double* __restrict__ tc, S* __restrict__ eps,
-                                                     S* __restrict__ dV, uint64_t seed, uint32_t tick_arg,
-                                                     const uint32_t* __restrict__ tick_ptr) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    S* lc = reinterpret_cast<S*>(smem_raw);  // [T][BS]
-    const int BS = blockDim.x, tid = threadIdx.x, a = blockIdx.y, T = P.T;
-    const int k = blockIdx.x * BS + tid;
+                                                     S* __restrict__ dP, S* __restrict__ Stot, uint64_t seed,
+                                                     uint32_t tick_arg, const uint32_t* __restrict__ tick_ptr) {
+    const int tid = threadIdx.x, a = blockIdx.y, T = P.T;
+    const int k = blockIdx.x * blockDim.x + tid;
     const bool active = k < P.K;
     const size_t Ks = (size_t)P.Ks;
     const double gx = goal[a * 3 + 0], gy = goal[a * 3 + 1], gth = goal[a * 3 + 2];
@@ -216,9 +227,11 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double*
     double c, s;
     sincos(th, &s, &c);
     S* eps_a = eps + (size_t)a * T * 2 * Ks + k;
+    S* dp = dP + (size_t)a * T * Ks + k;
     const double* tca = tc + (size_t)a * T * kTcW;
     const double half_kd = 0.5 * P.kth * P.dt;             // phi = half_kd * (u1 - u0) = h / 2
     const double sixth_rd = P.dt * P.rhalf * (1.0 / 6.0);  // Simpson weight of (u0 + u1)
+    const double hq0 = 0.5 * P.q0, hq1 = 0.5 * P.q1, hq2 = 0.5 * P.q2;
 
     uint32_t key0 = 0, key1 = 0, ctr0 = 0, tick = 0;
     float sigf = 0.f;
@@ -246,14 +259,15 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double*
             uint32_t o[4];
             philox4x32_10(ctr0, (uint32_t)((t0 + j) >> 1), tick, (uint32_t)a, key0, key1, o);
             float e0, e1, e2, e3;
-            box_muller(o[0], o[1], sigf, e0, e1);
-            box_muller(o[2], o[3], sigf, e2, e3);
+            box_muller<FASTBM>(o[0], o[1], sigf, e0, e1);
+            box_muller<FASTBM>(o[2], o[3], sigf, e2, e3);
             buf[j][0] = (S)e0; buf[j][1] = (S)e1;
             buf[j + 1][0] = (S)e2; buf[j + 1][1] = (S)e3;
         }
     };
     if (!PHILOX) load_chunk(0, cur);
 
+    double pre = 0.0;  // sum_{tau < t} (c[tau] - c_nom[tau])
     for (int t0 = 0; t0 < T; t0 += U) {
         if (PHILOX) draw_chunk(t0, cur);
         else load_chunk(t0 + U, nxt);  // prefetch: HBM latency hides under this chunk's math
@@ -264,9 +278,12 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double*
                 const double* tcp = tca + (size_t)t * kTcW;  // uniform -> scalar loads
                 const double un0 = tcp[0], un1 = tcp[1], w0 = tcp[2], w1 = tcp[3], cb = tcp[4];
                 const double e0 = (double)cur[j][0], e1 = (double)cur[j][1];
-                if (PHILOX && active) {
-                    eps_a[(size_t)(t * 2 + 0) * Ks] = cur[j][0];
-                    eps_a[(size_t)(t * 2 + 1) * Ks] = cur[j][1];
+                if (active) {
+                    if (PHILOX) {
+                        eps_a[(size_t)(t * 2 + 0) * Ks] = cur[j][0];
+                        eps_a[(size_t)(t * 2 + 1) * Ks] = cur[j][1];
+                    }
+                    dp[(size_t)t * Ks] = (S)pre;
                 }
                 // EXPLORE + CLIP (control/src/mppi:147-152)
                 const double u0 = clampd(un0 + e0, P.u_max), u1 = clampd(un1 + e1, P.u_max);
@@ -286,17 +303,20 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double*
                 }
                 x = fma(aa, c + 4.0 * c1 + c2, x);
                 y = fma(aa, s + 4.0 * s1 + s2, y);
-                th = wrap_theta(th + 2.0 * phi);
+                th += 2.0 * phi;
+                // theta -> (-pi, pi] (control/src/mppi:52-53); the formula is the identity inside
+                // the interval, so only lanes that left it pay for the ceil/divide
+                if (th > M_PI || th <= -M_PI) th = wrap_theta(th);
                 c = c2; s = s2;
                 // get_cost (control/src/mppi:180-184) minus the nominal stage cost (cb):
                 //   1/2 xQx + 1/2 uRu + lam*sig*(un . eps)  with u = NOMINAL, eps = UNCLIPPED
                 const double dx = x - gx, dy = y - gy, dth = th - gth;
-                double dc = 0.5 * (P.q0 * dx * dx + P.q1 * dy * dy + P.q2 * dth * dth) + cb;
+                double dc = fma(hq0 * dx, dx, fma(hq1 * dy, dy, fma(hq2 * dth, dth, cb)));
                 dc = fma(w0, e0, dc);
                 dc = fma(w1, e1, dc);
                 if (t == T - 1)  // terminal cost (control/src/mppi:165-173), theta error not wrapped
                     dc += P.p0 * dx * dx + P.p1 * dy * dy + P.p2 * dth * dth;
-                lc[t * BS + tid] = (S)dc;
+                pre += dc;
             }
         }
         if (!PHILOX) {
@@ -304,13 +324,8 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double*
             for (int j = 0; j < U; ++j) { cur[j][0] = nxt[j][0]; cur[j][1] = nxt[j][1]; }
         }
     }
-    // value_fcn = reverse cumulative sum over t (control/src/mppi:175), as an offset from base[a][t]
-    double acc = 0.0;
-    S* dv = dV + (size_t)a * T * Ks + k;
-    for (int t = T - 1; t >= 0; --t) {
-        acc += (double)lc[t * BS + tid];
-        if (active) dv[(size_t)t * Ks] = (S)acc;
-    }
+    // value_fcn = reverse cumulative sum over t (control/src/mppi:175) = total - exclusive prefix
+    if (active) Stot[(size_t)a * Ks + k] = (S)pre;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -319,12 +334,14 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double*
 // w = exp(-(V - min)/lam) + 1e-8.  Each lane keeps an online-softmax tuple (running min m,
 // D = sum e, N = sum e*eps, E = sum eps) so V and eps are read exactly once (12 B/step fp32);
 // the 1e-8 floor is applied at merge time as floor*count / floor*E.
-// grid = (NCH, T, A) x 256 threads; block (ch,t,a) owns samples [ch*CH, min(K,(ch+1)*CH)).
+// grid = (T, NCH, A) x 256 threads; block (t,ch,a) owns samples [ch*CH, min(K,(ch+1)*CH)).
 // part[a][t][ch] = {m, D, N0, N1, E0, E1, count, 0} (float64).
 // ---------------------------------------------------------------------------------------------
 template <typename R> struct Exp2;
 template <> struct Exp2<float> {
-    static __device__ __forceinline__ float f(float v) { return exp2f(v); }
+    // arguments are <= 0 here: the bare v_exp_f32 (flush-to-zero below 2^-126) is exactly what a
+    // softmax weight wants; exp2f() would add denormal-range rescaling around it
+    static __device__ __forceinline__ float f(float v) { return __builtin_amdgcn_exp2f(v); }
 };
 template <> struct Exp2<double> {
     static __device__ __forceinline__ double f(double v) { return exp2(v); }
@@ -343,15 +360,19 @@ __device__ __forceinline__ R wave_sum(R v) {
     return v;
 }
 
-template <typename S>
+template <typename S, int MODE>
 __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __restrict__ eps,
-                                                    const S* __restrict__ dV, double* __restrict__ part,
-                                                    int NCH, int CH) {
+                                                    const S* __restrict__ dP, const S* __restrict__ Stot,
+                                                    double* __restrict__ part, int NCH, int CH) {
     using R = S;                                        // accumulate in the storage precision
     constexpr int VEC = 16 / (int)sizeof(S);            // elements per 16-byte lane load
-    const int ch = blockIdx.x, t = blockIdx.y, a = blockIdx.z, tid = threadIdx.x;
+    // blockIdx.x = t (fastest): the T blocks that share one chunk of Stot are dispatched back to
+    // back, so each XCD's L2 fetches that chunk once instead of once per timestep
+    const int t = (MODE & 2) ? blockIdx.y : blockIdx.x, ch = (MODE & 2) ? blockIdx.x : blockIdx.y;
+    const int a = blockIdx.z, tid = threadIdx.x;
     const size_t Ks = (size_t)P.Ks;
-    const S* v_row = dV + ((size_t)a * P.T + t) * Ks;
+    const S* v_row = dP + ((size_t)a * P.T + t) * Ks;   // exclusive cost prefix of row t
+    const S* s_row = Stot + (size_t)a * Ks;               // per-sample total (L2-resident, re-read per t)
     const S* e0_row = eps + (((size_t)a * P.T + t) * 2 + 0) * Ks;
     const S* e1_row = e0_row + Ks;
     const int k_begin = ch * CH;
@@ -359,23 +380,11 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
     const R scale = (R)(P.inv_lambda * 1.4426950408889634);  // log2(e) / lambda
     R m = (R)INFINITY, D = 0, N0 = 0, N1 = 0, E0 = 0, E1 = 0;
 
-    for (int k = k_begin + tid * VEC; k < k_end; k += 256 * VEC) {
-        S v[VEC], a0[VEC], a1[VEC];
-        if (k + VEC <= k_end) {  // rows are 256-byte aligned, k % VEC == 0 -> 16-byte aligned
-            typedef S vec_t __attribute__((ext_vector_type(VEC)));
-            const vec_t vv = *reinterpret_cast<const vec_t*>(v_row + k);
-            const vec_t x0 = *reinterpret_cast<const vec_t*>(e0_row + k);
-            const vec_t x1 = *reinterpret_cast<const vec_t*>(e1_row + k);
+    auto accumulate = [&](const S (&v)[VEC], const S (&a0)[VEC], const S (&a1)[VEC]) {
+        if (MODE & 1) {  // timing probe: memory traffic only
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) { v[i] = vv[i]; a0[i] = x0[i]; a1[i] = x1[i]; }
-        } else {
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) {
-                const bool ok = k + i < k_end;
-                v[i] = ok ? v_row[k + i] : (S)INFINITY;  // weight 0, eps 0: no contribution
-                a0[i] = ok ? e0_row[k + i] : (S)0;
-                a1[i] = ok ? e1_row[k + i] : (S)0;
-            }
+            for (int i = 0; i < VEC; ++i) { D += v[i]; E0 += a0[i]; E1 += a1[i]; }
+            return;
         }
         R vm = v[0];
 #pragma unroll
@@ -394,6 +403,48 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
             E0 += a0[i];
             E1 += a1[i];
         }
+    };
+    typedef S vec_t __attribute__((ext_vector_type(VEC)));
+    constexpr int STRIDE = 256 * VEC;
+    int k = k_begin + tid * VEC;
+    // two 16-byte vectors of each of the 4 streams in flight per lane (rows are 256-byte aligned
+    // and k % VEC == 0, so every vector load is 16-byte aligned)
+    for (; k + STRIDE + VEC <= k_end; k += 2 * STRIDE) {
+        const vec_t vA = *reinterpret_cast<const vec_t*>(v_row + k);
+        const vec_t sA = *reinterpret_cast<const vec_t*>(s_row + k);
+        const vec_t xA = *reinterpret_cast<const vec_t*>(e0_row + k);
+        const vec_t yA = *reinterpret_cast<const vec_t*>(e1_row + k);
+        const vec_t vB = *reinterpret_cast<const vec_t*>(v_row + k + STRIDE);
+        const vec_t sB = *reinterpret_cast<const vec_t*>(s_row + k + STRIDE);
+        const vec_t xB = *reinterpret_cast<const vec_t*>(e0_row + k + STRIDE);
+        const vec_t yB = *reinterpret_cast<const vec_t*>(e1_row + k + STRIDE);
+        S v[VEC], a0[VEC], a1[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { v[i] = sA[i] - vA[i]; a0[i] = xA[i]; a1[i] = yA[i]; }
+        accumulate(v, a0, a1);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { v[i] = sB[i] - vB[i]; a0[i] = xB[i]; a1[i] = yB[i]; }
+        accumulate(v, a0, a1);
+    }
+    for (; k < k_end; k += STRIDE) {
+        S v[VEC], a0[VEC], a1[VEC];
+        if (k + VEC <= k_end) {
+            const vec_t vv = *reinterpret_cast<const vec_t*>(v_row + k);
+            const vec_t ss = *reinterpret_cast<const vec_t*>(s_row + k);
+            const vec_t x0 = *reinterpret_cast<const vec_t*>(e0_row + k);
+            const vec_t x1 = *reinterpret_cast<const vec_t*>(e1_row + k);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) { v[i] = ss[i] - vv[i]; a0[i] = x0[i]; a1[i] = x1[i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const bool ok = k + i < k_end;
+                v[i] = ok ? s_row[k + i] - v_row[k + i] : (S)INFINITY;  // weight 0, eps 0: no contribution
+                a0[i] = ok ? e0_row[k + i] : (S)0;
+                a1[i] = ok ? e1_row[k + i] : (S)0;
+            }
+        }
+        accumulate(v, a0, a1);
     }
     // lanes -> wave -> block
     __shared__ R red[4][6];
@@ -406,19 +457,22 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
     const int wid = tid >> 6, lane = tid & 63;
     if (lane == 0) { red[wid][0] = wm; red[wid][1] = D; red[wid][2] = N0; red[wid][3] = N1; red[wid][4] = E0; red[wid][5] = E1; }
     __syncthreads();
-    if (tid == 0) {
-        double M = INFINITY;
-        for (int w = 0; w < 4; ++w) M = fmin(M, (double)red[w][0]);
-        double d = 0, n0 = 0, n1 = 0, e0 = 0, e1 = 0;
-        for (int w = 0; w < 4; ++w) {
-            const double mw = (double)red[w][0];
-            const double sc = (mw == INFINITY) ? 0.0 : exp((M - mw) * P.inv_lambda);
-            d += sc * (double)red[w][1]; n0 += sc * (double)red[w][2]; n1 += sc * (double)red[w][3];
-            e0 += (double)red[w][4]; e1 += (double)red[w][5];
+    if (wid == 0) {  // 4 wave tuples -> 1, in parallel on wave 0 (lanes 0..3 hold one tuple each)
+        const bool has = lane < 4;
+        const R mw = has ? red[lane][0] : (R)INFINITY;
+        const R M = wave_min(mw);
+        const R sc = (mw == (R)INFINITY) ? (R)0 : Exp2<R>::f((M - mw) * scale);
+        const R d = wave_sum(has ? sc * red[lane][1] : (R)0);
+        const R n0 = wave_sum(has ? sc * red[lane][2] : (R)0);
+        const R n1 = wave_sum(has ? sc * red[lane][3] : (R)0);
+        const R e0 = wave_sum(has ? red[lane][4] : (R)0);
+        const R e1 = wave_sum(has ? red[lane][5] : (R)0);
+        if (lane == 0) {
+            double* o = part + (((size_t)a * P.T + t) * NCH + ch) * kTupleW;
+            o[0] = (double)M; o[1] = (double)d; o[2] = (double)n0; o[3] = (double)n1;
+            o[4] = (double)e0; o[5] = (double)e1;
+            o[6] = (double)max(0, k_end - k_begin); o[7] = 0.0;
         }
-        double* o = part + (((size_t)a * P.T + t) * NCH + ch) * kTupleW;
-        o[0] = M; o[1] = d; o[2] = n0; o[3] = n1; o[4] = e0; o[5] = e1;
-        o[6] = (double)max(0, k_end - k_begin); o[7] = 0.0;
     }
 }
 
@@ -581,6 +635,26 @@ __global__ void unpack_rows_kernel(const S* __restrict__ src, double* __restrict
     const double b = row_bias ? row_bias[row / rows_per_bias] : 0.0;
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x)
         dst[row * K + k] = (double)src[row * Ks + k] + b;
+}
+// value_fcn <-> resident form.  unpack: V[a][t][k] = base[a][t] + Stot[a][k] - dP[a][t][k];
+// pack (caller-made V): dP = -(V - base), Stot = 0.   grid = (blocks over k, A*T)
+template <typename S>
+__global__ void value_unpack_kernel(const S* __restrict__ dP, const S* __restrict__ Stot,
+                                    const double* __restrict__ base, double* __restrict__ dst, int K, int Ks, int T) {
+    const size_t row = blockIdx.y, a = row / T;
+    const double b = base[row];
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x)
+        dst[row * K + k] = b + ((double)Stot[a * Ks + k] - (double)dP[row * Ks + k]);
+}
+template <typename S>
+__global__ void value_pack_kernel(const double* __restrict__ src, const double* __restrict__ base,
+                                  S* __restrict__ dP, S* __restrict__ Stot, int K, int Ks, int T) {
+    const size_t row = blockIdx.y, a = row / T;
+    const double b = base[row];
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
+        dP[row * Ks + k] = (S)(b - src[row * K + k]);
+        if (row % T == 0) Stot[a * Ks + k] = (S)0;
+    }
 }
 // per-row minimum of a [rows][K] float64 array (mppi_upload_value picks it as the baseline)
 __global__ __launch_bounds__(256) void row_min_kernel(const double* __restrict__ src, int K, double* __restrict__ out) {

@@ -9,8 +9,6 @@ xGMI; "gloo" on CPU in the tests) and every rank finishes the tick identically
 (merge, control update, clip, filter, clip, plant step, shift).  The message is
 latency-bound, so it is ONE collective of the whole [A][T][8] block, not one per timestep.
 """
-import numpy as np
-
 TUPLE_W = 8
 
 
@@ -74,7 +72,8 @@ class ShardedTicker(object):
         self.world = self.dist.get_world_size(group) if self.dist else 1
         self.rank = self.dist.get_rank(group) if self.dist else 0
         part = shard.partials_tensor()
-        self._gathered = torch.empty((self.world,) + tuple(part.shape), dtype=part.dtype,
+        # flat [world * A*T*8] receive buffer (rank-major), the layout mppi_tick_finish expects
+        self._gathered = torch.empty(self.world * part.numel(), dtype=part.dtype,
                                      device=part.device) if self.world > 1 else None
 
     def tick_async(self, state=None, goal=None, noise="philox", seed=0, tick_id=0):

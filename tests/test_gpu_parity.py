@@ -405,9 +405,11 @@ def test_error_behaviour():
             e.rollout([0, 0, 0], [0, 0, 0], noise="injected")  # no noise uploaded
         assert ei.value.code == -3
         with pytest.raises(MppiError):
-            e.tick_begin(None, None)  # state never set
-        with pytest.raises(MppiError):
             e.update()
+    with _engine(16, 10, "f32") as e:
+        with pytest.raises(MppiError) as ei:
+            e.tick_begin(None, None)  # state never set
+        assert ei.value.code == -3
         with pytest.raises(ValueError):
             e.set_nominal(np.zeros((2, 11)))
 

@@ -1,0 +1,136 @@
+"""The N>1 path on CPU: two processes, gloo backend, the product's ShardedTicker driving an
+oracle-backed shard (the HIP engine needs a GPU; the exchange logic does not).  Checks that
+K split over 2 ranks + one all-gather per tick reproduces the unsharded controller, tick
+after tick, on every rank."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIG, LAM = 0.9, 0.001
+
+
+class OracleShard(object):
+    """HipShard's interface on top of the CPU oracle, for one rank's slice [lo, hi) of K."""
+
+    def __init__(self, orc, K_total, lo, hi, T, u0):
+        import torch
+        self.orc, self.K, self.lo, self.hi, self.T = orc, K_total, lo, hi, T
+        self.u = u0.copy()
+        self.S = orc.savgol_matrix(T)
+        self.part = torch.zeros(T * 8, dtype=torch.float64)
+        self.state = None
+        self.goal = None
+        self.out = None
+
+    def tick_begin(self, state, goal, noise, seed, tick_id):
+        import torch
+        if state is not None:
+            self.state = np.asarray(state, dtype=np.float64).reshape(3)
+        if goal is not None:
+            self.goal = np.asarray(goal, dtype=np.float64).reshape(3)
+        # global sample ids key the stream: this rank draws only its own slice
+        eps = self.orc.philox_noise(seed, 0, tick_id, self.lo, self.hi - self.lo, self.T, SIG)
+        V = self.orc.get_cost2go(self.state, self.u, self.goal, LAM, SIG, eps)
+        p = self.orc.shard_partials(eps, V, 0, self.hi - self.lo, LAM)          # [T][6]
+        full = np.zeros((self.T, 8))
+        full[:, :6] = p
+        full[:, 6] = self.hi - self.lo
+        self.part.copy_(torch.from_numpy(full.reshape(-1)))
+
+    def partials_tensor(self):
+        return self.part
+
+    def tick_finish(self, gathered, n_shards):
+        g = (self.part if gathered is None else gathered).numpy().reshape(n_shards, self.T, 8)
+        du = self.orc.merge_partials(np.ascontiguousarray(g[:, :, :6]), g[:, 0, 6], LAM)
+        un = np.clip(self.u + du, -6.35492, 6.35492)
+        uf = np.clip(un @ self.S, -6.35492, 6.35492)
+        nxt = self.orc.rk4(self.state, uf[:, 0], 1.0 / self.T)
+        self.out = (nxt[None].copy(), uf[:, 0][None].copy())
+        self.state = nxt
+        self.u = np.concatenate([uf[:, 1:], np.zeros((2, 1))], axis=1)
+
+    def get_outputs(self):
+        return self.out
+
+
+def _worker(rank, world, port, K, T, n_ticks, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from motion_planning_amd import sharded
+    from oracle import oracle as orc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        u0 = np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
+        lo, hi = sharded.shard_range(K, world, rank)
+        ticker = sharded.ShardedTicker(OracleShard(orc, K, lo, hi, T, u0))
+        assert ticker.world == world and ticker.rank == rank
+        outs = []
+        for i in range(n_ticks):
+            first = i == 0
+            nxt, ua = ticker.tick([0.0, 0.0, 0.0] if first else None, [0.0, -1.0, 0.0] if first else None,
+                                  "philox", 7, i)
+            outs.append(np.concatenate([nxt[0], ua[0]]))
+        q.put((rank, np.array(outs), ticker.shard.u))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_shard_range_is_a_partition():
+    from motion_planning_amd.sharded import shard_range
+    for K in (1, 7, 64, 1000003):
+        for W in (1, 2, 3, 8):
+            r = [shard_range(K, W, i) for i in range(W)]
+            assert r[0][0] == 0 and r[-1][1] == K
+            assert all(r[i][1] == r[i + 1][0] for i in range(W - 1))
+            sizes = [b - a for a, b in r]
+            assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_ticks_equal_unsharded_gloo(orc, world):
+    import torch.multiprocessing as mp
+    K, T, n_ticks = 301, 20, 3   # K not divisible by the world size: ragged shards
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, K, T, n_ticks, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference: the same controller with all K samples on one shard
+    from motion_planning_amd import sharded
+    u0 = np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
+    one = sharded.ShardedTicker(OracleShard(orc, K, 0, K, T, u0))
+    ref = []
+    for i in range(n_ticks):
+        first = i == 0
+        nxt, ua = one.tick([0.0, 0.0, 0.0] if first else None, [0.0, -1.0, 0.0] if first else None, "philox", 7, i)
+        ref.append(np.concatenate([nxt[0], ua[0]]))
+    ref = np.array(ref)
+    for rank, outs, u in res:
+        assert np.abs(outs - ref).max() < 1e-12, rank
+        assert np.abs(u - one.shard.u).max() < 1e-12, rank
+    # and the unsharded controller is the oracle's own get_path on the same noise
+    st, lat = np.zeros(3), u0.copy()
+    for i in range(n_ticks):
+        eps = orc.philox_noise(7, 0, i, 0, K, T, SIG)
+        st, ua, lat = orc.get_path(st, [0.0, -1.0, 0.0], lat, eps, LAM, SIG)
+        assert np.abs(np.concatenate([st, ua]) - ref[i]).max() < 1e-12
