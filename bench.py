@@ -138,9 +138,9 @@ def main():
     tick(0, first=True)
     for i in range(1, args.warmup + 1):
         tick(i)
-    # timed region: exactly --steps ticks, rollout+update kernels bracketed by HIP events on the
-    # engine's stream (2 x 2 event records per tick)
-    eng.kernel_timing(("rollout", "update"))
+    # timed region: exactly --steps ticks, every kernel bracketed by HIP events on the engine's
+    # stream (2 event records per launch)
+    eng.kernel_timing(("nominal", "rollout", "update", "merge", "finalize"))
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -179,6 +179,7 @@ def main():
                 gbs = BYTES_PER_STEP_PER_KERNEL * steps_per_launch / avg_s / 1e9
                 kern[name] = {"avg_us": avg_s * 1e6, "launches": n, "achieved_GBs": gbs}
         dom = max(kern, key=lambda k: kern[k]["avg_us"]) if kern else None
+        kernels_us = {name: (ktimes[name][0] * 1e3 / ktimes[name][1] if ktimes[name][1] else None) for name in ktimes}
         roofline = None
         if dom:
             roofline = {"kernel": dom + "_kernel", "bound": "hbm", "achieved": kern[dom]["achieved_GBs"],
@@ -205,7 +206,7 @@ def main():
                        "graph": bool(args.graph)},
             "state_steps_per_s": value * T,
             "ms_per_step_no_events": 1e3 * elapsed2 / args.steps,
-            "roofline": roofline, "cpu_baseline": cpu,
+            "kernels_us": kernels_us, "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     if world > 1:

@@ -70,10 +70,20 @@ struct mppi_engine {
     int NCH = 1, CH = 1024;
     int variant = 0;  // MPPI_VARIANT env: A/B switches for tuning runs (bit0: libm Box-Muller)
 
+    // intra-tick software pipeline: K is cut into pieces; the VALU-bound rollout of piece p+1 runs
+    // while the HBM-bound update of piece p streams its (still Infinity-Cache-resident) output back
+    struct Piece { int k0, k1, ch0, nch; };
+    std::vector<Piece> pieces;
+    hipStream_t s_roll[2] = {nullptr, nullptr}, s_upd = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    std::vector<hipEvent_t> ev_piece;
+
     // device buffers
     void* d_eps = nullptr;   // S [A][T][2][Ks]
     void* d_dP = nullptr;    // S [A][T][Ks]  exclusive prefix of (stage cost - nominal stage cost)
     void* d_stot = nullptr;  // S [A][Ks]     per-sample total of the same
+    void* d_epart = nullptr; // S [A][T][2][Ks/64]  per-wave sums of eps (E of the floor term)
+    bool epart_ready = false;
     double* d_tc = nullptr;  // [A][T][8]
     double* d_base = nullptr;
     double* d_unom = nullptr;
@@ -122,6 +132,7 @@ struct mppi_engine {
     void drain_timing() {
         if (pending.empty()) return;
         HIPCHK(hipStreamSynchronize(stream));
+        for (hipStream_t w : {s_roll[0], s_roll[1], s_upd}) if (w) HIPCHK(hipStreamSynchronize(w));
         for (auto& p : pending) {
             float ms = 0.f;
             HIPCHK(hipEventElapsedTime(&ms, p.a, p.b));
@@ -130,15 +141,15 @@ struct mppi_engine {
         }
         pending.clear();
     }
-    struct Scope {  // brackets one kernel launch with events when its bit is set
-        mppi_engine* e; int kid; hipEvent_t a = nullptr;
-        Scope(mppi_engine* e_, int kid_) : e(e_), kid(kid_) {
-            if (e->time_mask & (1u << kid)) { a = e->get_event(); HIPCHK(hipEventRecord(a, e->stream)); }
+    struct Scope {  // brackets one kernel launch with events (on the stream it goes to) when its bit is set
+        mppi_engine* e; int kid; hipStream_t st; hipEvent_t a = nullptr;
+        Scope(mppi_engine* e_, int kid_, hipStream_t st_ = nullptr) : e(e_), kid(kid_), st(st_ ? st_ : e_->stream) {
+            if (e->time_mask & (1u << kid)) { a = e->get_event(); HIPCHK(hipEventRecord(a, st)); }
         }
         ~Scope() noexcept(false) {
             if (a) {
                 hipEvent_t b = e->get_event();
-                HIPCHK(hipEventRecord(b, e->stream));
+                HIPCHK(hipEventRecord(b, st));
                 e->pending.push_back({kid, a, b});
                 if (e->pending.size() >= 4096) e->drain_timing();
             }
@@ -171,26 +182,87 @@ struct mppi_engine {
     }
 
     template <typename S, int NT, bool PH, bool FB>
-    void launch_rollout_f(uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
+    void launch_rollout_f(hipStream_t st, int k0, int k1, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
         auto kern = mppi::rollout_kernel<S, NT, PH, FB>;
-        dim3 grid(roll_blocks, cfg.n_agents);
-        hipLaunchKernelGGL(kern, grid, dim3(roll_bs), 0, stream, P, d_state, d_goal, d_tc, static_cast<S*>(d_eps),
-                           static_cast<S*>(d_dP), static_cast<S*>(d_stot), seed, tick, tick_ptr);
+        dim3 grid((k1 - k0 + roll_bs - 1) / roll_bs, cfg.n_agents);
+        hipLaunchKernelGGL(kern, grid, dim3(roll_bs), 0, st, P, d_state, d_goal, d_tc, static_cast<S*>(d_eps),
+                           static_cast<S*>(d_dP), static_cast<S*>(d_stot), seed, tick, tick_ptr, k0, k1,
+                           static_cast<S*>(d_epart));
         HIPCHK(hipGetLastError());
     }
     template <typename S, int NT, bool PH>
-    void launch_rollout_t(uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
-        if (!PH) launch_rollout_f<S, NT, false, false>(seed, tick, tick_ptr);
-        else if (variant & 1) launch_rollout_f<S, NT, PH, false>(seed, tick, tick_ptr);
-        else launch_rollout_f<S, NT, PH, true>(seed, tick, tick_ptr);
+    void launch_rollout_t(hipStream_t st, int k0, int k1, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
+        if (!PH) launch_rollout_f<S, NT, false, false>(st, k0, k1, seed, tick, tick_ptr);
+        else if (variant & 1) launch_rollout_f<S, NT, PH, false>(st, k0, k1, seed, tick, tick_ptr);
+        else launch_rollout_f<S, NT, PH, true>(st, k0, k1, seed, tick, tick_ptr);
     }
     template <typename S, bool PH>
-    void launch_rollout_s(uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
-        if (nterm == 4) launch_rollout_t<S, 4, PH>(seed, tick, tick_ptr);
-        else if (nterm == 7) launch_rollout_t<S, 7, PH>(seed, tick, tick_ptr);
-        else launch_rollout_t<S, 0, PH>(seed, tick, tick_ptr);
+    void launch_rollout_s(hipStream_t st, int k0, int k1, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
+        if (nterm == 4) launch_rollout_t<S, 4, PH>(st, k0, k1, seed, tick, tick_ptr);
+        else if (nterm == 7) launch_rollout_t<S, 7, PH>(st, k0, k1, seed, tick, tick_ptr);
+        else launch_rollout_t<S, 0, PH>(st, k0, k1, seed, tick, tick_ptr);
     }
-
+    void launch_rollout(hipStream_t st, int k0, int k1, bool ph, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
+        Scope sc(this, MPPI_KERNEL_ROLLOUT, st);
+        if (f64()) { if (ph) launch_rollout_s<double, true>(st, k0, k1, seed, tick, tick_ptr); else launch_rollout_s<double, false>(st, k0, k1, seed, tick, tick_ptr); }
+        else { if (ph) launch_rollout_s<float, true>(st, k0, k1, seed, tick, tick_ptr); else launch_rollout_s<float, false>(st, k0, k1, seed, tick, tick_ptr); }
+    }
+    void launch_update(hipStream_t st, int ch0, int nch) {
+        Scope sc(this, MPPI_KERNEL_UPDATE, st);
+        dim3 grid(cfg.horizon, nch, cfg.n_agents);
+        if (f64())
+            hipLaunchKernelGGL(mppi::update_kernel<double>, grid, dim3(256), 0, st, P, static_cast<const double*>(d_eps),
+                               static_cast<const double*>(d_dP), static_cast<const double*>(d_stot), d_part, NCH, ch0);
+        else
+            hipLaunchKernelGGL(mppi::update_kernel<float>, grid, dim3(256), 0, st, P, static_cast<const float*>(d_eps),
+                               static_cast<const float*>(d_dP), static_cast<const float*>(d_stot), d_part, NCH, ch0);
+        HIPCHK(hipGetLastError());
+    }
+    void launch_merge() {
+        Scope sc(this, MPPI_KERNEL_MERGE);
+        if (!epart_ready) {  // noise uploaded by the caller and never rolled out: sum it now
+            dim3 g((cfg.samples + 255) / 256, cfg.horizon * 2, cfg.n_agents);
+            if (f64()) hipLaunchKernelGGL(mppi::eps_wavesum_kernel<double>, g, dim3(256), 0, stream, P, static_cast<const double*>(d_eps), static_cast<double*>(d_epart));
+            else hipLaunchKernelGGL(mppi::eps_wavesum_kernel<float>, g, dim3(256), 0, stream, P, static_cast<const float*>(d_eps), static_cast<float*>(d_epart));
+            HIPCHK(hipGetLastError());
+            epart_ready = true;
+        }
+        dim3 grid(cfg.horizon, cfg.n_agents);
+        if (f64()) hipLaunchKernelGGL(mppi::merge_kernel<double>, grid, dim3(mppi::kMergeThreads), 0, stream, P, d_part, NCH, static_cast<const double*>(d_epart), d_merged);
+        else hipLaunchKernelGGL(mppi::merge_kernel<float>, grid, dim3(mppi::kMergeThreads), 0, stream, P, d_part, NCH, static_cast<const float*>(d_epart), d_merged);
+        HIPCHK(hipGetLastError());
+    }
+    void check_noise_mode(int noise_mode) {
+        if (noise_mode == MPPI_NOISE_INJECTED && !noise_ready)
+            fail(MPPI_E_STATE, "MPPI_NOISE_INJECTED but mppi_upload_noise was never called");
+        if (noise_mode != MPPI_NOISE_INJECTED && noise_mode != MPPI_NOISE_PHILOX)
+            fail(MPPI_E_INVALID, "unknown noise_mode %d", noise_mode);
+    }
+    // rollout + update + merge of one tick, software-pipelined over the pieces (see `pieces`)
+    void run_pipeline(int noise_mode, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
+        check_noise_mode(noise_mode);
+        const bool ph = noise_mode == MPPI_NOISE_PHILOX;
+        if (pieces.size() <= 1) {
+            launch_rollout(stream, 0, cfg.samples, ph, seed, tick, tick_ptr);
+            launch_update(stream, 0, NCH);
+        } else {
+            HIPCHK(hipEventRecord(ev_fork, stream));
+            HIPCHK(hipStreamWaitEvent(s_roll[0], ev_fork, 0));
+            HIPCHK(hipStreamWaitEvent(s_roll[1], ev_fork, 0));
+            for (size_t p = 0; p < pieces.size(); ++p) {
+                const Piece& pc = pieces[p];
+                hipStream_t sr = s_roll[p & 1];
+                launch_rollout(sr, pc.k0, pc.k1, ph, seed, tick, tick_ptr);
+                HIPCHK(hipEventRecord(ev_piece[p], sr));
+                HIPCHK(hipStreamWaitEvent(s_upd, ev_piece[p], 0));
+                launch_update(s_upd, pc.ch0, pc.nch);
+            }
+            HIPCHK(hipEventRecord(ev_join, s_upd));
+            HIPCHK(hipStreamWaitEvent(stream, ev_join, 0));
+        }
+        launch_merge();
+        noise_ready = true; value_ready = true; partials_ready = true; epart_ready = true;
+    }
     void run_nominal() {
         Scope sc(this, MPPI_KERNEL_NOMINAL);
         hipLaunchKernelGGL(mppi::nominal_kernel, dim3(cfg.n_agents), dim3(mppi::kNomThreads),
@@ -198,39 +270,14 @@ struct mppi_engine {
         HIPCHK(hipGetLastError());
     }
     void run_rollout(int noise_mode, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
-        if (noise_mode == MPPI_NOISE_INJECTED && !noise_ready)
-            fail(MPPI_E_STATE, "MPPI_NOISE_INJECTED but mppi_upload_noise was never called");
-        if (noise_mode != MPPI_NOISE_INJECTED && noise_mode != MPPI_NOISE_PHILOX)
-            fail(MPPI_E_INVALID, "unknown noise_mode %d", noise_mode);
-        Scope sc(this, MPPI_KERNEL_ROLLOUT);
-        const bool ph = noise_mode == MPPI_NOISE_PHILOX;
-        if (f64()) { if (ph) launch_rollout_s<double, true>(seed, tick, tick_ptr); else launch_rollout_s<double, false>(seed, tick, tick_ptr); }
-        else { if (ph) launch_rollout_s<float, true>(seed, tick, tick_ptr); else launch_rollout_s<float, false>(seed, tick, tick_ptr); }
-        noise_ready = true; value_ready = true; partials_ready = false;
+        check_noise_mode(noise_mode);
+        launch_rollout(stream, 0, cfg.samples, noise_mode == MPPI_NOISE_PHILOX, seed, tick, tick_ptr);
+        noise_ready = true; value_ready = true; partials_ready = false; epart_ready = true;
     }
     void run_update() {
         if (!noise_ready || !value_ready) fail(MPPI_E_STATE, "update needs a rollout (or uploaded V and eps) first");
-        {
-            Scope sc(this, MPPI_KERNEL_UPDATE);
-            const int mode = (variant >> 1) & 3;
-            dim3 grid = (mode & 2) ? dim3(NCH, cfg.horizon, cfg.n_agents) : dim3(cfg.horizon, NCH, cfg.n_agents);
-#define LAUNCH_UPD(TYPE, MODE)                                                                              \
-    hipLaunchKernelGGL((mppi::update_kernel<TYPE, MODE>), grid, dim3(256), 0, stream, P,                    \
-                       static_cast<const TYPE*>(d_eps), static_cast<const TYPE*>(d_dP),                     \
-                       static_cast<const TYPE*>(d_stot), d_part, NCH, CH)
-            if (f64()) LAUNCH_UPD(double, 0);
-            else if (mode == 0) LAUNCH_UPD(float, 0);
-            else if (mode == 1) LAUNCH_UPD(float, 1);
-            else if (mode == 2) LAUNCH_UPD(float, 2);
-            else LAUNCH_UPD(float, 3);
-#undef LAUNCH_UPD
-            HIPCHK(hipGetLastError());
-        }
-        {
-            Scope sc(this, MPPI_KERNEL_MERGE);
-            hipLaunchKernelGGL(mppi::merge_kernel, dim3(cfg.horizon, cfg.n_agents), dim3(64), 0, stream, P, d_part, NCH, d_merged);
-            HIPCHK(hipGetLastError());
-        }
+        launch_update(stream, 0, NCH);
+        launch_merge();
         partials_ready = true;
     }
     void run_finalize(const double* gathered, int G, int flags) {
@@ -271,6 +318,7 @@ struct mppi_engine {
 
         const int A = cfg.n_agents, K = cfg.samples, T = cfg.horizon;
         P.A = A; P.K = K; P.T = T; P.Ks = (K + 63) / 64 * 64;
+        if (const char* v = std::getenv("MPPI_PAD")) P.Ks += std::atoi(v) / 64 * 64;
         P.sample_offset = cfg.sample_offset;
         P.dt = cfg.dt;
         P.q0 = cfg.q[0]; P.q1 = cfg.q[1]; P.q2 = cfg.q[2];
@@ -287,20 +335,29 @@ struct mppi_engine {
         const double phi_max = P.kth * P.dt * P.u_max;  // |h/2| <= kth*dt*(2 u_max)/2
         nterm = phi_max <= 0.03 ? 4 : (phi_max <= 0.25 ? 7 : 0);
 
-        // update geometry: ~4096 blocks on 256 CUs, chunks are multiples of 1024 samples
-        {
-            const long rows = (long)T * A;
-            long target = 4096;
-            if (const char* v = std::getenv("MPPI_UPD_BLOCKS")) target = std::max(1L, std::atol(v));
-            long nch = (target + rows - 1) / rows;
-            const long max_ch = ((long)K + 1023) / 1024;
-            nch = std::max(1L, std::min(nch, max_ch));
-            long ch = ((long)K + nch - 1) / nch;
-            ch = (ch + 1023) / 1024 * 1024;
-            CH = (int)ch;
-            NCH = (int)(((long)K + ch - 1) / ch);
+        // update geometry: each block keeps one chunk of a row in registers
+        CH = f64() ? mppi::UpdCfg<double>::CH : mppi::UpdCfg<float>::CH;
+        NCH = (K + CH - 1) / CH;
+        {   // pieces of ~96 MB of eps+dP each (>= 2 only when the tick moves enough bytes to matter)
+            const double tick_bytes = 12.0 * (f64() ? 2.0 : 1.0) * (double)K * T * A;
+            long np = 1;  // cross-stream fork/join costs more than the overlap buys on this stack (measured)
+            (void)tick_bytes;
+            if (const char* v = std::getenv("MPPI_PIECES")) np = std::atol(v);
+            np = std::max(1L, std::min({np, 16L, (long)NCH}));
+            const int m = (NCH + (int)np - 1) / (int)np;
+            for (int c0 = 0; c0 < NCH; c0 += m) {
+                const int nch = std::min(m, NCH - c0);
+                pieces.push_back({c0 * CH, std::min(K, (c0 + nch) * CH), c0, nch});
+            }
+            if (pieces.size() > 1) {
+                for (auto& st : s_roll) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+                HIPCHK(hipStreamCreateWithFlags(&s_upd, hipStreamNonBlocking));
+                HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+                HIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+                ev_piece.resize(pieces.size());
+                for (auto& e : ev_piece) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            }
         }
-
         const size_t Ks = (size_t)P.Ks;
         {
             void* p = nullptr;
@@ -310,6 +367,9 @@ struct mppi_engine {
             HIPCHK(hipMalloc(&p, bytes)); hbm_bytes += bytes; d_dP = p;
             bytes = (size_t)A * Ks * esz();
             HIPCHK(hipMalloc(&p, bytes)); hbm_bytes += bytes; d_stot = p;
+            bytes = (size_t)A * T * 2 * (Ks / 64) * esz();
+            HIPCHK(hipMalloc(&p, bytes)); hbm_bytes += bytes; d_epart = p;
+            HIPCHK(hipMemsetAsync(d_epart, 0, bytes, stream));
         }
         d_tc = dev_alloc<double>((size_t)A * T * mppi::kTcW, hbm_bytes);
         d_base = dev_alloc<double>((size_t)A * T, hbm_bytes);
@@ -351,8 +411,12 @@ struct mppi_engine {
         for (auto& p : pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
         for (auto e : ev_pool) hipEventDestroy(e);
         for (int i = 0; i < kRing; ++i) if (ring_ev[i]) hipEventDestroy(ring_ev[i]);
+        for (hipStream_t w : {s_roll[0], s_roll[1], s_upd}) if (w) { hipStreamSynchronize(w); hipStreamDestroy(w); }
+        for (auto e : ev_piece) hipEventDestroy(e);
+        if (ev_fork) hipEventDestroy(ev_fork);
+        if (ev_join) hipEventDestroy(ev_join);
         if (h_stage) hipHostFree(h_stage);
-        void* bufs[] = {d_eps, d_dP, d_stot, d_tc, d_base, d_unom, d_ufilt, d_state, d_goal, d_part, d_merged, d_S, d_out, d_tick, d_tmp};
+        void* bufs[] = {d_eps, d_dP, d_stot, d_epart, d_tc, d_base, d_unom, d_ufilt, d_state, d_goal, d_part, d_merged, d_S, d_out, d_tick, d_tmp};
         for (void* b : bufs) if (b) hipFree(b);
         if (own_stream) hipStreamDestroy(own_stream);
     }
@@ -479,6 +543,7 @@ int mppi_upload_noise(mppi_engine* h, const double* eps) {
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     h->noise_ready = true;
+    h->epart_ready = false;
     API_END(h)
 }
 
@@ -580,8 +645,7 @@ int mppi_tick_begin(mppi_engine* h, const double* state, const double* goal, int
     API_BEGIN(h)
     h->set_inputs(state, goal);
     h->run_nominal();
-    h->run_rollout(noise_mode, seed, tick_id, nullptr);
-    h->run_update();
+    h->run_pipeline(noise_mode, seed, tick_id, nullptr);
     API_END(h)
 }
 
@@ -632,8 +696,7 @@ int mppi_tick_graph(mppi_engine* h, uint64_t seed) {
         HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
         try {
             h->run_nominal();
-            h->run_rollout(MPPI_NOISE_PHILOX, seed, 0, h->d_tick);
-            h->run_update();
+            h->run_pipeline(MPPI_NOISE_PHILOX, seed, 0, h->d_tick);
             h->run_finalize(nullptr, 1, 1 | 2 | 4);
         } catch (...) {
             hipGraph_t g = nullptr;

@@ -10,8 +10,8 @@
 //   rollout_kernel   1 lane / sample    noise -> clip -> RK4 step -> stage cost, all in registers;
 //                                       writes eps[a][t][2][K] and the running cost prefix
 //                                       dP[a][t][K] (+ one total per sample): 12 B/step to HBM
-//   update_kernel    1 block / (chunk,t,a)  streaming per-timestep online softmax over K
-//                                       (reads the 12 B/step back) -> partial tuples
+//   update_kernel    1 block / (chunk,t,a)  per-timestep softmax over K: reads the cost prefix back
+//                                       (4 B/step) and eps only for the few samples with weight
 //   merge_kernel     1 wave / (t,a)     merges chunk partials -> shard partial [A][T][8]
 //   finalize_kernel  1 block / agent    merges shard partials (after the RCCL all-gather),
 //                                       control update, clip, Savitzky-Golay, clip, plant step, shift
@@ -164,6 +164,47 @@ __global__ __launch_bounds__(kNomThreads) void nominal_kernel(DevParams P, const
     }
 }
 
+template <typename R> struct Exp2;
+template <> struct Exp2<float> {
+    // arguments are <= 0 here: the bare v_exp_f32 (flush-to-zero below 2^-126) is exactly what a
+    // softmax weight wants; exp2f() would add denormal-range rescaling around it
+    static __device__ __forceinline__ float f(float v) { return __builtin_amdgcn_exp2f(v); }
+};
+template <> struct Exp2<double> {
+    static __device__ __forceinline__ double f(double v) { return exp2(v); }
+};
+
+template <typename R>
+__device__ __forceinline__ R wave_min(R v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+    return v;
+}
+template <typename R>
+__device__ __forceinline__ R wave_sum(R v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+
+// 64-lane sum with DPP adds only (no LDS traffic): after the four row steps every lane of a
+// 16-lane row holds its row sum, row_bcast15 / row_bcast31 chain the rows; LANE 63 holds the total.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+    v += dpp_mov<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141, 0xF>(v);  // row_half_mirror
+    v += dpp_mov<0x140, 0xF>(v);  // row_mirror
+    v += dpp_mov<0x142, 0xA>(v);  // row_bcast:15 -> rows 1, 3
+    v += dpp_mov<0x143, 0xC>(v);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+__device__ __forceinline__ double wave_sum_lane63(double v) { return wave_sum(v); }
+
 // ---------------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11) -- the generator hipRAND exposes as
 // HIPRAND_RNG_PSEUDO_PHILOX4_32_10 -- inlined so that (seed, tick, agent, global sample, t)
@@ -217,10 +258,11 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double*
                                                      const double* __restrict__ goal,
                                                      const double* __restrict__ tc, S* __restrict__ eps,
                                                      S* __restrict__ dP, S* __restrict__ Stot, uint64_t seed,
-                                                     uint32_t tick_arg, const uint32_t* __restrict__ tick_ptr) {
+                                                     uint32_t tick_arg, const uint32_t* __restrict__ tick_ptr,
+                                                     int k_first, int k_last, S* __restrict__ epart) {
     const int tid = threadIdx.x, a = blockIdx.y, T = P.T;
-    const int k = blockIdx.x * blockDim.x + tid;
-    const bool active = k < P.K;
+    const int k = k_first + blockIdx.x * blockDim.x + tid;  // this launch covers samples [k_first, k_last)
+    const bool active = k < k_last;
     const size_t Ks = (size_t)P.Ks;
     const double gx = goal[a * 3 + 0], gy = goal[a * 3 + 1], gth = goal[a * 3 + 2];
     double x = state[a * 3 + 0], y = state[a * 3 + 1], th = state[a * 3 + 2];
@@ -232,6 +274,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double*
     const double half_kd = 0.5 * P.kth * P.dt;             // phi = half_kd * (u1 - u0) = h / 2
     const double sixth_rd = P.dt * P.rhalf * (1.0 / 6.0);  // Simpson weight of (u0 + u1)
     const double hq0 = 0.5 * P.q0, hq1 = 0.5 * P.q1, hq2 = 0.5 * P.q2;
+    const size_t NW = Ks >> 6;  // waves per agent row (Ks is a multiple of 64)
 
     uint32_t key0 = 0, key1 = 0, ctr0 = 0, tick = 0;
     float sigf = 0.f;
@@ -278,6 +321,15 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double*
                 const double* tcp = tca + (size_t)t * kTcW;  // uniform -> scalar loads
                 const double un0 = tcp[0], un1 = tcp[1], w0 = tcp[2], w1 = tcp[3], cb = tcp[4];
                 const double e0 = (double)cur[j][0], e1 = (double)cur[j][1];
+                {   // sum_k eps per wave and step (the E of the softmax floor term, control/src/mppi:193):
+                    // 2 x 6 DPP adds here save the update kernel from reading eps (8 of its 12 B/step)
+                    const S w0s = wave_sum_lane63(active ? cur[j][0] : (S)0);
+                    const S w1s = wave_sum_lane63(active ? cur[j][1] : (S)0);
+                    if ((tid & 63) == 63 && (size_t)(k >> 6) < NW) {
+                        S* ep = epart + (((size_t)a * T + t) * 2) * NW + (k >> 6);
+                        ep[0] = w0s; ep[NW] = w1s;
+                    }
+                }
                 if (active) {
                     if (PHILOX) {
                         eps_a[(size_t)(t * 2 + 0) * Ks] = cur[j][0];
@@ -329,151 +381,110 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double*
 }
 
 // ---------------------------------------------------------------------------------------------
-// update_kernel: the K-reduction of MPPI.update_action (control/src/mppi:187-196) as a single
-// streaming pass.  Per timestep the reference needs min_k V, sum_k w and sum_k eps*w with
-// w = exp(-(V - min)/lam) + 1e-8.  Each lane keeps an online-softmax tuple (running min m,
-// D = sum e, N = sum e*eps, E = sum eps) so V and eps are read exactly once (12 B/step fp32);
-// the 1e-8 floor is applied at merge time as floor*count / floor*E.
-// grid = (T, NCH, A) x 256 threads; block (t,ch,a) owns samples [ch*CH, min(K,(ch+1)*CH)).
-// part[a][t][ch] = {m, D, N0, N1, E0, E1, count, 0} (float64).
+// update_kernel: the K-reduction of MPPI.update_action (control/src/mppi:187-196).  Per timestep
+// the reference needs min_k V, sum_k w and sum_k eps*w with w = exp(-(V - min)/lam) + 1e-8.
+//   w = e + floor  =>  sum w = D + floor*K,  sum eps*w = N + floor*E   (floor applied at merge time)
+// E = sum eps comes from the rollout kernel's per-wave sums, and e underflows to exactly 0 for
+// every sample more than ~0.06 (= 60 lam) above the row minimum, so eps is fetched ONLY for the
+// handful of samples that carry weight: the kernel streams 4 B/step (dP) instead of 12.
+// Block (t, ch, a) keeps its chunk of v = Stot - dP in registers (kUpdNV 16-byte vectors per lane):
+//   pass 1  load, block minimum M;   pass 2  e = exp2((M - v) * log2e/lam), D += e, and for lanes
+//   with e > 2^-kCand: N += e * eps  (predicated scalar loads, wave-uniformly skipped otherwise).
+// grid = (T, chunks of this launch, A) x 256 threads; part[a][t][ch] = {M, D, N0, N1, -, -, count, 0}.
 // ---------------------------------------------------------------------------------------------
-template <typename R> struct Exp2;
-template <> struct Exp2<float> {
-    // arguments are <= 0 here: the bare v_exp_f32 (flush-to-zero below 2^-126) is exactly what a
-    // softmax weight wants; exp2f() would add denormal-range rescaling around it
-    static __device__ __forceinline__ float f(float v) { return __builtin_amdgcn_exp2f(v); }
-};
-template <> struct Exp2<double> {
-    static __device__ __forceinline__ double f(double v) { return exp2(v); }
-};
+constexpr int kUpdNV = 8;  // 16-byte vectors per lane: chunk = 256 * kUpdNV * (16 / sizeof(S)) samples
+template <typename S> struct UpdCfg { static constexpr int VEC = 16 / (int)sizeof(S); static constexpr int CH = 256 * kUpdNV * VEC; };
 
-template <typename R>
-__device__ __forceinline__ R wave_min(R v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
-    return v;
-}
-template <typename R>
-__device__ __forceinline__ R wave_sum(R v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
-template <typename S, int MODE>
+template <typename S>
 __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __restrict__ eps,
                                                     const S* __restrict__ dP, const S* __restrict__ Stot,
-                                                    double* __restrict__ part, int NCH, int CH) {
-    using R = S;                                        // accumulate in the storage precision
-    constexpr int VEC = 16 / (int)sizeof(S);            // elements per 16-byte lane load
+                                                    double* __restrict__ part, int NCH, int ch_first) {
+    using R = S;
+    constexpr int VEC = UpdCfg<S>::VEC, CH = UpdCfg<S>::CH;
+    typedef S vec_t __attribute__((ext_vector_type(VEC)));
     // blockIdx.x = t (fastest): the T blocks that share one chunk of Stot are dispatched back to
-    // back, so each XCD's L2 fetches that chunk once instead of once per timestep
-    const int t = (MODE & 2) ? blockIdx.y : blockIdx.x, ch = (MODE & 2) ? blockIdx.x : blockIdx.y;
-    const int a = blockIdx.z, tid = threadIdx.x;
+    // back, so each XCD's L2 fetches that chunk once instead of once per timestep.  Chunks are
+    // walked from the highest k down: the rollout kernel wrote the high-k columns last, so they
+    // are the part still resident in the 256 MB Infinity Cache.
+    const int t = blockIdx.x, ch = ch_first + (int)gridDim.y - 1 - (int)blockIdx.y;
+    const int a = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const size_t Ks = (size_t)P.Ks;
     const S* v_row = dP + ((size_t)a * P.T + t) * Ks;   // exclusive cost prefix of row t
-    const S* s_row = Stot + (size_t)a * Ks;               // per-sample total (L2-resident, re-read per t)
+    const S* s_row = Stot + (size_t)a * Ks;               // per-sample totals (L2-resident, re-read per t)
     const S* e0_row = eps + (((size_t)a * P.T + t) * 2 + 0) * Ks;
     const S* e1_row = e0_row + Ks;
     const int k_begin = ch * CH;
     const int k_end = min(P.K, k_begin + CH);
-    const R scale = (R)(P.inv_lambda * 1.4426950408889634);  // log2(e) / lambda
-    R m = (R)INFINITY, D = 0, N0 = 0, N1 = 0, E0 = 0, E1 = 0;
-
-    auto accumulate = [&](const S (&v)[VEC], const S (&a0)[VEC], const S (&a1)[VEC]) {
-        if (MODE & 1) {  // timing probe: memory traffic only
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) { D += v[i]; E0 += a0[i]; E1 += a1[i]; }
-            return;
-        }
-        R vm = v[0];
-#pragma unroll
-        for (int i = 1; i < VEC; ++i) vm = fmin(vm, v[i]);
-        if (vm < m) {  // new running minimum: rescale what has been accumulated
-            const R sc = Exp2<R>::f((vm - m) * scale);  // m = +inf the first time -> 0
-            D *= sc; N0 *= sc; N1 *= sc;
-            m = vm;
-        }
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            const R e = Exp2<R>::f((m - v[i]) * scale);
-            D += e;
-            N0 = fma(e, (R)a0[i], N0);
-            N1 = fma(e, (R)a1[i], N1);
-            E0 += a0[i];
-            E1 += a1[i];
-        }
-    };
-    typedef S vec_t __attribute__((ext_vector_type(VEC)));
-    constexpr int STRIDE = 256 * VEC;
-    int k = k_begin + tid * VEC;
-    // two 16-byte vectors of each of the 4 streams in flight per lane (rows are 256-byte aligned
-    // and k % VEC == 0, so every vector load is 16-byte aligned)
-    for (; k + STRIDE + VEC <= k_end; k += 2 * STRIDE) {
-        const vec_t vA = *reinterpret_cast<const vec_t*>(v_row + k);
-        const vec_t sA = *reinterpret_cast<const vec_t*>(s_row + k);
-        const vec_t xA = *reinterpret_cast<const vec_t*>(e0_row + k);
-        const vec_t yA = *reinterpret_cast<const vec_t*>(e1_row + k);
-        const vec_t vB = *reinterpret_cast<const vec_t*>(v_row + k + STRIDE);
-        const vec_t sB = *reinterpret_cast<const vec_t*>(s_row + k + STRIDE);
-        const vec_t xB = *reinterpret_cast<const vec_t*>(e0_row + k + STRIDE);
-        const vec_t yB = *reinterpret_cast<const vec_t*>(e1_row + k + STRIDE);
-        S v[VEC], a0[VEC], a1[VEC];
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) { v[i] = sA[i] - vA[i]; a0[i] = xA[i]; a1[i] = yA[i]; }
-        accumulate(v, a0, a1);
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) { v[i] = sB[i] - vB[i]; a0[i] = xB[i]; a1[i] = yB[i]; }
-        accumulate(v, a0, a1);
+    double* o = part + (((size_t)a * P.T + t) * NCH + ch) * kTupleW;
+    if (k_end <= k_begin) {  // empty chunk (uniform)
+        if (tid == 0) { o[0] = INFINITY; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = 0; o[7] = 0; }
+        return;
     }
-    for (; k < k_end; k += STRIDE) {
-        S v[VEC], a0[VEC], a1[VEC];
-        if (k + VEC <= k_end) {
-            const vec_t vv = *reinterpret_cast<const vec_t*>(v_row + k);
-            const vec_t ss = *reinterpret_cast<const vec_t*>(s_row + k);
-            const vec_t x0 = *reinterpret_cast<const vec_t*>(e0_row + k);
-            const vec_t x1 = *reinterpret_cast<const vec_t*>(e1_row + k);
+    __shared__ R red[4][4];
+
+    // pass 1: the chunk into registers, lane minimum
+    S v[kUpdNV][VEC];
+    R m = (R)INFINITY;
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) { v[i] = ss[i] - vv[i]; a0[i] = x0[i]; a1[i] = x1[i]; }
+    for (int j = 0; j < kUpdNV; ++j) {
+        const int k = k_begin + (j * 256 + tid) * VEC;
+        if (k + VEC <= k_end) {  // rows are 256-byte aligned and k % VEC == 0: 16-byte aligned loads
+            const vec_t pv = *reinterpret_cast<const vec_t*>(v_row + k);
+            const vec_t sv = *reinterpret_cast<const vec_t*>(s_row + k);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v[j][i] = sv[i] - pv[i];
         } else {
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) {
-                const bool ok = k + i < k_end;
-                v[i] = ok ? s_row[k + i] - v_row[k + i] : (S)INFINITY;  // weight 0, eps 0: no contribution
-                a0[i] = ok ? e0_row[k + i] : (S)0;
-                a1[i] = ok ? e1_row[k + i] : (S)0;
+            for (int i = 0; i < VEC; ++i) v[j][i] = (k + i < k_end) ? s_row[k + i] - v_row[k + i] : (S)INFINITY;
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) m = fmin(m, v[j][i]);
+    }
+    m = wave_min(m);
+    if (lane == 0) red[wid][0] = m;
+    __syncthreads();
+    const R M = fmin(fmin(red[0][0], red[1][0]), fmin(red[2][0], red[3][0]));
+    __syncthreads();
+
+    // pass 2: weights relative to the block minimum; eps only where the weight is representable
+    const R scale = (R)(P.inv_lambda * 1.4426950408889634);  // log2(e) / lambda
+    const R cand = (R)(sizeof(S) == 4 ? -80.0 : -100.0);     // log2 of the smallest weight that is kept
+    R D = 0, N0 = 0, N1 = 0;
+#pragma unroll
+    for (int j = 0; j < kUpdNV; ++j) {
+        const int k = k_begin + (j * 256 + tid) * VEC;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const R x = (M - v[j][i]) * scale;  // <= 0; -inf for the padding
+            const R e = Exp2<R>::f(x);
+            D += e;
+            if (x > cand) {  // rare: wave-uniformly skipped for almost every vector
+                N0 = fma(e, (R)e0_row[k + i], N0);
+                N1 = fma(e, (R)e1_row[k + i], N1);
             }
         }
-        accumulate(v, a0, a1);
     }
-    // lanes -> wave -> block
-    __shared__ R red[4][6];
-    const R wm = wave_min(m);
-    {
-        const R sc = (m == (R)INFINITY) ? (R)0 : Exp2<R>::f((wm - m) * scale);
-        D *= sc; N0 *= sc; N1 *= sc;
-    }
-    D = wave_sum(D); N0 = wave_sum(N0); N1 = wave_sum(N1); E0 = wave_sum(E0); E1 = wave_sum(E1);
-    const int wid = tid >> 6, lane = tid & 63;
-    if (lane == 0) { red[wid][0] = wm; red[wid][1] = D; red[wid][2] = N0; red[wid][3] = N1; red[wid][4] = E0; red[wid][5] = E1; }
+    D = wave_sum(D); N0 = wave_sum(N0); N1 = wave_sum(N1);
+    if (lane == 0) { red[wid][1] = D; red[wid][2] = N0; red[wid][3] = N1; }
     __syncthreads();
-    if (wid == 0) {  // 4 wave tuples -> 1, in parallel on wave 0 (lanes 0..3 hold one tuple each)
-        const bool has = lane < 4;
-        const R mw = has ? red[lane][0] : (R)INFINITY;
-        const R M = wave_min(mw);
-        const R sc = (mw == (R)INFINITY) ? (R)0 : Exp2<R>::f((M - mw) * scale);
-        const R d = wave_sum(has ? sc * red[lane][1] : (R)0);
-        const R n0 = wave_sum(has ? sc * red[lane][2] : (R)0);
-        const R n1 = wave_sum(has ? sc * red[lane][3] : (R)0);
-        const R e0 = wave_sum(has ? red[lane][4] : (R)0);
-        const R e1 = wave_sum(has ? red[lane][5] : (R)0);
-        if (lane == 0) {
-            double* o = part + (((size_t)a * P.T + t) * NCH + ch) * kTupleW;
-            o[0] = (double)M; o[1] = (double)d; o[2] = (double)n0; o[3] = (double)n1;
-            o[4] = (double)e0; o[5] = (double)e1;
-            o[6] = (double)max(0, k_end - k_begin); o[7] = 0.0;
-        }
+    if (tid == 0) {
+        o[0] = (double)M;
+        o[1] = (double)red[0][1] + (double)red[1][1] + (double)red[2][1] + (double)red[3][1];
+        o[2] = (double)red[0][2] + (double)red[1][2] + (double)red[2][2] + (double)red[3][2];
+        o[3] = (double)red[0][3] + (double)red[1][3] + (double)red[2][3] + (double)red[3][3];
+        o[4] = 0.0; o[5] = 0.0; o[6] = (double)(k_end - k_begin); o[7] = 0.0;
     }
+}
+
+// per-wave sums of eps for noise that did not come out of a rollout (mppi_upload_noise followed
+// directly by mppi_update): same layout as the rollout kernel's epart.  grid = (ceil(K/256), T*2, A)
+template <typename S>
+__global__ __launch_bounds__(256) void eps_wavesum_kernel(DevParams P, const S* __restrict__ eps, S* __restrict__ epart) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const size_t row = (size_t)blockIdx.z * P.T * 2 + blockIdx.y, Ks = (size_t)P.Ks, NW = Ks >> 6;
+    const S val = (k < P.K) ? eps[row * Ks + k] : (S)0;
+    const S sum = wave_sum_lane63(val);
+    if ((threadIdx.x & 63) == 63 && (size_t)(k >> 6) < NW) epart[row * NW + (k >> 6)] = sum;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -481,27 +492,42 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
 // E, count add.  Exact algebra of splitting the K-sum of control/src/mppi:189-196.
 // merge_kernel: one wave per (t, a) reduces the NCH chunk tuples of this shard.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void merge_kernel(DevParams P, const double* __restrict__ part, int NCH,
-                                                  double* __restrict__ merged) {
-    const int t = blockIdx.x, a = blockIdx.y, lane = threadIdx.x;
+constexpr int kMergeThreads = 1024;
+template <typename S>
+__global__ __launch_bounds__(kMergeThreads) void merge_kernel(DevParams P, const double* __restrict__ part, int NCH,
+                                                             const S* __restrict__ epart, double* __restrict__ merged) {
+    const int t = blockIdx.x, a = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    __shared__ double red[kMergeThreads / 64][2];
+    // E = sum_k eps: the per-wave sums written by the rollout (or eps_wavesum) kernel, all 16 waves
+    const size_t NW = (size_t)P.Ks >> 6, nw_used = ((size_t)P.K + 63) >> 6;
+    const S* ep = epart + (((size_t)a * P.T + t) * 2) * NW;
+    double e0 = 0, e1 = 0;
+#pragma unroll 4
+    for (size_t i = tid; i < nw_used; i += kMergeThreads) { e0 += (double)ep[i]; e1 += (double)ep[NW + i]; }
+    e0 = wave_sum(e0); e1 = wave_sum(e1);
+    if (lane == 0) { red[wid][0] = e0; red[wid][1] = e1; }
+    __syncthreads();
+    if (wid != 0) return;
+    // chunk tuples: wave 0
     const double* src = part + ((size_t)a * P.T + t) * NCH * kTupleW;
     double m = INFINITY;
     for (int i = lane; i < NCH; i += 64)
         if (src[i * kTupleW + 6] > 0.0) m = fmin(m, src[i * kTupleW]);
     const double M = wave_min(m);
-    double d = 0, n0 = 0, n1 = 0, e0 = 0, e1 = 0, cnt = 0;
+    double d = 0, n0 = 0, n1 = 0, cnt = 0;
     for (int i = lane; i < NCH; i += 64) {
         const double* q = src + i * kTupleW;
         if (q[6] > 0.0) {
             const double sc = exp((M - q[0]) * P.inv_lambda);
-            d += sc * q[1]; n0 += sc * q[2]; n1 += sc * q[3]; e0 += q[4]; e1 += q[5]; cnt += q[6];
+            d += sc * q[1]; n0 += sc * q[2]; n1 += sc * q[3]; cnt += q[6];
         }
     }
-    d = wave_sum(d); n0 = wave_sum(n0); n1 = wave_sum(n1);
-    e0 = wave_sum(e0); e1 = wave_sum(e1); cnt = wave_sum(cnt);
+    d = wave_sum(d); n0 = wave_sum(n0); n1 = wave_sum(n1); cnt = wave_sum(cnt);
     if (lane == 0) {
+        double s0 = 0, s1 = 0;
+        for (int w = 0; w < kMergeThreads / 64; ++w) { s0 += red[w][0]; s1 += red[w][1]; }
         double* o = merged + ((size_t)a * P.T + t) * kTupleW;
-        o[0] = M; o[1] = d; o[2] = n0; o[3] = n1; o[4] = e0; o[5] = e1; o[6] = cnt; o[7] = 0.0;
+        o[0] = M; o[1] = d; o[2] = n0; o[3] = n1; o[4] = s0; o[5] = s1; o[6] = cnt; o[7] = 0.0;
     }
 }
 

@@ -333,6 +333,37 @@ def test_update_properties(orc):
         assert np.abs(u - np.clip((u0 + eps.mean(axis=2).T) @ S, -6.35492, 6.35492)).max() < 1e-9
 
 
+@pytest.mark.parametrize("storage", ["f64", "f32"])
+def test_floor_term_uses_sum_of_eps(orc, storage):
+    """The +1e-8 weight floor (control/src/mppi:193) couples the update to sum_k eps.  With the
+    floor raised to 1.0 that term dominates, which pins the per-wave eps sums the rollout kernel
+    produces (and the standalone path after mppi_upload_noise) -- injected and device noise."""
+    K, T = 3000, 20
+    u0 = 0.5 * np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
+    state, goal = [0.0, 0.0, 0.2], [0.4, -0.3, 0.0]
+    p = orc.default_params()
+    p.floor_w = 1.0
+    eps = _round_eps(orc.reference_noise(21, SIG, T, K), storage)
+    tol = 1e-9 if storage == "f64" else 2e-6
+    with _engine(K, T, storage, floor_w=1.0) as e:
+        # (a) full tick, injected noise: E comes from the rollout kernel
+        e.set_nominal(u0); e.upload_noise(eps)
+        nxt, ua = e.tick(state, goal, noise="injected")
+        so, uo, lo = orc.get_path(state, goal, u0, eps, LAM, SIG, params=p)
+        assert np.abs(ua[0] - uo).max() < tol and np.abs(e.get_nominal() - lo).max() < tol
+        # (b) update_action alone on uploaded V / eps: E comes from the standalone wave-sum kernel
+        V = orc.get_cost2go(state, u0, goal, LAM, SIG, eps)
+        e.set_nominal(u0); e.upload_noise(eps); e.upload_value(V)
+        u = e.update()[0]
+        assert np.abs(u - orc.update_action(u0, eps, V, LAM, params=p)).max() < tol
+        # (c) device noise
+        e.set_nominal(u0)
+        nxt, ua = e.tick(state, goal, noise="philox", seed=5, tick_id=2)
+        dev = e.download_noise()[0]
+        so, uo, _ = orc.get_path(state, goal, u0, dev, LAM, SIG, params=p)
+        assert np.abs(ua[0] - uo).max() < tol
+
+
 @pytest.mark.parametrize("K,T", [(100000, 100), (1000000, 50)])
 def test_full_size_properties(orc, K, T):
     """BASELINE configs 3 and 4 at full size (device RNG).  The oracle cannot replay 5e7 steps
