@@ -84,6 +84,11 @@ struct mppi_engine {
     void* d_stot = nullptr;  // S [A][Ks]     per-sample total of the same
     void* d_epart = nullptr; // S [A][T][2][Ks/64]  per-wave sums of eps (E of the floor term)
     bool epart_ready = false;
+    // device noise that was drawn but not stored (tick path): regenerated on demand from these
+    bool eps_lazy = false, lazy_from_counter = false, lazy_counter_bumped = false;
+    uint64_t lazy_seed = 0;
+    uint32_t lazy_tick = 0;
+    bool store_eps_always = false;  // MPPI_STORE_EPS=1: the tick path writes eps like mppi_rollout does
     double* d_tc = nullptr;  // [A][T][8]
     double* d_base = nullptr;
     double* d_unom = nullptr;
@@ -181,55 +186,71 @@ struct mppi_engine {
         if (!have_state || !have_goal) fail(MPPI_E_STATE, "state/goal passed as NULL before ever being set");
     }
 
-    template <typename S, int NT, bool PH, bool FB>
+    template <typename S, int NT, bool PH, bool SE>
     void launch_rollout_f(hipStream_t st, int k0, int k1, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
-        auto kern = mppi::rollout_kernel<S, NT, PH, FB>;
+        auto kern = mppi::rollout_kernel<S, NT, PH, SE>;
         dim3 grid((k1 - k0 + roll_bs - 1) / roll_bs, cfg.n_agents);
         hipLaunchKernelGGL(kern, grid, dim3(roll_bs), 0, st, P, d_state, d_goal, d_tc, static_cast<S*>(d_eps),
                            static_cast<S*>(d_dP), static_cast<S*>(d_stot), seed, tick, tick_ptr, k0, k1,
                            static_cast<S*>(d_epart));
         HIPCHK(hipGetLastError());
     }
-    template <typename S, int NT, bool PH>
-    void launch_rollout_t(hipStream_t st, int k0, int k1, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
-        if (!PH) launch_rollout_f<S, NT, false, false>(st, k0, k1, seed, tick, tick_ptr);
-        else if (variant & 1) launch_rollout_f<S, NT, PH, false>(st, k0, k1, seed, tick, tick_ptr);
-        else launch_rollout_f<S, NT, PH, true>(st, k0, k1, seed, tick, tick_ptr);
+    template <typename S, int NT>
+    void launch_rollout_t(hipStream_t st, int k0, int k1, bool ph, bool store, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
+        if (!ph) launch_rollout_f<S, NT, false, false>(st, k0, k1, seed, tick, tick_ptr);
+        else if (store) launch_rollout_f<S, NT, true, true>(st, k0, k1, seed, tick, tick_ptr);
+        else launch_rollout_f<S, NT, true, false>(st, k0, k1, seed, tick, tick_ptr);
     }
-    template <typename S, bool PH>
-    void launch_rollout_s(hipStream_t st, int k0, int k1, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
-        if (nterm == 4) launch_rollout_t<S, 4, PH>(st, k0, k1, seed, tick, tick_ptr);
-        else if (nterm == 7) launch_rollout_t<S, 7, PH>(st, k0, k1, seed, tick, tick_ptr);
-        else launch_rollout_t<S, 0, PH>(st, k0, k1, seed, tick, tick_ptr);
+    template <typename S>
+    void launch_rollout_s(hipStream_t st, int k0, int k1, bool ph, bool store, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
+        if (nterm == 4) launch_rollout_t<S, 4>(st, k0, k1, ph, store, seed, tick, tick_ptr);
+        else if (nterm == 7) launch_rollout_t<S, 7>(st, k0, k1, ph, store, seed, tick, tick_ptr);
+        else launch_rollout_t<S, 0>(st, k0, k1, ph, store, seed, tick, tick_ptr);
     }
-    void launch_rollout(hipStream_t st, int k0, int k1, bool ph, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
+    void launch_rollout(hipStream_t st, int k0, int k1, bool ph, bool store, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
         Scope sc(this, MPPI_KERNEL_ROLLOUT, st);
-        if (f64()) { if (ph) launch_rollout_s<double, true>(st, k0, k1, seed, tick, tick_ptr); else launch_rollout_s<double, false>(st, k0, k1, seed, tick, tick_ptr); }
-        else { if (ph) launch_rollout_s<float, true>(st, k0, k1, seed, tick, tick_ptr); else launch_rollout_s<float, false>(st, k0, k1, seed, tick, tick_ptr); }
+        if (f64()) launch_rollout_s<double>(st, k0, k1, ph, store, seed, tick, tick_ptr);
+        else launch_rollout_s<float>(st, k0, k1, ph, store, seed, tick, tick_ptr);
     }
-    void launch_update(hipStream_t st, int ch0, int nch) {
+    // write the lazily-drawn noise of the last tick into d_eps (bit-identical re-draw)
+    void materialise_eps() {
+        if (!eps_lazy) return;
+        uint32_t tick = lazy_tick;
+        if (lazy_from_counter) {
+            HIPCHK(hipMemcpyAsync(&tick, d_tick, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            if (lazy_counter_bumped) tick -= 1u;
+        }
+        dim3 g((cfg.samples + 255) / 256, (cfg.horizon + 1) / 2, cfg.n_agents);
+        if (f64()) hipLaunchKernelGGL(mppi::eps_regen_kernel<double>, g, dim3(256), 0, stream, P, static_cast<double*>(d_eps), lazy_seed, tick);
+        else hipLaunchKernelGGL(mppi::eps_regen_kernel<float>, g, dim3(256), 0, stream, P, static_cast<float*>(d_eps), lazy_seed, tick);
+        HIPCHK(hipGetLastError());
+        eps_lazy = false;
+    }
+    void ensure_epart(hipStream_t st) {
+        if (epart_ready) return;  // noise uploaded by the caller and never rolled out: sum it now
+        dim3 g((cfg.samples + 255) / 256, cfg.horizon * 2, cfg.n_agents);
+        if (f64()) hipLaunchKernelGGL(mppi::eps_wavesum_kernel<double>, g, dim3(256), 0, st, P, static_cast<const double*>(d_eps), static_cast<double*>(d_epart));
+        else hipLaunchKernelGGL(mppi::eps_wavesum_kernel<float>, g, dim3(256), 0, st, P, static_cast<const float*>(d_eps), static_cast<float*>(d_epart));
+        HIPCHK(hipGetLastError());
+        epart_ready = true;
+    }
+    void launch_update(hipStream_t st, int ch0, int nch, const uint32_t* tick_ptr = nullptr) {
+        ensure_epart(st);
         Scope sc(this, MPPI_KERNEL_UPDATE, st);
         dim3 grid(cfg.horizon, nch, cfg.n_agents);
-        if (f64())
-            hipLaunchKernelGGL(mppi::update_kernel<double>, grid, dim3(256), 0, st, P, static_cast<const double*>(d_eps),
-                               static_cast<const double*>(d_dP), static_cast<const double*>(d_stot), d_part, NCH, ch0);
-        else
-            hipLaunchKernelGGL(mppi::update_kernel<float>, grid, dim3(256), 0, st, P, static_cast<const float*>(d_eps),
-                               static_cast<const float*>(d_dP), static_cast<const float*>(d_stot), d_part, NCH, ch0);
+#define LAUNCH_UPD(TYPE, REGEN)                                                                                  \
+    hipLaunchKernelGGL((mppi::update_kernel<TYPE, REGEN>), grid, dim3(256), 0, st, P, static_cast<const TYPE*>(d_eps), \
+                       static_cast<const TYPE*>(d_dP), static_cast<const TYPE*>(d_stot), d_part, NCH, ch0,         \
+                       static_cast<const TYPE*>(d_epart), lazy_seed, lazy_tick, tick_ptr)
+        if (f64()) { if (eps_lazy) LAUNCH_UPD(double, true); else LAUNCH_UPD(double, false); }
+        else { if (eps_lazy) LAUNCH_UPD(float, true); else LAUNCH_UPD(float, false); }
+#undef LAUNCH_UPD
         HIPCHK(hipGetLastError());
     }
     void launch_merge() {
         Scope sc(this, MPPI_KERNEL_MERGE);
-        if (!epart_ready) {  // noise uploaded by the caller and never rolled out: sum it now
-            dim3 g((cfg.samples + 255) / 256, cfg.horizon * 2, cfg.n_agents);
-            if (f64()) hipLaunchKernelGGL(mppi::eps_wavesum_kernel<double>, g, dim3(256), 0, stream, P, static_cast<const double*>(d_eps), static_cast<double*>(d_epart));
-            else hipLaunchKernelGGL(mppi::eps_wavesum_kernel<float>, g, dim3(256), 0, stream, P, static_cast<const float*>(d_eps), static_cast<float*>(d_epart));
-            HIPCHK(hipGetLastError());
-            epart_ready = true;
-        }
-        dim3 grid(cfg.horizon, cfg.n_agents);
-        if (f64()) hipLaunchKernelGGL(mppi::merge_kernel<double>, grid, dim3(mppi::kMergeThreads), 0, stream, P, d_part, NCH, static_cast<const double*>(d_epart), d_merged);
-        else hipLaunchKernelGGL(mppi::merge_kernel<float>, grid, dim3(mppi::kMergeThreads), 0, stream, P, d_part, NCH, static_cast<const float*>(d_epart), d_merged);
+        hipLaunchKernelGGL(mppi::merge_kernel, dim3(cfg.horizon, cfg.n_agents), dim3(64), 0, stream, P, d_part, NCH, d_merged);
         HIPCHK(hipGetLastError());
     }
     void check_noise_mode(int noise_mode) {
@@ -242,9 +263,12 @@ struct mppi_engine {
     void run_pipeline(int noise_mode, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
         check_noise_mode(noise_mode);
         const bool ph = noise_mode == MPPI_NOISE_PHILOX;
+        const bool store = !ph || store_eps_always;
+        eps_lazy = ph && !store;
+        lazy_seed = seed; lazy_tick = tick; lazy_from_counter = tick_ptr != nullptr; lazy_counter_bumped = false;
         if (pieces.size() <= 1) {
-            launch_rollout(stream, 0, cfg.samples, ph, seed, tick, tick_ptr);
-            launch_update(stream, 0, NCH);
+            launch_rollout(stream, 0, cfg.samples, ph, store, seed, tick, tick_ptr);
+            launch_update(stream, 0, NCH, tick_ptr);
         } else {
             HIPCHK(hipEventRecord(ev_fork, stream));
             HIPCHK(hipStreamWaitEvent(s_roll[0], ev_fork, 0));
@@ -252,10 +276,10 @@ struct mppi_engine {
             for (size_t p = 0; p < pieces.size(); ++p) {
                 const Piece& pc = pieces[p];
                 hipStream_t sr = s_roll[p & 1];
-                launch_rollout(sr, pc.k0, pc.k1, ph, seed, tick, tick_ptr);
+                launch_rollout(sr, pc.k0, pc.k1, ph, store, seed, tick, tick_ptr);
                 HIPCHK(hipEventRecord(ev_piece[p], sr));
                 HIPCHK(hipStreamWaitEvent(s_upd, ev_piece[p], 0));
-                launch_update(s_upd, pc.ch0, pc.nch);
+                launch_update(s_upd, pc.ch0, pc.nch, tick_ptr);
             }
             HIPCHK(hipEventRecord(ev_join, s_upd));
             HIPCHK(hipStreamWaitEvent(stream, ev_join, 0));
@@ -271,11 +295,13 @@ struct mppi_engine {
     }
     void run_rollout(int noise_mode, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
         check_noise_mode(noise_mode);
-        launch_rollout(stream, 0, cfg.samples, noise_mode == MPPI_NOISE_PHILOX, seed, tick, tick_ptr);
+        launch_rollout(stream, 0, cfg.samples, noise_mode == MPPI_NOISE_PHILOX, true, seed, tick, tick_ptr);
+        eps_lazy = false;
         noise_ready = true; value_ready = true; partials_ready = false; epart_ready = true;
     }
     void run_update() {
         if (!noise_ready || !value_ready) fail(MPPI_E_STATE, "update needs a rollout (or uploaded V and eps) first");
+        materialise_eps();
         launch_update(stream, 0, NCH);
         launch_merge();
         partials_ready = true;
@@ -300,6 +326,7 @@ struct mppi_engine {
     void init(const mppi_config& c) {
         cfg = c;
         if (const char* v = std::getenv("MPPI_VARIANT")) variant = std::atoi(v);
+        if (const char* v = std::getenv("MPPI_STORE_EPS")) store_eps_always = std::atoi(v) != 0;
         if (cfg.n_agents < 1 || cfg.samples < 1) fail(MPPI_E_INVALID, "n_agents and samples must be >= 1");
         if (cfg.horizon < 5 || ((cfg.horizon - 1) % 2) == 0)
             fail(MPPI_E_INVALID, "horizon=%d: the Savitzky-Golay window horizon-1 must be odd and > 3 "
@@ -544,6 +571,7 @@ int mppi_upload_noise(mppi_engine* h, const double* eps) {
     HIPCHK(hipStreamSynchronize(h->stream));
     h->noise_ready = true;
     h->epart_ready = false;
+    h->eps_lazy = false;
     API_END(h)
 }
 
@@ -551,6 +579,7 @@ int mppi_download_noise(mppi_engine* h, double* eps) {
     API_BEGIN(h)
     if (!eps) fail(MPPI_E_INVALID, "eps is NULL");
     if (!h->noise_ready) fail(MPPI_E_STATE, "no noise resident");
+    h->materialise_eps();
     const int A = h->cfg.n_agents, T = h->cfg.horizon, K = h->cfg.samples;
     const size_t n = (size_t)A * T * 2 * K;
     h->ensure_tmp(n);
@@ -711,7 +740,8 @@ int mppi_tick_graph(mppi_engine* h, uint64_t seed) {
         h->time_mask = saved;
     }
     HIPCHK(hipGraphLaunch(h->graph_exec, h->stream));
-    h->noise_ready = true; h->value_ready = true; h->partials_ready = false;
+    h->noise_ready = true; h->value_ready = true; h->partials_ready = false; h->epart_ready = true;
+    h->eps_lazy = !h->store_eps_always; h->lazy_seed = seed; h->lazy_from_counter = true; h->lazy_counter_bumped = true;
     API_END(h)
 }
 

@@ -226,34 +226,40 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 
 // two N(0, sigma^2) draws from two 32-bit words: Box-Muller in fp32 on a 23-bit radius uniform
 // u1 = (w0>>9 + 1/2) / 2^23 in (0,1) and a 24-bit angle uniform u2 = (w1>>8) / 2^24 in [0,1)
-// (both exact in fp32).  FAST: the gfx950 transcendental units directly -- v_log_f32 (log2),
+// (both exact in fp32), on the gfx950 transcendental units directly -- v_log_f32 (log2),
 // v_sqrt_f32, v_sin_f32 / v_cos_f32 (argument in revolutions, exactly what Box-Muller wants).
-template <bool FAST>
+// Only multiplies follow the transcendentals, so every kernel that calls this with the same
+// words gets bit-identical noise (no contraction-dependent rounding).
 __device__ __forceinline__ void box_muller(uint32_t w0, uint32_t w1, float sigma, float& e0, float& e1) {
     const float u1 = ((float)(w0 >> 9) + 0.5f) * (1.0f / 8388608.0f);
     const float u2 = (float)(w1 >> 8) * (1.0f / 16777216.0f);
-    float r, sn, cs;
-    if (FAST) {
-        r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // -2 ln2 log2(u1)
-        sn = __builtin_amdgcn_sinf(u2);
-        cs = __builtin_amdgcn_cosf(u2);
-    } else {
-        r = sqrtf(-2.0f * logf(u1));
-        sincospif(2.0f * u2, &sn, &cs);
-    }
-    e0 = sigma * (r * cs);
-    e1 = sigma * (r * sn);
+    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // -2 ln2 log2(u1)
+    e0 = sigma * (r * __builtin_amdgcn_cosf(u2));
+    e1 = sigma * (r * __builtin_amdgcn_sinf(u2));
+}
+
+// the noise of global sample `gk`, agent a, steps 2*pair and 2*pair+1: e[0..1] and e[2..3]
+__device__ __forceinline__ void philox_normals(uint32_t gk, uint32_t pair, uint32_t tick, uint32_t a, uint32_t key0,
+                                               uint32_t key1, float sigf, float (&e)[4]) {
+    uint32_t o[4];
+    philox4x32_10(gk, pair, tick, a, key0, key1, o);
+    box_muller(o[0], o[1], sigf, e[0], e[1]);
+    box_muller(o[2], o[3], sigf, e[2], e[3]);
 }
 
 // ---------------------------------------------------------------------------------------------
 // rollout_kernel: MPPI.get_cost2go (control/src/mppi:127-178) for one sample per lane.
 //   S      storage type of eps / dP / Stot in HBM (float | double)
 //   NTERM  4 | 7: Taylor terms for the per-step heading rotation; 0: full sincos every step
-//   PHILOX true: draw eps in-kernel and WRITE it; false: READ the injected eps
+//   PHILOX true: draw eps in-kernel; false: READ the injected eps
+//   STORE_EPS (PHILOX only) write the drawn eps to HBM.  The tick path does not: the noise is a
+//          pure function of (seed, tick, agent, sample, t), so the update kernel regenerates the
+//          few values it needs and mppi_download_noise regenerates all of it on demand --
+//          8 of the 12 B/step never touch HBM.
 // grid = (ceil(K / 256), A), block = 256, no LDS.  Per lane and step: 2 eps + 1 dP element
 // through HBM, fully coalesced (consecutive lanes = consecutive k).
 // ---------------------------------------------------------------------------------------------
-template <typename S, int NTERM, bool PHILOX, bool FASTBM>
+template <typename S, int NTERM, bool PHILOX, bool STORE_EPS>
 __global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double* __restrict__ state,
                                                      const double* __restrict__ goal,
                                                      const double* __restrict__ tc, S* __restrict__ eps,
@@ -299,13 +305,10 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double*
     auto draw_chunk = [&](int t0, S (&buf)[U][2]) {  // U == 4: two Philox calls
 #pragma unroll
         for (int j = 0; j < U; j += 2) {
-            uint32_t o[4];
-            philox4x32_10(ctr0, (uint32_t)((t0 + j) >> 1), tick, (uint32_t)a, key0, key1, o);
-            float e0, e1, e2, e3;
-            box_muller<FASTBM>(o[0], o[1], sigf, e0, e1);
-            box_muller<FASTBM>(o[2], o[3], sigf, e2, e3);
-            buf[j][0] = (S)e0; buf[j][1] = (S)e1;
-            buf[j + 1][0] = (S)e2; buf[j + 1][1] = (S)e3;
+            float e[4];
+            philox_normals(ctr0, (uint32_t)((t0 + j) >> 1), tick, (uint32_t)a, key0, key1, sigf, e);
+            buf[j][0] = (S)e[0]; buf[j][1] = (S)e[1];
+            buf[j + 1][0] = (S)e[2]; buf[j + 1][1] = (S)e[3];
         }
     };
     if (!PHILOX) load_chunk(0, cur);
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double*
                     }
                 }
                 if (active) {
-                    if (PHILOX) {
+                    if (PHILOX && STORE_EPS) {
                         eps_a[(size_t)(t * 2 + 0) * Ks] = cur[j][0];
                         eps_a[(size_t)(t * 2 + 1) * Ks] = cur[j][1];
                     }
@@ -347,14 +350,19 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double*
                 if (NTERM == 0) {
                     sincos(th + phi, &s1, &c1);
                     sincos(th + 2.0 * phi, &s2, &c2);
+                    x = fma(aa, c + 4.0 * c1 + c2, x);
+                    y = fma(aa, s + 4.0 * s1 + s2, y);
                 } else {
                     double sp, cp;
                     small_sincos<NTERM>(phi, sp, cp);
                     c1 = c * cp - s * sp; s1 = s * cp + c * sp;
                     c2 = c1 * cp - s1 * sp; s2 = s1 * cp + c1 * sp;
+                    // Simpson weights k1 + 2 k2 + 2 k3 + k4: cos(th) + cos(th + 2 phi) = 2 cos(phi) cos(th + phi),
+                    // so the bracket is (4 + 2 cos phi) times the mid-step heading
+                    const double g = aa * fma(2.0, cp, 4.0);
+                    x = fma(g, c1, x);
+                    y = fma(g, s1, y);
                 }
-                x = fma(aa, c + 4.0 * c1 + c2, x);
-                y = fma(aa, s + 4.0 * s1 + s2, y);
                 th += 2.0 * phi;
                 // theta -> (-pi, pi] (control/src/mppi:52-53); the formula is the identity inside
                 // the interval, so only lanes that left it pay for the ceil/divide
@@ -362,12 +370,15 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double*
                 c = c2; s = s2;
                 // get_cost (control/src/mppi:180-184) minus the nominal stage cost (cb):
                 //   1/2 xQx + 1/2 uRu + lam*sig*(un . eps)  with u = NOMINAL, eps = UNCLIPPED
-                const double dx = x - gx, dy = y - gy, dth = th - gth;
-                double dc = fma(hq0 * dx, dx, fma(hq1 * dy, dy, fma(hq2 * dth, dth, cb)));
+                const double dx = x - gx, dy = y - gy;
+                double dc = fma(hq0 * dx, dx, fma(hq1 * dy, dy, cb));
+                if (hq2 != 0.0) { const double dth = th - gth; dc = fma(hq2 * dth, dth, dc); }  // Q[2,2] = 0 in the node
                 dc = fma(w0, e0, dc);
                 dc = fma(w1, e1, dc);
-                if (t == T - 1)  // terminal cost (control/src/mppi:165-173), theta error not wrapped
+                if (t == T - 1) {  // terminal cost (control/src/mppi:165-173), theta error not wrapped
+                    const double dth = th - gth;
                     dc += P.p0 * dx * dx + P.p1 * dy * dy + P.p2 * dth * dth;
+                }
                 pre += dc;
             }
         }
@@ -390,15 +401,17 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double*
 // Block (t, ch, a) keeps its chunk of v = Stot - dP in registers (kUpdNV 16-byte vectors per lane):
 //   pass 1  load, block minimum M;   pass 2  e = exp2((M - v) * log2e/lam), D += e, and for lanes
 //   with e > 2^-kCand: N += e * eps  (predicated scalar loads, wave-uniformly skipped otherwise).
-// grid = (T, chunks of this launch, A) x 256 threads; part[a][t][ch] = {M, D, N0, N1, -, -, count, 0}.
+// grid = (T, chunks of this launch, A) x 256 threads; part[a][t][ch] = {M, D, N0, N1, E0, E1, count, 0}.
 // ---------------------------------------------------------------------------------------------
 constexpr int kUpdNV = 8;  // 16-byte vectors per lane: chunk = 256 * kUpdNV * (16 / sizeof(S)) samples
 template <typename S> struct UpdCfg { static constexpr int VEC = 16 / (int)sizeof(S); static constexpr int CH = 256 * kUpdNV * VEC; };
 
-template <typename S>
+template <typename S, bool REGEN>
 __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __restrict__ eps,
                                                     const S* __restrict__ dP, const S* __restrict__ Stot,
-                                                    double* __restrict__ part, int NCH, int ch_first) {
+                                                    double* __restrict__ part, int NCH, int ch_first,
+                                                    const S* __restrict__ epart, uint64_t seed, uint32_t tick_arg,
+                                                    const uint32_t* __restrict__ tick_ptr) {
     using R = S;
     constexpr int VEC = UpdCfg<S>::VEC, CH = UpdCfg<S>::CH;
     typedef S vec_t __attribute__((ext_vector_type(VEC)));
@@ -420,7 +433,15 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
         if (tid == 0) { o[0] = INFINITY; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = 0; o[7] = 0; }
         return;
     }
-    __shared__ R red[4][4];
+    __shared__ R red[4][6];
+    // E = sum_k eps of this chunk from the per-wave sums (CH/64 entries per wheel, a few hundred bytes)
+    R E0 = 0, E1 = 0;
+    {
+        const size_t NW = Ks >> 6;
+        const S* ep = epart + (((size_t)a * P.T + t) * 2) * NW;
+        const int w_begin = k_begin >> 6, w_end = (k_end + 63) >> 6;
+        for (int w = w_begin + tid; w < w_end; w += 256) { E0 += ep[w]; E1 += ep[NW + w]; }
+    }
 
     // pass 1: the chunk into registers, lane minimum
     S v[kUpdNV][VEC];
@@ -459,20 +480,31 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
             const R e = Exp2<R>::f(x);
             D += e;
             if (x > cand) {  // rare: wave-uniformly skipped for almost every vector
-                N0 = fma(e, (R)e0_row[k + i], N0);
-                N1 = fma(e, (R)e1_row[k + i], N1);
+                R a0, a1;
+                if (REGEN) {  // eps was never stored: re-draw this sample's step (same Philox counter)
+                    float ev[4];
+                    philox_normals(P.sample_offset + (uint32_t)(k + i), (uint32_t)(t >> 1),
+                                   tick_ptr ? *tick_ptr : tick_arg, (uint32_t)a, (uint32_t)seed,
+                                   (uint32_t)(seed >> 32), (float)P.sigma, ev);
+                    a0 = (R)((t & 1) ? ev[2] : ev[0]);
+                    a1 = (R)((t & 1) ? ev[3] : ev[1]);
+                } else {
+                    a0 = (R)e0_row[k + i];
+                    a1 = (R)e1_row[k + i];
+                }
+                N0 = fma(e, a0, N0);
+                N1 = fma(e, a1, N1);
             }
         }
     }
-    D = wave_sum(D); N0 = wave_sum(N0); N1 = wave_sum(N1);
-    if (lane == 0) { red[wid][1] = D; red[wid][2] = N0; red[wid][3] = N1; }
+    D = wave_sum(D); N0 = wave_sum(N0); N1 = wave_sum(N1); E0 = wave_sum(E0); E1 = wave_sum(E1);
+    if (lane == 0) { red[wid][1] = D; red[wid][2] = N0; red[wid][3] = N1; red[wid][4] = E0; red[wid][5] = E1; }
     __syncthreads();
-    if (tid == 0) {
-        o[0] = (double)M;
-        o[1] = (double)red[0][1] + (double)red[1][1] + (double)red[2][1] + (double)red[3][1];
-        o[2] = (double)red[0][2] + (double)red[1][2] + (double)red[2][2] + (double)red[3][2];
-        o[3] = (double)red[0][3] + (double)red[1][3] + (double)red[2][3] + (double)red[3][3];
-        o[4] = 0.0; o[5] = 0.0; o[6] = (double)(k_end - k_begin); o[7] = 0.0;
+    if (tid < 5) {
+        const int c = tid + 1;
+        o[c] = (double)red[0][c] + (double)red[1][c] + (double)red[2][c] + (double)red[3][c];
+    } else if (tid == 5) {
+        o[0] = (double)M; o[6] = (double)(k_end - k_begin); o[7] = 0.0;
     }
 }
 
@@ -487,47 +519,47 @@ __global__ __launch_bounds__(256) void eps_wavesum_kernel(DevParams P, const S* 
     if ((threadIdx.x & 63) == 63 && (size_t)(k >> 6) < NW) epart[row * NW + (k >> 6)] = sum;
 }
 
+// materialise the device noise of a rollout that did not store it (mppi_download_noise, or a
+// separate mppi_update after a tick).  grid = (ceil(K/256), ceil(T/2), A)
+template <typename S>
+__global__ __launch_bounds__(256) void eps_regen_kernel(DevParams P, S* __restrict__ eps, uint64_t seed, uint32_t tick) {
+    const int k = blockIdx.x * 256 + threadIdx.x, pair = blockIdx.y, a = blockIdx.z;
+    if (k >= P.K) return;
+    float e[4];
+    philox_normals(P.sample_offset + (uint32_t)k, (uint32_t)pair, tick, (uint32_t)a, (uint32_t)seed,
+                   (uint32_t)(seed >> 32), (float)P.sigma, e);
+    const size_t Ks = (size_t)P.Ks;
+    S* row = eps + (((size_t)a * P.T + 2 * pair) * 2) * Ks + k;
+    row[0] = (S)e[0]; row[Ks] = (S)e[1];
+    if (2 * pair + 1 < P.T) { row[2 * Ks] = (S)e[2]; row[3 * Ks] = (S)e[3]; }
+}
+
 // ---------------------------------------------------------------------------------------------
 // tuple merge:  M = min m_i;  D = sum exp(-(m_i - M)/lam) D_i  (same for N);
 // E, count add.  Exact algebra of splitting the K-sum of control/src/mppi:189-196.
 // merge_kernel: one wave per (t, a) reduces the NCH chunk tuples of this shard.
 // ---------------------------------------------------------------------------------------------
-constexpr int kMergeThreads = 1024;
-template <typename S>
-__global__ __launch_bounds__(kMergeThreads) void merge_kernel(DevParams P, const double* __restrict__ part, int NCH,
-                                                             const S* __restrict__ epart, double* __restrict__ merged) {
-    const int t = blockIdx.x, a = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    __shared__ double red[kMergeThreads / 64][2];
-    // E = sum_k eps: the per-wave sums written by the rollout (or eps_wavesum) kernel, all 16 waves
-    const size_t NW = (size_t)P.Ks >> 6, nw_used = ((size_t)P.K + 63) >> 6;
-    const S* ep = epart + (((size_t)a * P.T + t) * 2) * NW;
-    double e0 = 0, e1 = 0;
-#pragma unroll 4
-    for (size_t i = tid; i < nw_used; i += kMergeThreads) { e0 += (double)ep[i]; e1 += (double)ep[NW + i]; }
-    e0 = wave_sum(e0); e1 = wave_sum(e1);
-    if (lane == 0) { red[wid][0] = e0; red[wid][1] = e1; }
-    __syncthreads();
-    if (wid != 0) return;
-    // chunk tuples: wave 0
+__global__ __launch_bounds__(64) void merge_kernel(DevParams P, const double* __restrict__ part, int NCH,
+                                                  double* __restrict__ merged) {
+    const int t = blockIdx.x, a = blockIdx.y, lane = threadIdx.x;
     const double* src = part + ((size_t)a * P.T + t) * NCH * kTupleW;
     double m = INFINITY;
     for (int i = lane; i < NCH; i += 64)
         if (src[i * kTupleW + 6] > 0.0) m = fmin(m, src[i * kTupleW]);
     const double M = wave_min(m);
-    double d = 0, n0 = 0, n1 = 0, cnt = 0;
+    double d = 0, n0 = 0, n1 = 0, e0 = 0, e1 = 0, cnt = 0;
     for (int i = lane; i < NCH; i += 64) {
         const double* q = src + i * kTupleW;
         if (q[6] > 0.0) {
             const double sc = exp((M - q[0]) * P.inv_lambda);
-            d += sc * q[1]; n0 += sc * q[2]; n1 += sc * q[3]; cnt += q[6];
+            d += sc * q[1]; n0 += sc * q[2]; n1 += sc * q[3]; e0 += q[4]; e1 += q[5]; cnt += q[6];
         }
     }
-    d = wave_sum(d); n0 = wave_sum(n0); n1 = wave_sum(n1); cnt = wave_sum(cnt);
+    d = wave_sum(d); n0 = wave_sum(n0); n1 = wave_sum(n1);
+    e0 = wave_sum(e0); e1 = wave_sum(e1); cnt = wave_sum(cnt);
     if (lane == 0) {
-        double s0 = 0, s1 = 0;
-        for (int w = 0; w < kMergeThreads / 64; ++w) { s0 += red[w][0]; s1 += red[w][1]; }
         double* o = merged + ((size_t)a * P.T + t) * kTupleW;
-        o[0] = M; o[1] = d; o[2] = n0; o[3] = n1; o[4] = s0; o[5] = s1; o[6] = cnt; o[7] = 0.0;
+        o[0] = M; o[1] = d; o[2] = n0; o[3] = n1; o[4] = e0; o[5] = e1; o[6] = cnt; o[7] = 0.0;
     }
 }
 

@@ -270,7 +270,8 @@ def test_philox_tick_against_oracle_on_device_noise(orc):
     Vo = orc.get_cost2go([0, 0, 0], u0, [0, -1, 0], LAM, SIG, eps)
     assert np.abs(V - Vo).max() <= _vtol(orc, [0, 0, 0], u0, [0, -1, 0], Vo, T, K)
     so, uo, _ = orc.get_path([0, 0, 0], [0, -1, 0], u0, eps, LAM, SIG)
-    assert np.abs(ua[0] - uo).max() < 1e-6 and np.abs(nxt[0] - so).max() < 1e-9
+    # f32 storage: u to 1e-6 (module docstring); the state inherits dt * r/wb * |du| ~ 4e-3 * |du|
+    assert np.abs(ua[0] - uo).max() < 1e-6 and np.abs(nxt[0] - so).max() < 1e-8
 
 
 def test_shard_partials_merge_equals_single_engine(orc):
@@ -421,6 +422,9 @@ def test_tick_graph_equals_eager():
         eb = b.get_outputs()
         assert np.array_equal(ea[0], eb[0]) and np.array_equal(ea[1], eb[1])
         assert np.array_equal(a.get_nominal(), b.get_nominal())
+        # the tick path never stored its noise: both engines re-draw the last tick's identically
+        na, nb = a.download_noise(), b.download_noise()
+        assert np.array_equal(na, nb) and abs(na.std() - SIG) < 0.01
 
 
 def test_error_behaviour():
