@@ -182,6 +182,9 @@ int mppi_savgol_matrix(int horizon, double *S);
  * duration (ms) and the number of launches since timing was (re)enabled.
  */
 int mppi_kernel_timing(mppi_engine *h, uint32_t mask);
+/* Bracket only every `period`-th launch of each selected kernel (default 1 = every launch):
+ * an event pair costs a few microseconds of stream time, sampling keeps a timed region honest. */
+int mppi_kernel_timing_period(mppi_engine *h, int period);
 int mppi_kernel_times(mppi_engine *h, double *ms /*[MPPI_KERNEL_COUNT]*/,
                       int64_t *launches /*[MPPI_KERNEL_COUNT]*/);
 

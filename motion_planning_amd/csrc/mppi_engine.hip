@@ -114,6 +114,8 @@ struct mppi_engine {
 
     // kernel timing
     uint32_t time_mask = 0;
+    int time_period = 1;
+    int64_t time_seen[MPPI_KERNEL_COUNT]{};
     struct Pending { int kid; hipEvent_t a, b; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> ev_pool;
@@ -149,7 +151,10 @@ struct mppi_engine {
     struct Scope {  // brackets one kernel launch with events (on the stream it goes to) when its bit is set
         mppi_engine* e; int kid; hipStream_t st; hipEvent_t a = nullptr;
         Scope(mppi_engine* e_, int kid_, hipStream_t st_ = nullptr) : e(e_), kid(kid_), st(st_ ? st_ : e_->stream) {
-            if (e->time_mask & (1u << kid)) { a = e->get_event(); HIPCHK(hipEventRecord(a, st)); }
+            if ((e->time_mask & (1u << kid)) && (e->time_seen[kid]++ % e->time_period) == 0) {
+                a = e->get_event();
+                HIPCHK(hipEventRecord(a, st));
+            }
         }
         ~Scope() noexcept(false) {
             if (a) {
@@ -266,6 +271,7 @@ struct mppi_engine {
         const bool store = !ph || store_eps_always;
         eps_lazy = ph && !store;
         lazy_seed = seed; lazy_tick = tick; lazy_from_counter = tick_ptr != nullptr; lazy_counter_bumped = false;
+        epart_ready = true;  // every rollout launch below writes its waves' eps sums
         if (pieces.size() <= 1) {
             launch_rollout(stream, 0, cfg.samples, ph, store, seed, tick, tick_ptr);
             launch_update(stream, 0, NCH, tick_ptr);
@@ -765,7 +771,14 @@ int mppi_kernel_timing(mppi_engine* h, uint32_t mask) {
     API_BEGIN(h)
     h->drain_timing();
     h->time_mask = mask;
-    for (int i = 0; i < MPPI_KERNEL_COUNT; ++i) { h->t_ms[i] = 0.0; h->t_n[i] = 0; }
+    for (int i = 0; i < MPPI_KERNEL_COUNT; ++i) { h->t_ms[i] = 0.0; h->t_n[i] = 0; h->time_seen[i] = 0; }
+    API_END(h)
+}
+
+int mppi_kernel_timing_period(mppi_engine* h, int period) {
+    API_BEGIN(h)
+    if (period < 1) fail(MPPI_E_INVALID, "period must be >= 1");
+    h->time_period = period;
     API_END(h)
 }
 

@@ -203,7 +203,8 @@ class Engine(object):
         self._ck(self._lib.mppi_synchronize(self._h))
 
     # -- instrumentation -----------------------------------------------------------------
-    def kernel_timing(self, kernels=()):
+    def kernel_timing(self, kernels=(), period=1):
+        self._ck(self._lib.mppi_kernel_timing_period(self._h, int(period)))
         mask = 0
         for k in kernels:
             mask |= 1 << _capi.KERNELS.index(k)

@@ -23,15 +23,16 @@ class _DevBuf(object):
 class HipShard(object):
     """Adapter: one libmppi_hip Engine as a shard (partials exposed as a torch CUDA tensor)."""
 
-    def __init__(self, engine, torch_device):
+    def __init__(self, engine, torch_device, use_torch_stream=True):
         import torch
         self.engine = engine
         self.device = torch_device
         ptr, nbytes = engine.partials()
         self._part = torch.as_tensor(_DevBuf(ptr, nbytes // 8), device=torch_device)
         assert self._part.data_ptr() == ptr, "torch copied the partials buffer instead of aliasing it"
-        # all work of the engine goes to torch's current stream so that collectives order with it
-        engine.set_stream(torch.cuda.current_stream(torch_device).cuda_stream)
+        if use_torch_stream:
+            # all work of the engine goes to torch's current stream so that collectives order with it
+            engine.set_stream(torch.cuda.current_stream(torch_device).cuda_stream)
 
     def tick_begin(self, state, goal, noise, seed, tick_id):
         self.engine.tick_begin(state, goal, noise=noise, seed=seed, tick_id=tick_id)
@@ -101,5 +102,7 @@ def make_hip_ticker(samples_total, horizon, n_agents=1, storage="f32", local_ran
     torch.cuda.set_device(local_rank)
     eng = Engine(hi - lo, horizon, n_agents=n_agents, storage=storage, device=local_rank,
                  sample_offset=lo, **engine_kw)
-    shard = HipShard(eng, torch.device("cuda", local_rank))
+    # a single process has no collective to order with: keep the engine's own stream (which is
+    # also what hipGraph capture needs -- the null stream cannot be captured)
+    shard = HipShard(eng, torch.device("cuda", local_rank), use_torch_stream=world > 1)
     return ShardedTicker(shard, group), eng
