@@ -116,7 +116,8 @@ def main():
             raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
         args.gpus = world
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    in_group = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ  # launched by torch.distributed.run
+    if in_group:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -144,7 +145,7 @@ def main():
 
     seed = 0
     def tick(i, first=False):
-        if args.graph and world == 1 and not first:
+        if args.graph and not in_group and not first:
             eng.tick_graph(seed)
         else:
             ticker.tick_async(states if first else None, goals if first else None, "philox", seed, i)
@@ -191,6 +192,8 @@ def main():
     if rank == 0:
         steps_per_launch = A * K_local * T
         ms, n = ktimes["rollout"]
+        if n == 0:  # hipGraph replay: launches are not individually bracketed
+            ms, n = dtimes["rollout"] if dtimes["rollout"][1] else (float("nan"), 1)
         avg_s = ms * 1e-3 / max(n, 1)
         gbs = BYTES_PER_STEP_PER_KERNEL * steps_per_launch / avg_s / 1e9
         tick_s = elapsed / args.steps
@@ -234,10 +237,11 @@ def main():
                        "parallelism": ("K-sharded x%d + all-gather" % world) if args.workload != "c5" else "agent replicas",
                        "graph": bool(args.graph)},
             "state_steps_per_s": value * T,
+            "final_state": [float(x) for x in nxt[0]], "final_u": [float(x) for x in ua[0]],
             "kernels_us": kernels_us, "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
-    if world > 1:
+    if in_group:
         dist.destroy_process_group()
 
 

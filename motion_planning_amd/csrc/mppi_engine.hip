@@ -295,8 +295,12 @@ struct mppi_engine {
     }
     void run_nominal() {
         Scope sc(this, MPPI_KERNEL_NOMINAL);
-        hipLaunchKernelGGL(mppi::nominal_kernel, dim3(cfg.n_agents), dim3(mppi::kNomThreads),
-                           (size_t)cfg.horizon * sizeof(double), stream, P, d_state, d_goal, d_unom, d_tc, d_base);
+        if (cfg.horizon <= 64)
+            hipLaunchKernelGGL(mppi::nominal_wave_kernel, dim3(cfg.n_agents), dim3(64), 0, stream, P, d_state, d_goal,
+                               d_unom, d_tc, d_base);
+        else
+            hipLaunchKernelGGL(mppi::nominal_kernel, dim3(cfg.n_agents), dim3(mppi::kNomThreads),
+                               (size_t)cfg.horizon * sizeof(double), stream, P, d_state, d_goal, d_unom, d_tc, d_base);
         HIPCHK(hipGetLastError());
     }
     void run_rollout(int noise_mode, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {

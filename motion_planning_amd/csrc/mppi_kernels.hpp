@@ -205,6 +205,63 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
 }
 __device__ __forceinline__ double wave_sum_lane63(double v) { return wave_sum(v); }
 
+
+// 64-lane inclusive prefix sum by shuffles (no LDS, no barriers)
+__device__ __forceinline__ double wave_scan_incl(double v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double y = __shfl_up(v, off, 64);
+        if (lane >= off) v += y;
+    }
+    return v;
+}
+
+// nominal_kernel for T <= 64: one wave per agent, lanes = timesteps, every scan stays in
+// registers (the launch-bound small-K tick and the strong-scaling fixed cost both want this short).
+__global__ __launch_bounds__(64) void nominal_wave_kernel(DevParams P, const double* __restrict__ state,
+                                                         const double* __restrict__ goal,
+                                                         const double* __restrict__ unom,
+                                                         double* __restrict__ tc, double* __restrict__ base) {
+    const int a = blockIdx.x, t = threadIdx.x, T = P.T;
+    const bool valid = t < T;
+    const double gx = goal[a * 3 + 0], gy = goal[a * 3 + 1], gth = goal[a * 3 + 2];
+    const double un0 = valid ? unom[(a * 2 + 0) * T + t] : 0.0;
+    const double un1 = valid ? unom[(a * 2 + 1) * T + t] : 0.0;
+    const double u0 = clampd(un0, P.u_max), u1 = clampd(un1, P.u_max);
+    const double h = valid ? P.kth * P.dt * (u1 - u0) : 0.0;
+    const double th = state[a * 3 + 2] + (wave_scan_incl(h, t) - h);
+    double s0, c0, s1, c1, s2, c2;
+    sincos(th, &s0, &c0);
+    if (fabs(h) <= 0.5) {  // mid / end headings by a small rotation instead of two more sincos
+        double sp, cp;
+        small_sincos<7>(0.5 * h, sp, cp);
+        c1 = c0 * cp - s0 * sp; s1 = s0 * cp + c0 * sp;
+        c2 = c1 * cp - s1 * sp; s2 = s1 * cp + c1 * sp;
+    } else {
+        sincos(th + 0.5 * h, &s1, &c1);
+        sincos(th + h, &s2, &c2);
+    }
+    const double aa = P.dt * P.rhalf * (u0 + u1) * (1.0 / 6.0);
+    const double X = state[a * 3 + 0] + wave_scan_incl(valid ? aa * (c0 + 4.0 * c1 + c2) : 0.0, t);
+    const double Y = state[a * 3 + 1] + wave_scan_incl(valid ? aa * (s0 + 4.0 * s1 + s2) : 0.0, t);
+    double cst = 0.0;
+    if (valid) {
+        const double thn = wrap_theta(th + h);
+        const double dx = X - gx, dy = Y - gy, dth = thn - gth;
+        const double xqx = P.q0 * dx * dx + P.q1 * dy * dy + P.q2 * dth * dth;
+        const double uru = P.r0 * un0 * un0 + P.r1 * un1 * un1;
+        cst = 0.5 * (xqx + uru);
+        if (t == T - 1) cst += P.p0 * dx * dx + P.p1 * dy * dy + P.p2 * dth * dth;
+        const double ls = P.lambda * P.sigma;
+        double* o = tc + ((size_t)a * T + t) * kTcW;
+        o[0] = un0; o[1] = un1; o[2] = ls * un0; o[3] = ls * un1;
+        o[4] = 0.5 * uru - cst; o[5] = 0.0; o[6] = 0.0; o[7] = 0.0;
+    }
+    const double inc = wave_scan_incl(cst, t);
+    const double tot = __shfl(inc, 63, 64);
+    if (valid) base[(size_t)a * T + t] = tot - (inc - cst);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11) -- the generator hipRAND exposes as
 // HIPRAND_RNG_PSEUDO_PHILOX4_32_10 -- inlined so that (seed, tick, agent, global sample, t)
@@ -596,6 +653,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(DevParams P, const double
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* un = reinterpret_cast<double*>(smem_raw);  // [2][T] updated + clipped
     double* uf = un + 2 * P.T;                          // [2][T] filtered + clipped
+    __shared__ double trig[3][2];
     const int a = blockIdx.x, tid = threadIdx.x, T = P.T;
     for (int t = tid; t < T; t += blockDim.x) {
         double M = INFINITY;
@@ -607,7 +665,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(DevParams P, const double
         for (int g = 0; g < G; ++g) {
             const double* q = gathered + (((size_t)g * P.A + a) * T + t) * kTupleW;
             if (q[6] > 0.0) {
-                const double sc = exp((M - q[0]) * P.inv_lambda);
+                const double sc = (q[0] == M) ? 1.0 : exp((M - q[0]) * P.inv_lambda);
                 d += sc * q[1]; n0 += sc * q[2]; n1 += sc * q[3]; e0 += q[4]; e1 += q[5]; cnt += q[6];
             }
         }
@@ -618,17 +676,22 @@ __global__ __launch_bounds__(256) void finalize_kernel(DevParams P, const double
         un[T + t] = clampd(unom[((size_t)a * 2 + 1) * T + t] + du1, P.u_max);
     }
     __syncthreads();
-    for (int j = tid; j < T; j += blockDim.x) {  // savgol_filter as u @ S  (:202), then clip (:205-206)
-        double s0 = 0.0, s1 = 0.0;
-        for (int t = 0; t < T; ++t) {
-            const double w = Smat[(size_t)t * T + j];
-            s0 = fma(un[t], w, s0);
-            s1 = fma(un[T + t], w, s1);
-        }
-        uf[j] = clampd(s0, P.u_max);
-        uf[T + j] = clampd(s1, P.u_max);
+    for (int idx = tid; idx < 2 * T; idx += blockDim.x) {  // savgol_filter as u @ S (:202), clip (:205-206)
+        const int c = idx >= T, j = idx - c * T;
+        const double* ur = un + c * T;
+        double acc = 0.0;
+        for (int t = 0; t < T; ++t) acc = fma(ur[t], Smat[(size_t)t * T + j], acc);
+        uf[idx] = clampd(acc, P.u_max);
     }
     __syncthreads();
+    // perform_action (:210-213): the three distinct stage angles of rk4 evaluated by three lanes
+    const double sum = uf[0] + uf[T], om = P.kth * (uf[T] - uf[0]);
+    const double th0 = state[a * 3 + 2], k_th = P.dt * om;
+    if ((flags & 1) && tid < 3) {
+        const double ang = (tid == 0) ? th0 : (tid == 1 ? th0 + k_th / 2 : th0 + k_th);
+        trig[tid][0] = cos(ang);
+        trig[tid][1] = sin(ang);
+    }
     for (int j = tid; j < T; j += blockDim.x) {
         ufilt[((size_t)a * 2 + 0) * T + j] = uf[j];
         ufilt[((size_t)a * 2 + 1) * T + j] = uf[T + j];
@@ -640,10 +703,18 @@ __global__ __launch_bounds__(256) void finalize_kernel(DevParams P, const double
             unom[((size_t)a * 2 + 1) * T + j] = uf[T + j];
         }
     }
+    __syncthreads();
     if (tid == 0) {
-        if (flags & 1) {
-            double x0[3] = {state[a * 3 + 0], state[a * 3 + 1], state[a * 3 + 2]}, xn[3];
-            rk4_exact(P, x0, uf[0], uf[T], xn);
+        if (flags & 1) {  // same operation order as rk4 (:39-54) with dd_dynamics (:23-30)
+            const double x0[3] = {state[a * 3 + 0], state[a * 3 + 1], th0};
+            double k1[3], k2[3], k3[3], k4[3], xn[3];
+            k1[0] = P.dt * (P.rhalf * trig[0][0] * sum); k1[1] = P.dt * (P.rhalf * trig[0][1] * sum); k1[2] = k_th;
+            k2[0] = P.dt * (P.rhalf * trig[1][0] * sum); k2[1] = P.dt * (P.rhalf * trig[1][1] * sum); k2[2] = k_th;
+            k3[0] = k2[0]; k3[1] = k2[1]; k3[2] = k_th;
+            k4[0] = P.dt * (P.rhalf * trig[2][0] * sum); k4[1] = P.dt * (P.rhalf * trig[2][1] * sum); k4[2] = k_th;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) xn[i] = x0[i] + (1.0 / 6.0) * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]);
+            xn[2] = wrap_theta(xn[2]);
             double* o = outv + (size_t)a * 8;
             o[0] = xn[0]; o[1] = xn[1]; o[2] = xn[2]; o[3] = uf[0]; o[4] = uf[T];
             state[a * 3 + 0] = xn[0]; state[a * 3 + 1] = xn[1]; state[a * 3 + 2] = xn[2];

@@ -74,12 +74,13 @@ class ShardedTicker(object):
         self.rank = self.dist.get_rank(group) if self.dist else 0
         part = shard.partials_tensor()
         # flat [world * A*T*8] receive buffer (rank-major), the layout mppi_tick_finish expects
+        # (a 1-rank process group still goes through the collective: same code path as N ranks)
         self._gathered = torch.empty(self.world * part.numel(), dtype=part.dtype,
-                                     device=part.device) if self.world > 1 else None
+                                     device=part.device) if self.dist else None
 
     def tick_async(self, state=None, goal=None, noise="philox", seed=0, tick_id=0):
         self.shard.tick_begin(state, goal, noise, seed, tick_id)
-        if self.world > 1:
+        if self.dist:
             # one all-gather of [A][T][8] f64 per tick (RCCL over xGMI on GPUs)
             self.dist.all_gather_into_tensor(self._gathered, self.shard.partials_tensor(), group=self.group)
             self.shard.tick_finish(self._gathered, self.world)
@@ -104,5 +105,6 @@ def make_hip_ticker(samples_total, horizon, n_agents=1, storage="f32", local_ran
                  sample_offset=lo, **engine_kw)
     # a single process has no collective to order with: keep the engine's own stream (which is
     # also what hipGraph capture needs -- the null stream cannot be captured)
-    shard = HipShard(eng, torch.device("cuda", local_rank), use_torch_stream=world > 1)
+    in_group = dist.is_available() and dist.is_initialized()
+    shard = HipShard(eng, torch.device("cuda", local_rank), use_torch_stream=in_group)
     return ShardedTicker(shard, group), eng

@@ -473,3 +473,28 @@ def test_controller_state_machine_golden(golden, name, waypoints):
         assert abs(vx - r[8]) < 1e-9 and abs(wz - r[9]) < 1e-8, i
         assert (c.idx, float(c.done), float(c.init)) == (int(r[10]), r[11], r[12]), i
         plant = rk4(plant.reshape(3, 1), u.reshape(2, 1), c.mppi.dt)[:, 0]
+
+
+def test_bench_under_torchrun_uses_the_rccl_path():
+    """bench.py launched exactly like the driver launches N > 1 (torch.distributed.run, backend nccl =
+    RCCL), with the one GPU this box has: the tick goes tick_begin -> all_gather_into_tensor on the
+    aliased partials buffer -> tick_finish(gathered), and must agree with the plain single-process run."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    common = ["bench.py", "--gpus", "1", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--samples", "50000"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port)] + common,
+                         cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 1e6 and line["config"]["samples_total"] == 50000
+    plain = subprocess.run([sys.executable] + common, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    ref = json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["final_state"] == ref["final_state"] and line["final_u"] == ref["final_u"]
