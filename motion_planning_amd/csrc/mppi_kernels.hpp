@@ -205,6 +205,43 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
 }
 __device__ __forceinline__ double wave_sum_lane63(double v) { return wave_sum(v); }
 
+// Eight 64-lane sums at once (the eps sums of one 4-step chunk: 2 wheels x 4 steps) as a
+// reduce-scatter: each exchange halves the values a lane still carries (4+2+1 selects/adds instead
+// of 8 x 6), the last three levels are plain adds (row_ror:8, v_permlane16_swap, v_permlane32_swap --
+// the latter two are gfx950 additions).  Every lane ends with the total of value
+// sum8_index(lane); 33 VALU ops instead of ~110 for eight separate DPP reductions.
+__device__ __forceinline__ int sum8_index(int lane) { return ((lane >> 2) & 1) | (lane & 2) | ((lane & 1) << 2); }
+__device__ __forceinline__ float wave_sum8(const float (&v)[8], int lane) {
+    const bool b1 = lane & 1, b2 = lane & 2, b4 = lane & 4;
+    float w[4], x[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)  // partner lane ^ 1
+        w[i] = (b1 ? v[i + 4] : v[i]) + dpp_mov<0xB1, 0xF>(b1 ? v[i] : v[i + 4]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)  // partner lane ^ 2
+        x[i] = (b2 ? w[i + 2] : w[i]) + dpp_mov<0x4E, 0xF>(b2 ? w[i] : w[i + 2]);
+    float y = (b4 ? x[1] : x[0]) + dpp_mov<0x124, 0xF>(b4 ? x[0] : x[1]);  // row_ror:4 (a lane with the other bit 2)
+    y += dpp_mov<0x128, 0xF>(y);                                             // row_ror:8
+    {
+        const unsigned u = __float_as_uint(y);
+        const auto p = __builtin_amdgcn_permlane16_swap(u, u, false, false);  // rows 0<->1, 2<->3
+        y = __uint_as_float(p[0]) + __uint_as_float(p[1]);
+    }
+    {
+        const unsigned u = __float_as_uint(y);
+        const auto p = __builtin_amdgcn_permlane32_swap(u, u, false, false);  // lanes 0-31 <-> 32-63
+        y = __uint_as_float(p[0]) + __uint_as_float(p[1]);
+    }
+    return y;
+}
+__device__ __forceinline__ double wave_sum8(const double (&v)[8], int lane) {  // exact-parity mode: plain sums
+    double r = 0.0;
+    const int mine = sum8_index(lane);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const double t = wave_sum(v[i]); if (i == mine) r = t; }
+    return r;
+}
+
 
 // 64-lane inclusive prefix sum by shuffles (no LDS, no barriers)
 __device__ __forceinline__ double wave_scan_incl(double v, int lane) {
@@ -338,6 +375,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double*
     const double sixth_rd = P.dt * P.rhalf * (1.0 / 6.0);  // Simpson weight of (u0 + u1)
     const double hq0 = 0.5 * P.q0, hq1 = 0.5 * P.q1, hq2 = 0.5 * P.q2;
     const size_t NW = Ks >> 6;  // waves per agent row (Ks is a multiple of 64)
+    const bool block_full = k_first + (int)(blockIdx.x + 1) * (int)blockDim.x <= k_last;  // uniform
 
     uint32_t key0 = 0, key1 = 0, ctr0 = 0, tick = 0;
     float sigf = 0.f;
@@ -348,7 +386,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double*
         sigf = (float)P.sigma;
     }
 
-    constexpr int U = 4;  // steps per software-pipelined chunk
+    constexpr int U = 4;  // steps per software-pipelined chunk (wave_sum8 assumes 4)
     S cur[U][2], nxt[U][2];
     auto load_chunk = [&](int t0, S (&buf)[U][2]) {
 #pragma unroll
@@ -374,6 +412,19 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double*
     for (int t0 = 0; t0 < T; t0 += U) {
         if (PHILOX) draw_chunk(t0, cur);
         else load_chunk(t0 + U, nxt);  // prefetch: HBM latency hides under this chunk's math
+        {   // sum_k eps per wave for the chunk's 4 steps x 2 wheels (the E of the softmax floor term,
+            // control/src/mppi:193): saves the update kernel from reading eps at all (8 of its 12 B/step)
+            S ev[8];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                ev[2 * j] = (block_full || active) ? cur[j][0] : (S)0;
+                ev[2 * j + 1] = (block_full || active) ? cur[j][1] : (S)0;
+            }
+            const S tot = wave_sum8(ev, tid & 63);
+            const int idx = sum8_index(tid & 63), te = t0 + (idx >> 1);
+            if ((tid & 63) < 8 && te < T && (size_t)(k >> 6) < NW)
+                epart[(((size_t)a * T + te) * 2 + (idx & 1)) * NW + (k >> 6)] = tot;
+        }
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const int t = t0 + j;
@@ -381,15 +432,6 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double*
                 const double* tcp = tca + (size_t)t * kTcW;  // uniform -> scalar loads
                 const double un0 = tcp[0], un1 = tcp[1], w0 = tcp[2], w1 = tcp[3], cb = tcp[4];
                 const double e0 = (double)cur[j][0], e1 = (double)cur[j][1];
-                {   // sum_k eps per wave and step (the E of the softmax floor term, control/src/mppi:193):
-                    // 2 x 6 DPP adds here save the update kernel from reading eps (8 of its 12 B/step)
-                    const S w0s = wave_sum_lane63(active ? cur[j][0] : (S)0);
-                    const S w1s = wave_sum_lane63(active ? cur[j][1] : (S)0);
-                    if ((tid & 63) == 63 && (size_t)(k >> 6) < NW) {
-                        S* ep = epart + (((size_t)a * T + t) * 2) * NW + (k >> 6);
-                        ep[0] = w0s; ep[NW] = w1s;
-                    }
-                }
                 if (active) {
                     if (PHILOX && STORE_EPS) {
                         eps_a[(size_t)(t * 2 + 0) * Ks] = cur[j][0];
