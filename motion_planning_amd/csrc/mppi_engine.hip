@@ -195,7 +195,7 @@ struct mppi_engine {
     void launch_rollout_f(hipStream_t st, int k0, int k1, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
         auto kern = mppi::rollout_kernel<S, NT, PH, SE>;
         dim3 grid((k1 - k0 + roll_bs - 1) / roll_bs, cfg.n_agents);
-        hipLaunchKernelGGL(kern, grid, dim3(roll_bs), 0, st, P, d_state, d_goal, d_tc, static_cast<S*>(d_eps),
+        hipLaunchKernelGGL(kern, grid, dim3(roll_bs), (size_t)cfg.horizon * 5 * sizeof(double), st, P, d_state, d_goal, d_tc, static_cast<S*>(d_eps),
                            static_cast<S*>(d_dP), static_cast<S*>(d_stot), seed, tick, tick_ptr, k0, k1,
                            static_cast<S*>(d_epart));
         HIPCHK(hipGetLastError());
@@ -226,11 +226,14 @@ struct mppi_engine {
             HIPCHK(hipStreamSynchronize(stream));
             if (lazy_counter_bumped) tick -= 1u;
         }
-        dim3 g((cfg.samples + 255) / 256, (cfg.horizon + 1) / 2, cfg.n_agents);
-        if (f64()) hipLaunchKernelGGL(mppi::eps_regen_kernel<double>, g, dim3(256), 0, stream, P, static_cast<double*>(d_eps), lazy_seed, tick);
-        else hipLaunchKernelGGL(mppi::eps_regen_kernel<float>, g, dim3(256), 0, stream, P, static_cast<float*>(d_eps), lazy_seed, tick);
-        HIPCHK(hipGetLastError());
+        launch_regen(stream, lazy_seed, tick, nullptr);
         eps_lazy = false;
+    }
+    void launch_regen(hipStream_t st, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
+        dim3 g((cfg.samples + 255) / 256, (cfg.horizon + 1) / 2, cfg.n_agents);
+        if (f64()) hipLaunchKernelGGL(mppi::eps_regen_kernel<double>, g, dim3(256), 0, st, P, static_cast<double*>(d_eps), seed, tick, tick_ptr);
+        else hipLaunchKernelGGL(mppi::eps_regen_kernel<float>, g, dim3(256), 0, st, P, static_cast<float*>(d_eps), seed, tick, tick_ptr);
+        HIPCHK(hipGetLastError());
     }
     void ensure_epart(hipStream_t st) {
         if (epart_ready) return;  // noise uploaded by the caller and never rolled out: sum it now
@@ -341,6 +344,8 @@ struct mppi_engine {
         if (cfg.horizon < 5 || ((cfg.horizon - 1) % 2) == 0)
             fail(MPPI_E_INVALID, "horizon=%d: the Savitzky-Golay window horizon-1 must be odd and > 3 "
                  "(scipy.signal.savgol_filter at control/src/mppi:202)", cfg.horizon);
+        if ((size_t)cfg.horizon * 40 > 64 * 1024)
+            fail(MPPI_E_INVALID, "horizon %d: the per-step table (40 B/step) must fit 64 KB of LDS (horizon <= 1638)", cfg.horizon);
         if (cfg.storage != MPPI_STORE_F32 && cfg.storage != MPPI_STORE_F64) fail(MPPI_E_INVALID, "bad storage %d", cfg.storage);
         if (!(cfg.lambda > 0.0) || !(cfg.sigma >= 0.0)) fail(MPPI_E_INVALID, "lambda must be > 0 and sigma >= 0");
         if (!(cfg.dt > 0.0)) cfg.dt = 1.0 / (double)cfg.horizon;  // control/src/mppi:67

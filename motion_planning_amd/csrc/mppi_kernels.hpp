@@ -350,7 +350,7 @@ __device__ __forceinline__ void philox_normals(uint32_t gk, uint32_t pair, uint3
 //          pure function of (seed, tick, agent, sample, t), so the update kernel regenerates the
 //          few values it needs and mppi_download_noise regenerates all of it on demand --
 //          8 of the 12 B/step never touch HBM.
-// grid = (ceil(K / 256), A), block = 256, no LDS.  Per lane and step: 2 eps + 1 dP element
+// grid = (ceil(K / 256), A), block = 256, LDS = the 40*T-byte per-step table.  Per lane and step: 2 eps + 1 dP element
 // through HBM, fully coalesced (consecutive lanes = consecutive k).
 // ---------------------------------------------------------------------------------------------
 template <typename S, int NTERM, bool PHILOX, bool STORE_EPS>
@@ -360,7 +360,13 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double*
                                                      S* __restrict__ dP, S* __restrict__ Stot, uint64_t seed,
                                                      uint32_t tick_arg, const uint32_t* __restrict__ tick_ptr,
                                                      int k_first, int k_last, S* __restrict__ epart) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* lt = reinterpret_cast<double*>(smem_raw);  // [T][5] per-step table {un0, un1, w0, w1, cb}
     const int tid = threadIdx.x, a = blockIdx.y, T = P.T;
+    // stage the per-step table in LDS once: read back as wave-uniform (broadcast) ds_reads that the
+    // scheduler can hoist, instead of an s_load + s_waitcnt round trip on every step
+    for (int i = tid; i < T * 5; i += blockDim.x) lt[i] = tc[((size_t)a * T + i / 5) * kTcW + i % 5];
+    __syncthreads();
     const int k = k_first + blockIdx.x * blockDim.x + tid;  // this launch covers samples [k_first, k_last)
     const bool active = k < k_last;
     const size_t Ks = (size_t)P.Ks;
@@ -370,7 +376,6 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double*
     sincos(th, &s, &c);
     S* eps_a = eps + (size_t)a * T * 2 * Ks + k;
     S* dp = dP + (size_t)a * T * Ks + k;
-    const double* tca = tc + (size_t)a * T * kTcW;
     const double half_kd = 0.5 * P.kth * P.dt;             // phi = half_kd * (u1 - u0) = h / 2
     const double sixth_rd = P.dt * P.rhalf * (1.0 / 6.0);  // Simpson weight of (u0 + u1)
     const double hq0 = 0.5 * P.q0, hq1 = 0.5 * P.q1, hq2 = 0.5 * P.q2;
@@ -429,7 +434,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double*
         for (int j = 0; j < U; ++j) {
             const int t = t0 + j;
             if (t < T) {  // wave-uniform
-                const double* tcp = tca + (size_t)t * kTcW;  // uniform -> scalar loads
+                const double* tcp = lt + t * 5;
                 const double un0 = tcp[0], un1 = tcp[1], w0 = tcp[2], w1 = tcp[3], cb = tcp[4];
                 const double e0 = (double)cur[j][0], e1 = (double)cur[j][1];
                 if (active) {
@@ -618,12 +623,16 @@ __global__ __launch_bounds__(256) void eps_wavesum_kernel(DevParams P, const S* 
     if ((threadIdx.x & 63) == 63 && (size_t)(k >> 6) < NW) epart[row * NW + (k >> 6)] = sum;
 }
 
-// materialise the device noise of a rollout that did not store it (mppi_download_noise, or a
-// separate mppi_update after a tick).  grid = (ceil(K/256), ceil(T/2), A)
+// The device noise as a kernel of its own, one lane per (sample, step pair): materialises the
+// noise of a rollout that did not store it (mppi_download_noise, or a separate mppi_update after a
+// tick).  (Drawing the noise first and rolling out on the stored eps was tried as a small-K tick
+// path: slower than the fused rollout at every K from 1e4 to 5e5.)   grid = (ceil(K/256), ceil(T/2), A)
 template <typename S>
-__global__ __launch_bounds__(256) void eps_regen_kernel(DevParams P, S* __restrict__ eps, uint64_t seed, uint32_t tick) {
+__global__ __launch_bounds__(256) void eps_regen_kernel(DevParams P, S* __restrict__ eps, uint64_t seed, uint32_t tick_arg,
+                                                       const uint32_t* __restrict__ tick_ptr) {
     const int k = blockIdx.x * 256 + threadIdx.x, pair = blockIdx.y, a = blockIdx.z;
     if (k >= P.K) return;
+    const uint32_t tick = tick_ptr ? *tick_ptr : tick_arg;
     float e[4];
     philox_normals(P.sample_offset + (uint32_t)k, (uint32_t)pair, tick, (uint32_t)a, (uint32_t)seed,
                    (uint32_t)(seed >> 32), (float)P.sigma, e);
