@@ -68,7 +68,6 @@ struct mppi_engine {
     // launch geometry
     int roll_bs = 256, roll_blocks = 0, nterm = 4;
     int NCH = 1, CH = 1024;
-    int variant = 0;  // MPPI_VARIANT env: A/B switches for tuning runs (bit0: libm Box-Muller)
 
     // intra-tick software pipeline: K is cut into pieces; the VALU-bound rollout of piece p+1 runs
     // while the HBM-bound update of piece p streams its (still Infinity-Cache-resident) output back
@@ -338,7 +337,6 @@ struct mppi_engine {
 
     void init(const mppi_config& c) {
         cfg = c;
-        if (const char* v = std::getenv("MPPI_VARIANT")) variant = std::atoi(v);
         if (const char* v = std::getenv("MPPI_STORE_EPS")) store_eps_always = std::atoi(v) != 0;
         if (cfg.n_agents < 1 || cfg.samples < 1) fail(MPPI_E_INVALID, "n_agents and samples must be >= 1");
         if (cfg.horizon < 5 || ((cfg.horizon - 1) % 2) == 0)
@@ -360,7 +358,6 @@ struct mppi_engine {
 
         const int A = cfg.n_agents, K = cfg.samples, T = cfg.horizon;
         P.A = A; P.K = K; P.T = T; P.Ks = (K + 63) / 64 * 64;
-        if (const char* v = std::getenv("MPPI_PAD")) P.Ks += std::atoi(v) / 64 * 64;
         P.sample_offset = cfg.sample_offset;
         P.dt = cfg.dt;
         P.q0 = cfg.q[0]; P.q1 = cfg.q[1]; P.q2 = cfg.q[2];
