@@ -165,7 +165,7 @@ def main():
     EVENT_PERIOD = 8
     # (the kernel before it is bracketed too, so that the rollout's start marker sits behind a completed
     # predecessor and not behind a just-dispatched one)
-    eng.kernel_timing(("nominal", "rollout"), period=EVENT_PERIOD)
+    eng.kernel_timing(("finalize", "nominal", "rollout"), period=EVENT_PERIOD)
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):

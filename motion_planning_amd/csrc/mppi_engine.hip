@@ -190,14 +190,19 @@ struct mppi_engine {
         if (!have_state || !have_goal) fail(MPPI_E_STATE, "state/goal passed as NULL before ever being set");
     }
 
-    template <typename S, int NT, bool PH, bool SE>
-    void launch_rollout_f(hipStream_t st, int k0, int k1, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
-        auto kern = mppi::rollout_kernel<S, NT, PH, SE>;
+    template <typename S, int NT, bool PH, bool SE, bool IN>
+    void launch_rollout_g(hipStream_t st, int k0, int k1, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
+        auto kern = mppi::rollout_kernel<S, NT, PH, SE, IN>;
         dim3 grid((k1 - k0 + roll_bs - 1) / roll_bs, cfg.n_agents);
         hipLaunchKernelGGL(kern, grid, dim3(roll_bs), (size_t)cfg.horizon * 5 * sizeof(double), st, P, d_state, d_goal, d_tc, static_cast<S*>(d_eps),
                            static_cast<S*>(d_dP), static_cast<S*>(d_stot), seed, tick, tick_ptr, k0, k1,
-                           static_cast<S*>(d_epart));
+                           static_cast<S*>(d_epart), d_unom, d_base);
         HIPCHK(hipGetLastError());
+    }
+    template <typename S, int NT, bool PH, bool SE>
+    void launch_rollout_f(hipStream_t st, int k0, int k1, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
+        if (inline_nominal()) launch_rollout_g<S, NT, PH, SE, true>(st, k0, k1, seed, tick, tick_ptr);
+        else launch_rollout_g<S, NT, PH, SE, false>(st, k0, k1, seed, tick, tick_ptr);
     }
     template <typename S, int NT>
     void launch_rollout_t(hipStream_t st, int k0, int k1, bool ph, bool store, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
@@ -295,14 +300,13 @@ struct mppi_engine {
         launch_merge();
         noise_ready = true; value_ready = true; partials_ready = true; epart_ready = true;
     }
+    // T <= 64: the nominal rollout runs inside every rollout block (one wave, lanes = timesteps)
+    bool inline_nominal() const { return cfg.horizon <= 64; }
     void run_nominal() {
+        if (inline_nominal()) return;
         Scope sc(this, MPPI_KERNEL_NOMINAL);
-        if (cfg.horizon <= 64)
-            hipLaunchKernelGGL(mppi::nominal_wave_kernel, dim3(cfg.n_agents), dim3(64), 0, stream, P, d_state, d_goal,
-                               d_unom, d_tc, d_base);
-        else
-            hipLaunchKernelGGL(mppi::nominal_kernel, dim3(cfg.n_agents), dim3(mppi::kNomThreads),
-                               (size_t)cfg.horizon * sizeof(double), stream, P, d_state, d_goal, d_unom, d_tc, d_base);
+        hipLaunchKernelGGL(mppi::nominal_kernel, dim3(cfg.n_agents), dim3(mppi::kNomThreads),
+                           (size_t)cfg.horizon * sizeof(double), stream, P, d_state, d_goal, d_unom, d_tc, d_base);
         HIPCHK(hipGetLastError());
     }
     void run_rollout(int noise_mode, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {

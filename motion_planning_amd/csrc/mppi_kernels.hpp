@@ -253,13 +253,12 @@ __device__ __forceinline__ double wave_scan_incl(double v, int lane) {
     return v;
 }
 
-// nominal_kernel for T <= 64: one wave per agent, lanes = timesteps, every scan stays in
-// registers (the launch-bound small-K tick and the strong-scaling fixed cost both want this short).
-__global__ __launch_bounds__(64) void nominal_wave_kernel(DevParams P, const double* __restrict__ state,
-                                                         const double* __restrict__ goal,
-                                                         const double* __restrict__ unom,
-                                                         double* __restrict__ tc, double* __restrict__ base) {
-    const int a = blockIdx.x, t = threadIdx.x, T = P.T;
+// The nominal (eps = 0) rollout for T <= 64 on ONE wave, lanes = timesteps, every scan in registers.
+// Lane t < T gets its table row {un0, un1, lam*sig*un0, lam*sig*un1, cb} and base[t].
+__device__ __forceinline__ void nominal_wave(const DevParams& P, const double* __restrict__ state,
+                                             const double* __restrict__ goal, const double* __restrict__ unom,
+                                             int a, int t, double (&row)[5], double& base_t) {
+    const int T = P.T;
     const bool valid = t < T;
     const double gx = goal[a * 3 + 0], gy = goal[a * 3 + 1], gth = goal[a * 3 + 2];
     const double un0 = valid ? unom[(a * 2 + 0) * T + t] : 0.0;
@@ -282,6 +281,7 @@ __global__ __launch_bounds__(64) void nominal_wave_kernel(DevParams P, const dou
     const double X = state[a * 3 + 0] + wave_scan_incl(valid ? aa * (c0 + 4.0 * c1 + c2) : 0.0, t);
     const double Y = state[a * 3 + 1] + wave_scan_incl(valid ? aa * (s0 + 4.0 * s1 + s2) : 0.0, t);
     double cst = 0.0;
+    row[0] = un0; row[1] = un1; row[2] = 0.0; row[3] = 0.0; row[4] = 0.0;
     if (valid) {
         const double thn = wrap_theta(th + h);
         const double dx = X - gx, dy = Y - gy, dth = thn - gth;
@@ -290,13 +290,11 @@ __global__ __launch_bounds__(64) void nominal_wave_kernel(DevParams P, const dou
         cst = 0.5 * (xqx + uru);
         if (t == T - 1) cst += P.p0 * dx * dx + P.p1 * dy * dy + P.p2 * dth * dth;
         const double ls = P.lambda * P.sigma;
-        double* o = tc + ((size_t)a * T + t) * kTcW;
-        o[0] = un0; o[1] = un1; o[2] = ls * un0; o[3] = ls * un1;
-        o[4] = 0.5 * uru - cst; o[5] = 0.0; o[6] = 0.0; o[7] = 0.0;
+        row[2] = ls * un0; row[3] = ls * un1; row[4] = 0.5 * uru - cst;
     }
     const double inc = wave_scan_incl(cst, t);
     const double tot = __shfl(inc, 63, 64);
-    if (valid) base[(size_t)a * T + t] = tot - (inc - cst);
+    base_t = tot - (inc - cst);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -353,19 +351,40 @@ __device__ __forceinline__ void philox_normals(uint32_t gk, uint32_t pair, uint3
 // grid = (ceil(K / 256), A), block = 256, LDS = the 40*T-byte per-step table.  Per lane and step: 2 eps + 1 dP element
 // through HBM, fully coalesced (consecutive lanes = consecutive k).
 // ---------------------------------------------------------------------------------------------
-template <typename S, int NTERM, bool PHILOX, bool STORE_EPS>
+template <typename S, int NTERM, bool PHILOX, bool STORE_EPS, bool INLINE_NOM>
 __global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double* __restrict__ state,
                                                      const double* __restrict__ goal,
-                                                     const double* __restrict__ tc, S* __restrict__ eps,
+                                                     double* __restrict__ tc, S* __restrict__ eps,
                                                      S* __restrict__ dP, S* __restrict__ Stot, uint64_t seed,
                                                      uint32_t tick_arg, const uint32_t* __restrict__ tick_ptr,
-                                                     int k_first, int k_last, S* __restrict__ epart) {
+                                                     int k_first, int k_last, S* __restrict__ epart,
+                                                     const double* __restrict__ unom, double* __restrict__ base) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* lt = reinterpret_cast<double*>(smem_raw);  // [T][5] per-step table {un0, un1, w0, w1, cb}
     const int tid = threadIdx.x, a = blockIdx.y, T = P.T;
-    // stage the per-step table in LDS once: read back as wave-uniform (broadcast) ds_reads that the
-    // scheduler can hoist, instead of an s_load + s_waitcnt round trip on every step
-    for (int i = tid; i < T * 5; i += blockDim.x) lt[i] = tc[((size_t)a * T + i / 5) * kTcW + i % 5];
+    // The per-step table lives in LDS: read back as wave-uniform (broadcast) ds_reads that the
+    // scheduler can hoist, instead of an s_load + s_waitcnt round trip on every step.
+    if (INLINE_NOM) {
+        // T <= 64: wave 0 of every block runs the nominal rollout itself (lanes = timesteps, ~600
+        // instructions) -- no separate kernel, no launch boundary in front of the rollout.  The
+        // first block also publishes base[] (and tc[]) for mppi_download_value.
+        if (tid < 64) {
+            double row[5], base_t;
+            nominal_wave(P, state, goal, unom, a, tid, row, base_t);
+            if (tid < T) {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) lt[tid * 5 + i] = row[i];
+                if (blockIdx.x == 0 && k_first == 0) {
+                    base[(size_t)a * T + tid] = base_t;
+                    double* o = tc + ((size_t)a * T + tid) * kTcW;
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) o[i] = row[i];
+                }
+            }
+        }
+    } else {
+        for (int i = tid; i < T * 5; i += blockDim.x) lt[i] = tc[((size_t)a * T + i / 5) * kTcW + i % 5];
+    }
     __syncthreads();
     const int k = k_first + blockIdx.x * blockDim.x + tid;  // this launch covers samples [k_first, k_last)
     const bool active = k < k_last;
