@@ -200,6 +200,29 @@ def test_odd_sizes_and_ragged_tail(orc):
         assert np.abs(ua[0] - uo).max() < 1e-9 and np.abs(nxt[0] - so).max() < 1e-12, (K, T)
 
 
+@pytest.mark.parametrize("T", [64, 66, 130, 300, 1000])
+def test_long_horizons(orc, T):
+    """T = 64 is the last horizon whose nominal rollout runs inside the rollout kernel (one wave);
+    above it the block-scan nominal kernel takes over (T > 256: several scan chunks with carries)."""
+    K = 96
+    eps = orc.reference_noise(T, SIG, T, K)
+    u0 = 0.4 * np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
+    state, goal = [0.1, -0.1, 0.5], [0.6, 0.3, -0.2]
+    for storage in ("f64", "f32"):
+        e_in = _round_eps(eps, storage)
+        with _engine(K, T, storage) as e:
+            e.set_nominal(u0)
+            e.upload_noise(e_in)
+            nxt, ua = e.tick(state, goal, noise="injected")
+            V = e.download_value()[0]
+        Vo = orc.get_cost2go(state, u0, goal, LAM, SIG, e_in)
+        tol = 1e-9 * np.abs(Vo).max() if storage == "f64" else _vtol(orc, state, u0, goal, Vo, T, K)
+        assert np.abs(V - Vo).max() <= tol, (T, storage)
+        so, uo, _ = orc.get_path(state, goal, u0, e_in, LAM, SIG)
+        assert np.abs(ua[0] - uo).max() < (1e-9 if storage == "f64" else 1e-6), (T, storage)
+        assert np.abs(nxt[0] - so).max() < (1e-12 if storage == "f64" else 1e-8), (T, storage)
+
+
 def test_large_step_uses_full_sincos(orc):
     """dt so large that |h/2| > 0.25 rad: the rotation falls back to sincos (NTERM=0); also the
     mid branch (NTERM=7)."""
