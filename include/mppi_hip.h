@@ -57,6 +57,10 @@ extern "C" {
 #define MPPI_NOISE_INJECTED 0 /* use the buffer filled by mppi_upload_noise (reference-RNG parity) */
 #define MPPI_NOISE_PHILOX 1   /* device Philox4x32-10 + Box-Muller keyed by (seed, tick, agent, sample) */
 
+/* dynamics + integrator pairs the reference's `model=` argument can select (control/src/mppi:62) */
+#define MPPI_MODEL_DIFFDRIVE_RK4 0   /* rk4 :39-54 over dd_dynamics :23-30 -- what the node runs      */
+#define MPPI_MODEL_UNICYCLE_EULER 1  /* euler :57-58 over unicycle_dynamics :33-36 (no theta wrap)   */
+
 /* kernels, for mppi_kernel_timing */
 #define MPPI_KERNEL_NOMINAL 0
 #define MPPI_KERNEL_ROLLOUT 1
@@ -74,6 +78,8 @@ typedef struct mppi_config {
     int32_t storage;       /* MPPI_STORE_F32 | MPPI_STORE_F64                                 */
     int32_t device;        /* HIP device ordinal                                              */
     uint32_t sample_offset;/* global index of local sample 0                                  */
+    int32_t model;         /* MPPI_MODEL_*: the `model=` ctor argument (control/src/mppi:62)   */
+    int32_t reserved;      /* must be 0                                                       */
     double dt;             /* <= 0: 1/T  (control/src/mppi:67)                                */
     double sigma;          /* noise std-dev = sig[0,0] (control/src/mppi:145); default 0.9    */
     double lambda;         /* temperature; default 0.001 (control/src/mppi:89)                */
@@ -104,6 +110,18 @@ int mppi_set_stream(mppi_engine *h, void *hip_stream);
 
 /* Per-call sig / lam of get_path (control/src/mppi:88-89). */
 int mppi_set_sigma_lambda(mppi_engine *h, double sigma, double lambda);
+
+/*
+ * EXTENSION (not in the reference's cost; off unless called with weight != 0):
+ * an obstacle stage cost read from an occupancy grid in the format map::Grid exports
+ * (map/src/map/grid.cpp:126-144: int8 0 free / 50 inflation / 100 occupied; row-major
+ * index x + y*width, :251-266; origin = map_min; square cells of `resolution`):
+ *     stage cost += weight * cell(x_t, y_t) / 100          (0 outside the grid)
+ * for the post-step state of every step, shared by all agents.  cells == NULL or weight == 0
+ * removes it.  The grid is copied to the device.
+ */
+int mppi_set_obstacle_grid(mppi_engine *h, const int8_t *cells, int32_t width, int32_t height,
+                           double resolution, double origin_x, double origin_y, double weight);
 
 /* MPPI.initialize, control/src/mppi:79-83: zero the nominal controls of one agent (-1: all). */
 int mppi_reset(mppi_engine *h, int agent);

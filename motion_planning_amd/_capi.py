@@ -9,6 +9,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmppi_hip.so")
 
 MPPI_STORE_F32, MPPI_STORE_F64 = 0, 1
 MPPI_NOISE_INJECTED, MPPI_NOISE_PHILOX = 0, 1
+MPPI_MODEL_DIFFDRIVE_RK4, MPPI_MODEL_UNICYCLE_EULER = 0, 1
 KERNELS = ("nominal", "rollout", "update", "merge", "finalize")
 ABI_VERSION = 1
 
@@ -16,6 +17,7 @@ ABI_VERSION = 1
 class MppiConfig(C.Structure):
     _fields_ = [("n_agents", C.c_int32), ("samples", C.c_int32), ("horizon", C.c_int32),
                 ("storage", C.c_int32), ("device", C.c_int32), ("sample_offset", C.c_uint32),
+                ("model", C.c_int32), ("reserved", C.c_int32),
                 ("dt", C.c_double), ("sigma", C.c_double), ("lambda_", C.c_double),
                 ("q", C.c_double * 3), ("r", C.c_double * 2), ("p1", C.c_double * 3),
                 ("u_max", C.c_double), ("wheel_radius", C.c_double), ("wheel_base", C.c_double),
@@ -41,6 +43,8 @@ SIGNATURES = {
     "mppi_set_stream": (C.c_int, [_H, C.c_void_p]),
     "mppi_set_sigma_lambda": (C.c_int, [_H, C.c_double, C.c_double]),
     "mppi_reset": (C.c_int, [_H, C.c_int]),
+    "mppi_set_obstacle_grid": (C.c_int, [_H, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double,
+                                         C.c_double]),
     "mppi_set_nominal": (C.c_int, [_H, C.c_int, _dp]),
     "mppi_get_nominal": (C.c_int, [_H, C.c_int, _dp]),
     "mppi_upload_noise": (C.c_int, [_H, _dp]),

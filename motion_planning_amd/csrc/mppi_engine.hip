@@ -99,6 +99,8 @@ struct mppi_engine {
     double* d_S = nullptr;
     double* d_out = nullptr;
     uint32_t* d_tick = nullptr;
+    signed char* d_grid = nullptr;
+    size_t grid_bytes = 0;
     double* d_tmp = nullptr;
     size_t tmp_elems = 0;
 
@@ -190,9 +192,9 @@ struct mppi_engine {
         if (!have_state || !have_goal) fail(MPPI_E_STATE, "state/goal passed as NULL before ever being set");
     }
 
-    template <typename S, int NT, bool PH, bool SE, bool IN>
+    template <typename S, int NT, bool PH, bool SE, bool IN, int MODEL>
     void launch_rollout_g(hipStream_t st, int k0, int k1, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
-        auto kern = mppi::rollout_kernel<S, NT, PH, SE, IN>;
+        auto kern = mppi::rollout_kernel<S, NT, PH, SE, IN, MODEL>;
         dim3 grid((k1 - k0 + roll_bs - 1) / roll_bs, cfg.n_agents);
         hipLaunchKernelGGL(kern, grid, dim3(roll_bs), (size_t)cfg.horizon * 5 * sizeof(double), st, P, d_state, d_goal, d_tc, static_cast<S*>(d_eps),
                            static_cast<S*>(d_dP), static_cast<S*>(d_stot), seed, tick, tick_ptr, k0, k1,
@@ -201,8 +203,9 @@ struct mppi_engine {
     }
     template <typename S, int NT, bool PH, bool SE>
     void launch_rollout_f(hipStream_t st, int k0, int k1, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
-        if (inline_nominal()) launch_rollout_g<S, NT, PH, SE, true>(st, k0, k1, seed, tick, tick_ptr);
-        else launch_rollout_g<S, NT, PH, SE, false>(st, k0, k1, seed, tick, tick_ptr);
+        if (cfg.model == MPPI_MODEL_UNICYCLE_EULER) launch_rollout_g<S, NT, PH, SE, false, 1>(st, k0, k1, seed, tick, tick_ptr);
+        else if (inline_nominal()) launch_rollout_g<S, NT, PH, SE, true, 0>(st, k0, k1, seed, tick, tick_ptr);
+        else launch_rollout_g<S, NT, PH, SE, false, 0>(st, k0, k1, seed, tick, tick_ptr);
     }
     template <typename S, int NT>
     void launch_rollout_t(hipStream_t st, int k0, int k1, bool ph, bool store, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
@@ -301,7 +304,7 @@ struct mppi_engine {
         noise_ready = true; value_ready = true; partials_ready = true; epart_ready = true;
     }
     // T <= 64: the nominal rollout runs inside every rollout block (one wave, lanes = timesteps)
-    bool inline_nominal() const { return cfg.horizon <= 64; }
+    bool inline_nominal() const { return cfg.horizon <= 64 && cfg.model == MPPI_MODEL_DIFFDRIVE_RK4; }
     void run_nominal() {
         if (inline_nominal()) return;
         Scope sc(this, MPPI_KERNEL_NOMINAL);
@@ -349,6 +352,9 @@ struct mppi_engine {
         if ((size_t)cfg.horizon * 40 > 64 * 1024)
             fail(MPPI_E_INVALID, "horizon %d: the per-step table (40 B/step) must fit 64 KB of LDS (horizon <= 1638)", cfg.horizon);
         if (cfg.storage != MPPI_STORE_F32 && cfg.storage != MPPI_STORE_F64) fail(MPPI_E_INVALID, "bad storage %d", cfg.storage);
+        if (cfg.model != MPPI_MODEL_DIFFDRIVE_RK4 && cfg.model != MPPI_MODEL_UNICYCLE_EULER)
+            fail(MPPI_E_INVALID, "unknown model %d (rk4 + dd_dynamics = 0, euler + unicycle_dynamics = 1)", cfg.model);
+        if (cfg.reserved != 0) fail(MPPI_E_INVALID, "mppi_config.reserved must be 0");
         if (!(cfg.lambda > 0.0) || !(cfg.sigma >= 0.0)) fail(MPPI_E_INVALID, "lambda must be > 0 and sigma >= 0");
         if (!(cfg.dt > 0.0)) cfg.dt = 1.0 / (double)cfg.horizon;  // control/src/mppi:67
         int ndev = 0;
@@ -375,7 +381,10 @@ struct mppi_engine {
 
         roll_bs = 256;
         roll_blocks = (K + roll_bs - 1) / roll_bs;
-        const double phi_max = P.kth * P.dt * P.u_max;  // |h/2| <= kth*dt*(2 u_max)/2
+        P.model = cfg.model;
+        P.grid = nullptr; P.grid_w = 0; P.grid_h = 0; P.grid_res = 1.0; P.grid_ox = 0.0; P.grid_oy = 0.0; P.grid_weight = 0.0;
+        // largest rotation of the heading vector in one step: h/2 <= kth*dt*u_max (rk4), dt*u_max (euler)
+        const double phi_max = (cfg.model == MPPI_MODEL_UNICYCLE_EULER ? 1.0 : P.kth) * P.dt * P.u_max;
         nterm = phi_max <= 0.03 ? 4 : (phi_max <= 0.25 ? 7 : 0);
 
         // update geometry: each block keeps one chunk of a row in registers
@@ -459,7 +468,7 @@ struct mppi_engine {
         if (ev_fork) hipEventDestroy(ev_fork);
         if (ev_join) hipEventDestroy(ev_join);
         if (h_stage) hipHostFree(h_stage);
-        void* bufs[] = {d_eps, d_dP, d_stot, d_epart, d_tc, d_base, d_unom, d_ufilt, d_state, d_goal, d_part, d_merged, d_S, d_out, d_tick, d_tmp};
+        void* bufs[] = {d_eps, d_dP, d_stot, d_epart, d_tc, d_base, d_unom, d_ufilt, d_state, d_goal, d_part, d_merged, d_S, d_out, d_tick, d_tmp, d_grid};
         for (void* b : bufs) if (b) hipFree(b);
         if (own_stream) hipStreamDestroy(own_stream);
     }
@@ -493,6 +502,8 @@ int mppi_default_config(mppi_config* cfg) {
     cfg->storage = MPPI_STORE_F32;
     cfg->device = 0;
     cfg->sample_offset = 0;
+    cfg->model = MPPI_MODEL_DIFFDRIVE_RK4;  // MPPI(model=rk4), control/src/mppi:62
+    cfg->reserved = 0;
     cfg->dt = 0.0;
     cfg->sigma = 0.9;     // control/src/mppi:88
     cfg->lambda = 0.001;  // control/src/mppi:89
@@ -543,6 +554,28 @@ int mppi_set_sigma_lambda(mppi_engine* h, double sigma, double lambda) {
     h->cfg.sigma = sigma; h->cfg.lambda = lambda;
     h->refresh_params();
     h->destroy_graph();
+    API_END(h)
+}
+
+int mppi_set_obstacle_grid(mppi_engine* h, const int8_t* cells, int32_t width, int32_t height, double resolution,
+                           double origin_x, double origin_y, double weight) {
+    API_BEGIN(h)
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->destroy_graph();
+    if (!cells || weight == 0.0) {
+        h->P.grid = nullptr; h->P.grid_weight = 0.0;
+    } else {
+        if (width < 1 || height < 1 || !(resolution > 0.0)) fail(MPPI_E_INVALID, "bad grid geometry %d x %d @ %g", width, height, resolution);
+        const size_t bytes = (size_t)width * height;
+        if (bytes > h->grid_bytes) {
+            if (h->d_grid) { HIPCHK(hipFree(h->d_grid)); h->hbm_bytes -= h->grid_bytes; h->d_grid = nullptr; h->grid_bytes = 0; }
+            h->d_grid = dev_alloc<signed char>(bytes, h->hbm_bytes);
+            h->grid_bytes = bytes;
+        }
+        HIPCHK(hipMemcpy(h->d_grid, cells, bytes, hipMemcpyHostToDevice));
+        h->P.grid = h->d_grid; h->P.grid_w = width; h->P.grid_h = height;
+        h->P.grid_res = resolution; h->P.grid_ox = origin_x; h->P.grid_oy = origin_y; h->P.grid_weight = weight;
+    }
     API_END(h)
 }
 

@@ -39,7 +39,19 @@ struct DevParams {
     double dt, sigma, lambda, inv_lambda;
     double q0, q1, q2, r0, r1, p0, p1, p2;
     double u_max, kth, rhalf, floor_w;  // kth = wheel_radius / wheel_base, rhalf = wheel_radius / 2
+    int model;                          // 0: rk4 + dd_dynamics, 1: euler + unicycle_dynamics
+    // optional obstacle-grid stage cost (extension, include/mppi_hip.h mppi_set_obstacle_grid)
+    const signed char* grid;
+    int grid_w, grid_h;
+    double grid_res, grid_ox, grid_oy, grid_weight;
 };
+
+// weight * cell / 100 of the cell holding (x, y); same arithmetic (divide + floor) as the oracle
+__device__ __forceinline__ double obstacle_cost(const DevParams& P, double x, double y) {
+    const int ix = (int)floor((x - P.grid_ox) / P.grid_res), iy = (int)floor((y - P.grid_oy) / P.grid_res);
+    if (ix < 0 || iy < 0 || ix >= P.grid_w || iy >= P.grid_h) return 0.0;
+    return P.grid_weight * ((double)P.grid[ix + iy * P.grid_w] / 100.0);
+}
 
 __device__ __forceinline__ double clampd(double v, double lim) { return fmin(fmax(v, -lim), lim); }
 
@@ -125,21 +137,27 @@ __global__ __launch_bounds__(kNomThreads) void nominal_kernel(DevParams P, const
         const double un0 = valid ? unom[(a * 2 + 0) * T + t] : 0.0;
         const double un1 = valid ? unom[(a * 2 + 1) * T + t] : 0.0;
         const double u0 = clampd(un0, P.u_max), u1 = clampd(un1, P.u_max);
-        const double h = valid ? P.kth * P.dt * (u1 - u0) : 0.0;
+        const double h = valid ? (P.model == 1 ? P.dt * u1 : P.kth * P.dt * (u1 - u0)) : 0.0;
         double tot_h, tot_x, tot_y;
         const double hin = block_scan_incl<kNomThreads>(h, sh, tot_h);
         const double th = car_th + (hin - h);
-        double s0, c0, s1, c1, s2, c2;
+        double s0, c0, ix, iy;
         sincos(th, &s0, &c0);
-        sincos(th + 0.5 * h, &s1, &c1);
-        sincos(th + h, &s2, &c2);
-        const double aa = P.dt * P.rhalf * (u0 + u1) * (1.0 / 6.0);
-        const double ix = valid ? aa * (c0 + 4.0 * c1 + c2) : 0.0;
-        const double iy = valid ? aa * (s0 + 4.0 * s1 + s2) : 0.0;
+        if (P.model == 1) {  // euler + unicycle
+            ix = valid ? P.dt * (c0 * u0) : 0.0;
+            iy = valid ? P.dt * (s0 * u0) : 0.0;
+        } else {
+            double s1, c1, s2, c2;
+            sincos(th + 0.5 * h, &s1, &c1);
+            sincos(th + h, &s2, &c2);
+            const double aa = P.dt * P.rhalf * (u0 + u1) * (1.0 / 6.0);
+            ix = valid ? aa * (c0 + 4.0 * c1 + c2) : 0.0;
+            iy = valid ? aa * (s0 + 4.0 * s1 + s2) : 0.0;
+        }
         const double X = car_x + block_scan_incl<kNomThreads>(ix, sh, tot_x);
         const double Y = car_y + block_scan_incl<kNomThreads>(iy, sh, tot_y);
         if (valid) {
-            const double thn = wrap_theta(th + h);
+            const double thn = (P.model == 1) ? th + h : wrap_theta(th + h);
             const double dx = X - gx, dy = Y - gy, dth = thn - gth;
             const double xqx = P.q0 * dx * dx + P.q1 * dy * dy + P.q2 * dth * dth;
             const double uru = P.r0 * un0 * un0 + P.r1 * un1 * un1;
@@ -264,26 +282,32 @@ __device__ __forceinline__ void nominal_wave(const DevParams& P, const double* _
     const double un0 = valid ? unom[(a * 2 + 0) * T + t] : 0.0;
     const double un1 = valid ? unom[(a * 2 + 1) * T + t] : 0.0;
     const double u0 = clampd(un0, P.u_max), u1 = clampd(un1, P.u_max);
-    const double h = valid ? P.kth * P.dt * (u1 - u0) : 0.0;
+    const double h = valid ? (P.model == 1 ? P.dt * u1 : P.kth * P.dt * (u1 - u0)) : 0.0;
     const double th = state[a * 3 + 2] + (wave_scan_incl(h, t) - h);
-    double s0, c0, s1, c1, s2, c2;
+    double s0, c0, ix, iy;
     sincos(th, &s0, &c0);
-    if (fabs(h) <= 0.5) {  // mid / end headings by a small rotation instead of two more sincos
-        double sp, cp;
-        small_sincos<7>(0.5 * h, sp, cp);
-        c1 = c0 * cp - s0 * sp; s1 = s0 * cp + c0 * sp;
-        c2 = c1 * cp - s1 * sp; s2 = s1 * cp + c1 * sp;
+    if (P.model == 1) {  // euler + unicycle: x += dt * cos(theta) * u0
+        ix = P.dt * (c0 * u0); iy = P.dt * (s0 * u0);
     } else {
-        sincos(th + 0.5 * h, &s1, &c1);
-        sincos(th + h, &s2, &c2);
+        double s1, c1, s2, c2;
+        if (fabs(h) <= 0.5) {  // mid / end headings by a small rotation instead of two more sincos
+            double sp, cp;
+            small_sincos<7>(0.5 * h, sp, cp);
+            c1 = c0 * cp - s0 * sp; s1 = s0 * cp + c0 * sp;
+            c2 = c1 * cp - s1 * sp; s2 = s1 * cp + c1 * sp;
+        } else {
+            sincos(th + 0.5 * h, &s1, &c1);
+            sincos(th + h, &s2, &c2);
+        }
+        const double aa = P.dt * P.rhalf * (u0 + u1) * (1.0 / 6.0);
+        ix = aa * (c0 + 4.0 * c1 + c2); iy = aa * (s0 + 4.0 * s1 + s2);
     }
-    const double aa = P.dt * P.rhalf * (u0 + u1) * (1.0 / 6.0);
-    const double X = state[a * 3 + 0] + wave_scan_incl(valid ? aa * (c0 + 4.0 * c1 + c2) : 0.0, t);
-    const double Y = state[a * 3 + 1] + wave_scan_incl(valid ? aa * (s0 + 4.0 * s1 + s2) : 0.0, t);
+    const double X = state[a * 3 + 0] + wave_scan_incl(valid ? ix : 0.0, t);
+    const double Y = state[a * 3 + 1] + wave_scan_incl(valid ? iy : 0.0, t);
     double cst = 0.0;
     row[0] = un0; row[1] = un1; row[2] = 0.0; row[3] = 0.0; row[4] = 0.0;
     if (valid) {
-        const double thn = wrap_theta(th + h);
+        const double thn = (P.model == 1) ? th + h : wrap_theta(th + h);
         const double dx = X - gx, dy = Y - gy, dth = thn - gth;
         const double xqx = P.q0 * dx * dx + P.q1 * dy * dy + P.q2 * dth * dth;
         const double uru = P.r0 * un0 * un0 + P.r1 * un1 * un1;
@@ -351,7 +375,7 @@ __device__ __forceinline__ void philox_normals(uint32_t gk, uint32_t pair, uint3
 // grid = (ceil(K / 256), A), block = 256, LDS = the 40*T-byte per-step table.  Per lane and step: 2 eps + 1 dP element
 // through HBM, fully coalesced (consecutive lanes = consecutive k).
 // ---------------------------------------------------------------------------------------------
-template <typename S, int NTERM, bool PHILOX, bool STORE_EPS, bool INLINE_NOM>
+template <typename S, int NTERM, bool PHILOX, bool STORE_EPS, bool INLINE_NOM, int MODEL>
 __global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double* __restrict__ state,
                                                      const double* __restrict__ goal,
                                                      double* __restrict__ tc, S* __restrict__ eps,
@@ -465,6 +489,23 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double*
                 }
                 // EXPLORE + CLIP (control/src/mppi:147-152)
                 const double u0 = clampd(un0 + e0, P.u_max), u1 = clampd(un1 + e1, P.u_max);
+                if (MODEL == 1) {
+                    // euler (control/src/mppi:57-58) over unicycle_dynamics (:33-36): x += dt cos(th) u0,
+                    // th += dt u1, no wrap; the heading vector is rotated by the step's dt*u1
+                    const double phi = P.dt * u1, du = P.dt * u0;
+                    x = fma(du, c, x);
+                    y = fma(du, s, y);
+                    th += phi;
+                    if (NTERM == 0) {
+                        sincos(th, &s, &c);
+                    } else {
+                        double sp, cp;
+                        small_sincos<NTERM>(phi, sp, cp);
+                        const double cn = c * cp - s * sp;
+                        s = s * cp + c * sp;
+                        c = cn;
+                    }
+                } else {
                 // rk4 (control/src/mppi:39-54) for dd_dynamics (:23-30): theta_dot is constant
                 // over the step, so the four stages sit at theta, theta+h/2 (twice), theta+h.
                 const double phi = half_kd * (u1 - u0);
@@ -491,6 +532,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double*
                 // the interval, so only lanes that left it pay for the ceil/divide
                 if (th > M_PI || th <= -M_PI) th = wrap_theta(th);
                 c = c2; s = s2;
+                }
                 // get_cost (control/src/mppi:180-184) minus the nominal stage cost (cb):
                 //   1/2 xQx + 1/2 uRu + lam*sig*(un . eps)  with u = NOMINAL, eps = UNCLIPPED
                 const double dx = x - gx, dy = y - gy;
@@ -498,6 +540,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double*
                 if (hq2 != 0.0) { const double dth = th - gth; dc = fma(hq2 * dth, dth, dc); }  // Q[2,2] = 0 in the node
                 dc = fma(w0, e0, dc);
                 dc = fma(w1, e1, dc);
+                if (P.grid_weight != 0.0) dc += obstacle_cost(P, x, y);  // extension, off in the node (uniform branch)
                 if (t == T - 1) {  // terminal cost (control/src/mppi:165-173), theta error not wrapped
                     const double dth = th - gth;
                     dc += P.p0 * dx * dx + P.p1 * dy * dy + P.p2 * dth * dth;
@@ -755,7 +798,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(DevParams P, const double
     }
     __syncthreads();
     // perform_action (:210-213): the three distinct stage angles of rk4 evaluated by three lanes
-    const double sum = uf[0] + uf[T], om = P.kth * (uf[T] - uf[0]);
+    // (euler + unicycle only needs the first)
+    const double sum = uf[0] + uf[T], om = (P.model == 1) ? uf[T] : P.kth * (uf[T] - uf[0]);
     const double th0 = state[a * 3 + 2], k_th = P.dt * om;
     if ((flags & 1) && tid < 3) {
         const double ang = (tid == 0) ? th0 : (tid == 1 ? th0 + k_th / 2 : th0 + k_th);
@@ -778,6 +822,11 @@ __global__ __launch_bounds__(256) void finalize_kernel(DevParams P, const double
         if (flags & 1) {  // same operation order as rk4 (:39-54) with dd_dynamics (:23-30)
             const double x0[3] = {state[a * 3 + 0], state[a * 3 + 1], th0};
             double k1[3], k2[3], k3[3], k4[3], xn[3];
+            if (P.model == 1) {  // euler (:57-58) over unicycle_dynamics (:33-36)
+                xn[0] = x0[0] + P.dt * (trig[0][0] * uf[0]);
+                xn[1] = x0[1] + P.dt * (trig[0][1] * uf[0]);
+                xn[2] = x0[2] + P.dt * uf[T];
+            } else {
             k1[0] = P.dt * (P.rhalf * trig[0][0] * sum); k1[1] = P.dt * (P.rhalf * trig[0][1] * sum); k1[2] = k_th;
             k2[0] = P.dt * (P.rhalf * trig[1][0] * sum); k2[1] = P.dt * (P.rhalf * trig[1][1] * sum); k2[2] = k_th;
             k3[0] = k2[0]; k3[1] = k2[1]; k3[2] = k_th;
@@ -785,6 +834,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(DevParams P, const double
 #pragma unroll
             for (int i = 0; i < 3; ++i) xn[i] = x0[i] + (1.0 / 6.0) * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]);
             xn[2] = wrap_theta(xn[2]);
+            }
             double* o = outv + (size_t)a * 8;
             o[0] = xn[0]; o[1] = xn[1]; o[2] = xn[2]; o[3] = uf[0]; o[4] = uf[T];
             state[a * 3 + 0] = xn[0]; state[a * 3 + 1] = xn[1]; state[a * 3 + 2] = xn[2];
@@ -801,7 +851,13 @@ __global__ void plant_kernel(DevParams P, const double* __restrict__ state, cons
     const double x0[3] = {state[a * 3 + 0], state[a * 3 + 1], state[a * 3 + 2]};
     const double u0 = unom[((size_t)a * 2 + 0) * P.T], u1 = unom[((size_t)a * 2 + 1) * P.T];
     double xn[3];
-    rk4_exact(P, x0, u0, u1, xn);
+    if (P.model == 1) {  // euler (:57-58) over unicycle_dynamics (:33-36)
+        xn[0] = x0[0] + P.dt * (cos(x0[2]) * u0);
+        xn[1] = x0[1] + P.dt * (sin(x0[2]) * u0);
+        xn[2] = x0[2] + P.dt * u1;
+    } else {
+        rk4_exact(P, x0, u0, u1, xn);
+    }
     double* o = outv + (size_t)a * 8;
     o[0] = xn[0]; o[1] = xn[1]; o[2] = xn[2]; o[3] = u0; o[4] = u1;
 }

@@ -43,6 +43,23 @@ def rk4(x0, u, dt):
     return xnew
 
 
+def unicycle_dynamics(x, u):
+    """control/src/mppi:33-36.  Host utility (see dd_dynamics)."""
+    x = np.asarray(x, dtype=np.float64)
+    u = np.asarray(u, dtype=np.float64)
+    return np.array([np.cos(x[2, :]) * u[0, :], np.sin(x[2, :]) * u[0, :], u[1, :]])
+
+
+def euler(x0, u, dt):
+    """control/src/mppi:57-58.  Host utility; passing it as ``model=`` selects the engine's
+    euler + unicycle rollout (the reference's alternative to the default rk4 + diff drive)."""
+    return np.asarray(x0, dtype=np.float64) + dt * unicycle_dynamics(x0, u)
+
+
+_MODELS = {"rk4": _capi.MPPI_MODEL_DIFFDRIVE_RK4, "euler": _capi.MPPI_MODEL_UNICYCLE_EULER,
+           _capi.MPPI_MODEL_DIFFDRIVE_RK4: _capi.MPPI_MODEL_DIFFDRIVE_RK4,
+           _capi.MPPI_MODEL_UNICYCLE_EULER: _capi.MPPI_MODEL_UNICYCLE_EULER}
+
 _STORAGE = {"f32": MPPI_STORE_F32, "f64": MPPI_STORE_F64, MPPI_STORE_F32: MPPI_STORE_F32,
             MPPI_STORE_F64: MPPI_STORE_F64}
 
@@ -58,13 +75,14 @@ class Engine(object):
     """One libmppi_hip engine: A agents x K samples (this GPU's shard) x T horizon."""
 
     def __init__(self, samples, horizon, n_agents=1, storage="f32", device=0, sample_offset=0,
-                 dt=None, sigma=0.9, lam=0.001, **overrides):
+                 dt=None, sigma=0.9, lam=0.001, model="rk4", **overrides):
         self._lib = _capi.load()
         cfg = _capi.default_config()
         cfg.n_agents, cfg.samples, cfg.horizon = int(n_agents), int(samples), int(horizon)
         cfg.storage = _STORAGE[storage]
         cfg.device = int(device)
         cfg.sample_offset = int(sample_offset)
+        cfg.model = _MODELS[model]
         cfg.dt = 0.0 if dt is None else float(dt)
         cfg.sigma, cfg.lambda_ = float(sigma), float(lam)
         for key, val in overrides.items():
@@ -115,6 +133,19 @@ class Engine(object):
         if sigma != self.sigma or lam != self.lam:
             self._ck(self._lib.mppi_set_sigma_lambda(self._h, float(sigma), float(lam)))
             self.sigma, self.lam = float(sigma), float(lam)
+
+    def set_obstacle_grid(self, cells, resolution, origin, weight):
+        """EXTENSION (not in the reference cost): occupancy grid in map::Grid's export format,
+        cells [height][width] int8 in {0, 50, 100}; stage cost += weight * cell / 100.
+        cells=None or weight=0 removes it."""
+        if cells is None or weight == 0:
+            self._ck(self._lib.mppi_set_obstacle_grid(self._h, None, 0, 0, 1.0, 0.0, 0.0, 0.0))
+            return
+        g = np.ascontiguousarray(cells, dtype=np.int8)
+        if g.ndim != 2:
+            raise ValueError("cells must be [height][width]")
+        self._ck(self._lib.mppi_set_obstacle_grid(self._h, g.ctypes.data, g.shape[1], g.shape[0], float(resolution),
+                                                  float(origin[0]), float(origin[1]), float(weight)))
 
     def reset(self, agent=-1):
         self._ck(self._lib.mppi_reset(self._h, int(agent)))
@@ -246,8 +277,13 @@ class MPPI(object):
 
     def __init__(self, model=rk4, horizon=100, samples=10, thresh=0.05, rng="numpy", seed=0,
                  storage="f32", device=0):
-        if model is not rk4 and model != "rk4":
-            raise NotImplementedError("only the reference's default model=rk4 (diff drive) is built in")
+        if model is rk4 or model == "rk4":
+            model_id = "rk4"
+        elif model is euler or model == "euler":
+            model_id = "euler"
+        else:
+            raise NotImplementedError("model must be rk4 (diff drive, the node's default) or euler (unicycle): "
+                                      "the two integrators control/src/mppi defines")
         if rng not in ("numpy", "philox"):
             raise ValueError("rng must be 'numpy' or 'philox'")
         self.horizon = int(horizon)
@@ -264,7 +300,7 @@ class MPPI(object):
         self.rng = rng
         self.seed = int(seed)
         self._tick = 0
-        self._eng = Engine(self.samples, self.horizon, 1, storage=storage, device=device)
+        self._eng = Engine(self.samples, self.horizon, 1, storage=storage, device=device, model=model_id)
         self.initialize()
 
     # control/src/mppi:79-83

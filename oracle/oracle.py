@@ -19,7 +19,10 @@ c_dp = C.POINTER(C.c_double)
 class OrcParams(C.Structure):
     _fields_ = [("q", C.c_double * 3), ("r", C.c_double * 2), ("p1", C.c_double * 3),
                 ("u_max", C.c_double), ("wheel_radius", C.c_double),
-                ("wheel_base", C.c_double), ("floor_w", C.c_double)]
+                ("wheel_base", C.c_double), ("floor_w", C.c_double), ("model", C.c_int),
+                ("grid", C.c_void_p), ("grid_w", C.c_int), ("grid_h", C.c_int),
+                ("grid_res", C.c_double), ("grid_ox", C.c_double), ("grid_oy", C.c_double),
+                ("grid_weight", C.c_double)]
 
 
 def build(force=False):
@@ -56,6 +59,24 @@ def default_params():
     p = OrcParams()
     lib().orc_default_params(C.byref(p))
     return p
+
+
+def set_obstacle_grid(params, cells, resolution, origin, weight):
+    """cells [height][width] int8 (map::Grid export: 0 / 50 / 100); keeps the array alive on params."""
+    cells = np.ascontiguousarray(cells, dtype=np.int8)
+    params._grid_keepalive = cells
+    params.grid = cells.ctypes.data
+    params.grid_h, params.grid_w = cells.shape
+    params.grid_res, params.grid_ox, params.grid_oy = float(resolution), float(origin[0]), float(origin[1])
+    params.grid_weight = float(weight)
+    return params
+
+
+def euler(x0, u, dt, params=None):
+    p = params or default_params()
+    out = np.zeros(3)
+    lib().orc_euler(C.byref(p), _p(_d(x0)), _p(_d(u)), C.c_double(dt), _p(out))
+    return out
 
 
 def set_threads(n):

@@ -263,6 +263,34 @@ def main():
                                    K=16, T=20, thresh=0.97)
     out["ctl_wp_meta"] = np.array([16, 20, 12, 60], dtype=np.int64)
 
+    # ---------------- G: the alternative model of the ctor argument: euler + unicycle (:33-36, :57-58)
+    K, T, seed = 32, 50, 8
+    mp = ref.MPPI(model=ref.euler, horizon=T, samples=K)
+    u0 = nominal_warm(T)
+    sig = np.array([[SIG, 0.0], [0.0, SIG]])
+    np.random.seed(seed)
+    V, eps = mp.get_cost2go(np.array([0.1, -0.2, 0.3]), u0.copy(), np.array([1.0, 0.5, 0.2]), LAM, sig)
+    assert np.array_equal(np.array(eps), np.random.RandomState(seed).normal(0.0, SIG, (T, 2, K)))
+    out["euler_c2g_V"] = V.copy()
+    out["euler_c2g_unew"] = mp.update_action(u0.copy(), eps, V.copy(), sig, LAM)
+    out["euler_c2g_meta"] = np.array([K, T, seed], dtype=np.int64)
+    out["euler_c2g_state"] = np.array([0.1, -0.2, 0.3])
+    out["euler_c2g_goal"] = np.array([1.0, 0.5, 0.2])
+    out["euler_c2g_u0"] = u0
+    K, T, seed, nt = 16, 20, 9, 6
+    mp = ref.MPPI(model=ref.euler, horizon=T, samples=K)
+    np.random.seed(seed)
+    st = np.array([0.0, 0.0, 2.5])
+    states, us = [], []
+    for _ in range(nt):
+        st = mp.get_path(st, np.array([-0.5, 0.4, 3.0]))
+        states.append(st.copy())
+        us.append(mp.uvec[-1].copy())
+    out["euler_seq_states"] = np.array(states)
+    out["euler_seq_u"] = np.array(us)
+    out["euler_seq_meta"] = np.array([K, T, seed, nt], dtype=np.int64)
+    kat["euler_step"] = ref.euler(np.array([[0.3], [-0.2], [3.1]]), np.array([[1.25], [-0.5]]), 0.25)[:, 0].tolist()
+
     np.savez_compressed(os.path.join(HERE, "mppi_golden.npz"), **out)
     with open(os.path.join(HERE, "mppi_kat.json"), "w") as f:
         json.dump(kat, f, indent=1, sort_keys=True)

@@ -223,6 +223,78 @@ def test_long_horizons(orc, T):
         assert np.abs(nxt[0] - so).max() < (1e-12 if storage == "f64" else 1e-8), (T, storage)
 
 
+@pytest.mark.parametrize("storage", ["f64", "f32"])
+def test_euler_unicycle_model_golden(orc, golden, kat, storage):
+    """MPPI(model=euler): the reference's alternative integrator/model pair (control/src/mppi:33-36,
+    :57-58), pinned by golden vectors from the reference constructed with model=euler."""
+    from motion_planning_amd import MPPI, euler
+    K, T, seed = [int(x) for x in golden["euler_c2g_meta"]]
+    eps = _round_eps(orc.reference_noise(seed, SIG, T, K), storage)
+    state, goal, u0 = golden["euler_c2g_state"], golden["euler_c2g_goal"], golden["euler_c2g_u0"]
+    p = orc.default_params(); p.model = 1
+    with _engine(K, T, storage, model="euler") as e:
+        e.set_nominal(u0); e.upload_noise(eps)
+        e.rollout(state, goal, noise="injected")
+        V = e.download_value()[0]
+        u = e.update()[0]
+        nxt = e.plant_step([0.3, -0.2, 3.1])[0]
+    Vo = orc.get_cost2go(state, u0, goal, LAM, SIG, eps, params=p)
+    if storage == "f64":
+        assert np.abs(V - golden["euler_c2g_V"]).max() < 1e-9
+        assert np.abs(u - golden["euler_c2g_unew"]).max() < 1e-9
+    else:
+        Vn = orc.get_cost2go(state, u0, goal, LAM, SIG, np.zeros((T, 2, 1)), params=p)
+        assert np.abs(V - Vo).max() <= 3e-7 * max(1.0, np.abs(Vo - Vn).max())
+        assert np.abs(u - golden["euler_c2g_unew"]).max() < 1e-6
+    assert np.allclose(nxt, orc.euler([0.3, -0.2, 3.1], u[:, 0], 1.0 / T, params=p), rtol=0, atol=1e-15)
+    # closed loop through the drop-in class, numpy RNG like the reference
+    K, T, seed, nt = [int(x) for x in golden["euler_seq_meta"]]
+    m = MPPI(model=euler, horizon=T, samples=K, storage=storage)
+    np.random.seed(seed)
+    st = np.array([0.0, 0.0, 2.5])
+    for i in range(nt):
+        st = m.get_path(st, np.array([-0.5, 0.4, 3.0]))
+        assert np.abs(st - golden["euler_seq_states"][i]).max() < (1e-10 if storage == "f64" else 1e-7), i
+        assert np.abs(m.uvec[-1] - golden["euler_seq_u"][i]).max() < (1e-9 if storage == "f64" else 1e-5), i
+    with pytest.raises(NotImplementedError):
+        MPPI(model=lambda x, u, dt: x)
+
+
+@pytest.mark.parametrize("model", ["rk4", "euler"])
+def test_obstacle_grid_extension(orc, model):
+    """Optional obstacle-grid stage cost (map::Grid export format).  Not in the reference: checked
+    against the oracle's restatement; weight 0 must reproduce the plain engine bit for bit."""
+    K, T = 500, 50
+    eps = orc.reference_noise(31, SIG, T, K)
+    u0 = np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
+    state, goal = [0.02, -0.03, 0.4], [0.6, -0.4, 0.0]
+    cells = (50 * ((np.arange(120)[:, None] + 2 * np.arange(160)[None, :]) % 3)).astype(np.int8)
+    res, origin, w = 0.0125, (-0.5, -0.9), 300.0
+    p = orc.default_params(); p.model = 1 if model == "euler" else 0
+    with _engine(K, T, "f64", model=model) as e:
+        e.set_nominal(u0); e.upload_noise(eps)
+        e.rollout(state, goal, noise="injected")
+        V_plain = e.download_value()[0]
+        e.set_obstacle_grid(cells, res, origin, 0.0)
+        e.rollout(state, goal, noise="injected")
+        assert np.array_equal(e.download_value()[0], V_plain)
+        e.set_obstacle_grid(cells, res, origin, w)
+        e.set_nominal(u0)
+        nxt, ua = e.tick(state, goal, noise="injected")
+        V = e.download_value()[0]
+        lat = e.get_nominal()
+        e.set_obstacle_grid(None, 1.0, (0, 0), 0.0)
+        e.set_nominal(u0)
+        e.rollout(state, goal, noise="injected")
+        assert np.array_equal(e.download_value()[0], V_plain)
+    orc.set_obstacle_grid(p, cells, res, origin, w)
+    Vo = orc.get_cost2go(state, u0, goal, LAM, SIG, eps, params=p)
+    assert np.abs(Vo - V_plain).max() > 100.0          # the grid matters here
+    assert np.abs(V - Vo).max() <= 1e-9 * np.abs(Vo).max()
+    so, uo, lo = orc.get_path(state, goal, u0, eps, LAM, SIG, params=p)
+    assert np.abs(ua[0] - uo).max() < 1e-9 and np.abs(lat - lo).max() < 1e-9 and np.abs(nxt[0] - so).max() < 1e-12
+
+
 def test_large_step_uses_full_sincos(orc):
     """dt so large that |h/2| > 0.25 rad: the rotation falls back to sincos (NTERM=0); also the
     mid branch (NTERM=7)."""

@@ -148,3 +148,40 @@ def test_philox_noise_statistics(orc):
     a = orc.philox_noise(3, 1, 2, 0, 64, 7, 0.9)
     b = orc.philox_noise(3, 1, 2, 32, 32, 7, 0.9)
     assert np.array_equal(a[:, :, 32:], b)
+
+
+def test_euler_unicycle_model(orc, golden, kat):
+    """The `model=euler` constructor path (control/src/mppi:33-36, :57-58): unicycle kinematics, no wrap."""
+    p = orc.default_params()
+    p.model = 1
+    assert np.allclose(orc.euler([0.3, -0.2, 3.1], [1.25, -0.5], 0.25), kat["euler_step"], rtol=0, atol=1e-16)
+    K, T, seed = [int(x) for x in golden["euler_c2g_meta"]]
+    eps = orc.reference_noise(seed, SIG, T, K)
+    V = orc.get_cost2go(golden["euler_c2g_state"], golden["euler_c2g_u0"], golden["euler_c2g_goal"], LAM, SIG, eps, params=p)
+    assert np.abs(V - golden["euler_c2g_V"]).max() < 1e-9
+    assert np.abs(orc.update_action(golden["euler_c2g_u0"], eps, V, LAM, params=p) - golden["euler_c2g_unew"]).max() < 1e-9
+    K, T, seed, nt = [int(x) for x in golden["euler_seq_meta"]]
+    noise = orc.reference_noise(seed, SIG, T, K, n_ticks=nt)
+    st, lat = np.array([0.0, 0.0, 2.5]), np.zeros((2, T))
+    for i in range(nt):
+        st, ua, lat = orc.get_path(st, [-0.5, 0.4, 3.0], lat, noise[i], LAM, SIG, params=p)
+        assert np.abs(st - golden["euler_seq_states"][i]).max() < 1e-10
+        assert np.abs(ua - golden["euler_seq_u"][i]).max() < 1e-9
+
+
+def test_obstacle_grid_extension_is_off_by_default(orc, golden):
+    """The obstacle-grid stage cost is NOT in the reference: weight 0 / no grid must
+    leave the golden results untouched, a weighted grid must add exactly weight*value/100 per step."""
+    name = "c2g_warm"
+    K, T, seed = [int(x) for x in golden[name + "_meta"]]
+    eps = orc.reference_noise(seed, SIG, T, K)
+    p = orc.default_params()
+    cells = (50 * ((np.arange(120)[:, None] + 2 * np.arange(160)[None, :]) % 3)).astype(np.int8)  # 0/50/100 stripes
+    orc.set_obstacle_grid(p, cells, 0.0125, (-0.5, -0.9), 0.0)
+    args = (golden[name + "_state"], golden[name + "_u0"], golden[name + "_goal"], LAM, SIG, eps)
+    assert np.array_equal(orc.get_cost2go(*args, params=p), orc.get_cost2go(*args))
+    orc.set_obstacle_grid(p, cells, 0.0125, (-0.5, -0.9), 300.0)
+    V, c, xT = orc.get_cost2go(*args, params=p, want_costs=True)
+    V0, c0, _ = orc.get_cost2go(*args, want_costs=True)
+    extra = c - c0
+    assert extra.min() >= 0 and set(np.unique(np.round(extra, 9))) <= {0.0, 150.0, 300.0} and extra.max() > 0
