@@ -190,6 +190,18 @@ def main():
     eng.kernel_timing(())
     nxt, ua = eng.get_outputs()
     assert np.isfinite(nxt).all() and np.isfinite(ua).all()
+    final_nxt, final_ua = nxt.copy(), ua.copy()
+
+    # Diagnostic: the node's own call pattern -- host state in, blocking, host controls out
+    # (mppi_tick; what Controller.pos_cb pays per odometry message), N = 1 only.
+    sync_tick_us = None
+    if not in_group:
+        n_lat = min(args.steps, 50)
+        t0 = time.perf_counter()
+        st = nxt
+        for i in range(n_lat):
+            st, _ = eng.tick(st, goals, noise="philox", seed=seed, tick_id=10_000_000 + i)
+        sync_tick_us = 1e6 * (time.perf_counter() - t0) / n_lat
 
     if rank == 0:
         steps_per_launch = A * K_local * T
@@ -239,7 +251,8 @@ def main():
                        "parallelism": ("K-sharded x%d + all-gather" % world) if args.workload != "c5" else "agent replicas",
                        "graph": bool(args.graph)},
             "state_steps_per_s": value * T,
-            "final_state": [float(x) for x in nxt[0]], "final_u": [float(x) for x in ua[0]],
+            "final_state": [float(x) for x in final_nxt[0]], "final_u": [float(x) for x in final_ua[0]],
+            "sync_tick_us": sync_tick_us,
             "kernels_us": kernels_us, "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))

@@ -107,6 +107,7 @@ struct mppi_engine {
     // pinned staging ring for state/goal uploads
     static constexpr int kRing = 16;
     double* h_stage = nullptr;  // [kRing][A*6]
+    double* h_out = nullptr;    // [A][8] pinned landing zone of mppi_get_outputs / mppi_plant_step
     hipEvent_t ring_ev[kRing]{};
     bool ring_used[kRing]{};
     int ring_pos = 0;
@@ -449,6 +450,7 @@ struct mppi_engine {
 
         HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_stage), (size_t)kRing * A * 6 * sizeof(double), hipHostMallocDefault));
         for (int i = 0; i < kRing; ++i) HIPCHK(hipEventCreateWithFlags(&ring_ev[i], hipEventDisableTiming));
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_out), (size_t)A * 8 * sizeof(double), hipHostMallocDefault));
     }
 
     void destroy_graph() {
@@ -468,6 +470,7 @@ struct mppi_engine {
         if (ev_fork) hipEventDestroy(ev_fork);
         if (ev_join) hipEventDestroy(ev_join);
         if (h_stage) hipHostFree(h_stage);
+        if (h_out) hipHostFree(h_out);
         void* bufs[] = {d_eps, d_dP, d_stot, d_epart, d_tc, d_base, d_unom, d_ufilt, d_state, d_goal, d_part, d_merged, d_S, d_out, d_tick, d_tmp, d_grid};
         for (void* b : bufs) if (b) hipFree(b);
         if (own_stream) hipStreamDestroy(own_stream);
@@ -704,8 +707,8 @@ int mppi_plant_step(mppi_engine* h, const double* state, double* next_state) {
     hipLaunchKernelGGL(mppi::plant_kernel, dim3((A + 63) / 64), dim3(64), 0, h->stream, h->P, h->d_state, h->d_unom, h->d_out);
     HIPCHK(hipGetLastError());
     if (next_state) {
-        std::vector<double> o((size_t)A * 8);
-        HIPCHK(hipMemcpyAsync(o.data(), h->d_out, o.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        const double* o = h->h_out;
+        HIPCHK(hipMemcpyAsync(h->h_out, h->d_out, (size_t)A * 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         for (int a = 0; a < A; ++a) for (int i = 0; i < 3; ++i) next_state[a * 3 + i] = o[(size_t)a * 8 + i];
     }
@@ -743,8 +746,8 @@ int mppi_tick_finish(mppi_engine* h, const void* gathered_dev, int n_shards) {
 int mppi_get_outputs(mppi_engine* h, double* next_state, double* u_applied) {
     API_BEGIN(h)
     const int A = h->cfg.n_agents;
-    std::vector<double> o((size_t)A * 8);
-    HIPCHK(hipMemcpyAsync(o.data(), h->d_out, o.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    const double* o = h->h_out;
+    HIPCHK(hipMemcpyAsync(h->h_out, h->d_out, (size_t)A * 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     for (int a = 0; a < A; ++a) {
         if (next_state) for (int i = 0; i < 3; ++i) next_state[a * 3 + i] = o[(size_t)a * 8 + i];

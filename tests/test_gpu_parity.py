@@ -497,6 +497,34 @@ def test_full_size_properties(orc, K, T):
     assert np.abs(nxt[0] - orc.rk4(state, ua[0], 1.0 / T)).max() < 1e-12
 
 
+def test_config5_64_agents_full_size(orc):
+    """BASELINE config 5 at full size: 64 agents x K = 16384, T = 50 in ONE engine (device RNG).
+    Agents are independent controllers: each agent's tick must equal the oracle replay of that
+    agent alone on the noise the device drew for it (subset replay for V, full replay for u)."""
+    A, K, T = 64, 16384, 50
+    states = np.array([[0.05 * a, 0.0, 0.0] for a in range(A)])
+    goals = np.array([[0.05 * a, -1.0, 0.0] for a in range(A)])
+    u0 = np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
+    with _engine(K, T, "f32", n_agents=A) as e:
+        for a in range(A):
+            e.set_nominal(u0, agent=a)
+        nxt, ua = e.tick(states, goals, noise="philox", seed=77, tick_id=4)
+        eps = e.download_noise()
+        V = e.download_value()
+        lat = np.stack([e.get_nominal(a) for a in range(A)])
+    assert np.isfinite(V).all() and abs(eps.std() - SIG) < 2e-3
+    assert not np.array_equal(eps[0], eps[1])                       # per-agent streams
+    for a in (0, 7, 63):
+        so, uo, lo = orc.get_path(states[a], goals[a], u0, eps[a], LAM, SIG)
+        gap = np.sort(V[a], axis=1)[:, :2]
+        if ((gap[:, 1] - gap[:, 0]) > 50 * LAM).all():             # argmin cannot flip within the fp32 offset error
+            assert np.abs(ua[a] - uo).max() < 1e-5 and np.abs(lat[a] - lo).max() < 1e-5
+        idx = np.random.RandomState(a).choice(K, 128, replace=False)
+        Vo = orc.get_cost2go(states[a], u0, goals[a], LAM, SIG, eps[a][:, :, idx])
+        assert np.abs(V[a][:, idx] - Vo).max() <= _vtol(orc, states[a], u0, goals[a], Vo, T, 128)
+        assert np.abs(nxt[a] - orc.rk4(states[a], ua[a], 1.0 / T)).max() < 1e-12
+
+
 def test_tick_graph_equals_eager():
     K, T, seed = 2048, 50, 17
     u0 = np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
