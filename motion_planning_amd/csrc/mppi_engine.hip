@@ -158,12 +158,17 @@ struct mppi_engine {
                 HIPCHK(hipEventRecord(a, st));
             }
         }
-        ~Scope() noexcept(false) {
-            if (a) {
-                hipEvent_t b = e->get_event();
-                HIPCHK(hipEventRecord(b, st));
-                e->pending.push_back({kid, a, b});
-                if (e->pending.size() >= 4096) e->drain_timing();
+        ~Scope() {  // never throws: a failed end marker only loses one timing sample
+            if (!a) return;
+            hipEvent_t b = nullptr;
+            if (!e->ev_pool.empty()) { b = e->ev_pool.back(); e->ev_pool.pop_back(); }
+            else if (hipEventCreate(&b) != hipSuccess) b = nullptr;
+            if (b && hipEventRecord(b, st) == hipSuccess) {
+                try { e->pending.push_back({kid, a, b}); } catch (...) { hipEventDestroy(a); hipEventDestroy(b); return; }
+                if (e->pending.size() >= 4096) { try { e->drain_timing(); } catch (...) {} }
+            } else {
+                hipEventDestroy(a);
+                if (b) hipEventDestroy(b);
             }
         }
     };

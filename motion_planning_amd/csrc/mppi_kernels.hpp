@@ -5,11 +5,14 @@
 //   update_action :186-208, perform_action :210-213, get_path :85-102.
 //
 // Pipeline of one control tick (DESIGN.md has the byte accounting):
-//   nominal_kernel   1 block / agent    nominal (eps = 0) rollout by block scans -> per-step table
-//                                       tc[a][t] + baseline cost-to-go base[a][t]
-//   rollout_kernel   1 lane / sample    noise -> clip -> RK4 step -> stage cost, all in registers;
-//                                       writes eps[a][t][2][K] and the running cost prefix
-//                                       dP[a][t][K] (+ one total per sample): 12 B/step to HBM
+//   rollout_kernel   1 lane / sample    prologue (T <= 64): wave 0 runs the nominal (eps = 0) rollout,
+//                                       lanes = timesteps, into the LDS per-step table; then
+//                                       noise -> clip -> RK4 step -> stage cost, all in registers;
+//                                       streams the running cost prefix dP[a][t][K] (4 B/step),
+//                                       one total per sample and the per-wave sums of eps.  The noise
+//                                       itself is written only by the stand-alone mppi_rollout: it is
+//                                       a pure function of its Philox counter and is re-drawn on demand.
+//   (nominal_kernel  1 block / agent    the same nominal rollout by block scans, only for T > 64)
 //   update_kernel    1 block / (chunk,t,a)  per-timestep softmax over K: reads the cost prefix back
 //                                       (4 B/step) and eps only for the few samples with weight
 //   merge_kernel     1 wave / (t,a)     merges chunk partials -> shard partial [A][T][8]
@@ -23,7 +26,7 @@
 // absolute accuracy where the softmax weights live:
 //     V[t][k] = base[t] + Stot[k] - dP[t][k],   dP[t][k] = sum_{tau<t} (c[tau][k] - c_nom[tau])
 // (the reverse cumsum of control/src/mppi:175 written as total minus exclusive prefix, so the
-// rollout streams its output step by step and needs no per-lane history -- no LDS, no T limit).
+// rollout streams its output step by step and needs no per-lane history).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -34,7 +37,7 @@ constexpr int kTupleW = 8;  // {min, D, N0, N1, E0, E1, count, pad}
 constexpr int kTcW = 8;     // {un0, un1, w0, w1, cb, 0, 0, 0}
 
 struct DevParams {
-    int A, K, Ks, T;          // Ks: padded row pitch (elements) of eps / dV rows
+    int A, K, Ks, T;          // Ks: padded row pitch (elements) of eps / dP rows
     uint32_t sample_offset;
     double dt, sigma, lambda, inv_lambda;
     double q0, q1, q2, r0, r1, p0, p1, p2;
