@@ -378,8 +378,8 @@ __device__ __forceinline__ void philox_normals(uint32_t gk, uint32_t pair, uint3
 // grid = (ceil(K / 256), A), block = 256, LDS = the 40*T-byte per-step table.  Per lane and step: 2 eps + 1 dP element
 // through HBM, fully coalesced (consecutive lanes = consecutive k).
 // ---------------------------------------------------------------------------------------------
-template <typename S, int NTERM, bool PHILOX, bool STORE_EPS, bool INLINE_NOM, int MODEL>
-__global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double* __restrict__ state,
+template <typename S, int NTERM, bool PHILOX, bool STORE_EPS, bool INLINE_NOM, int MODEL, bool SPLIT>
+__global__ __launch_bounds__(SPLIT ? 512 : 256) void rollout_kernel(DevParams P, const double* __restrict__ state,
                                                      const double* __restrict__ goal,
                                                      double* __restrict__ tc, S* __restrict__ eps,
                                                      S* __restrict__ dP, S* __restrict__ Stot, uint64_t seed,
@@ -388,14 +388,20 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double*
                                                      const double* __restrict__ unom, double* __restrict__ base) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* lt = reinterpret_cast<double*>(smem_raw);  // [T][5] per-step table {un0, un1, w0, w1, cb}
-    const int tid = threadIdx.x, a = blockIdx.y, T = P.T;
+    // SPLIT (device noise, few samples per SIMD): 512 threads serve the block's 256 samples -- waves 4..7
+    // only draw the noise (Philox + Box-Muller + the eps sums) one chunk ahead into an LDS ring, waves
+    // 0..3 only integrate.  Twice the waves per sample and half the serial instruction stream per wave:
+    // what a latency-bound (small / strongly sharded K) rollout needs; no gain once the SIMDs are full.
+    const int tid = SPLIT ? (threadIdx.x & 255) : threadIdx.x, a = blockIdx.y, T = P.T;
+    const bool producer = SPLIT && threadIdx.x >= 256;
+    S* ring = reinterpret_cast<S*>(lt + (size_t)T * 5);  // SPLIT: [2][U=4][2][256]
     // The per-step table lives in LDS: read back as wave-uniform (broadcast) ds_reads that the
     // scheduler can hoist, instead of an s_load + s_waitcnt round trip on every step.
     if (INLINE_NOM) {
         // T <= 64: wave 0 of every block runs the nominal rollout itself (lanes = timesteps, ~600
         // instructions) -- no separate kernel, no launch boundary in front of the rollout.  The
         // first block also publishes base[] (and tc[]) for mppi_download_value.
-        if (tid < 64) {
+        if (threadIdx.x < 64) {
             double row[5], base_t;
             nominal_wave(P, state, goal, unom, a, tid, row, base_t);
             if (tid < T) {
@@ -410,10 +416,10 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double*
             }
         }
     } else {
-        for (int i = tid; i < T * 5; i += blockDim.x) lt[i] = tc[((size_t)a * T + i / 5) * kTcW + i % 5];
+        for (int i = threadIdx.x; i < T * 5; i += blockDim.x) lt[i] = tc[((size_t)a * T + i / 5) * kTcW + i % 5];
     }
     __syncthreads();
-    const int k = k_first + blockIdx.x * blockDim.x + tid;  // this launch covers samples [k_first, k_last)
+    const int k = k_first + blockIdx.x * 256 + tid;  // this launch covers samples [k_first, k_last)
     const bool active = k < k_last;
     const size_t Ks = (size_t)P.Ks;
     const double gx = goal[a * 3 + 0], gy = goal[a * 3 + 1], gth = goal[a * 3 + 2];
@@ -426,7 +432,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double*
     const double sixth_rd = P.dt * P.rhalf * (1.0 / 6.0);  // Simpson weight of (u0 + u1)
     const double hq0 = 0.5 * P.q0, hq1 = 0.5 * P.q1, hq2 = 0.5 * P.q2;
     const size_t NW = Ks >> 6;  // waves per agent row (Ks is a multiple of 64)
-    const bool block_full = k_first + (int)(blockIdx.x + 1) * (int)blockDim.x <= k_last;  // uniform
+    const bool block_full = k_first + (int)(blockIdx.x + 1) * 256 <= k_last;  // uniform
 
     uint32_t key0 = 0, key1 = 0, ctr0 = 0, tick = 0;
     float sigf = 0.f;
@@ -460,9 +466,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double*
     if (!PHILOX) load_chunk(0, cur);
 
     double pre = 0.0;  // sum_{tau < t} (c[tau] - c_nom[tau])
-    for (int t0 = 0; t0 < T; t0 += U) {
-        if (PHILOX) draw_chunk(t0, cur);
-        else load_chunk(t0 + U, nxt);  // prefetch: HBM latency hides under this chunk's math
+    auto eps_sums = [&](int t0) {
         {   // sum_k eps per wave for the chunk's 4 steps x 2 wheels (the E of the softmax floor term,
             // control/src/mppi:193): saves the update kernel from reading eps at all (8 of its 12 B/step)
             S ev[8];
@@ -476,6 +480,8 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double*
             if ((tid & 63) < 8 && te < T && (size_t)(k >> 6) < NW)
                 epart[(((size_t)a * T + te) * 2 + (idx & 1)) * NW + (k >> 6)] = tot;
         }
+    };
+    auto integrate = [&](int t0) {
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const int t = t0 + j;
@@ -551,10 +557,38 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevParams P, const double*
                 pre += dc;
             }
         }
+    };
+    if (SPLIT) {
+        const int nch = (T + U - 1) / U;
+        for (int i = 0; i <= nch; ++i) {
+            if (producer) {
+                if (i < nch) {
+                    draw_chunk(i * U, cur);
+                    eps_sums(i * U);
+                    S* rb = ring + (size_t)(i & 1) * U * 2 * 256 + tid;
+#pragma unroll
+                    for (int j = 0; j < U; ++j) { rb[(j * 2 + 0) * 256] = cur[j][0]; rb[(j * 2 + 1) * 256] = cur[j][1]; }
+                }
+            } else if (i > 0) {
+                const S* rb = ring + (size_t)((i - 1) & 1) * U * 2 * 256 + tid;
+#pragma unroll
+                for (int j = 0; j < U; ++j) { cur[j][0] = rb[(j * 2 + 0) * 256]; cur[j][1] = rb[(j * 2 + 1) * 256]; }
+                integrate((i - 1) * U);
+            }
+            __syncthreads();  // one barrier per chunk: ring slot i&1 is full, slot (i-1)&1 is free again
+        }
+        if (producer) return;
+    } else {
+    for (int t0 = 0; t0 < T; t0 += U) {
+        if (PHILOX) draw_chunk(t0, cur);
+        else load_chunk(t0 + U, nxt);  // prefetch: HBM latency hides under this chunk's math
+        eps_sums(t0);
+        integrate(t0);
         if (!PHILOX) {
 #pragma unroll
             for (int j = 0; j < U; ++j) { cur[j][0] = nxt[j][0]; cur[j][1] = nxt[j][1]; }
         }
+    }
     }
     // value_fcn = reverse cumulative sum over t (control/src/mppi:175) = total - exclusive prefix
     if (active) Stot[(size_t)a * Ks + k] = (S)pre;
