@@ -201,7 +201,13 @@ struct mppi_engine {
 
     template <typename S, int NT, bool PH, bool SE, bool IN, int MODEL, bool SPLIT>
     void launch_rollout_h(hipStream_t st, int k0, int k1, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
-        auto kern = mppi::rollout_kernel<S, NT, PH, SE, IN, MODEL, SPLIT>;
+        // the node's cost (Q[2,2] = 0, no obstacle grid) runs the branch-free instantiation
+        if (P.q2 != 0.0 || P.grid_weight != 0.0) launch_rollout_i<S, NT, PH, SE, IN, MODEL, SPLIT, true>(st, k0, k1, seed, tick, tick_ptr);
+        else launch_rollout_i<S, NT, PH, SE, IN, MODEL, SPLIT, false>(st, k0, k1, seed, tick, tick_ptr);
+    }
+    template <typename S, int NT, bool PH, bool SE, bool IN, int MODEL, bool SPLIT, bool GEN>
+    void launch_rollout_i(hipStream_t st, int k0, int k1, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
+        auto kern = mppi::rollout_kernel<S, NT, PH, SE, IN, MODEL, SPLIT, GEN>;
         dim3 grid((k1 - k0 + 255) / 256, cfg.n_agents);
         const size_t lds = (size_t)cfg.horizon * 5 * sizeof(double) + (SPLIT ? (size_t)2 * 4 * 2 * 256 * sizeof(S) : 0);
         hipLaunchKernelGGL(kern, grid, dim3(SPLIT ? 512 : 256), lds, st, P, d_state, d_goal, d_tc, static_cast<S*>(d_eps),

@@ -31,6 +31,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace mppi {
 
 constexpr int kTupleW = 8;  // {min, D, N0, N1, E0, E1, count, pad}
@@ -371,6 +373,11 @@ __device__ __forceinline__ void philox_normals(uint32_t gk, uint32_t pair, uint3
 //   S      storage type of eps / dP / Stot in HBM (float | double)
 //   NTERM  4 | 7: Taylor terms for the per-step heading rotation; 0: full sincos every step
 //   PHILOX true: draw eps in-kernel; false: READ the injected eps
+//   GENERAL false: the node's cost (Q[2,2] = 0, no obstacle grid) -- every full 4-step chunk is one
+//          straight-line basic block (no per-step branch at all: theta is wrapped where it is
+//          used, the terminal cost is added after the loop), so the scheduler can interleave the
+//          Philox / Box-Muller chains with four steps of fp64 dynamics; true: adds the theta term of
+//          the stage cost and the optional obstacle-grid lookup
 //   STORE_EPS (PHILOX only) write the drawn eps to HBM.  The tick path does not: the noise is a
 //          pure function of (seed, tick, agent, sample, t), so the update kernel regenerates the
 //          few values it needs and mppi_download_noise regenerates all of it on demand --
@@ -378,7 +385,7 @@ __device__ __forceinline__ void philox_normals(uint32_t gk, uint32_t pair, uint3
 // grid = (ceil(K / 256), A), block = 256, LDS = the 40*T-byte per-step table.  Per lane and step: 2 eps + 1 dP element
 // through HBM, fully coalesced (consecutive lanes = consecutive k).
 // ---------------------------------------------------------------------------------------------
-template <typename S, int NTERM, bool PHILOX, bool STORE_EPS, bool INLINE_NOM, int MODEL, bool SPLIT>
+template <typename S, int NTERM, bool PHILOX, bool STORE_EPS, bool INLINE_NOM, int MODEL, bool SPLIT, bool GENERAL>
 __global__ __launch_bounds__(SPLIT ? 512 : 256) void rollout_kernel(DevParams P, const double* __restrict__ state,
                                                      const double* __restrict__ goal,
                                                      double* __restrict__ tc, S* __restrict__ eps,
@@ -481,11 +488,15 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void rollout_kernel(DevParams P,
                 epart[(((size_t)a * T + te) * 2 + (idx & 1)) * NW + (k >> 6)] = tot;
         }
     };
-    auto integrate = [&](int t0) {
+    // theta is carried UNWRAPPED inside the loop: only cos/sin of it (carried separately as the heading
+    // vector) enter the dynamics, and the reference's per-step wrap to (-pi, pi] (control/src/mppi:52-53)
+    // is applied where theta itself is used -- the Q[2,2] stage term and the terminal cost.
+    auto integrate = [&](int t0, auto guard_tag) {
+        constexpr bool GUARD = decltype(guard_tag)::value;  // tail chunk: steps beyond T are skipped
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const int t = t0 + j;
-            if (t < T) {  // wave-uniform
+            if (!GUARD || t < T) {
                 const double* tcp = lt + t * 5;
                 const double un0 = tcp[0], un1 = tcp[1], w0 = tcp[2], w1 = tcp[3], cb = tcp[4];
                 const double e0 = (double)cur[j][0], e1 = (double)cur[j][1];
@@ -515,49 +526,57 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void rollout_kernel(DevParams P,
                         c = cn;
                     }
                 } else {
-                // rk4 (control/src/mppi:39-54) for dd_dynamics (:23-30): theta_dot is constant
-                // over the step, so the four stages sit at theta, theta+h/2 (twice), theta+h.
-                const double phi = half_kd * (u1 - u0);
-                const double aa = sixth_rd * (u0 + u1);
-                double c1, s1, c2, s2;
-                if (NTERM == 0) {
-                    sincos(th + phi, &s1, &c1);
-                    sincos(th + 2.0 * phi, &s2, &c2);
-                    x = fma(aa, c + 4.0 * c1 + c2, x);
-                    y = fma(aa, s + 4.0 * s1 + s2, y);
-                } else {
-                    double sp, cp;
-                    small_sincos<NTERM>(phi, sp, cp);
-                    c1 = c * cp - s * sp; s1 = s * cp + c * sp;
-                    c2 = c1 * cp - s1 * sp; s2 = s1 * cp + c1 * sp;
-                    // Simpson weights k1 + 2 k2 + 2 k3 + k4: cos(th) + cos(th + 2 phi) = 2 cos(phi) cos(th + phi),
-                    // so the bracket is (4 + 2 cos phi) times the mid-step heading
-                    const double g = aa * fma(2.0, cp, 4.0);
-                    x = fma(g, c1, x);
-                    y = fma(g, s1, y);
-                }
-                th += 2.0 * phi;
-                // theta -> (-pi, pi] (control/src/mppi:52-53); the formula is the identity inside
-                // the interval, so only lanes that left it pay for the ceil/divide
-                if (th > M_PI || th <= -M_PI) th = wrap_theta(th);
-                c = c2; s = s2;
+                    // rk4 (control/src/mppi:39-54) for dd_dynamics (:23-30): theta_dot is constant
+                    // over the step, so the four stages sit at theta, theta+h/2 (twice), theta+h.
+                    const double phi = half_kd * (u1 - u0);
+                    const double aa = sixth_rd * (u0 + u1);
+                    double c1, s1, c2, s2;
+                    if (NTERM == 0) {
+                        sincos(th + phi, &s1, &c1);
+                        sincos(th + 2.0 * phi, &s2, &c2);
+                        x = fma(aa, c + 4.0 * c1 + c2, x);
+                        y = fma(aa, s + 4.0 * s1 + s2, y);
+                    } else {
+                        double sp, cp;
+                        small_sincos<NTERM>(phi, sp, cp);
+                        c1 = c * cp - s * sp; s1 = s * cp + c * sp;
+                        c2 = c1 * cp - s1 * sp; s2 = s1 * cp + c1 * sp;
+                        // Simpson weights k1 + 2 k2 + 2 k3 + k4: cos(th) + cos(th + 2 phi) = 2 cos(phi) cos(th + phi),
+                        // so the bracket is (4 + 2 cos phi) times the mid-step heading
+                        const double g = aa * fma(2.0, cp, 4.0);
+                        x = fma(g, c1, x);
+                        y = fma(g, s1, y);
+                    }
+                    th += 2.0 * phi;
+                    c = c2; s = s2;
                 }
                 // get_cost (control/src/mppi:180-184) minus the nominal stage cost (cb):
                 //   1/2 xQx + 1/2 uRu + lam*sig*(un . eps)  with u = NOMINAL, eps = UNCLIPPED
                 const double dx = x - gx, dy = y - gy;
                 double dc = fma(hq0 * dx, dx, fma(hq1 * dy, dy, cb));
-                if (hq2 != 0.0) { const double dth = th - gth; dc = fma(hq2 * dth, dth, dc); }  // Q[2,2] = 0 in the node
                 dc = fma(w0, e0, dc);
                 dc = fma(w1, e1, dc);
-                if (P.grid_weight != 0.0) dc += obstacle_cost(P, x, y);  // extension, off in the node (uniform branch)
-                if (t == T - 1) {  // terminal cost (control/src/mppi:165-173), theta error not wrapped
-                    const double dth = th - gth;
-                    dc += P.p0 * dx * dx + P.p1 * dy * dy + P.p2 * dth * dth;
+                if (GENERAL) {
+                    if (hq2 != 0.0) {  // Q[2,2] = 0 in the node
+                        const double thw = (MODEL == 0 && (th > M_PI || th <= -M_PI)) ? wrap_theta(th) : th;
+                        const double dth = thw - gth;
+                        dc = fma(hq2 * dth, dth, dc);
+                    }
+                    if (P.grid_weight != 0.0) dc += obstacle_cost(P, x, y);  // extension, off in the node
                 }
                 pre += dc;
             }
         }
     };
+    // terminal cost (control/src/mppi:165-173), theta error not wrapped beyond rk4's own wrap; the nominal
+    // terminal cost is already inside cb[T-1], and dP[T-1] is the prefix BEFORE the last step, so the
+    // sample's terminal cost only enters the total
+    auto terminal = [&]() {
+        const double thw = (MODEL == 0 && (th > M_PI || th <= -M_PI)) ? wrap_theta(th) : th;
+        const double dx = x - gx, dy = y - gy, dth = thw - gth;
+        pre += P.p0 * dx * dx + P.p1 * dy * dy + P.p2 * dth * dth;
+    };
+    const int T4 = T & ~(U - 1);  // steps covered by full chunks
     if (SPLIT) {
         const int nch = (T + U - 1) / U;
         for (int i = 0; i <= nch; ++i) {
@@ -573,23 +592,30 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void rollout_kernel(DevParams P,
                 const S* rb = ring + (size_t)((i - 1) & 1) * U * 2 * 256 + tid;
 #pragma unroll
                 for (int j = 0; j < U; ++j) { cur[j][0] = rb[(j * 2 + 0) * 256]; cur[j][1] = rb[(j * 2 + 1) * 256]; }
-                integrate((i - 1) * U);
+                if ((i - 1) * U < T4) integrate((i - 1) * U, std::false_type{});
+                else integrate((i - 1) * U, std::true_type{});
             }
             __syncthreads();  // one barrier per chunk: ring slot i&1 is full, slot (i-1)&1 is free again
         }
         if (producer) return;
     } else {
-    for (int t0 = 0; t0 < T; t0 += U) {
-        if (PHILOX) draw_chunk(t0, cur);
-        else load_chunk(t0 + U, nxt);  // prefetch: HBM latency hides under this chunk's math
-        eps_sums(t0);
-        integrate(t0);
-        if (!PHILOX) {
+        for (int t0 = 0; t0 < T4; t0 += U) {  // full chunks: straight-line code
+            if (PHILOX) draw_chunk(t0, cur);
+            else load_chunk(t0 + U, nxt);  // prefetch: HBM latency hides under this chunk's math
+            eps_sums(t0);
+            integrate(t0, std::false_type{});
+            if (!PHILOX) {
 #pragma unroll
-            for (int j = 0; j < U; ++j) { cur[j][0] = nxt[j][0]; cur[j][1] = nxt[j][1]; }
+                for (int j = 0; j < U; ++j) { cur[j][0] = nxt[j][0]; cur[j][1] = nxt[j][1]; }
+            }
+        }
+        if (T4 < T) {  // ragged tail
+            if (PHILOX) draw_chunk(T4, cur);
+            eps_sums(T4);
+            integrate(T4, std::true_type{});
         }
     }
-    }
+    terminal();
     // value_fcn = reverse cumulative sum over t (control/src/mppi:175) = total - exclusive prefix
     if (active) Stot[(size_t)a * Ks + k] = (S)pre;
 }
