@@ -386,7 +386,7 @@ __device__ __forceinline__ void philox_normals(uint32_t gk, uint32_t pair, uint3
 // through HBM, fully coalesced (consecutive lanes = consecutive k).
 // ---------------------------------------------------------------------------------------------
 template <typename S, int NTERM, bool PHILOX, bool STORE_EPS, bool INLINE_NOM, int MODEL, bool SPLIT, bool GENERAL>
-__global__ __launch_bounds__(SPLIT ? 512 : 256) void rollout_kernel(DevParams P, const double* __restrict__ state,
+__global__ __launch_bounds__(SPLIT ? 512 : 256) __attribute__((amdgpu_waves_per_eu(5, 8))) void rollout_kernel(DevParams P, const double* __restrict__ state,
                                                      const double* __restrict__ goal,
                                                      double* __restrict__ tc, S* __restrict__ eps,
                                                      S* __restrict__ dP, S* __restrict__ Stot, uint64_t seed,
@@ -491,8 +491,9 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void rollout_kernel(DevParams P,
     // theta is carried UNWRAPPED inside the loop: only cos/sin of it (carried separately as the heading
     // vector) enter the dynamics, and the reference's per-step wrap to (-pi, pi] (control/src/mppi:52-53)
     // is applied where theta itself is used -- the Q[2,2] stage term and the terminal cost.
-    auto integrate = [&](int t0, auto guard_tag) {
+    auto integrate = [&](int t0, auto guard_tag, auto full_tag) {
         constexpr bool GUARD = decltype(guard_tag)::value;  // tail chunk: steps beyond T are skipped
+        constexpr bool FULL = decltype(full_tag)::value;    // every lane of the block has a sample: plain stores
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const int t = t0 + j;
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void rollout_kernel(DevParams P,
                 const double* tcp = lt + t * 5;
                 const double un0 = tcp[0], un1 = tcp[1], w0 = tcp[2], w1 = tcp[3], cb = tcp[4];
                 const double e0 = (double)cur[j][0], e1 = (double)cur[j][1];
-                if (active) {
+                if (FULL || active) {
                     if (PHILOX && STORE_EPS) {
                         eps_a[(size_t)(t * 2 + 0) * Ks] = cur[j][0];
                         eps_a[(size_t)(t * 2 + 1) * Ks] = cur[j][1];
@@ -577,44 +578,48 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void rollout_kernel(DevParams P,
         pre += P.p0 * dx * dx + P.p1 * dy * dy + P.p2 * dth * dth;
     };
     const int T4 = T & ~(U - 1);  // steps covered by full chunks
-    if (SPLIT) {
-        const int nch = (T + U - 1) / U;
-        for (int i = 0; i <= nch; ++i) {
-            if (producer) {
-                if (i < nch) {
-                    draw_chunk(i * U, cur);
-                    eps_sums(i * U);
-                    S* rb = ring + (size_t)(i & 1) * U * 2 * 256 + tid;
+    auto run = [&](auto full_tag) {
+        if (SPLIT) {
+            const int nch = (T + U - 1) / U;
+            for (int i = 0; i <= nch; ++i) {
+                if (producer) {
+                    if (i < nch) {
+                        draw_chunk(i * U, cur);
+                        eps_sums(i * U);
+                        S* rb = ring + (size_t)(i & 1) * U * 2 * 256 + tid;
 #pragma unroll
-                    for (int j = 0; j < U; ++j) { rb[(j * 2 + 0) * 256] = cur[j][0]; rb[(j * 2 + 1) * 256] = cur[j][1]; }
+                        for (int j = 0; j < U; ++j) { rb[(j * 2 + 0) * 256] = cur[j][0]; rb[(j * 2 + 1) * 256] = cur[j][1]; }
+                    }
+                } else if (i > 0) {
+                    const S* rb = ring + (size_t)((i - 1) & 1) * U * 2 * 256 + tid;
+#pragma unroll
+                    for (int j = 0; j < U; ++j) { cur[j][0] = rb[(j * 2 + 0) * 256]; cur[j][1] = rb[(j * 2 + 1) * 256]; }
+                    if ((i - 1) * U < T4) integrate((i - 1) * U, std::false_type{}, full_tag);
+                    else integrate((i - 1) * U, std::true_type{}, full_tag);
                 }
-            } else if (i > 0) {
-                const S* rb = ring + (size_t)((i - 1) & 1) * U * 2 * 256 + tid;
-#pragma unroll
-                for (int j = 0; j < U; ++j) { cur[j][0] = rb[(j * 2 + 0) * 256]; cur[j][1] = rb[(j * 2 + 1) * 256]; }
-                if ((i - 1) * U < T4) integrate((i - 1) * U, std::false_type{});
-                else integrate((i - 1) * U, std::true_type{});
+                __syncthreads();  // one barrier per chunk: ring slot i&1 is full, slot (i-1)&1 is free again
             }
-            __syncthreads();  // one barrier per chunk: ring slot i&1 is full, slot (i-1)&1 is free again
-        }
-        if (producer) return;
-    } else {
-        for (int t0 = 0; t0 < T4; t0 += U) {  // full chunks: straight-line code
-            if (PHILOX) draw_chunk(t0, cur);
-            else load_chunk(t0 + U, nxt);  // prefetch: HBM latency hides under this chunk's math
-            eps_sums(t0);
-            integrate(t0, std::false_type{});
-            if (!PHILOX) {
+        } else {
+            for (int t0 = 0; t0 < T4; t0 += U) {  // full chunks: straight-line code
+                if (PHILOX) draw_chunk(t0, cur);
+                else load_chunk(t0 + U, nxt);  // prefetch: HBM latency hides under this chunk's math
+                eps_sums(t0);
+                integrate(t0, std::false_type{}, full_tag);
+                if (!PHILOX) {
 #pragma unroll
-                for (int j = 0; j < U; ++j) { cur[j][0] = nxt[j][0]; cur[j][1] = nxt[j][1]; }
+                    for (int j = 0; j < U; ++j) { cur[j][0] = nxt[j][0]; cur[j][1] = nxt[j][1]; }
+                }
+            }
+            if (T4 < T) {  // ragged tail
+                if (PHILOX) draw_chunk(T4, cur);
+                eps_sums(T4);
+                integrate(T4, std::true_type{}, full_tag);
             }
         }
-        if (T4 < T) {  // ragged tail
-            if (PHILOX) draw_chunk(T4, cur);
-            eps_sums(T4);
-            integrate(T4, std::true_type{});
-        }
-    }
+    };
+    if (block_full) run(std::true_type{});   // uniform: all but (at most) the last block of a launch
+    else run(std::false_type{});
+    if (producer) return;
     terminal();
     // value_fcn = reverse cumulative sum over t (control/src/mppi:175) = total - exclusive prefix
     if (active) Stot[(size_t)a * Ks + k] = (S)pre;
