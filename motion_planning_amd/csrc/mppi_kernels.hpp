@@ -439,6 +439,9 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) __attribute__((amdgpu_waves_per_
     const double sixth_rd = P.dt * P.rhalf * (1.0 / 6.0);  // Simpson weight of (u0 + u1)
     const double hq0 = 0.5 * P.q0, hq1 = 0.5 * P.q1, hq2 = 0.5 * P.q2;
     const size_t NW = Ks >> 6;  // waves per agent row (Ks is a multiple of 64)
+    // raw buffer view of epart (byte-addressed, bounds-checked by the hardware); < 4 GB by construction
+    const __amdgpu_buffer_rsrc_t ep_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        epart, 0, (int)min((size_t)0x7FFFFFFF, (size_t)P.A * T * 2 * NW * sizeof(S)), 0x00020000);
     const bool block_full = k_first + (int)(blockIdx.x + 1) * 256 <= k_last;  // uniform
 
     uint32_t key0 = 0, key1 = 0, ctr0 = 0, tick = 0;
@@ -473,19 +476,29 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) __attribute__((amdgpu_waves_per_
     if (!PHILOX) load_chunk(0, cur);
 
     double pre = 0.0;  // sum_{tau < t} (c[tau] - c_nom[tau])
-    auto eps_sums = [&](int t0) {
+    auto eps_sums = [&](int t0, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
         {   // sum_k eps per wave for the chunk's 4 steps x 2 wheels (the E of the softmax floor term,
             // control/src/mppi:193): saves the update kernel from reading eps at all (8 of its 12 B/step)
             S ev[8];
 #pragma unroll
             for (int j = 0; j < U; ++j) {
-                ev[2 * j] = (block_full || active) ? cur[j][0] : (S)0;
-                ev[2 * j + 1] = (block_full || active) ? cur[j][1] : (S)0;
+                ev[2 * j] = (FULL || active) ? cur[j][0] : (S)0;
+                ev[2 * j + 1] = (FULL || active) ? cur[j][1] : (S)0;
             }
             const S tot = wave_sum8(ev, tid & 63);
             const int idx = sum8_index(tid & 63), te = t0 + (idx >> 1);
-            if ((tid & 63) < 8 && te < T && (size_t)(k >> 6) < NW)
-                epart[(((size_t)a * T + te) * 2 + (idx & 1)) * NW + (k >> 6)] = tot;
+            const bool mine = (tid & 63) < 8 && te < T && (size_t)(k >> 6) < NW;
+            const size_t at = (((size_t)a * T + te) * 2 + (idx & 1)) * NW + (k >> 6);
+            if (sizeof(S) == 4) {
+                // predication by address instead of by branch: a buffer store whose offset lies beyond
+                // num_records is dropped by the hardware, so the chunk stays one basic block and the
+                // scheduler may interleave the noise chains with the fp64 dynamics that follow
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)tot), ep_rsrc,
+                                                      mine ? (unsigned)(at * 4) : 0xFFFFFFFFu, 0, 0);
+            } else if (mine) {
+                epart[at] = tot;
+            }
         }
     };
     // theta is carried UNWRAPPED inside the loop: only cos/sin of it (carried separately as the heading
@@ -585,7 +598,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) __attribute__((amdgpu_waves_per_
                 if (producer) {
                     if (i < nch) {
                         draw_chunk(i * U, cur);
-                        eps_sums(i * U);
+                        eps_sums(i * U, full_tag);
                         S* rb = ring + (size_t)(i & 1) * U * 2 * 256 + tid;
 #pragma unroll
                         for (int j = 0; j < U; ++j) { rb[(j * 2 + 0) * 256] = cur[j][0]; rb[(j * 2 + 1) * 256] = cur[j][1]; }
@@ -603,7 +616,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) __attribute__((amdgpu_waves_per_
             for (int t0 = 0; t0 < T4; t0 += U) {  // full chunks: straight-line code
                 if (PHILOX) draw_chunk(t0, cur);
                 else load_chunk(t0 + U, nxt);  // prefetch: HBM latency hides under this chunk's math
-                eps_sums(t0);
+                eps_sums(t0, full_tag);
                 integrate(t0, std::false_type{}, full_tag);
                 if (!PHILOX) {
 #pragma unroll
@@ -612,7 +625,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) __attribute__((amdgpu_waves_per_
             }
             if (T4 < T) {  // ragged tail
                 if (PHILOX) draw_chunk(T4, cur);
-                eps_sums(T4);
+                eps_sums(T4, full_tag);
                 integrate(T4, std::true_type{}, full_tag);
             }
         }
