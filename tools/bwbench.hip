@@ -34,5 +34,25 @@ int main() {
     for (int blocks : {2048, 4096, 8192, 16384}) { char nm[64]; snprintf(nm, 64, "read float4 chunked, %d blocks", blocks); size_t c = (n4 + blocks - 1) / blocks; run(nm, [&] { hipLaunchKernelGGL(read4_chunk, dim3(blocks), dim3(256), 0, 0, (const float4*)buf, n4, c, out); }); }
     run("write 4B/lane, 150 rows x 1M (rollout)", [&] { hipLaunchKernelGGL(write1, dim3((1048576 + 255) / 256), dim3(256), 0, 0, buf, (size_t)150 * 1048576, 150); });
     for (int blocks : {2048, 8192}) { char nm[64]; snprintf(nm, 64, "write float4 grid-stride, %d blocks", blocks); run(nm, [&] { hipLaunchKernelGGL(write4, dim3(blocks), dim3(256), 0, 0, (float4*)buf, n4); }); }
+    // Infinity Cache (256 MB) residency: the same chunked read over smaller buffers, and write-then-read
+    for (size_t mb : {32, 64, 128, 200, 256, 400}) {
+        const size_t b2 = mb << 20, m4 = b2 / 16; const int blocks = 8192; size_t c = (m4 + blocks - 1) / blocks;
+        for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(read4_chunk, dim3(blocks), dim3(256), 0, 0, (const float4*)buf, m4, c, out);
+        hipDeviceSynchronize(); hipEventRecord(a, 0);
+        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(read4_chunk, dim3(blocks), dim3(256), 0, 0, (const float4*)buf, m4, c, out);
+        hipEventRecord(b, 0); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b);
+        printf("re-read %4zu MB (chunked float4)            %8.1f us  %7.1f GB/s\n", mb, ms * 100, b2 / (ms * 1e-4) / 1e9);
+        // write (4 B/lane rows) then read back once: what the update kernel sees after the rollout
+        float tw = 0, tr = 0;
+        for (int i = 0; i < 5; ++i) {
+            hipEventRecord(a, 0);
+            hipLaunchKernelGGL(write1, dim3((1048576 + 255) / 256), dim3(256), 0, 0, buf, b2 / 4, (int)(b2 / 4 / 1048576));
+            hipEventRecord(b, 0); hipEventSynchronize(b); hipEventElapsedTime(&ms, a, b); tw += ms;
+            hipEventRecord(a, 0);
+            hipLaunchKernelGGL(read4_chunk, dim3(blocks), dim3(256), 0, 0, (const float4*)buf, m4, c, out);
+            hipEventRecord(b, 0); hipEventSynchronize(b); hipEventElapsedTime(&ms, a, b); tr += ms;
+        }
+        printf("write %4zu MB then read it                  write %7.1f GB/s  read %7.1f GB/s\n", mb, b2 / (tw / 5 * 1e-3) / 1e9, b2 / (tr / 5 * 1e-3) / 1e9);
+    }
     return 0;
 }
