@@ -87,7 +87,6 @@ struct mppi_engine {
     bool eps_lazy = false, lazy_from_counter = false, lazy_counter_bumped = false;
     uint64_t lazy_seed = 0;
     uint32_t lazy_tick = 0;
-    bool split_rollout = false;     // rollout as producer (noise) + consumer (dynamics) waves: few samples per SIMD
     bool store_eps_always = false;  // MPPI_STORE_EPS=1: the tick path writes eps like mppi_rollout does
     double* d_tc = nullptr;  // [A][T][8]
     double* d_base = nullptr;
@@ -199,27 +198,20 @@ struct mppi_engine {
         if (!have_state || !have_goal) fail(MPPI_E_STATE, "state/goal passed as NULL before ever being set");
     }
 
-    template <typename S, int NT, bool PH, bool SE, bool IN, int MODEL, bool SPLIT>
-    void launch_rollout_h(hipStream_t st, int k0, int k1, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
-        // the node's cost (Q[2,2] = 0, no obstacle grid) runs the branch-free instantiation
-        if (P.q2 != 0.0 || P.grid_weight != 0.0) launch_rollout_i<S, NT, PH, SE, IN, MODEL, SPLIT, true>(st, k0, k1, seed, tick, tick_ptr);
-        else launch_rollout_i<S, NT, PH, SE, IN, MODEL, SPLIT, false>(st, k0, k1, seed, tick, tick_ptr);
-    }
-    template <typename S, int NT, bool PH, bool SE, bool IN, int MODEL, bool SPLIT, bool GEN>
-    void launch_rollout_i(hipStream_t st, int k0, int k1, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
-        auto kern = mppi::rollout_kernel<S, NT, PH, SE, IN, MODEL, SPLIT, GEN>;
-        dim3 grid((k1 - k0 + 255) / 256, cfg.n_agents);
-        const size_t lds = (size_t)cfg.horizon * 5 * sizeof(double) + (SPLIT ? (size_t)2 * 4 * 2 * 256 * sizeof(S) : 0);
-        hipLaunchKernelGGL(kern, grid, dim3(SPLIT ? 512 : 256), lds, st, P, d_state, d_goal, d_tc, static_cast<S*>(d_eps),
-                           static_cast<S*>(d_dP), static_cast<S*>(d_stot), seed, tick, tick_ptr, k0, k1,
-                           static_cast<S*>(d_epart), d_unom, d_base);
-        HIPCHK(hipGetLastError());
-    }
     template <typename S, int NT, bool PH, bool SE, bool IN, int MODEL>
     void launch_rollout_g(hipStream_t st, int k0, int k1, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
-        // producer/consumer wave split only pays while the SIMDs are not full anyway (device noise only)
-        if (PH && split_rollout) launch_rollout_h<S, NT, PH, SE, IN, MODEL, PH>(st, k0, k1, seed, tick, tick_ptr);
-        else launch_rollout_h<S, NT, PH, SE, IN, MODEL, false>(st, k0, k1, seed, tick, tick_ptr);
+        // the node's cost (Q[2,2] = 0, no obstacle grid) runs the branch-free instantiation
+        if (P.q2 != 0.0 || P.grid_weight != 0.0) launch_rollout_i<S, NT, PH, SE, IN, MODEL, true>(st, k0, k1, seed, tick, tick_ptr);
+        else launch_rollout_i<S, NT, PH, SE, IN, MODEL, false>(st, k0, k1, seed, tick, tick_ptr);
+    }
+    template <typename S, int NT, bool PH, bool SE, bool IN, int MODEL, bool GEN>
+    void launch_rollout_i(hipStream_t st, int k0, int k1, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
+        auto kern = mppi::rollout_kernel<S, NT, PH, SE, IN, MODEL, GEN>;
+        dim3 grid((k1 - k0 + 255) / 256, cfg.n_agents);
+        hipLaunchKernelGGL(kern, grid, dim3(256), (size_t)cfg.horizon * 5 * sizeof(double), st, P, d_state, d_goal, d_tc,
+                           static_cast<S*>(d_eps), static_cast<S*>(d_dP), static_cast<S*>(d_stot), seed, tick, tick_ptr, k0, k1,
+                           static_cast<S*>(d_epart), d_unom, d_base);
+        HIPCHK(hipGetLastError());
     }
     template <typename S, int NT, bool PH, bool SE>
     void launch_rollout_f(hipStream_t st, int k0, int k1, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
@@ -401,11 +393,6 @@ struct mppi_engine {
 
         roll_bs = 256;
         roll_blocks = (K + roll_bs - 1) / roll_bs;
-        // up to ~1.5 sample-waves per SIMD (256 CUs x 4 SIMDs) the rollout is latency-bound: split every
-        // sample-wave into a noise wave and a dynamics wave (measured: -7 % tick at K = 1e4 and 6e4, break-even
-        // at 1.25e5, +4..10 % from 2.5e5 up)
-        split_rollout = (long)A * K <= 98304;
-        if (const char* v = std::getenv("MPPI_SPLIT")) split_rollout = std::atoi(v) != 0;
         P.model = cfg.model;
         P.grid = nullptr; P.grid_w = 0; P.grid_h = 0; P.grid_res = 1.0; P.grid_ox = 0.0; P.grid_oy = 0.0; P.grid_weight = 0.0;
         // largest rotation of the heading vector in one step: h/2 <= kth*dt*u_max (rk4), dt*u_max (euler)

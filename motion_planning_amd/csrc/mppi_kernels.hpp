@@ -385,8 +385,8 @@ __device__ __forceinline__ void philox_normals(uint32_t gk, uint32_t pair, uint3
 // grid = (ceil(K / 256), A), block = 256, LDS = the 40*T-byte per-step table.  Per lane and step: 2 eps + 1 dP element
 // through HBM, fully coalesced (consecutive lanes = consecutive k).
 // ---------------------------------------------------------------------------------------------
-template <typename S, int NTERM, bool PHILOX, bool STORE_EPS, bool INLINE_NOM, int MODEL, bool SPLIT, bool GENERAL>
-__global__ __launch_bounds__(SPLIT ? 512 : 256) __attribute__((amdgpu_waves_per_eu(5, 8))) void rollout_kernel(DevParams P, const double* __restrict__ state,
+template <typename S, int NTERM, bool PHILOX, bool STORE_EPS, bool INLINE_NOM, int MODEL, bool GENERAL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void rollout_kernel(DevParams P, const double* __restrict__ state,
                                                      const double* __restrict__ goal,
                                                      double* __restrict__ tc, S* __restrict__ eps,
                                                      S* __restrict__ dP, S* __restrict__ Stot, uint64_t seed,
@@ -395,20 +395,14 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) __attribute__((amdgpu_waves_per_
                                                      const double* __restrict__ unom, double* __restrict__ base) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* lt = reinterpret_cast<double*>(smem_raw);  // [T][5] per-step table {un0, un1, w0, w1, cb}
-    // SPLIT (device noise, few samples per SIMD): 512 threads serve the block's 256 samples -- waves 4..7
-    // only draw the noise (Philox + Box-Muller + the eps sums) one chunk ahead into an LDS ring, waves
-    // 0..3 only integrate.  Twice the waves per sample and half the serial instruction stream per wave:
-    // what a latency-bound (small / strongly sharded K) rollout needs; no gain once the SIMDs are full.
-    const int tid = SPLIT ? (threadIdx.x & 255) : threadIdx.x, a = blockIdx.y, T = P.T;
-    const bool producer = SPLIT && threadIdx.x >= 256;
-    S* ring = reinterpret_cast<S*>(lt + (size_t)T * 5);  // SPLIT: [2][U=4][2][256]
+    const int tid = threadIdx.x, a = blockIdx.y, T = P.T;
     // The per-step table lives in LDS: read back as wave-uniform (broadcast) ds_reads that the
     // scheduler can hoist, instead of an s_load + s_waitcnt round trip on every step.
     if (INLINE_NOM) {
         // T <= 64: wave 0 of every block runs the nominal rollout itself (lanes = timesteps, ~600
         // instructions) -- no separate kernel, no launch boundary in front of the rollout.  The
         // first block also publishes base[] (and tc[]) for mppi_download_value.
-        if (threadIdx.x < 64) {
+        if (tid < 64) {
             double row[5], base_t;
             nominal_wave(P, state, goal, unom, a, tid, row, base_t);
             if (tid < T) {
@@ -423,7 +417,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) __attribute__((amdgpu_waves_per_
             }
         }
     } else {
-        for (int i = threadIdx.x; i < T * 5; i += blockDim.x) lt[i] = tc[((size_t)a * T + i / 5) * kTcW + i % 5];
+        for (int i = tid; i < T * 5; i += blockDim.x) lt[i] = tc[((size_t)a * T + i / 5) * kTcW + i % 5];
     }
     __syncthreads();
     const int k = k_first + blockIdx.x * 256 + tid;  // this launch covers samples [k_first, k_last)
@@ -592,47 +586,24 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) __attribute__((amdgpu_waves_per_
     };
     const int T4 = T & ~(U - 1);  // steps covered by full chunks
     auto run = [&](auto full_tag) {
-        if (SPLIT) {
-            const int nch = (T + U - 1) / U;
-            for (int i = 0; i <= nch; ++i) {
-                if (producer) {
-                    if (i < nch) {
-                        draw_chunk(i * U, cur);
-                        eps_sums(i * U, full_tag);
-                        S* rb = ring + (size_t)(i & 1) * U * 2 * 256 + tid;
+        for (int t0 = 0; t0 < T4; t0 += U) {  // full chunks: straight-line code
+            if (PHILOX) draw_chunk(t0, cur);
+            else load_chunk(t0 + U, nxt);  // prefetch: HBM latency hides under this chunk's math
+            eps_sums(t0, full_tag);
+            integrate(t0, std::false_type{}, full_tag);
+            if (!PHILOX) {
 #pragma unroll
-                        for (int j = 0; j < U; ++j) { rb[(j * 2 + 0) * 256] = cur[j][0]; rb[(j * 2 + 1) * 256] = cur[j][1]; }
-                    }
-                } else if (i > 0) {
-                    const S* rb = ring + (size_t)((i - 1) & 1) * U * 2 * 256 + tid;
-#pragma unroll
-                    for (int j = 0; j < U; ++j) { cur[j][0] = rb[(j * 2 + 0) * 256]; cur[j][1] = rb[(j * 2 + 1) * 256]; }
-                    if ((i - 1) * U < T4) integrate((i - 1) * U, std::false_type{}, full_tag);
-                    else integrate((i - 1) * U, std::true_type{}, full_tag);
-                }
-                __syncthreads();  // one barrier per chunk: ring slot i&1 is full, slot (i-1)&1 is free again
+                for (int j = 0; j < U; ++j) { cur[j][0] = nxt[j][0]; cur[j][1] = nxt[j][1]; }
             }
-        } else {
-            for (int t0 = 0; t0 < T4; t0 += U) {  // full chunks: straight-line code
-                if (PHILOX) draw_chunk(t0, cur);
-                else load_chunk(t0 + U, nxt);  // prefetch: HBM latency hides under this chunk's math
-                eps_sums(t0, full_tag);
-                integrate(t0, std::false_type{}, full_tag);
-                if (!PHILOX) {
-#pragma unroll
-                    for (int j = 0; j < U; ++j) { cur[j][0] = nxt[j][0]; cur[j][1] = nxt[j][1]; }
-                }
-            }
-            if (T4 < T) {  // ragged tail
-                if (PHILOX) draw_chunk(T4, cur);
-                eps_sums(T4, full_tag);
-                integrate(T4, std::true_type{}, full_tag);
-            }
+        }
+        if (T4 < T) {  // ragged tail
+            if (PHILOX) draw_chunk(T4, cur);
+            eps_sums(T4, full_tag);
+            integrate(T4, std::true_type{}, full_tag);
         }
     };
     if (block_full) run(std::true_type{});   // uniform: all but (at most) the last block of a launch
     else run(std::false_type{});
-    if (producer) return;
     terminal();
     // value_fcn = reverse cumulative sum over t (control/src/mppi:175) = total - exclusive prefix
     if (active) Stot[(size_t)a * Ks + k] = (S)pre;
