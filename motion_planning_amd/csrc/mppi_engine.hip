@@ -249,7 +249,7 @@ struct mppi_engine {
         eps_lazy = false;
     }
     void launch_regen(hipStream_t st, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
-        dim3 g((cfg.samples + 255) / 256, (cfg.horizon + 1) / 2, cfg.n_agents);
+        dim3 g((cfg.samples + 255) / 256, (cfg.horizon + mppi::kStepsPerDraw - 1) / mppi::kStepsPerDraw, cfg.n_agents);
         if (f64()) hipLaunchKernelGGL(mppi::eps_regen_kernel<double>, g, dim3(256), 0, st, P, static_cast<double*>(d_eps), seed, tick, tick_ptr);
         else hipLaunchKernelGGL(mppi::eps_regen_kernel<float>, g, dim3(256), 0, st, P, static_cast<float*>(d_eps), seed, tick, tick_ptr);
         HIPCHK(hipGetLastError());

@@ -228,40 +228,46 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
 }
 __device__ __forceinline__ double wave_sum_lane63(double v) { return wave_sum(v); }
 
-// Eight 64-lane sums at once (the eps sums of one 4-step chunk: 2 wheels x 4 steps) as a
-// reduce-scatter: each exchange halves the values a lane still carries (4+2+1 selects/adds instead
-// of 8 x 6), the last three levels are plain adds (row_ror:8, v_permlane16_swap, v_permlane32_swap --
-// the latter two are gfx950 additions).  Every lane ends with the total of value
-// sum8_index(lane); 33 VALU ops instead of ~110 for eight separate DPP reductions.
-__device__ __forceinline__ int sum8_index(int lane) { return ((lane >> 2) & 1) | (lane & 2) | ((lane & 1) << 2); }
-__device__ __forceinline__ float wave_sum8(const float (&v)[8], int lane) {
-    const bool b1 = lane & 1, b2 = lane & 2, b4 = lane & 4;
-    float w[4], x[2];
+// Sixteen 64-lane sums at once (the eps sums of one 6-step chunk use 12 of them) as a reduce-scatter:
+// each exchange halves the values a lane still carries (8+4+2+1 select/add pairs instead of 16 x 6 adds).
+// The partner of a halving must hold the same set of values, and must be reachable by ONE symmetric DPP
+// pattern: lane^7 (row_half_mirror), ^1, ^2 (quad_perm) generate all 8 lanes of a half row, lane^8
+// (row_ror:8) joins the two halves; the two row exchanges that remain are plain adds
+// (v_permlane16_swap, v_permlane32_swap -- gfx950 additions).  Every lane ends with the total of value
+// sum16_index(lane).
+__device__ __forceinline__ int sum16_index(int lane) {
+    return ((lane >> 3) & 1) | (lane & 2) | ((lane & 1) << 2) | ((lane & 4) << 1);
+}
+__device__ __forceinline__ float wave_sum16(const float (&v)[16], int lane) {
+    const bool b1 = lane & 1, b2 = lane & 2, b4 = lane & 4, b8 = lane & 8;
+    float u[8], w[4], x[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)  // partner lane ^ 1
-        w[i] = (b1 ? v[i + 4] : v[i]) + dpp_mov<0xB1, 0xF>(b1 ? v[i] : v[i + 4]);
+    for (int i = 0; i < 8; ++i)  // partner lane ^ 7 (same half row, other bit 2): keep i + 8*b4
+        u[i] = (b4 ? v[i + 8] : v[i]) + dpp_mov<0x141, 0xF>(b4 ? v[i] : v[i + 8]);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)  // partner lane ^ 2
+    for (int i = 0; i < 4; ++i)  // partner lane ^ 1: keep i + 4*b1 (+ 8*b4)
+        w[i] = (b1 ? u[i + 4] : u[i]) + dpp_mov<0xB1, 0xF>(b1 ? u[i] : u[i + 4]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)  // partner lane ^ 2: keep i + 2*b2 (+ ...)
         x[i] = (b2 ? w[i + 2] : w[i]) + dpp_mov<0x4E, 0xF>(b2 ? w[i] : w[i + 2]);
-    float y = (b4 ? x[1] : x[0]) + dpp_mov<0x124, 0xF>(b4 ? x[0] : x[1]);  // row_ror:4 (a lane with the other bit 2)
-    y += dpp_mov<0x128, 0xF>(y);                                             // row_ror:8
+    float y = (b8 ? x[1] : x[0]) + dpp_mov<0x128, 0xF>(b8 ? x[0] : x[1]);  // partner lane ^ 8: keep b8 (+ ...)
     {
-        const unsigned u = __float_as_uint(y);
-        const auto p = __builtin_amdgcn_permlane16_swap(u, u, false, false);  // rows 0<->1, 2<->3
+        const unsigned t = __float_as_uint(y);
+        const auto p = __builtin_amdgcn_permlane16_swap(t, t, false, false);  // rows 0<->1, 2<->3
         y = __uint_as_float(p[0]) + __uint_as_float(p[1]);
     }
     {
-        const unsigned u = __float_as_uint(y);
-        const auto p = __builtin_amdgcn_permlane32_swap(u, u, false, false);  // lanes 0-31 <-> 32-63
+        const unsigned t = __float_as_uint(y);
+        const auto p = __builtin_amdgcn_permlane32_swap(t, t, false, false);  // lanes 0-31 <-> 32-63
         y = __uint_as_float(p[0]) + __uint_as_float(p[1]);
     }
     return y;
 }
-__device__ __forceinline__ double wave_sum8(const double (&v)[8], int lane) {  // exact-parity mode: plain sums
+__device__ __forceinline__ double wave_sum16(const double (&v)[16], int lane) {  // exact-parity mode: plain sums
     double r = 0.0;
-    const int mine = sum8_index(lane);
+    const int mine = sum16_index(lane);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { const double t = wave_sum(v[i]); if (i == mine) r = t; }
+    for (int i = 0; i < 16; ++i) { const double t = wave_sum(v[i]); if (i == mine) r = t; }
     return r;
 }
 
@@ -345,27 +351,33 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// two N(0, sigma^2) draws from two 32-bit words: Box-Muller in fp32 on a 23-bit radius uniform
-// u1 = (w0>>9 + 1/2) / 2^23 in (0,1) and a 24-bit angle uniform u2 = (w1>>8) / 2^24 in [0,1)
-// (both exact in fp32), on the gfx950 transcendental units directly -- v_log_f32 (log2),
-// v_sqrt_f32, v_sin_f32 / v_cos_f32 (argument in revolutions, exactly what Box-Muller wants).
-// Only multiplies follow the transcendentals, so every kernel that calls this with the same
+// Two N(0, sigma^2) draws from two 21-bit uniforms: Box-Muller in fp32 with u1 = (a + 1/2) / 2^21 in
+// (0,1) and the angle u2 = b / 2^21 in [0,1) (both exact in fp32), on the gfx950 transcendental units
+// directly -- v_log_f32 (log2), v_sqrt_f32, v_sin_f32 / v_cos_f32 (argument in revolutions, exactly what
+// Box-Muller wants).  sigma * sqrt(-2 ln u1) = sqrt(nscale * log2 u1), nscale = -2 ln2 sigma^2.
+// Only multiplies surround the transcendentals, so every kernel that calls this with the same
 // words gets bit-identical noise (no contraction-dependent rounding).
-__device__ __forceinline__ void box_muller(uint32_t w0, uint32_t w1, float sigma, float& e0, float& e1) {
-    const float u1 = ((float)(w0 >> 9) + 0.5f) * (1.0f / 8388608.0f);
-    const float u2 = (float)(w1 >> 8) * (1.0f / 16777216.0f);
-    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // -2 ln2 log2(u1)
-    e0 = sigma * (r * __builtin_amdgcn_cosf(u2));
-    e1 = sigma * (r * __builtin_amdgcn_sinf(u2));
+__device__ __forceinline__ void box_muller(uint32_t a21, uint32_t b21, float nscale, float& e0, float& e1) {
+    const float u1 = ((float)a21 + 0.5f) * (1.0f / 2097152.0f);
+    const float u2 = (float)b21 * (1.0f / 2097152.0f);
+    const float r = __builtin_amdgcn_sqrtf(nscale * __builtin_amdgcn_logf(u1));
+    e0 = r * __builtin_amdgcn_cosf(u2);
+    e1 = r * __builtin_amdgcn_sinf(u2);
 }
 
-// the noise of global sample `gk`, agent a, steps 2*pair and 2*pair+1: e[0..1] and e[2..3]
-__device__ __forceinline__ void philox_normals(uint32_t gk, uint32_t pair, uint32_t tick, uint32_t a, uint32_t key0,
-                                               uint32_t key1, float sigf, float (&e)[4]) {
+// The noise of global sample `gk`, agent a, steps 3*triple .. 3*triple+2: e[2j], e[2j+1] = (eps0, eps1)
+// of step 3*triple + j.  One Philox call = 128 bits = three pairs of 21-bit uniforms (the top 21 bits of
+// the four words, plus the 2 x 21 bits assembled from their low 11): 1/3 call per step instead of 1/2.
+constexpr int kStepsPerDraw = 3;
+__device__ __forceinline__ void philox_normals(uint32_t gk, uint32_t triple, uint32_t tick, uint32_t a, uint32_t key0,
+                                               uint32_t key1, float sigf, float (&e)[6]) {
     uint32_t o[4];
-    philox4x32_10(gk, pair, tick, a, key0, key1, o);
-    box_muller(o[0], o[1], sigf, e[0], e[1]);
-    box_muller(o[2], o[3], sigf, e[2], e[3]);
+    philox4x32_10(gk, triple, tick, a, key0, key1, o);
+    const float nscale = -1.3862943611198906f * (sigf * sigf);
+    box_muller(o[0] >> 11, o[1] >> 11, nscale, e[0], e[1]);
+    box_muller(o[2] >> 11, o[3] >> 11, nscale, e[2], e[3]);
+    box_muller(((o[0] & 0x7FFu) << 10) | ((o[1] & 0x7FFu) >> 1), ((o[2] & 0x7FFu) << 10) | ((o[3] & 0x7FFu) >> 1),
+               nscale, e[4], e[5]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -447,7 +459,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         sigf = (float)P.sigma;
     }
 
-    constexpr int U = 4;  // steps per software-pipelined chunk (wave_sum8 assumes 4)
+    constexpr int U = 6;  // steps per chunk = two Philox draws (wave_sum16 carries its 12 eps sums)
     S cur[U][2], nxt[U][2];
     auto load_chunk = [&](int t0, S (&buf)[U][2]) {
 #pragma unroll
@@ -458,13 +470,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
             buf[j][1] = ok ? eps_a[(size_t)(t * 2 + 1) * Ks] : (S)0;
         }
     };
-    auto draw_chunk = [&](int t0, S (&buf)[U][2]) {  // U == 4: two Philox calls
+    auto draw_chunk = [&](int t0, S (&buf)[U][2]) {  // two Philox calls, three steps each
 #pragma unroll
-        for (int j = 0; j < U; j += 2) {
-            float e[4];
-            philox_normals(ctr0, (uint32_t)((t0 + j) >> 1), tick, (uint32_t)a, key0, key1, sigf, e);
-            buf[j][0] = (S)e[0]; buf[j][1] = (S)e[1];
-            buf[j + 1][0] = (S)e[2]; buf[j + 1][1] = (S)e[3];
+        for (int j = 0; j < U; j += kStepsPerDraw) {
+            float e[6];
+            philox_normals(ctr0, (uint32_t)((t0 + j) / kStepsPerDraw), tick, (uint32_t)a, key0, key1, sigf, e);
+#pragma unroll
+            for (int i = 0; i < kStepsPerDraw; ++i) { buf[j + i][0] = (S)e[2 * i]; buf[j + i][1] = (S)e[2 * i + 1]; }
         }
     };
     if (!PHILOX) load_chunk(0, cur);
@@ -472,17 +484,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     double pre = 0.0;  // sum_{tau < t} (c[tau] - c_nom[tau])
     auto eps_sums = [&](int t0, auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
-        {   // sum_k eps per wave for the chunk's 4 steps x 2 wheels (the E of the softmax floor term,
+        {   // sum_k eps per wave for the chunk's 6 steps x 2 wheels (the E of the softmax floor term,
             // control/src/mppi:193): saves the update kernel from reading eps at all (8 of its 12 B/step)
-            S ev[8];
+            S ev[16];
 #pragma unroll
             for (int j = 0; j < U; ++j) {
                 ev[2 * j] = (FULL || active) ? cur[j][0] : (S)0;
                 ev[2 * j + 1] = (FULL || active) ? cur[j][1] : (S)0;
             }
-            const S tot = wave_sum8(ev, tid & 63);
-            const int idx = sum8_index(tid & 63), te = t0 + (idx >> 1);
-            const bool mine = (tid & 63) < 8 && te < T && (size_t)(k >> 6) < NW;
+#pragma unroll
+            for (int j = 2 * U; j < 16; ++j) ev[j] = (S)0;
+            const S tot = wave_sum16(ev, tid & 63);
+            const int idx = sum16_index(tid & 63), te = t0 + (idx >> 1);
+            const bool mine = (tid & 63) < 16 && idx < 2 * U && te < T && (size_t)(k >> 6) < NW;
             const size_t at = (((size_t)a * T + te) * 2 + (idx & 1)) * NW + (k >> 6);
             if (sizeof(S) == 4) {
                 // predication by address instead of by branch: a buffer store whose offset lies beyond
@@ -584,7 +598,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         const double dx = x - gx, dy = y - gy, dth = thw - gth;
         pre += P.p0 * dx * dx + P.p1 * dy * dy + P.p2 * dth * dth;
     };
-    const int T4 = T & ~(U - 1);  // steps covered by full chunks
+    const int T4 = T - T % U;  // steps covered by full chunks
     auto run = [&](auto full_tag) {
         for (int t0 = 0; t0 < T4; t0 += U) {  // full chunks: straight-line code
             if (PHILOX) draw_chunk(t0, cur);
@@ -700,12 +714,13 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
             if (x > cand) {  // rare: wave-uniformly skipped for almost every vector
                 R a0, a1;
                 if (REGEN) {  // eps was never stored: re-draw this sample's step (same Philox counter)
-                    float ev[4];
-                    philox_normals(P.sample_offset + (uint32_t)(k + i), (uint32_t)(t >> 1),
+                    float ev[6];
+                    philox_normals(P.sample_offset + (uint32_t)(k + i), (uint32_t)(t / kStepsPerDraw),
                                    tick_ptr ? *tick_ptr : tick_arg, (uint32_t)a, (uint32_t)seed,
                                    (uint32_t)(seed >> 32), (float)P.sigma, ev);
-                    a0 = (R)((t & 1) ? ev[2] : ev[0]);
-                    a1 = (R)((t & 1) ? ev[3] : ev[1]);
+                    const int sel = t % kStepsPerDraw;
+                    a0 = (R)(sel == 0 ? ev[0] : (sel == 1 ? ev[2] : ev[4]));
+                    a1 = (R)(sel == 0 ? ev[1] : (sel == 1 ? ev[3] : ev[5]));
                 } else {
                     a0 = (R)e0_row[k + i];
                     a1 = (R)e1_row[k + i];
@@ -740,20 +755,25 @@ __global__ __launch_bounds__(256) void eps_wavesum_kernel(DevParams P, const S* 
 // The device noise as a kernel of its own, one lane per (sample, step pair): materialises the
 // noise of a rollout that did not store it (mppi_download_noise, or a separate mppi_update after a
 // tick).  (Drawing the noise first and rolling out on the stored eps was tried as a small-K tick
-// path: slower than the fused rollout at every K from 1e4 to 5e5.)   grid = (ceil(K/256), ceil(T/2), A)
+// path: slower than the fused rollout at every K from 1e4 to 5e5.)   grid = (ceil(K/256), ceil(T/3), A)
 template <typename S>
 __global__ __launch_bounds__(256) void eps_regen_kernel(DevParams P, S* __restrict__ eps, uint64_t seed, uint32_t tick_arg,
                                                        const uint32_t* __restrict__ tick_ptr) {
-    const int k = blockIdx.x * 256 + threadIdx.x, pair = blockIdx.y, a = blockIdx.z;
+    const int k = blockIdx.x * 256 + threadIdx.x, triple = blockIdx.y, a = blockIdx.z;
     if (k >= P.K) return;
     const uint32_t tick = tick_ptr ? *tick_ptr : tick_arg;
-    float e[4];
-    philox_normals(P.sample_offset + (uint32_t)k, (uint32_t)pair, tick, (uint32_t)a, (uint32_t)seed,
+    float e[6];
+    philox_normals(P.sample_offset + (uint32_t)k, (uint32_t)triple, tick, (uint32_t)a, (uint32_t)seed,
                    (uint32_t)(seed >> 32), (float)P.sigma, e);
     const size_t Ks = (size_t)P.Ks;
-    S* row = eps + (((size_t)a * P.T + 2 * pair) * 2) * Ks + k;
-    row[0] = (S)e[0]; row[Ks] = (S)e[1];
-    if (2 * pair + 1 < P.T) { row[2 * Ks] = (S)e[2]; row[3 * Ks] = (S)e[3]; }
+#pragma unroll
+    for (int i = 0; i < kStepsPerDraw; ++i) {
+        const int t = kStepsPerDraw * triple + i;
+        if (t < P.T) {
+            S* row = eps + (((size_t)a * P.T + t) * 2) * Ks + k;
+            row[0] = (S)e[2 * i]; row[Ks] = (S)e[2 * i + 1];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
