@@ -265,10 +265,10 @@ struct mppi_engine {
     void launch_update(hipStream_t st, int ch0, int nch, const uint32_t* tick_ptr = nullptr) {
         ensure_epart(st);
         Scope sc(this, MPPI_KERNEL_UPDATE, st);
-        dim3 grid(cfg.horizon, nch, cfg.n_agents);
+        dim3 grid(8 * cfg.horizon, (cfg.n_agents * nch + 7) / 8);  // XCD-aware decode inside the kernel
 #define LAUNCH_UPD(TYPE, REGEN)                                                                                  \
     hipLaunchKernelGGL((mppi::update_kernel<TYPE, REGEN>), grid, dim3(256), 0, st, P, static_cast<const TYPE*>(d_eps), \
-                       static_cast<const TYPE*>(d_dP), static_cast<const TYPE*>(d_stot), d_part, NCH, ch0,         \
+                       static_cast<const TYPE*>(d_dP), static_cast<const TYPE*>(d_stot), d_part, NCH, ch0, nch,    \
                        static_cast<const TYPE*>(d_epart), lazy_seed, lazy_tick, tick_ptr)
         if (f64()) { if (eps_lazy) LAUNCH_UPD(double, true); else LAUNCH_UPD(double, false); }
         else { if (eps_lazy) LAUNCH_UPD(float, true); else LAUNCH_UPD(float, false); }

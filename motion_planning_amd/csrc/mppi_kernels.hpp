@@ -633,7 +633,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
 // Block (t, ch, a) keeps its chunk of v = Stot - dP in registers (kUpdNV 16-byte vectors per lane):
 //   pass 1  load, block minimum M;   pass 2  e = exp2((M - v) * log2e/lam), D += e, and for lanes
 //   with e > 2^-kCand: N += e * eps  (predicated scalar loads, wave-uniformly skipped otherwise).
-// grid = (T, chunks of this launch, A) x 256 threads; part[a][t][ch] = {M, D, N0, N1, E0, E1, count, 0}.
+// grid = (8 T, ceil(A * chunks of this launch / 8)) x 256 threads; part[a][t][ch] = {M, D, N0, N1, E0, E1, count, 0}.
 // ---------------------------------------------------------------------------------------------
 constexpr int kUpdNV = 8;  // 16-byte vectors per lane: chunk = 256 * kUpdNV * (16 / sizeof(S)) samples
 template <typename S> struct UpdCfg { static constexpr int VEC = 16 / (int)sizeof(S); static constexpr int CH = 256 * kUpdNV * VEC; };
@@ -641,18 +641,26 @@ template <typename S> struct UpdCfg { static constexpr int VEC = 16 / (int)sizeo
 template <typename S, bool REGEN>
 __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __restrict__ eps,
                                                     const S* __restrict__ dP, const S* __restrict__ Stot,
-                                                    double* __restrict__ part, int NCH, int ch_first,
+                                                    double* __restrict__ part, int NCH, int ch_first, int n_local,
                                                     const S* __restrict__ epart, uint64_t seed, uint32_t tick_arg,
                                                     const uint32_t* __restrict__ tick_ptr) {
     using R = S;
     constexpr int VEC = UpdCfg<S>::VEC, CH = UpdCfg<S>::CH;
     typedef S vec_t __attribute__((ext_vector_type(VEC)));
-    // blockIdx.x = t (fastest): the T blocks that share one chunk of Stot are dispatched back to
-    // back, so each XCD's L2 fetches that chunk once instead of once per timestep.  Chunks are
-    // walked from the highest k down: the rollout kernel wrote the high-k columns last, so they
-    // are the part still resident in the 256 MB Infinity Cache.
-    const int t = blockIdx.x, ch = ch_first + (int)gridDim.y - 1 - (int)blockIdx.y;
-    const int a = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // XCD-aware block -> (t, chunk) map.  Workgroups go to the 8 XCDs round-robin by linear id, and
+    // each XCD has its own L2: id = xcd + 8 * (t + T * group) puts all T blocks that share chunk
+    // column (8 * group + xcd) of Stot on ONE XCD, so that chunk crosses into L2 once per tick instead of once
+    // per XCD (placement only changes speed, never results).  Chunks are walked from the highest k down:
+    // the rollout kernel wrote the high-k columns last, they are what the Infinity Cache still holds.
+    // The columns of this launch are the (agent, chunk) pairs, numbered agent-major.
+    const int T_ = P.T;
+    const int id = blockIdx.x + (int)gridDim.x * blockIdx.y;  // grid = (8 * T, ceil(A * chunks / 8))
+    const int xcd = id & 7, q = id >> 3, t = q % T_, grp = q / T_;
+    const int col = grp * 8 + xcd;
+    if (col >= P.A * n_local) return;
+    const int a = col / n_local, local = col % n_local;
+    const int ch = ch_first + n_local - 1 - local;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const size_t Ks = (size_t)P.Ks;
     const S* v_row = dP + ((size_t)a * P.T + t) * Ks;   // exclusive cost prefix of row t
     const S* s_row = Stot + (size_t)a * Ks;               // per-sample totals (L2-resident, re-read per t)
