@@ -222,7 +222,7 @@ def main():
                                    "achieved": 2 * BYTES_PER_STEP_PER_KERNEL * steps_per_launch / tick_s / 1e9,
                                    "frac": 2 * BYTES_PER_STEP_PER_KERNEL * steps_per_launch / tick_s / 1e9 / HBM_PEAK_GBS}}
         # HBM bytes actually moved per launch of that kernel: rocprofv3 --pmc passes of this same command
-        # (tools_pmc.sh), summary committed under profiles/ -- bench.py itself cannot host the profiler
+        # (tools/pmc.sh), summary committed under profiles/ -- bench.py itself cannot host the profiler
         pmc_file = os.path.join(ROOT, "profiles", "r1_pmc_summary_bench_c4.json")
         if args.workload == "c4" and args.storage == "f32" and world == 1 and not args.samples and os.path.exists(pmc_file):
             pm = json.load(open(pmc_file))

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Run ON THE GPU BOX (via gpurun): tools_pmc.sh <tag> [bench args...]
+# Run ON THE GPU BOX (via gpurun): tools/pmc.sh <tag> [bench args...]
 # One rocprofv3 --pmc pass per counter group (never combined with sys/hip tracing), then a
 # summary JSON (per-launch averages per kernel) next to the raw CSVs under gpurun_out/<tag>/.
 R=$GRAFT_REPO_ROOT; TAG=$1; shift
