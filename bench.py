@@ -196,12 +196,15 @@ def main():
     # (mppi_tick; what Controller.pos_cb pays per odometry message), N = 1 only.
     sync_tick_us = None
     if not in_group:
-        n_lat = min(args.steps, 50)
-        t0 = time.perf_counter()
-        st = nxt
+        n_lat = min(args.steps, 200)
+        st, lat = nxt, []
         for i in range(n_lat):
+            t0 = time.perf_counter()
             st, _ = eng.tick(st, goals, noise="philox", seed=seed, tick_id=10_000_000 + i)
-        sync_tick_us = 1e6 * (time.perf_counter() - t0) / n_lat
+            lat.append(1e6 * (time.perf_counter() - t0))
+        lat = np.sort(np.array(lat))
+        sync_tick_us = {"mean": float(lat.mean()), "median": float(np.median(lat)),
+                        "p99": float(lat[min(len(lat) - 1, int(0.99 * len(lat)))]), "ticks": n_lat}
 
     if rank == 0:
         steps_per_launch = A * K_local * T
