@@ -198,13 +198,13 @@ struct mppi_engine {
         if (!have_state || !have_goal) fail(MPPI_E_STATE, "state/goal passed as NULL before ever being set");
     }
 
-    template <typename S, int NT, bool PH, bool SE, bool IN, int MODEL>
+    template <typename S, int NT, bool PH, bool SE, int IN, int MODEL>
     void launch_rollout_g(hipStream_t st, int k0, int k1, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
         // the node's cost (Q[2,2] = 0, no obstacle grid) runs the branch-free instantiation
         if (P.q2 != 0.0 || P.grid_weight != 0.0) launch_rollout_i<S, NT, PH, SE, IN, MODEL, true>(st, k0, k1, seed, tick, tick_ptr);
         else launch_rollout_i<S, NT, PH, SE, IN, MODEL, false>(st, k0, k1, seed, tick, tick_ptr);
     }
-    template <typename S, int NT, bool PH, bool SE, bool IN, int MODEL, bool GEN>
+    template <typename S, int NT, bool PH, bool SE, int IN, int MODEL, bool GEN>
     void launch_rollout_i(hipStream_t st, int k0, int k1, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
         auto kern = mppi::rollout_kernel<S, NT, PH, SE, IN, MODEL, GEN>;
         dim3 grid((k1 - k0 + 255) / 256, cfg.n_agents);
@@ -215,9 +215,10 @@ struct mppi_engine {
     }
     template <typename S, int NT, bool PH, bool SE>
     void launch_rollout_f(hipStream_t st, int k0, int k1, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
-        if (cfg.model == MPPI_MODEL_UNICYCLE_EULER) launch_rollout_g<S, NT, PH, SE, false, 1>(st, k0, k1, seed, tick, tick_ptr);
-        else if (inline_nominal()) launch_rollout_g<S, NT, PH, SE, true, 0>(st, k0, k1, seed, tick, tick_ptr);
-        else launch_rollout_g<S, NT, PH, SE, false, 0>(st, k0, k1, seed, tick, tick_ptr);
+        if (cfg.model == MPPI_MODEL_UNICYCLE_EULER) launch_rollout_g<S, NT, PH, SE, 0, 1>(st, k0, k1, seed, tick, tick_ptr);
+        else if (cfg.horizon <= 64) launch_rollout_g<S, NT, PH, SE, 1, 0>(st, k0, k1, seed, tick, tick_ptr);
+        else if (cfg.horizon <= 256) launch_rollout_g<S, NT, PH, SE, 2, 0>(st, k0, k1, seed, tick, tick_ptr);
+        else launch_rollout_g<S, NT, PH, SE, 0, 0>(st, k0, k1, seed, tick, tick_ptr);
     }
     template <typename S, int NT>
     void launch_rollout_t(hipStream_t st, int k0, int k1, bool ph, bool store, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
@@ -315,8 +316,8 @@ struct mppi_engine {
         launch_merge();
         noise_ready = true; value_ready = true; partials_ready = true; epart_ready = true;
     }
-    // T <= 64: the nominal rollout runs inside every rollout block (one wave, lanes = timesteps)
-    bool inline_nominal() const { return cfg.horizon <= 64 && cfg.model == MPPI_MODEL_DIFFDRIVE_RK4; }
+    // T <= 256: the nominal rollout runs inside every rollout block (lanes = timesteps)
+    bool inline_nominal() const { return cfg.horizon <= 256 && cfg.model == MPPI_MODEL_DIFFDRIVE_RK4; }
     void run_nominal() {
         if (inline_nominal()) return;
         Scope sc(this, MPPI_KERNEL_NOMINAL);

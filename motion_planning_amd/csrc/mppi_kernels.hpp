@@ -5,14 +5,14 @@
 //   update_action :186-208, perform_action :210-213, get_path :85-102.
 //
 // Pipeline of one control tick (DESIGN.md has the byte accounting):
-//   rollout_kernel   1 lane / sample    prologue (T <= 64): wave 0 runs the nominal (eps = 0) rollout,
+//   rollout_kernel   1 lane / sample    prologue (T <= 256): the block runs the nominal (eps = 0) rollout,
 //                                       lanes = timesteps, into the LDS per-step table; then
 //                                       noise -> clip -> RK4 step -> stage cost, all in registers;
 //                                       streams the running cost prefix dP[a][t][K] (4 B/step),
 //                                       one total per sample and the per-wave sums of eps.  The noise
 //                                       itself is written only by the stand-alone mppi_rollout: it is
 //                                       a pure function of its Philox counter and is re-drawn on demand.
-//   (nominal_kernel  1 block / agent    the same nominal rollout by block scans, only for T > 64)
+//   (nominal_kernel  1 block / agent    the same nominal rollout by block scans, only for T > 256)
 //   update_kernel    1 block / (chunk,t,a)  per-timestep softmax over K: reads the cost prefix back
 //                                       (4 B/step) and eps only for the few samples with weight
 //   merge_kernel     1 wave / (t,a)     merges chunk partials -> shard partial [A][T][8]
@@ -282,19 +282,40 @@ __device__ __forceinline__ double wave_scan_incl(double v, int lane) {
     return v;
 }
 
-// The nominal (eps = 0) rollout for T <= 64 on ONE wave, lanes = timesteps, every scan in registers.
-// Lane t < T gets its table row {un0, un1, lam*sig*un0, lam*sig*un1, cb} and base[t].
-__device__ __forceinline__ void nominal_wave(const DevParams& P, const double* __restrict__ state,
-                                             const double* __restrict__ goal, const double* __restrict__ unom,
-                                             int a, int t, double (&row)[5], double& base_t) {
+// inclusive prefix sum over NWAVES * 64 consecutive lanes: shuffles inside each wave, the wave totals
+// through LDS (two barriers; none for a single wave).  `total` = sum over all lanes.
+template <int NWAVES>
+__device__ __forceinline__ double lanes_scan_incl(double v, int t, double* sh, double& total) {
+    const int lane = t & 63;
+    v = wave_scan_incl(v, lane);
+    if (NWAVES == 1) { total = __shfl(v, 63, 64); return v; }
+    const int wid = t >> 6;
+    if (lane == 63) sh[wid] = v;
+    __syncthreads();
+    double carry = 0.0, tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < NWAVES; ++w) { const double x = sh[w]; tot += x; if (w < wid) carry += x; }
+    __syncthreads();
+    total = tot;
+    return v + carry;
+}
+
+// The nominal (eps = 0) rollout with lanes = timesteps: ONE wave for T <= 64 (every scan in registers),
+// the block's four waves for T <= 256.  Lane t < T gets its table row {un0, un1, lam*sig*un0,
+// lam*sig*un1, cb} and base[t].  All NWAVES * 64 lanes must call it (barriers when NWAVES > 1).
+template <int NWAVES>
+__device__ __forceinline__ void nominal_lanes(const DevParams& P, const double* __restrict__ state,
+                                              const double* __restrict__ goal, const double* __restrict__ unom,
+                                              int a, int t, double (&row)[5], double& base_t, double* sh) {
     const int T = P.T;
+    double tot_;
     const bool valid = t < T;
     const double gx = goal[a * 3 + 0], gy = goal[a * 3 + 1], gth = goal[a * 3 + 2];
     const double un0 = valid ? unom[(a * 2 + 0) * T + t] : 0.0;
     const double un1 = valid ? unom[(a * 2 + 1) * T + t] : 0.0;
     const double u0 = clampd(un0, P.u_max), u1 = clampd(un1, P.u_max);
     const double h = valid ? (P.model == 1 ? P.dt * u1 : P.kth * P.dt * (u1 - u0)) : 0.0;
-    const double th = state[a * 3 + 2] + (wave_scan_incl(h, t) - h);
+    const double th = state[a * 3 + 2] + (lanes_scan_incl<NWAVES>(h, t, sh, tot_) - h);
     double s0, c0, ix, iy;
     sincos(th, &s0, &c0);
     if (P.model == 1) {  // euler + unicycle: x += dt * cos(theta) * u0
@@ -313,8 +334,8 @@ __device__ __forceinline__ void nominal_wave(const DevParams& P, const double* _
         const double aa = P.dt * P.rhalf * (u0 + u1) * (1.0 / 6.0);
         ix = aa * (c0 + 4.0 * c1 + c2); iy = aa * (s0 + 4.0 * s1 + s2);
     }
-    const double X = state[a * 3 + 0] + wave_scan_incl(valid ? ix : 0.0, t);
-    const double Y = state[a * 3 + 1] + wave_scan_incl(valid ? iy : 0.0, t);
+    const double X = state[a * 3 + 0] + lanes_scan_incl<NWAVES>(valid ? ix : 0.0, t, sh, tot_);
+    const double Y = state[a * 3 + 1] + lanes_scan_incl<NWAVES>(valid ? iy : 0.0, t, sh, tot_);
     double cst = 0.0;
     row[0] = un0; row[1] = un1; row[2] = 0.0; row[3] = 0.0; row[4] = 0.0;
     if (valid) {
@@ -327,8 +348,8 @@ __device__ __forceinline__ void nominal_wave(const DevParams& P, const double* _
         const double ls = P.lambda * P.sigma;
         row[2] = ls * un0; row[3] = ls * un1; row[4] = 0.5 * uru - cst;
     }
-    const double inc = wave_scan_incl(cst, t);
-    const double tot = __shfl(inc, 63, 64);
+    double tot;
+    const double inc = lanes_scan_incl<NWAVES>(cst, t, sh, tot);
     base_t = tot - (inc - cst);
 }
 
@@ -397,7 +418,7 @@ __device__ __forceinline__ void philox_normals(uint32_t gk, uint32_t triple, uin
 // grid = (ceil(K / 256), A), block = 256, LDS = the 40*T-byte per-step table.  Per lane and step: 2 eps + 1 dP element
 // through HBM, fully coalesced (consecutive lanes = consecutive k).
 // ---------------------------------------------------------------------------------------------
-template <typename S, int NTERM, bool PHILOX, bool STORE_EPS, bool INLINE_NOM, int MODEL, bool GENERAL>
+template <typename S, int NTERM, bool PHILOX, bool STORE_EPS, int INLINE_NOM, int MODEL, bool GENERAL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void rollout_kernel(DevParams P, const double* __restrict__ state,
                                                      const double* __restrict__ goal,
                                                      double* __restrict__ tc, S* __restrict__ eps,
@@ -411,12 +432,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     // The per-step table lives in LDS: read back as wave-uniform (broadcast) ds_reads that the
     // scheduler can hoist, instead of an s_load + s_waitcnt round trip on every step.
     if (INLINE_NOM) {
-        // T <= 64: wave 0 of every block runs the nominal rollout itself (lanes = timesteps, ~600
-        // instructions) -- no separate kernel, no launch boundary in front of the rollout.  The
-        // first block also publishes base[] (and tc[]) for mppi_download_value.
-        if (tid < 64) {
+        // The block runs the nominal rollout itself, lanes = timesteps: wave 0 alone for T <= 64
+        // (INLINE_NOM 1, ~600 instructions, no barrier), all four waves for T <= 256 (INLINE_NOM 2) -- no
+        // separate kernel, no launch boundary in front of the rollout.  The first block also publishes
+        // base[] (and tc[]) for mppi_download_value.
+        __shared__ double nom_sh[4];
+        if (INLINE_NOM == 2 || tid < 64) {
             double row[5], base_t;
-            nominal_wave(P, state, goal, unom, a, tid, row, base_t);
+            nominal_lanes<(INLINE_NOM == 2 ? 4 : 1)>(P, state, goal, unom, a, tid, row, base_t, nom_sh);
             if (tid < T) {
 #pragma unroll
                 for (int i = 0; i < 5; ++i) lt[tid * 5 + i] = row[i];
