@@ -18,6 +18,7 @@
 
 #include "../../include/mppi_hip.h"
 #include "mppi_kernels.hpp"
+#include "rollout_launch.hpp"
 #include "savgol.hpp"
 
 namespace {
@@ -198,44 +199,20 @@ struct mppi_engine {
         if (!have_state || !have_goal) fail(MPPI_E_STATE, "state/goal passed as NULL before ever being set");
     }
 
-    template <typename S, int NT, bool PH, bool SE, int IN, int MODEL>
-    void launch_rollout_g(hipStream_t st, int k0, int k1, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
-        // the node's cost (Q[2,2] = 0, no obstacle grid) runs the branch-free instantiation
-        if (P.q2 != 0.0 || P.grid_weight != 0.0) launch_rollout_i<S, NT, PH, SE, IN, MODEL, true>(st, k0, k1, seed, tick, tick_ptr);
-        else launch_rollout_i<S, NT, PH, SE, IN, MODEL, false>(st, k0, k1, seed, tick, tick_ptr);
-    }
-    template <typename S, int NT, bool PH, bool SE, int IN, int MODEL, bool GEN>
-    void launch_rollout_i(hipStream_t st, int k0, int k1, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
-        auto kern = mppi::rollout_kernel<S, NT, PH, SE, IN, MODEL, GEN>;
-        dim3 grid((k1 - k0 + 255) / 256, cfg.n_agents);
-        hipLaunchKernelGGL(kern, grid, dim3(256), (size_t)cfg.horizon * 5 * sizeof(double), st, P, d_state, d_goal, d_tc,
-                           static_cast<S*>(d_eps), static_cast<S*>(d_dP), static_cast<S*>(d_stot), seed, tick, tick_ptr, k0, k1,
-                           static_cast<S*>(d_epart), d_unom, d_base);
-        HIPCHK(hipGetLastError());
-    }
-    template <typename S, int NT, bool PH, bool SE>
-    void launch_rollout_f(hipStream_t st, int k0, int k1, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
-        if (cfg.model == MPPI_MODEL_UNICYCLE_EULER) launch_rollout_g<S, NT, PH, SE, 0, 1>(st, k0, k1, seed, tick, tick_ptr);
-        else if (cfg.horizon <= 64) launch_rollout_g<S, NT, PH, SE, 1, 0>(st, k0, k1, seed, tick, tick_ptr);
-        else if (cfg.horizon <= 256) launch_rollout_g<S, NT, PH, SE, 2, 0>(st, k0, k1, seed, tick, tick_ptr);
-        else launch_rollout_g<S, NT, PH, SE, 0, 0>(st, k0, k1, seed, tick, tick_ptr);
-    }
-    template <typename S, int NT>
-    void launch_rollout_t(hipStream_t st, int k0, int k1, bool ph, bool store, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
-        if (!ph) launch_rollout_f<S, NT, false, false>(st, k0, k1, seed, tick, tick_ptr);
-        else if (store) launch_rollout_f<S, NT, true, true>(st, k0, k1, seed, tick, tick_ptr);
-        else launch_rollout_f<S, NT, true, false>(st, k0, k1, seed, tick, tick_ptr);
-    }
-    template <typename S>
-    void launch_rollout_s(hipStream_t st, int k0, int k1, bool ph, bool store, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
-        if (nterm == 4) launch_rollout_t<S, 4>(st, k0, k1, ph, store, seed, tick, tick_ptr);
-        else if (nterm == 7) launch_rollout_t<S, 7>(st, k0, k1, ph, store, seed, tick, tick_ptr);
-        else launch_rollout_t<S, 0>(st, k0, k1, ph, store, seed, tick, tick_ptr);
-    }
     void launch_rollout(hipStream_t st, int k0, int k1, bool ph, bool store, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
         Scope sc(this, MPPI_KERNEL_ROLLOUT, st);
-        if (f64()) launch_rollout_s<double>(st, k0, k1, ph, store, seed, tick, tick_ptr);
-        else launch_rollout_s<float>(st, k0, k1, ph, store, seed, tick, tick_ptr);
+        mppi::RolloutArgs a{};
+        a.P = P; a.stream = st; a.k0 = k0; a.k1 = k1; a.philox = ph; a.store_eps = store;
+        a.model = cfg.model;
+        a.inline_nominal = !inline_nominal() ? 0 : (cfg.horizon <= 64 ? 1 : 2);
+        a.general = P.q2 != 0.0 || P.grid_weight != 0.0;
+        a.seed = seed; a.tick = tick; a.tick_ptr = tick_ptr;
+        a.state = d_state; a.goal = d_goal; a.unom = d_unom; a.tc = d_tc; a.base = d_base;
+        a.eps = d_eps; a.dP = d_dP; a.stot = d_stot; a.epart = d_epart;
+        hipError_t e;
+        if (f64()) e = nterm == 4 ? mppi::launch_rollout_typed<double, 4>(a) : nterm == 7 ? mppi::launch_rollout_typed<double, 7>(a) : mppi::launch_rollout_typed<double, 0>(a);
+        else e = nterm == 4 ? mppi::launch_rollout_typed<float, 4>(a) : nterm == 7 ? mppi::launch_rollout_typed<float, 7>(a) : mppi::launch_rollout_typed<float, 0>(a);
+        if (e != hipSuccess) fail(MPPI_E_HIP, "rollout launch failed: %s", hipGetErrorString(e));
     }
     // write the lazily-drawn noise of the last tick into d_eps (bit-identical re-draw)
     void materialise_eps() {

@@ -124,6 +124,7 @@ __device__ __forceinline__ double block_scan_incl(double v, double* sh, double& 
 // ---------------------------------------------------------------------------------------------
 constexpr int kNomThreads = 256;
 
+#ifndef MPPI_ROLLOUT_TU  // non-template kernels are emitted by the engine translation unit only
 __global__ __launch_bounds__(kNomThreads) void nominal_kernel(DevParams P, const double* __restrict__ state,
                                                              const double* __restrict__ goal,
                                                              const double* __restrict__ unom,
@@ -186,6 +187,7 @@ __global__ __launch_bounds__(kNomThreads) void nominal_kernel(DevParams P, const
         carry += tot;
     }
 }
+#endif
 
 template <typename R> struct Exp2;
 template <> struct Exp2<float> {
@@ -812,6 +814,7 @@ __global__ __launch_bounds__(256) void eps_regen_kernel(DevParams P, S* __restri
 // E, count add.  Exact algebra of splitting the K-sum of control/src/mppi:189-196.
 // merge_kernel: one wave per (t, a) reduces the NCH chunk tuples of this shard.
 // ---------------------------------------------------------------------------------------------
+#ifndef MPPI_ROLLOUT_TU  // non-template kernels are emitted by the engine translation unit only
 __global__ __launch_bounds__(64) void merge_kernel(DevParams P, const double* __restrict__ part, int NCH,
                                                   double* __restrict__ merged) {
     const int t = blockIdx.x, a = blockIdx.y, lane = threadIdx.x;
@@ -835,6 +838,7 @@ __global__ __launch_bounds__(64) void merge_kernel(DevParams P, const double* __
         o[0] = M; o[1] = d; o[2] = n0; o[3] = n1; o[4] = e0; o[5] = e1; o[6] = cnt; o[7] = 0.0;
     }
 }
+#endif
 
 // exact rk4 step in the reference's operation order (control/src/mppi:39-54), used for the plant
 __device__ __forceinline__ void rk4_exact(const DevParams& P, const double x0[3], double u0, double u1,
@@ -862,6 +866,7 @@ __device__ __forceinline__ void rk4_exact(const DevParams& P, const double x0[3]
 //   ufilt [A][2][T] filtered controls (un-shifted), outv [A][8] = {next_state[3], u_applied[2]}
 // dynamic LDS = 4*T doubles.
 // ---------------------------------------------------------------------------------------------
+#ifndef MPPI_ROLLOUT_TU  // non-template kernels are emitted by the engine translation unit only
 __global__ __launch_bounds__(256) void finalize_kernel(DevParams P, const double* __restrict__ gathered, int G,
                                                       const double* __restrict__ Smat, double* __restrict__ unom,
                                                       double* __restrict__ ufilt, double* __restrict__ state,
@@ -945,8 +950,10 @@ __global__ __launch_bounds__(256) void finalize_kernel(DevParams P, const double
         if ((flags & 4) && a == 0 && tick_ptr) *tick_ptr = *tick_ptr + 1u;
     }
 }
+#endif
 
 // perform_action alone (control/src/mppi:210-213): next = rk4(state, unom[:,0])
+#ifndef MPPI_ROLLOUT_TU  // non-template kernels are emitted by the engine translation unit only
 __global__ void plant_kernel(DevParams P, const double* __restrict__ state, const double* __restrict__ unom,
                              double* __restrict__ outv) {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
@@ -964,9 +971,11 @@ __global__ void plant_kernel(DevParams P, const double* __restrict__ state, cons
     double* o = outv + (size_t)a * 8;
     o[0] = xn[0]; o[1] = xn[1]; o[2] = xn[2]; o[3] = u0; o[4] = u1;
 }
+#endif
 
 // receding-horizon shift alone (control/src/mppi:100-101); one block per (agent,row) so the
 // read of column j+1 and the write of column j cannot race across blocks
+#ifndef MPPI_ROLLOUT_TU  // non-template kernels are emitted by the engine translation unit only
 __global__ void shift_kernel(DevParams P, double* __restrict__ unom) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* row = reinterpret_cast<double*>(smem_raw);
@@ -975,6 +984,7 @@ __global__ void shift_kernel(DevParams P, double* __restrict__ unom) {
     __syncthreads();
     for (int j = threadIdx.x; j < P.T; j += blockDim.x) u[j] = (j + 1 < P.T) ? row[j + 1] : 0.0;
 }
+#endif
 
 // host <-> storage conversions (parity / compatibility paths, not on the tick path)
 //   rows: n_rows rows of K elements; src pitch K (host layout), dst pitch Ks
@@ -1015,6 +1025,7 @@ __global__ void value_pack_kernel(const double* __restrict__ src, const double* 
     }
 }
 // per-row minimum of a [rows][K] float64 array (mppi_upload_value picks it as the baseline)
+#ifndef MPPI_ROLLOUT_TU  // non-template kernels are emitted by the engine translation unit only
 __global__ __launch_bounds__(256) void row_min_kernel(const double* __restrict__ src, int K, double* __restrict__ out) {
     __shared__ double red[4];
     const size_t row = blockIdx.x;
@@ -1025,5 +1036,6 @@ __global__ __launch_bounds__(256) void row_min_kernel(const double* __restrict__
     __syncthreads();
     if (threadIdx.x == 0) out[row] = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
 }
+#endif
 
 }  // namespace mppi

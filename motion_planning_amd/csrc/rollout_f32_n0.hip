@@ -1,0 +1,4 @@
+// rollout_kernel instantiations: storage float, heading-rotation series NTERM = 0 (see rollout_launch.hpp)
+#define MPPI_ROLLOUT_TU 1
+#include "rollout_launch.hpp"
+namespace mppi { template hipError_t launch_rollout_typed<float, 0>(const RolloutArgs&); }
