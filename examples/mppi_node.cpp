@@ -1,0 +1,189 @@
+// mppi_node -- ROS-less C++ caller of libmppi_hip.so (include/mppi_hip.h).
+//
+// The shape of the reference's MPPI node shell (moribots/motion_planning, `Controller`,
+// control/src/mppi:296-389) in a compiled host program: one pose in per odometry message, one
+// (vx, wz) twist out, waypoint cycling / parallel parking in between.  Everything heavy happens
+// behind the C ABI; this file needs no HIP, no torch, no Python: g++ and the header are enough,
+// which is what a C++ ROS node binding the library would look like.
+//
+//   make -C examples            (g++ only; links motion_planning_amd/lib/libmppi_hip.so)
+//   build/mppi_node --task pentagon --samples 4096 --horizon 50 --callbacks 80 --seed 3
+//
+// Output: one line per odometry callback,
+//   i  x y theta  gx gy gtheta  ul ur  vx wz  idx done init
+// (the columns of tests/golden ctl_* rows).  The plant between callbacks is the reference's own
+// rk4 of the diff-drive model (control/src/mppi:23-30, :39-54), integrated on the host.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mppi_hip.h"
+
+namespace {
+
+struct Pose { double x, y, th; };
+
+const double kPi = 3.14159265358979323846;
+
+// control/src/mppi:23-30
+void dd_dynamics(const mppi_config& c, const Pose& p, const double u[2], double out[3]) {
+    out[0] = c.wheel_radius / 2.0 * std::cos(p.th) * (u[0] + u[1]);
+    out[1] = c.wheel_radius / 2.0 * std::sin(p.th) * (u[0] + u[1]);
+    out[2] = c.wheel_radius / c.wheel_base * (u[1] - u[0]);
+}
+
+// control/src/mppi:39-54 (k_i scaled by dt, heading wrapped into (-pi, pi])
+Pose rk4(const mppi_config& c, const Pose& p, const double u[2], double dt) {
+    double k1[3], k2[3], k3[3], k4[3];
+    dd_dynamics(c, p, u, k1);
+    for (double& v : k1) v *= dt;
+    dd_dynamics(c, Pose{p.x + k1[0] / 2, p.y + k1[1] / 2, p.th + k1[2] / 2}, u, k2);
+    for (double& v : k2) v *= dt;
+    dd_dynamics(c, Pose{p.x + k2[0] / 2, p.y + k2[1] / 2, p.th + k2[2] / 2}, u, k3);
+    for (double& v : k3) v *= dt;
+    dd_dynamics(c, Pose{p.x + k3[0], p.y + k3[1], p.th + k3[2]}, u, k4);
+    for (double& v : k4) v *= dt;
+    Pose n{p.x + (k1[0] + 2 * k2[0] + 2 * k3[0] + k4[0]) / 6.0,
+           p.y + (k1[1] + 2 * k2[1] + 2 * k3[1] + k4[1]) / 6.0,
+           p.th + (k1[2] + 2 * k2[2] + 2 * k3[2] + k4[2]) / 6.0};
+    n.th -= (std::ceil((n.th + kPi) / (2 * kPi)) - 1.0) * 2 * kPi;
+    return n;
+}
+
+// tf.transformations.euler_from_quaternion(q)[2] (control/src/mppi:330-335)
+double yaw_from_quaternion(double qx, double qy, double qz, double qw) {
+    return std::atan2(2.0 * (qw * qz + qx * qy), 1.0 - 2.0 * (qy * qy + qz * qz));
+}
+
+#define MPPI_CALL(call)                                                                  \
+    do {                                                                               \
+        int rc_ = (call);                                                              \
+        if (rc_ != 0) {                                                                \
+            std::fprintf(stderr, "%s -> %d: %s\n", #call, rc_, mppi_last_error(eng_)); \
+            std::exit(2);                                                              \
+        }                                                                              \
+    } while (0)
+
+// The node shell.  `publish` is stdout.
+class Controller {
+public:
+    Controller(const mppi_config& cfg, std::vector<std::pair<double, double>> waypoints, double thresh, uint64_t seed)
+        : cfg_(cfg), waypoints_(std::move(waypoints)), thresh_(thresh), seed_(seed) {
+        if (mppi_create(&cfg_, &eng_) != 0) {
+            std::fprintf(stderr, "mppi_create: %s\n", mppi_last_error(nullptr));
+            std::exit(2);
+        }
+        parallel_park_ = waypoints_.empty();  // :305-309
+    }
+    ~Controller() { mppi_destroy(eng_); }
+
+    // one odometry message -> one twist (control/src/mppi:327-389)
+    void odom_cb(double px, double py, double qx, double qy, double qz, double qw, double twist[2]) {
+        start_ = Pose{px, py, yaw_from_quaternion(qx, qy, qz, qw)};
+        if (parallel_park_) goal_ = Pose{0.0, -1.0, 0.0};  // :336-337
+        const bool far = std::hypot(start_.x - goal_.x, start_.y - goal_.y) > thresh_;
+        if (far && !init_) {  // :339-343  MPPI.get_path, :85-102
+            const double s[3] = {start_.x, start_.y, start_.th}, g[3] = {goal_.x, goal_.y, goal_.th};
+            double nxt[3];
+            MPPI_CALL(mppi_tick(eng_, s, g, MPPI_NOISE_PHILOX, seed_, tick_++, nxt, u_last_));
+            done_ = false;
+        } else if (init_) {  // :344-355
+            initialize();
+            if (!parallel_park_) goal_from_waypoint();
+            init_ = false;
+        } else {  // :356-375
+            if (!parallel_park_) {
+                idx_ = idx_ + 1 >= waypoints_.size() ? 0 : idx_ + 1;
+                initialize();
+                goal_from_waypoint();
+            } else {
+                done_ = true;
+            }
+        }
+        const double ul = done_ ? 0.0 : u_last_[0], ur = done_ ? 0.0 : u_last_[1];  // :377-381
+        twist[0] = cfg_.wheel_radius * (ul + ur) / 2.0;                             // wheelsToTwist :319-325
+        twist[1] = cfg_.wheel_radius * (ur - ul) / cfg_.wheel_base;
+    }
+
+    const Pose& start() const { return start_; }
+    const Pose& goal() const { return goal_; }
+    void applied(double u[2]) const { u[0] = done_ ? 0.0 : u_last_[0]; u[1] = done_ ? 0.0 : u_last_[1]; }
+    size_t idx() const { return idx_; }
+    bool done() const { return done_; }
+    bool init() const { return init_; }
+    double dt() const { return cfg_.dt; }
+    const mppi_config& cfg() const { return cfg_; }
+
+private:
+    void initialize() {  // MPPI.initialize, :79-83
+        MPPI_CALL(mppi_reset(eng_, -1));
+        u_last_[0] = u_last_[1] = 0.0;
+    }
+    void goal_from_waypoint() {  // :347-352
+        const auto& w = waypoints_[idx_];
+        goal_ = Pose{w.first, w.second, std::atan2(w.second - start_.y, w.first - start_.x)};
+    }
+
+    mppi_config cfg_;
+    mppi_engine* eng_ = nullptr;
+    std::vector<std::pair<double, double>> waypoints_;
+    double thresh_;
+    uint64_t seed_;
+    uint32_t tick_ = 0;
+    bool parallel_park_ = true, init_ = true, done_ = false;
+    size_t idx_ = 0;
+    Pose start_{0, 0, 0}, goal_{0, 0, 0};
+    double u_last_[2] = {0.0, 0.0};
+};
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    mppi_config cfg;
+    mppi_default_config(&cfg);
+    std::string task = "park";
+    int callbacks = 40;
+    double thresh = 0.05;
+    uint64_t seed = 0;
+    for (int i = 1; i < argc; ++i) {
+        auto val = [&](const char* name) -> const char* {
+            if (std::strcmp(argv[i], name) != 0) return nullptr;
+            if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", name); std::exit(1); }
+            return argv[++i];
+        };
+        if (const char* v = val("--task")) task = v;
+        else if (const char* v = val("--samples")) cfg.samples = std::atoi(v);
+        else if (const char* v = val("--horizon")) cfg.horizon = std::atoi(v);
+        else if (const char* v = val("--callbacks")) callbacks = std::atoi(v);
+        else if (const char* v = val("--thresh")) thresh = std::atof(v);
+        else if (const char* v = val("--seed")) seed = std::strtoull(v, nullptr, 10);
+        else if (const char* v = val("--storage")) cfg.storage = std::strcmp(v, "f64") == 0 ? MPPI_STORE_F64 : MPPI_STORE_F32;
+        else if (const char* v = val("--device")) cfg.device = std::atoi(v);
+        else {
+            std::fprintf(stderr, "usage: mppi_node [--task park|pentagon] [--samples K] [--horizon T] [--callbacks N]\n"
+                                 "                 [--thresh m] [--seed s] [--storage f32|f64] [--device d]\n");
+            return 1;
+        }
+    }
+    cfg.dt = 1.0 / cfg.horizon;  // control/src/mppi:67
+    std::vector<std::pair<double, double>> wp;
+    if (task == "pentagon")  // the `waypoints` parameter of the node (control/config/waypoints.yaml)
+        wp = {{1.0, 0.0}, {2.0, 1.0}, {1.0, 2.0}, {0.0, 2.0}, {0.0, 0.0}};
+    else if (task != "park") { std::fprintf(stderr, "unknown task %s\n", task.c_str()); return 1; }
+
+    Controller node(cfg, wp, thresh, seed);
+    Pose plant{0.0, 0.0, 0.0};
+    for (int i = 0; i < callbacks; ++i) {
+        double twist[2], u[2];
+        node.odom_cb(plant.x, plant.y, 0.0, 0.0, std::sin(plant.th / 2.0), std::cos(plant.th / 2.0), twist);
+        node.applied(u);
+        std::printf("%d %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %zu %d %d\n", i,
+                    node.start().x, node.start().y, node.start().th, node.goal().x, node.goal().y, node.goal().th,
+                    u[0], u[1], twist[0], twist[1], node.idx(), (int)node.done(), (int)node.init());
+        plant = rk4(node.cfg(), plant, u, node.dt());
+    }
+    return 0;
+}

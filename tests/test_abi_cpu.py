@@ -111,3 +111,18 @@ def test_product_never_touches_the_oracle():
                 txt = open(os.path.join(base, f)).read()
                 assert "libmppi_oracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, f
                 assert "/root/reference" not in txt, f
+
+
+def test_cpp_node_links_against_the_c_abi(tmp_path):
+    """examples/mppi_node.cpp (the compiled, ROS-less caller) builds with g++ against include/mppi_hip.h
+    and the in-tree library, and -- on a box without a GPU -- fails loudly instead of computing anything."""
+    import os
+    import subprocess
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "mppi_node")
+    subprocess.run(["make", "-B", "-C", os.path.join(root, "examples"), "OUT=" + exe], check=True, capture_output=True)
+    if torch.cuda.is_available():
+        return
+    out = subprocess.run([exe, "--callbacks", "2"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 2 and "mppi_create" in out.stderr and out.stdout == ""

@@ -621,3 +621,45 @@ def test_bench_under_torchrun_uses_the_rccl_path():
     assert plain.returncode == 0, plain.stderr[-2000:]
     ref = json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][-1])
     assert line["final_state"] == ref["final_state"] and line["final_u"] == ref["final_u"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("task,waypoints,thresh,n_cb", [
+    ("park", [], 0.05, 30),
+    ("pentagon", [[1, 0], [2, 1], [1, 2], [0, 2], [0, 0]], 0.97, 40),
+])
+def test_cpp_node_matches_the_python_shim(tmp_path, task, waypoints, thresh, n_cb):
+    """examples/mppi_node.cpp -- a compiled, Python-free caller of the C ABI with the node shell of
+    control/src/mppi:296-389 -- publishes the same twists as motion_planning_amd.Controller (itself
+    pinned to the reference's Controller by the ctl_* goldens) on the same device-Philox noise."""
+    import os
+    import subprocess
+    from motion_planning_amd import MPPI, Controller
+    from motion_planning_amd.mppi import rk4
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "mppi_node")
+    subprocess.run(["make", "-B", "-C", os.path.join(root, "examples"), "OUT=" + exe], check=True, capture_output=True)
+    K, T, seed = 2048, 50, 5
+    out = subprocess.run([exe, "--task", task, "--samples", str(K), "--horizon", str(T), "--callbacks", str(n_cb),
+                          "--thresh", str(thresh), "--seed", str(seed), "--storage", "f64"],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = np.array([[float(x) for x in ln.split()] for ln in out.stdout.strip().splitlines()])
+    assert rows.shape == (n_cb, 14)
+    c = Controller(waypoints, mppi=MPPI(horizon=T, samples=K, thresh=thresh, storage="f64", rng="philox", seed=seed))
+    plant = np.array([0.0, 0.0, 0.0])
+    ticks = 0
+    for i in range(n_cb):
+        q = (0.0, 0.0, np.sin(plant[2] / 2.0), np.cos(plant[2] / 2.0))
+        vx, wz = c.odom_cb(plant[0], plant[1], *q)
+        u = np.array([0.0, 0.0]) if c.done else c.mppi.uvec[-1, :].copy()
+        r = rows[i]
+        assert int(r[0]) == i
+        assert np.abs(c.mppi.start - r[1:4]).max() < 1e-12, i
+        assert np.abs(c.mppi.goal - r[4:7]).max() < 1e-12, i
+        assert np.abs(u - r[7:9]).max() < 1e-9, i
+        assert abs(vx - r[9]) < 1e-10 and abs(wz - r[10]) < 1e-9, i
+        assert (c.idx, c.done, c.init) == (int(r[11]), bool(r[12]), bool(r[13])), i
+        ticks += int(np.any(u != 0.0))
+        plant = rk4(plant.reshape(3, 1), u.reshape(2, 1), c.mppi.dt)[:, 0]
+    assert ticks > n_cb // 2  # the loop really drove the engine
