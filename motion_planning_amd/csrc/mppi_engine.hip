@@ -205,7 +205,8 @@ struct mppi_engine {
         a.P = P; a.stream = st; a.k0 = k0; a.k1 = k1; a.philox = ph; a.store_eps = store;
         a.model = cfg.model;
         a.inline_nominal = !inline_nominal() ? 0 : (cfg.horizon <= 64 ? 1 : 2);
-        a.general = P.q2 != 0.0 || P.grid_weight != 0.0;
+        // the lean instantiation is written for the node's cost: Q = diag(q, q, 0), q > 0, no obstacle grid
+        a.general = P.q2 != 0.0 || P.grid_weight != 0.0 || P.q0 != P.q1 || !(P.q0 > 0.0);
         a.seed = seed; a.tick = tick; a.tick_ptr = tick_ptr;
         a.state = d_state; a.goal = d_goal; a.unom = d_unom; a.tc = d_tc; a.base = d_base;
         a.eps = d_eps; a.dP = d_dP; a.stot = d_stot; a.epart = d_epart;

@@ -72,7 +72,10 @@ __device__ __forceinline__ double wrap_theta(double th) {
 template <int NTERM>
 __device__ __forceinline__ void small_sincos(double phi, double& s, double& c) {
     const double z = phi * phi;
-    if (NTERM == 4) {
+    if (NTERM == 3) {  // |phi| <= 0.03: truncation <= phi^6/720 < 1.1e-12, phi^7/5040 < 5e-15
+        s = phi * fma(z, fma(z, 1.0 / 120.0, -1.0 / 6.0), 1.0);
+        c = fma(z, fma(z, 1.0 / 24.0, -0.5), 1.0);
+    } else if (NTERM == 4) {
         s = phi * fma(z, fma(z, fma(z, -1.0 / 5040.0, 1.0 / 120.0), -1.0 / 6.0), 1.0);
         c = fma(z, fma(z, fma(z, -1.0 / 720.0, 1.0 / 24.0), -0.5), 1.0);
     } else {
@@ -230,29 +233,57 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
 }
 __device__ __forceinline__ double wave_sum_lane63(double v) { return wave_sum(v); }
 
-// Sixteen 64-lane sums at once (the eps sums of one 6-step chunk use 12 of them) as a reduce-scatter:
-// each exchange halves the values a lane still carries (8+4+2+1 select/add pairs instead of 16 x 6 adds).
-// The partner of a halving must hold the same set of values, and must be reachable by ONE symmetric DPP
-// pattern: lane^7 (row_half_mirror), ^1, ^2 (quad_perm) generate all 8 lanes of a half row, lane^8
-// (row_ror:8) joins the two halves; the two row exchanges that remain are plain adds
-// (v_permlane16_swap, v_permlane32_swap -- gfx950 additions).  Every lane ends with the total of value
-// sum16_index(lane).
+// Sixteen 64-lane sums at once (the eps sums of one 6-step chunk use the first 12 of them) as a
+// reduce-scatter: each exchange halves the values a lane still carries.  The partner of a halving must
+// hold the same set of values and must be reachable by ONE symmetric DPP pattern:
+//   lane^7 (row_half_mirror) and lane^8 (row_ror:8) -- the two big halvings (16 -> 8 -> 4 values).  The bit
+//       that tells which half a lane keeps is lane bit 2 resp. bit 3 = the DPP *bank*, so no select is
+//       needed at all: one unmasked v_add_f32_dpp forms the pair sum of the "low" value in every lane,
+//       a second one with bank_mask 0xA resp. 0xC overwrites it with the pair sum of the "high" value
+//       in the lanes that keep that one (2 instructions per kept value instead of 2 selects + 1 add);
+//       values 12..15 are padding, their overwrite is skipped (those lanes end with a duplicate);
+//   lane^1, lane^2 (quad_perm) -- the two small halvings (4 -> 2 -> 1 values), select + add;
+// the two row exchanges that remain are plain adds (v_permlane16_swap, v_permlane32_swap -- gfx950
+// additions).  Every lane ends with the total of value sum16_index(lane) (lanes whose index is >= 12:
+// a duplicate of value index - 8).  The DPP source operands need two wait states behind the VALU that
+// wrote them; the compiler cannot see into the asm, hence the leading s_nop 1 of each block.
 __device__ __forceinline__ int sum16_index(int lane) {
-    return ((lane >> 3) & 1) | (lane & 2) | ((lane & 1) << 2) | ((lane & 4) << 1);
+    return ((lane & 4) << 1) | ((lane & 8) >> 1) | ((lane & 1) << 1) | ((lane >> 1) & 1);
 }
 __device__ __forceinline__ float wave_sum16(const float (&v)[16], int lane) {
-    const bool b1 = lane & 1, b2 = lane & 2, b4 = lane & 4, b8 = lane & 8;
+    const bool b1 = lane & 1, b2 = lane & 2;
     float u[8], w[4], x[2];
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %9, %9 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %10, %10 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %11, %11 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %12, %12 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %5, %13, %13 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %6, %14, %14 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %7, %15, %15 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %16, %16 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %1, %17, %17 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %2, %18, %18 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %3, %19, %19 row_half_mirror row_mask:0xf bank_mask:0xa"
+        : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]), "=&v"(u[4]), "=&v"(u[5]), "=&v"(u[6]), "=&v"(u[7])
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]),
+          "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]));
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %1, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %2, %10, %10 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %3, %11, %11 row_ror:8 row_mask:0xf bank_mask:0xc"
+        : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3])
+        : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "v"(u[4]), "v"(u[5]), "v"(u[6]), "v"(u[7]));
 #pragma unroll
-    for (int i = 0; i < 8; ++i)  // partner lane ^ 7 (same half row, other bit 2): keep i + 8*b4
-        u[i] = (b4 ? v[i + 8] : v[i]) + dpp_mov<0x141, 0xF>(b4 ? v[i] : v[i + 8]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)  // partner lane ^ 1: keep i + 4*b1 (+ 8*b4)
-        w[i] = (b1 ? u[i + 4] : u[i]) + dpp_mov<0xB1, 0xF>(b1 ? u[i] : u[i + 4]);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)  // partner lane ^ 2: keep i + 2*b2 (+ ...)
-        x[i] = (b2 ? w[i + 2] : w[i]) + dpp_mov<0x4E, 0xF>(b2 ? w[i] : w[i + 2]);
-    float y = (b8 ? x[1] : x[0]) + dpp_mov<0x128, 0xF>(b8 ? x[0] : x[1]);  // partner lane ^ 8: keep b8 (+ ...)
+    for (int i = 0; i < 2; ++i)  // partner lane ^ 1: keep i + 2*b1 (+ ...)
+        x[i] = (b1 ? w[i + 2] : w[i]) + dpp_mov<0xB1, 0xF>(b1 ? w[i] : w[i + 2]);
+    float y = (b2 ? x[1] : x[0]) + dpp_mov<0x4E, 0xF>(b2 ? x[0] : x[1]);  // partner lane ^ 2: keep b2 (+ ...)
     {
         const unsigned t = __float_as_uint(y);
         const auto p = __builtin_amdgcn_permlane16_swap(t, t, false, false);  // rows 0<->1, 2<->3
@@ -378,14 +409,21 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 // (0,1) and the angle u2 = b / 2^21 in [0,1) (both exact in fp32), on the gfx950 transcendental units
 // directly -- v_log_f32 (log2), v_sqrt_f32, v_sin_f32 / v_cos_f32 (argument in revolutions, exactly what
 // Box-Muller wants).  sigma * sqrt(-2 ln u1) = sqrt(nscale * log2 u1), nscale = -2 ln2 sigma^2.
-// Only multiplies surround the transcendentals, so every kernel that calls this with the same
-// words gets bit-identical noise (no contraction-dependent rounding).
-__device__ __forceinline__ void box_muller(uint32_t a21, uint32_t b21, float nscale, float& e0, float& e1) {
-    const float u1 = ((float)a21 + 0.5f) * (1.0f / 2097152.0f);
-    const float u2 = (float)b21 * (1.0f / 2097152.0f);
+//   u1: one exact fma, a * 2^-21 + 2^-22;
+//   u2: never converted -- the 21 bits are dropped into the mantissa of a float in [1, 2) (`ang_mant` =
+//       b << 2) and sin/cos of 1 + u2 revolutions is sin/cos of u2 revolutions;
+//   (r cos, r sin): one packed multiply.
+// Every operation is exactly rounded or a hardware transcendental of exact inputs, so every kernel
+// that calls this with the same words gets bit-identical noise (no contraction-dependent rounding).
+typedef float float2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void box_muller(uint32_t a21, uint32_t ang_mant, float nscale, float& e0, float& e1) {
+    const float u1 = __builtin_fmaf((float)a21, 1.0f / 2097152.0f, 1.0f / 4194304.0f);
+    const float rev = __uint_as_float(0x3F800000u | ang_mant);
     const float r = __builtin_amdgcn_sqrtf(nscale * __builtin_amdgcn_logf(u1));
-    e0 = r * __builtin_amdgcn_cosf(u2);
-    e1 = r * __builtin_amdgcn_sinf(u2);
+    float2v cs = {__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev)};
+    cs *= r;
+    e0 = cs.x;
+    e1 = cs.y;
 }
 
 // The noise of global sample `gk`, agent a, steps 3*triple .. 3*triple+2: e[2j], e[2j+1] = (eps0, eps1)
@@ -397,9 +435,9 @@ __device__ __forceinline__ void philox_normals(uint32_t gk, uint32_t triple, uin
     uint32_t o[4];
     philox4x32_10(gk, triple, tick, a, key0, key1, o);
     const float nscale = -1.3862943611198906f * (sigf * sigf);
-    box_muller(o[0] >> 11, o[1] >> 11, nscale, e[0], e[1]);
-    box_muller(o[2] >> 11, o[3] >> 11, nscale, e[2], e[3]);
-    box_muller(((o[0] & 0x7FFu) << 10) | ((o[1] & 0x7FFu) >> 1), ((o[2] & 0x7FFu) << 10) | ((o[3] & 0x7FFu) >> 1),
+    box_muller(o[0] >> 11, (o[1] >> 9) & 0x7FFFFCu, nscale, e[0], e[1]);
+    box_muller(o[2] >> 11, (o[3] >> 9) & 0x7FFFFCu, nscale, e[2], e[3]);
+    box_muller(((o[0] & 0x7FFu) << 10) | ((o[1] & 0x7FFu) >> 1), ((o[2] & 0x7FFu) << 12) | ((o[3] & 0x7FEu) << 1),
                nscale, e[4], e[5]);
 }
 
@@ -431,6 +469,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* lt = reinterpret_cast<double*>(smem_raw);  // [T][5] per-step table {un0, un1, w0, w1, cb}
     const int tid = threadIdx.x, a = blockIdx.y, T = P.T;
+    // LEAN: the node's own cost and model (rk4 diff-drive, Q = diag(q, q, 0) with q > 0, no obstacle grid).
+    // Its step is written in scaled variables so that constants fold away (5 fp64 instructions fewer per step):
+    //   wheel speeds times half_kd (the table holds half_kd * un, the clip bound is half_kd * u_max):
+    //       phi = p1 - p0 directly;
+    //   positions times sqrt(q/2): the stage cost is dX^2 + dY^2 with no multiplies by Q;
+    //   fp32 storage only: the heading rotation keeps 3 series terms instead of 4 (truncation < 1.1e-12 per
+    //       step, four orders below the rounding of the fp32 prefix it ends up in).
+    constexpr bool LEAN = !GENERAL && MODEL == 0 && NTERM != 0;
+    constexpr int NT_ROT = (LEAN && NTERM == 4 && sizeof(S) == 4) ? 3 : NTERM;
     // The per-step table lives in LDS: read back as wave-uniform (broadcast) ds_reads that the
     // scheduler can hoist, instead of an s_load + s_waitcnt round trip on every step.
     if (INLINE_NOM) {
@@ -444,7 +491,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
             nominal_lanes<(INLINE_NOM == 2 ? 4 : 1)>(P, state, goal, unom, a, tid, row, base_t, nom_sh);
             if (tid < T) {
 #pragma unroll
-                for (int i = 0; i < 5; ++i) lt[tid * 5 + i] = row[i];
+                for (int i = 0; i < 5; ++i) lt[tid * 5 + i] = (LEAN && i < 2) ? row[i] * (0.5 * P.kth * P.dt) : row[i];
                 if (blockIdx.x == 0 && k_first == 0) {
                     base[(size_t)a * T + tid] = base_t;
                     double* o = tc + ((size_t)a * T + tid) * kTcW;
@@ -454,21 +501,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
             }
         }
     } else {
-        for (int i = tid; i < T * 5; i += blockDim.x) lt[i] = tc[((size_t)a * T + i / 5) * kTcW + i % 5];
+        for (int i = tid; i < T * 5; i += blockDim.x) {
+            const double v = tc[((size_t)a * T + i / 5) * kTcW + i % 5];
+            lt[i] = (LEAN && i % 5 < 2) ? v * (0.5 * P.kth * P.dt) : v;
+        }
     }
     __syncthreads();
     const int k = k_first + blockIdx.x * 256 + tid;  // this launch covers samples [k_first, k_last)
     const bool active = k < k_last;
     const size_t Ks = (size_t)P.Ks;
-    const double gx = goal[a * 3 + 0], gy = goal[a * 3 + 1], gth = goal[a * 3 + 2];
+    double gx = goal[a * 3 + 0], gy = goal[a * 3 + 1];
+    const double gth = goal[a * 3 + 2];
     double x = state[a * 3 + 0], y = state[a * 3 + 1], th = state[a * 3 + 2];
     double c, s;
     sincos(th, &s, &c);
+    if (LEAN) { const double f = sqrt(0.5 * P.q0); x *= f; y *= f; gx *= f; gy *= f; }
     S* eps_a = eps + (size_t)a * T * 2 * Ks + k;
     S* dp = dP + (size_t)a * T * Ks + k;
     const double half_kd = 0.5 * P.kth * P.dt;             // phi = half_kd * (u1 - u0) = h / 2
     const double sixth_rd = P.dt * P.rhalf * (1.0 / 6.0);  // Simpson weight of (u0 + u1)
     const double hq0 = 0.5 * P.q0, hq1 = 0.5 * P.q1, hq2 = 0.5 * P.q2;
+    const double sq = LEAN ? sqrt(hq0) : 1.0;                // LEAN: x, y below are sq * position
+    const double p_max = half_kd * P.u_max;                 // LEAN: clip bound of the scaled wheel speeds
+    const double g_scale = sq * sixth_rd / half_kd;         // LEAN: Simpson weight of (p0 + p1), in scaled position
     const size_t NW = Ks >> 6;  // waves per agent row (Ks is a multiple of 64)
     // raw buffer view of epart (byte-addressed, bounds-checked by the hardware); < 4 GB by construction
     const __amdgpu_buffer_rsrc_t ep_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -555,6 +610,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                     dp[(size_t)t * Ks] = (S)pre;
                 }
                 // EXPLORE + CLIP (control/src/mppi:147-152)
+                if (LEAN) {
+                    // un0, un1 hold half_kd * nominal: p = half_kd * clip(un + eps)
+                    const double p0 = clampd(fma(e0, half_kd, un0), p_max), p1 = clampd(fma(e1, half_kd, un1), p_max);
+                    const double phi = p1 - p0;
+                    double sp, cp;
+                    small_sincos<NT_ROT>(phi, sp, cp);
+                    const double c1 = c * cp - s * sp, s1 = s * cp + c * sp;
+                    const double c2 = c1 * cp - s1 * sp, s2 = s1 * cp + c1 * sp;
+                    const double g = (g_scale * (p0 + p1)) * fma(2.0, cp, 4.0);  // see the Simpson note below
+                    x = fma(g, c1, x);
+                    y = fma(g, s1, y);
+                    th = fma(2.0, phi, th);
+                    c = c2; s = s2;
+                    const double dx = x - gx, dy = y - gy;
+                    double dc = fma(dx, dx, fma(dy, dy, cb));
+                    dc = fma(w0, e0, dc);
+                    dc = fma(w1, e1, dc);
+                    pre += dc;
+                    continue;
+                }
                 const double u0 = clampd(un0 + e0, P.u_max), u1 = clampd(un1 + e1, P.u_max);
                 if (MODEL == 1) {
                     // euler (control/src/mppi:57-58) over unicycle_dynamics (:33-36): x += dt cos(th) u0,
@@ -620,7 +695,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     // sample's terminal cost only enters the total
     auto terminal = [&]() {
         const double thw = (MODEL == 0 && (th > M_PI || th <= -M_PI)) ? wrap_theta(th) : th;
-        const double dx = x - gx, dy = y - gy, dth = thw - gth;
+        const double dx = (x - gx) / sq, dy = (y - gy) / sq, dth = thw - gth;  // sq = 1 unless LEAN
         pre += P.p0 * dx * dx + P.p1 * dy * dy + P.p2 * dth * dth;
     };
     const int T4 = T - T % U;  // steps covered by full chunks
