@@ -59,6 +59,12 @@ __device__ __forceinline__ double obstacle_cost(const DevParams& P, double x, do
 }
 
 __device__ __forceinline__ double clampd(double v, double lim) { return fmin(fmax(v, -lim), lim); }
+// the same clip as ONE fp64 instruction (v_min_f64 with |v|) plus a 32-bit sign copy (v_bfi_b32)
+__device__ __forceinline__ double clamp_sym(double v, double lim) { return copysign(fmin(fabs(v), lim), v); }
+// 2 * v for a normal, finite v: exponent + 1 (a 32-bit integer add instead of an fp64 instruction)
+__device__ __forceinline__ double twice(double v) {
+    return __hiloint2double(__double2hiint(v) + 0x00100000, __double2loint(v));
+}
 
 // control/src/mppi:52-53 : theta -> (-pi, pi]
 __device__ __forceinline__ double wrap_theta(double th) {
@@ -515,7 +521,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     double x = state[a * 3 + 0], y = state[a * 3 + 1], th = state[a * 3 + 2];
     double c, s;
     sincos(th, &s, &c);
-    if (LEAN) { const double f = sqrt(0.5 * P.q0); x *= f; y *= f; gx *= f; gy *= f; }
+    if (LEAN) {
+        const double f = sqrt(0.5 * P.q0), rho = f * (P.dt * P.rhalf * (1.0 / 6.0)) / (0.5 * P.kth * P.dt);
+        x *= f; y *= f; gx *= f; gy *= f;
+        c *= rho; s *= rho;  // the Simpson weight of (p0 + p1), in scaled position, rides on the heading vector
+    }
     S* eps_a = eps + (size_t)a * T * 2 * Ks + k;
     S* dp = dP + (size_t)a * T * Ks + k;
     const double half_kd = 0.5 * P.kth * P.dt;             // phi = half_kd * (u1 - u0) = h / 2
@@ -523,7 +533,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     const double hq0 = 0.5 * P.q0, hq1 = 0.5 * P.q1, hq2 = 0.5 * P.q2;
     const double sq = LEAN ? sqrt(hq0) : 1.0;                // LEAN: x, y below are sq * position
     const double p_max = half_kd * P.u_max;                 // LEAN: clip bound of the scaled wheel speeds
-    const double g_scale = sq * sixth_rd / half_kd;         // LEAN: Simpson weight of (p0 + p1), in scaled position
     const size_t NW = Ks >> 6;  // waves per agent row (Ks is a multiple of 64)
     // raw buffer view of epart (byte-addressed, bounds-checked by the hardware); < 4 GB by construction
     const __amdgpu_buffer_rsrc_t ep_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -612,13 +621,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                 // EXPLORE + CLIP (control/src/mppi:147-152)
                 if (LEAN) {
                     // un0, un1 hold half_kd * nominal: p = half_kd * clip(un + eps)
-                    const double p0 = clampd(fma(e0, half_kd, un0), p_max), p1 = clampd(fma(e1, half_kd, un1), p_max);
+                    const double p0 = clamp_sym(fma(e0, half_kd, un0), p_max), p1 = clamp_sym(fma(e1, half_kd, un1), p_max);
                     const double phi = p1 - p0;
                     double sp, cp;
                     small_sincos<NT_ROT>(phi, sp, cp);
+                    // (c, s) is g_scale * (cos, sin)(theta).  Mid-step heading by a rotation; end-of-step heading by
+                    // cos(th + 2 phi) = 2 cos(phi) cos(th + phi) - cos(th) (one fma per component; it is applied
+                    // once per step behind an exact rotation, so it does not run away like the long recurrence).
                     const double c1 = c * cp - s * sp, s1 = s * cp + c * sp;
-                    const double c2 = c1 * cp - s1 * sp, s2 = s1 * cp + c1 * sp;
-                    const double g = (g_scale * (p0 + p1)) * fma(2.0, cp, 4.0);  // see the Simpson note below
+                    const double tcp = twice(cp);
+                    const double c2 = fma(tcp, c1, -c), s2 = fma(tcp, s1, -s);
+                    const double g = (p0 + p1) * (tcp + 4.0);  // Simpson bracket (4 + 2 cos phi), see below
                     x = fma(g, c1, x);
                     y = fma(g, s1, y);
                     th = fma(2.0, phi, th);
