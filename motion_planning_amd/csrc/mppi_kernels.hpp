@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     // Its step is written in scaled variables so that constants fold away (5 fp64 instructions fewer per step):
     //   wheel speeds times half_kd (the table holds half_kd * un, the clip bound is half_kd * u_max):
     //       phi = p1 - p0 directly;
-    //   positions times sqrt(q/2): the stage cost is dX^2 + dY^2 with no multiplies by Q;
+    //   positions relative to the goal and times sqrt(q/2): the stage cost is X^2 + Y^2, nothing else;
     //   fp32 storage only: the heading rotation keeps 3 series terms instead of 4 (truncation < 1.1e-12 per
     //       step, four orders below the rounding of the fp32 prefix it ends up in).
     constexpr bool LEAN = !GENERAL && MODEL == 0 && NTERM != 0;
@@ -523,7 +523,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     sincos(th, &s, &c);
     if (LEAN) {
         const double f = sqrt(0.5 * P.q0), rho = f * (P.dt * P.rhalf * (1.0 / 6.0)) / (0.5 * P.kth * P.dt);
-        x *= f; y *= f; gx *= f; gy *= f;
+        x = (x - gx) * f; y = (y - gy) * f;  // position is carried relative to the goal
+        gx = 0.0; gy = 0.0;
         c *= rho; s *= rho;  // the Simpson weight of (p0 + p1), in scaled position, rides on the heading vector
     }
     S* eps_a = eps + (size_t)a * T * 2 * Ks + k;
@@ -636,8 +637,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                     y = fma(g, s1, y);
                     th = fma(2.0, phi, th);
                     c = c2; s = s2;
-                    const double dx = x - gx, dy = y - gy;
-                    double dc = fma(dx, dx, fma(dy, dy, cb));
+                    double dc = fma(x, x, fma(y, y, cb));
                     dc = fma(w0, e0, dc);
                     dc = fma(w1, e1, dc);
                     pre += dc;
