@@ -159,13 +159,13 @@ def main():
     tick(0, first=True)
     for i in range(1, args.warmup + 1):
         tick(i)
-    # Timed region: exactly --steps ticks between barrier + synchronize pairs.  The dominant
-    # kernel (rollout) is bracketed by HIP events on the engine's stream on every EVENT_PERIOD-th
-    # launch: an event pair costs ~5 us of stream time, sampling keeps the clock honest (<1%).
-    EVENT_PERIOD = 8
-    # (the kernel before it is bracketed too, so that the rollout's start marker sits behind a completed
-    # predecessor and not behind a just-dispatched one)
-    eng.kernel_timing(("finalize", "nominal", "rollout"), period=EVENT_PERIOD)
+    # Timed region: exactly --steps ticks between barrier + synchronize pairs.  The dominant kernel
+    # (rollout) is timed live with HIP events that ride on its own launch (hipExtLaunchKernelGGL start /
+    # stop events on the engine's stream = the dispatch's begin / end timestamps, the clock rocprofv3
+    # --kernel-trace reads); no marker packets enter the stream, so every EVENT_PERIOD-th launch is sampled
+    # only to keep the event pool small.
+    EVENT_PERIOD = int(os.environ.get("MPPI_EVENT_PERIOD", "4"))
+    eng.kernel_timing(("rollout",), period=EVENT_PERIOD)
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -195,13 +195,17 @@ def main():
     # Diagnostic: the node's own call pattern -- host state in, blocking, host controls out
     # (mppi_tick; what Controller.pos_cb pays per odometry message), N = 1 only.
     sync_tick_us = None
+    btimes = None
     if not in_group:
         n_lat = min(args.steps, 200)
+        eng.kernel_timing(("rollout",), period=1)
         st, lat = nxt, []
         for i in range(n_lat):
             t0 = time.perf_counter()
             st, _ = eng.tick(st, goals, noise="philox", seed=seed, tick_id=10_000_000 + i)
             lat.append(1e6 * (time.perf_counter() - t0))
+        btimes = eng.kernel_times()
+        eng.kernel_timing(())
         lat = np.sort(np.array(lat))
         sync_tick_us = {"mean": float(lat.mean()), "median": float(np.median(lat)),
                         "p99": float(lat[min(len(lat) - 1, int(0.99 * len(lat)))]), "ticks": n_lat}
@@ -236,6 +240,13 @@ def main():
                     if rd and wr:
                         roofline["traffic"] = rd[0] + wr[0]
                         roofline["traffic_source"] = "profiles/r1_pmc_summary_bench_c4.json (FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)"
+        # the rollout launch in each phase of this command (what a rocprofv3 --kernel-trace --stats of the whole
+        # command averages over): back-to-back ticks run ~8 % longer than launches behind an idle gap
+        phases = {"timed": ktimes["rollout"], "diagnostic": dtimes["rollout"]}
+        if btimes:
+            phases["blocking"] = btimes["rollout"]
+        roofline["rollout_us_by_phase"] = {k: {"avg_us": (v[0] * 1e3 / v[1] if v[1] else None), "launches_timed": v[1]}
+                                           for k, v in phases.items()}
         kernels_us = {name: (dtimes[name][0] * 1e3 / dtimes[name][1] if dtimes[name][1] else None) for name in dtimes}
         cpu = None
         if not args.no_cpu_baseline:

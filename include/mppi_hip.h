@@ -196,8 +196,10 @@ int mppi_savgol_matrix(int horizon, double *S);
 
 /*
  * Kernel timing with HIP events on the engine's stream.  mask = OR of (1 << MPPI_KERNEL_*)
- * to bracket, 0 = off.  mppi_kernel_times synchronises and returns, per kernel, the summed
- * duration (ms) and the number of launches since timing was (re)enabled.
+ * to time, 0 = off.  mppi_kernel_times synchronises and returns, per kernel, the summed
+ * duration (ms) and the number of launches since timing was (re)enabled.  The rollout kernel's
+ * events ride on its own launch (dispatch begin / end timestamps, no marker packets in the
+ * stream); the small kernels are bracketed by recorded events.
  */
 int mppi_kernel_timing(mppi_engine *h, uint32_t mask);
 /* Bracket only every `period`-th launch of each selected kernel (default 1 = every launch):

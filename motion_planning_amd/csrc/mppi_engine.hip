@@ -70,14 +70,6 @@ struct mppi_engine {
     int roll_bs = 256, roll_blocks = 0, nterm = 4;
     int NCH = 1, CH = 1024;
 
-    // intra-tick software pipeline: K is cut into pieces; the VALU-bound rollout of piece p+1 runs
-    // while the HBM-bound update of piece p streams its (still Infinity-Cache-resident) output back
-    struct Piece { int k0, k1, ch0, nch; };
-    std::vector<Piece> pieces;
-    hipStream_t s_roll[2] = {nullptr, nullptr}, s_upd = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    std::vector<hipEvent_t> ev_piece;
-
     // device buffers
     void* d_eps = nullptr;   // S [A][T][2][Ks]
     void* d_dP = nullptr;    // S [A][T][Ks]  exclusive prefix of (stage cost - nominal stage cost)
@@ -142,7 +134,6 @@ struct mppi_engine {
     void drain_timing() {
         if (pending.empty()) return;
         HIPCHK(hipStreamSynchronize(stream));
-        for (hipStream_t w : {s_roll[0], s_roll[1], s_upd}) if (w) HIPCHK(hipStreamSynchronize(w));
         for (auto& p : pending) {
             float ms = 0.f;
             HIPCHK(hipEventElapsedTime(&ms, p.a, p.b));
@@ -200,8 +191,12 @@ struct mppi_engine {
     }
 
     void launch_rollout(hipStream_t st, int k0, int k1, bool ph, bool store, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
-        Scope sc(this, MPPI_KERNEL_ROLLOUT, st);
         mppi::RolloutArgs a{};
+        // timing: the launch carries its own start / stop events (no marker packets in the stream)
+        if ((time_mask & (1u << MPPI_KERNEL_ROLLOUT)) && (time_seen[MPPI_KERNEL_ROLLOUT]++ % time_period) == 0) {
+            a.ev_start = get_event();
+            a.ev_stop = get_event();
+        }
         a.P = P; a.stream = st; a.k0 = k0; a.k1 = k1; a.philox = ph; a.store_eps = store;
         a.model = cfg.model;
         a.inline_nominal = !inline_nominal() ? 0 : (cfg.horizon <= 64 ? 1 : 2);
@@ -213,6 +208,14 @@ struct mppi_engine {
         hipError_t e;
         if (f64()) e = nterm == 4 ? mppi::launch_rollout_typed<double, 4>(a) : nterm == 7 ? mppi::launch_rollout_typed<double, 7>(a) : mppi::launch_rollout_typed<double, 0>(a);
         else e = nterm == 4 ? mppi::launch_rollout_typed<float, 4>(a) : nterm == 7 ? mppi::launch_rollout_typed<float, 7>(a) : mppi::launch_rollout_typed<float, 0>(a);
+        if (a.ev_start) {
+            if (e == hipSuccess) {
+                pending.push_back({MPPI_KERNEL_ROLLOUT, a.ev_start, a.ev_stop});
+                if (pending.size() >= 4096) drain_timing();
+            } else {
+                ev_pool.push_back(a.ev_start); ev_pool.push_back(a.ev_stop);
+            }
+        }
         if (e != hipSuccess) fail(MPPI_E_HIP, "rollout launch failed: %s", hipGetErrorString(e));
     }
     // write the lazily-drawn noise of the last tick into d_eps (bit-identical re-draw)
@@ -265,7 +268,7 @@ struct mppi_engine {
         if (noise_mode != MPPI_NOISE_INJECTED && noise_mode != MPPI_NOISE_PHILOX)
             fail(MPPI_E_INVALID, "unknown noise_mode %d", noise_mode);
     }
-    // rollout + update + merge of one tick, software-pipelined over the pieces (see `pieces`)
+    // rollout + update + merge of one tick
     void run_pipeline(int noise_mode, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
         check_noise_mode(noise_mode);
         const bool ph = noise_mode == MPPI_NOISE_PHILOX;
@@ -273,24 +276,8 @@ struct mppi_engine {
         eps_lazy = ph && !store;
         lazy_seed = seed; lazy_tick = tick; lazy_from_counter = tick_ptr != nullptr; lazy_counter_bumped = false;
         epart_ready = true;  // every rollout launch below writes its waves' eps sums
-        if (pieces.size() <= 1) {
-            launch_rollout(stream, 0, cfg.samples, ph, store, seed, tick, tick_ptr);
-            launch_update(stream, 0, NCH, tick_ptr);
-        } else {
-            HIPCHK(hipEventRecord(ev_fork, stream));
-            HIPCHK(hipStreamWaitEvent(s_roll[0], ev_fork, 0));
-            HIPCHK(hipStreamWaitEvent(s_roll[1], ev_fork, 0));
-            for (size_t p = 0; p < pieces.size(); ++p) {
-                const Piece& pc = pieces[p];
-                hipStream_t sr = s_roll[p & 1];
-                launch_rollout(sr, pc.k0, pc.k1, ph, store, seed, tick, tick_ptr);
-                HIPCHK(hipEventRecord(ev_piece[p], sr));
-                HIPCHK(hipStreamWaitEvent(s_upd, ev_piece[p], 0));
-                launch_update(s_upd, pc.ch0, pc.nch, tick_ptr);
-            }
-            HIPCHK(hipEventRecord(ev_join, s_upd));
-            HIPCHK(hipStreamWaitEvent(stream, ev_join, 0));
-        }
+        launch_rollout(stream, 0, cfg.samples, ph, store, seed, tick, tick_ptr);
+        launch_update(stream, 0, NCH, tick_ptr);
         launch_merge();
         noise_ready = true; value_ready = true; partials_ready = true; epart_ready = true;
     }
@@ -381,26 +368,6 @@ struct mppi_engine {
         // update geometry: each block keeps one chunk of a row in registers
         CH = f64() ? mppi::UpdCfg<double>::CH : mppi::UpdCfg<float>::CH;
         NCH = (K + CH - 1) / CH;
-        {   // pieces of ~96 MB of eps+dP each (>= 2 only when the tick moves enough bytes to matter)
-            const double tick_bytes = 12.0 * (f64() ? 2.0 : 1.0) * (double)K * T * A;
-            long np = 1;  // cross-stream fork/join costs more than the overlap buys on this stack (measured)
-            (void)tick_bytes;
-            if (const char* v = std::getenv("MPPI_PIECES")) np = std::atol(v);
-            np = std::max(1L, std::min({np, 16L, (long)NCH}));
-            const int m = (NCH + (int)np - 1) / (int)np;
-            for (int c0 = 0; c0 < NCH; c0 += m) {
-                const int nch = std::min(m, NCH - c0);
-                pieces.push_back({c0 * CH, std::min(K, (c0 + nch) * CH), c0, nch});
-            }
-            if (pieces.size() > 1) {
-                for (auto& st : s_roll) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-                HIPCHK(hipStreamCreateWithFlags(&s_upd, hipStreamNonBlocking));
-                HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-                HIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-                ev_piece.resize(pieces.size());
-                for (auto& e : ev_piece) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            }
-        }
         const size_t Ks = (size_t)P.Ks;
         {
             void* p = nullptr;
@@ -455,10 +422,6 @@ struct mppi_engine {
         for (auto& p : pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
         for (auto e : ev_pool) hipEventDestroy(e);
         for (int i = 0; i < kRing; ++i) if (ring_ev[i]) hipEventDestroy(ring_ev[i]);
-        for (hipStream_t w : {s_roll[0], s_roll[1], s_upd}) if (w) { hipStreamSynchronize(w); hipStreamDestroy(w); }
-        for (auto e : ev_piece) hipEventDestroy(e);
-        if (ev_fork) hipEventDestroy(ev_fork);
-        if (ev_join) hipEventDestroy(ev_join);
         if (h_stage) hipHostFree(h_stage);
         if (h_out) hipHostFree(h_out);
         void* bufs[] = {d_eps, d_dP, d_stot, d_epart, d_tc, d_base, d_unom, d_ufilt, d_state, d_goal, d_part, d_merged, d_S, d_out, d_tick, d_tmp, d_grid};

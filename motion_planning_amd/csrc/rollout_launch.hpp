@@ -4,6 +4,7 @@
 // unit per (storage type, rotation series): rollout_f32_n4.hip ... rollout_f64_n0.hip.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "mppi_kernels.hpp"
@@ -24,6 +25,10 @@ struct RolloutArgs {
     const double *state, *goal, *unom;
     double *tc, *base;
     void *eps, *dP, *stot, *epart;  // S-typed buffers
+    // non-null: the launch itself carries the two events (hipExtLaunchKernelGGL) -- they take the
+    // dispatch's own begin / end timestamps, the clock rocprofv3 --kernel-trace reads, and put no
+    // marker packets into the stream
+    hipEvent_t ev_start, ev_stop;
 };
 
 // returns hipGetLastError() of the launch
@@ -36,9 +41,15 @@ template <typename S, int NT, bool PH, bool SE, int IN, int MODEL, bool GEN>
 static hipError_t rollout_go(const RolloutArgs& a) {
     auto kern = rollout_kernel<S, NT, PH, SE, IN, MODEL, GEN>;
     dim3 grid((a.k1 - a.k0 + 255) / 256, a.P.A);
-    hipLaunchKernelGGL(kern, grid, dim3(256), (size_t)a.P.T * 5 * sizeof(double), a.stream, a.P, a.state, a.goal, a.tc,
-                       static_cast<S*>(a.eps), static_cast<S*>(a.dP), static_cast<S*>(a.stot), a.seed, a.tick, a.tick_ptr,
-                       a.k0, a.k1, static_cast<S*>(a.epart), a.unom, a.base);
+    const unsigned lds = (unsigned)((size_t)a.P.T * 5 * sizeof(double));
+    if (a.ev_start)
+        hipExtLaunchKernelGGL(kern, grid, dim3(256), lds, a.stream, a.ev_start, a.ev_stop, 0, a.P, a.state, a.goal, a.tc,
+                              static_cast<S*>(a.eps), static_cast<S*>(a.dP), static_cast<S*>(a.stot), a.seed, a.tick,
+                              a.tick_ptr, a.k0, a.k1, static_cast<S*>(a.epart), a.unom, a.base);
+    else
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, a.stream, a.P, a.state, a.goal, a.tc,
+                           static_cast<S*>(a.eps), static_cast<S*>(a.dP), static_cast<S*>(a.stot), a.seed, a.tick, a.tick_ptr,
+                           a.k0, a.k1, static_cast<S*>(a.epart), a.unom, a.base);
     return hipGetLastError();
 }
 template <typename S, int NT, bool PH, bool SE, int IN, int MODEL>
