@@ -162,9 +162,12 @@ int main(int argc, char** argv) {
         else if (const char* v = val("--seed")) seed = std::strtoull(v, nullptr, 10);
         else if (const char* v = val("--storage")) cfg.storage = std::strcmp(v, "f64") == 0 ? MPPI_STORE_F64 : MPPI_STORE_F32;
         else if (const char* v = val("--device")) cfg.device = std::atoi(v);
+        else if (const char* v = val("--tick-path"))
+            cfg.tick_path = std::strcmp(v, "lanes") == 0 ? MPPI_TICK_LANES : std::strcmp(v, "scan") == 0 ? MPPI_TICK_SCAN : MPPI_TICK_AUTO;
         else {
             std::fprintf(stderr, "usage: mppi_node [--task park|pentagon] [--samples K] [--horizon T] [--callbacks N]\n"
-                                 "                 [--thresh m] [--seed s] [--storage f32|f64] [--device d]\n");
+                                 "                 [--thresh m] [--seed s] [--storage f32|f64] [--device d]\n"
+                                 "                 [--tick-path auto|lanes|scan]\n");
             return 1;
         }
     }

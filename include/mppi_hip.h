@@ -61,7 +61,18 @@ extern "C" {
 #define MPPI_MODEL_DIFFDRIVE_RK4 0   /* rk4 :39-54 over dd_dynamics :23-30 -- what the node runs      */
 #define MPPI_MODEL_UNICYCLE_EULER 1  /* euler :57-58 over unicycle_dynamics :33-36 (no theta wrap)   */
 
-/* kernels, for mppi_kernel_timing */
+/* How mppi_tick / mppi_tick_begin map the K x T rollouts onto the chip:
+ *   LANES  one lane per sample, T sequential steps (rollout kernel + update kernel): the throughput path;
+ *   SCAN   one wave (T <= 64) or block (T <= 256) per sample, lanes = timesteps, the trajectory as prefix
+ *          scans, rollout + cost-to-go + softmax partials in ONE kernel: the latency path for small K
+ *          (diff-drive rk4 model only; falls back to LANES where it does not apply);
+ *   AUTO   SCAN while n_agents * samples <= 2048 (measured crossover), else LANES.
+ * Both give the same results to rounding. */
+#define MPPI_TICK_AUTO 0
+#define MPPI_TICK_LANES 1
+#define MPPI_TICK_SCAN 2
+
+/* kernels, for mppi_kernel_timing (the scan kernel is timed as MPPI_KERNEL_ROLLOUT) */
 #define MPPI_KERNEL_NOMINAL 0
 #define MPPI_KERNEL_ROLLOUT 1
 #define MPPI_KERNEL_UPDATE 2
@@ -79,7 +90,7 @@ typedef struct mppi_config {
     int32_t device;        /* HIP device ordinal                                              */
     uint32_t sample_offset;/* global index of local sample 0                                  */
     int32_t model;         /* MPPI_MODEL_*: the `model=` ctor argument (control/src/mppi:62)   */
-    int32_t reserved;      /* must be 0                                                       */
+    int32_t tick_path;     /* MPPI_TICK_*: which kernels a tick runs; default MPPI_TICK_AUTO          */
     double dt;             /* <= 0: 1/T  (control/src/mppi:67)                                */
     double sigma;          /* noise std-dev = sig[0,0] (control/src/mppi:145); default 0.9    */
     double lambda;         /* temperature; default 0.001 (control/src/mppi:89)                */

@@ -10,6 +10,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmppi_hip.so")
 MPPI_STORE_F32, MPPI_STORE_F64 = 0, 1
 MPPI_NOISE_INJECTED, MPPI_NOISE_PHILOX = 0, 1
 MPPI_MODEL_DIFFDRIVE_RK4, MPPI_MODEL_UNICYCLE_EULER = 0, 1
+MPPI_TICK_AUTO, MPPI_TICK_LANES, MPPI_TICK_SCAN = 0, 1, 2
 KERNELS = ("nominal", "rollout", "update", "merge", "finalize")
 ABI_VERSION = 1
 
@@ -17,7 +18,7 @@ ABI_VERSION = 1
 class MppiConfig(C.Structure):
     _fields_ = [("n_agents", C.c_int32), ("samples", C.c_int32), ("horizon", C.c_int32),
                 ("storage", C.c_int32), ("device", C.c_int32), ("sample_offset", C.c_uint32),
-                ("model", C.c_int32), ("reserved", C.c_int32),
+                ("model", C.c_int32), ("tick_path", C.c_int32),
                 ("dt", C.c_double), ("sigma", C.c_double), ("lambda_", C.c_double),
                 ("q", C.c_double * 3), ("r", C.c_double * 2), ("p1", C.c_double * 3),
                 ("u_max", C.c_double), ("wheel_radius", C.c_double), ("wheel_base", C.c_double),

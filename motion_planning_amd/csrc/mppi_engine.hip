@@ -69,6 +69,11 @@ struct mppi_engine {
     // launch geometry
     int roll_bs = 256, roll_blocks = 0, nterm = 4;
     int NCH = 1, CH = 1024;
+    // small-K tick: ONE scan_tick_kernel (lanes = timesteps) instead of rollout + update
+    int small_nb = 0, small_spw = 1, small_nw = 1;  // blocks (0 = path not used), samples per unit, waves per unit
+    double* d_prev = nullptr;                        // pre-tick {unom [A][2][T], state [A][3], goal [A][3]}
+    bool value_lazy = false;                         // the last tick's V exists only as that snapshot + its noise
+    const double *ro_state = nullptr, *ro_goal = nullptr, *ro_unom = nullptr;  // rollout inputs override
 
     // device buffers
     void* d_eps = nullptr;   // S [A][T][2][Ks]
@@ -203,7 +208,8 @@ struct mppi_engine {
         // the lean instantiation is written for the node's cost: Q = diag(q, q, 0), q > 0, no obstacle grid
         a.general = P.q2 != 0.0 || P.grid_weight != 0.0 || P.q0 != P.q1 || !(P.q0 > 0.0);
         a.seed = seed; a.tick = tick; a.tick_ptr = tick_ptr;
-        a.state = d_state; a.goal = d_goal; a.unom = d_unom; a.tc = d_tc; a.base = d_base;
+        a.state = ro_state ? ro_state : d_state; a.goal = ro_goal ? ro_goal : d_goal;
+        a.unom = ro_unom ? ro_unom : d_unom; a.tc = d_tc; a.base = d_base;
         a.eps = d_eps; a.dP = d_dP; a.stot = d_stot; a.epart = d_epart;
         hipError_t e;
         if (f64()) e = nterm == 4 ? mppi::launch_rollout_typed<double, 4>(a) : nterm == 7 ? mppi::launch_rollout_typed<double, 7>(a) : mppi::launch_rollout_typed<double, 0>(a);
@@ -219,16 +225,57 @@ struct mppi_engine {
         if (e != hipSuccess) fail(MPPI_E_HIP, "rollout launch failed: %s", hipGetErrorString(e));
     }
     // write the lazily-drawn noise of the last tick into d_eps (bit-identical re-draw)
-    void materialise_eps() {
-        if (!eps_lazy) return;
+    uint32_t lazy_tick_now() {  // the tick id the last (lazy) tick drew its noise with
         uint32_t tick = lazy_tick;
         if (lazy_from_counter) {
             HIPCHK(hipMemcpyAsync(&tick, d_tick, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIPCHK(hipStreamSynchronize(stream));
             if (lazy_counter_bumped) tick -= 1u;
         }
-        launch_regen(stream, lazy_seed, tick, nullptr);
+        return tick;
+    }
+    void materialise_eps() {
+        if (!eps_lazy) return;
+        launch_regen(stream, lazy_seed, lazy_tick_now(), nullptr);
         eps_lazy = false;
+    }
+    // The small-K tick keeps V in registers.  When a caller asks for it afterwards (mppi_download_value,
+    // mppi_update), the lane-per-sample rollout kernel re-runs the tick's rollout from the pre-tick
+    // snapshot the scan kernel left behind, with the same noise (re-drawn bit-identically, or the
+    // injected buffer), and leaves dP / Stot / base / epart as any rollout does.
+    void materialise_value() {
+        if (!value_lazy) return;
+        const bool ph = eps_lazy;
+        const uint32_t tick = ph ? lazy_tick_now() : 0u;
+        ro_unom = d_prev;
+        ro_state = d_prev + (size_t)cfg.n_agents * 2 * cfg.horizon;
+        ro_goal = ro_state + (size_t)cfg.n_agents * 3;
+        try {
+            launch_rollout(stream, 0, cfg.samples, ph, true, lazy_seed, tick, nullptr);
+        } catch (...) {
+            ro_unom = ro_state = ro_goal = nullptr;
+            throw;
+        }
+        ro_unom = ro_state = ro_goal = nullptr;
+        if (ph) eps_lazy = false;
+        value_lazy = false; value_ready = true; epart_ready = true;
+    }
+    void launch_scan_tick(bool ph, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
+        Scope sc(this, MPPI_KERNEL_ROLLOUT);
+        dim3 grid(small_nb, cfg.n_agents);
+#define LAUNCH_SCAN(TYPE, NW, PH)                                                                                       \
+    hipLaunchKernelGGL((mppi::scan_tick_kernel<TYPE, NW, PH>), grid, dim3(256), 0, stream, P, (const double*)d_state,   \
+                       (const double*)d_goal, (const double*)d_unom, static_cast<const TYPE*>(d_eps), seed, tick,      \
+                       tick_ptr, small_spw, d_part, small_nb, d_prev)
+#define LAUNCH_SCAN_T(TYPE)                                                                \
+    do {                                                                                   \
+        if (small_nw == 1) { if (ph) LAUNCH_SCAN(TYPE, 1, true); else LAUNCH_SCAN(TYPE, 1, false); } \
+        else { if (ph) LAUNCH_SCAN(TYPE, 4, true); else LAUNCH_SCAN(TYPE, 4, false); }     \
+    } while (0)
+        if (f64()) LAUNCH_SCAN_T(double); else LAUNCH_SCAN_T(float);
+#undef LAUNCH_SCAN_T
+#undef LAUNCH_SCAN
+        HIPCHK(hipGetLastError());
     }
     void launch_regen(hipStream_t st, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
         dim3 g((cfg.samples + 255) / 256, (cfg.horizon + mppi::kStepsPerDraw - 1) / mppi::kStepsPerDraw, cfg.n_agents);
@@ -257,9 +304,9 @@ struct mppi_engine {
 #undef LAUNCH_UPD
         HIPCHK(hipGetLastError());
     }
-    void launch_merge() {
+    void launch_merge(int nch) {
         Scope sc(this, MPPI_KERNEL_MERGE);
-        hipLaunchKernelGGL(mppi::merge_kernel, dim3(cfg.horizon, cfg.n_agents), dim3(64), 0, stream, P, d_part, NCH, d_merged);
+        hipLaunchKernelGGL(mppi::merge_kernel, dim3(cfg.horizon, cfg.n_agents), dim3(64), 0, stream, P, d_part, nch, d_merged);
         HIPCHK(hipGetLastError());
     }
     void check_noise_mode(int noise_mode) {
@@ -276,10 +323,17 @@ struct mppi_engine {
         eps_lazy = ph && !store;
         lazy_seed = seed; lazy_tick = tick; lazy_from_counter = tick_ptr != nullptr; lazy_counter_bumped = false;
         epart_ready = true;  // every rollout launch below writes its waves' eps sums
+        if (small_nb > 0) {  // small K: rollout + cost-to-go + softmax partials in one kernel, V stays in registers
+            eps_lazy = ph;
+            launch_scan_tick(ph, seed, tick, tick_ptr);
+            launch_merge(small_nb);
+            noise_ready = true; value_ready = false; value_lazy = true; partials_ready = true; epart_ready = false;
+            return;
+        }
         launch_rollout(stream, 0, cfg.samples, ph, store, seed, tick, tick_ptr);
         launch_update(stream, 0, NCH, tick_ptr);
-        launch_merge();
-        noise_ready = true; value_ready = true; partials_ready = true; epart_ready = true;
+        launch_merge(NCH);
+        noise_ready = true; value_ready = true; value_lazy = false; partials_ready = true; epart_ready = true;
     }
     // T <= 256: the nominal rollout runs inside every rollout block (lanes = timesteps)
     bool inline_nominal() const { return cfg.horizon <= 256 && cfg.model == MPPI_MODEL_DIFFDRIVE_RK4; }
@@ -294,13 +348,14 @@ struct mppi_engine {
         check_noise_mode(noise_mode);
         launch_rollout(stream, 0, cfg.samples, noise_mode == MPPI_NOISE_PHILOX, true, seed, tick, tick_ptr);
         eps_lazy = false;
-        noise_ready = true; value_ready = true; partials_ready = false; epart_ready = true;
+        noise_ready = true; value_ready = true; value_lazy = false; partials_ready = false; epart_ready = true;
     }
     void run_update() {
+        materialise_value();
         if (!noise_ready || !value_ready) fail(MPPI_E_STATE, "update needs a rollout (or uploaded V and eps) first");
         materialise_eps();
         launch_update(stream, 0, NCH);
-        launch_merge();
+        launch_merge(NCH);
         partials_ready = true;
     }
     void run_finalize(const double* gathered, int G, int flags) {
@@ -332,7 +387,8 @@ struct mppi_engine {
         if (cfg.storage != MPPI_STORE_F32 && cfg.storage != MPPI_STORE_F64) fail(MPPI_E_INVALID, "bad storage %d", cfg.storage);
         if (cfg.model != MPPI_MODEL_DIFFDRIVE_RK4 && cfg.model != MPPI_MODEL_UNICYCLE_EULER)
             fail(MPPI_E_INVALID, "unknown model %d (rk4 + dd_dynamics = 0, euler + unicycle_dynamics = 1)", cfg.model);
-        if (cfg.reserved != 0) fail(MPPI_E_INVALID, "mppi_config.reserved must be 0");
+        if (cfg.tick_path != MPPI_TICK_AUTO && cfg.tick_path != MPPI_TICK_LANES && cfg.tick_path != MPPI_TICK_SCAN)
+            fail(MPPI_E_INVALID, "bad tick_path %d", cfg.tick_path);
         if (!(cfg.lambda > 0.0) || !(cfg.sigma >= 0.0)) fail(MPPI_E_INVALID, "lambda must be > 0 and sigma >= 0");
         if (!(cfg.dt > 0.0)) cfg.dt = 1.0 / (double)cfg.horizon;  // control/src/mppi:67
         int ndev = 0;
@@ -387,7 +443,20 @@ struct mppi_engine {
         d_ufilt = dev_alloc<double>((size_t)A * 2 * T, hbm_bytes);
         d_state = dev_alloc<double>((size_t)A * 3, hbm_bytes);
         d_goal = dev_alloc<double>((size_t)A * 3, hbm_bytes);
-        d_part = dev_alloc<double>((size_t)A * T * NCH * mppi::kTupleW, hbm_bytes);
+        {   // small-K path: lanes = timesteps, one wave (T <= 64) or one block (T <= 256) per sample
+            // AUTO: the scan kernel wins below ~2000 samples (K = 1000: 18.5 vs 29.4 us per tick), loses above 4000
+            const bool applies = T <= 256 && cfg.model == MPPI_MODEL_DIFFDRIVE_RK4;
+            const bool want = cfg.tick_path == MPPI_TICK_SCAN || (cfg.tick_path == MPPI_TICK_AUTO && (long)A * K <= 2048);
+            if (applies && want) {
+                small_nw = T <= 64 ? 1 : 4;
+                const long unit_cap = small_nw == 1 ? 4096 : 1024;  // units the chip keeps resident at once
+                small_spw = (int)std::max(1L, ((long)A * K + unit_cap - 1) / unit_cap);
+                const int units = (K + small_spw - 1) / small_spw;
+                small_nb = small_nw == 1 ? (units + 3) / 4 : units;
+            }
+        }
+        d_part = dev_alloc<double>((size_t)A * T * std::max(NCH, small_nb) * mppi::kTupleW, hbm_bytes);
+        d_prev = dev_alloc<double>((size_t)A * (2 * T + 6), hbm_bytes);
         d_merged = dev_alloc<double>((size_t)A * T * mppi::kTupleW, hbm_bytes);
         d_S = dev_alloc<double>((size_t)T * T, hbm_bytes);
         d_out = dev_alloc<double>((size_t)A * 8, hbm_bytes);
@@ -424,7 +493,7 @@ struct mppi_engine {
         for (int i = 0; i < kRing; ++i) if (ring_ev[i]) hipEventDestroy(ring_ev[i]);
         if (h_stage) hipHostFree(h_stage);
         if (h_out) hipHostFree(h_out);
-        void* bufs[] = {d_eps, d_dP, d_stot, d_epart, d_tc, d_base, d_unom, d_ufilt, d_state, d_goal, d_part, d_merged, d_S, d_out, d_tick, d_tmp, d_grid};
+        void* bufs[] = {d_eps, d_dP, d_stot, d_epart, d_tc, d_base, d_unom, d_ufilt, d_state, d_goal, d_part, d_merged, d_S, d_out, d_tick, d_tmp, d_grid, d_prev};
         for (void* b : bufs) if (b) hipFree(b);
         if (own_stream) hipStreamDestroy(own_stream);
     }
@@ -459,7 +528,7 @@ int mppi_default_config(mppi_config* cfg) {
     cfg->device = 0;
     cfg->sample_offset = 0;
     cfg->model = MPPI_MODEL_DIFFDRIVE_RK4;  // MPPI(model=rk4), control/src/mppi:62
-    cfg->reserved = 0;
+    cfg->tick_path = MPPI_TICK_AUTO;
     cfg->dt = 0.0;
     cfg->sigma = 0.9;     // control/src/mppi:88
     cfg->lambda = 0.001;  // control/src/mppi:89
@@ -577,6 +646,7 @@ int mppi_upload_noise(mppi_engine* h, const double* eps) {
     h->noise_ready = true;
     h->epart_ready = false;
     h->eps_lazy = false;
+    h->value_lazy = false;  // the snapshot no longer matches the resident noise
     API_END(h)
 }
 
@@ -608,6 +678,7 @@ int mppi_rollout(mppi_engine* h, const double* state, const double* goal, int no
 int mppi_download_value(mppi_engine* h, double* V) {
     API_BEGIN(h)
     if (!V) fail(MPPI_E_INVALID, "V is NULL");
+    h->materialise_value();
     if (!h->value_ready) fail(MPPI_E_STATE, "no value function resident");
     const int A = h->cfg.n_agents, T = h->cfg.horizon, K = h->cfg.samples;
     const size_t n = (size_t)A * T * K;
@@ -636,7 +707,7 @@ int mppi_upload_value(mppi_engine* h, const double* V) {
     else hipLaunchKernelGGL(mppi::value_pack_kernel<float>, grid, dim3(256), 0, h->stream, (const double*)h->d_tmp, (const double*)h->d_base, static_cast<float*>(h->d_dP), static_cast<float*>(h->d_stot), K, h->P.Ks, T);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
-    h->value_ready = true;
+    h->value_ready = true; h->value_lazy = false;
     API_END(h)
 }
 
@@ -745,8 +816,9 @@ int mppi_tick_graph(mppi_engine* h, uint64_t seed) {
         h->time_mask = saved;
     }
     HIPCHK(hipGraphLaunch(h->graph_exec, h->stream));
-    h->noise_ready = true; h->value_ready = true; h->partials_ready = false; h->epart_ready = true;
-    h->eps_lazy = !h->store_eps_always; h->lazy_seed = seed; h->lazy_from_counter = true; h->lazy_counter_bumped = true;
+    const bool small = h->small_nb > 0;
+    h->noise_ready = true; h->value_ready = !small; h->value_lazy = small; h->partials_ready = false; h->epart_ready = !small;
+    h->eps_lazy = small || !h->store_eps_always; h->lazy_seed = seed; h->lazy_from_counter = true; h->lazy_counter_bumped = true;
     API_END(h)
 }
 

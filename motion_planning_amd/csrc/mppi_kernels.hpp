@@ -928,6 +928,144 @@ __global__ __launch_bounds__(64) void merge_kernel(DevParams P, const double* __
 }
 #endif
 
+// ---------------------------------------------------------------------------------------------
+// scan_tick_kernel: rollout + cost-to-go + softmax partials of one tick in ONE kernel for small
+// K (BASELINE config 2, the node's own K = 10): lanes = TIMESTEPS, one wave (T <= 64) or one block of
+// four waves (T <= 256) per sample.  With constant wheel speeds over a step, theta is a prefix sum of
+// the per-step rotations and (x, y) prefix sums of the per-step RK4 increments (which need only theta
+// at the step's start), so a sample's whole trajectory is three scans deep instead of T steps long;
+// the cost-to-go V[t] = sum_{tau >= t} c[tau] is a fourth.  The lane of timestep t then folds the
+// sample into ITS running softmax tuple {min V, sum e, sum e*eps0, sum e*eps1, sum eps0, sum eps1,
+// count} (an online softmax over the samples this unit walks through) -- V and eps never leave
+// registers.  Same formulas as nominal_lanes (which is this with eps = 0); the noise is the same
+// Philox stream, addressed by (sample, t / 3), so the result equals the lane-per-sample path's to
+// rounding.  grid = (blocks, A) x 256; unit = wave (NWAVES 1: 4 units per block) or block (NWAVES 4);
+// unit u walks samples [u * spw, (u + 1) * spw).  part[a][t][block] = the block's tuple; block 0 also
+// snapshots (state, goal, nominal) so that V can be materialised later (mppi_download_value).
+// ---------------------------------------------------------------------------------------------
+template <typename S, int NWAVES, bool PHILOX>
+__global__ __launch_bounds__(256) void scan_tick_kernel(DevParams P, const double* __restrict__ state,
+                                                       const double* __restrict__ goal,
+                                                       const double* __restrict__ unom, const S* __restrict__ eps,
+                                                       uint64_t seed, uint32_t tick_arg,
+                                                       const uint32_t* __restrict__ tick_ptr, int spw,
+                                                       double* __restrict__ part, int NB, double* __restrict__ prev) {
+    __shared__ double sh_scan[4];
+    __shared__ double sh_tup[NWAVES == 1 ? 4 * 64 * 7 : 1];
+    const int tid = threadIdx.x, a = blockIdx.y, T = P.T, K = P.K;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int t = NWAVES == 1 ? lane : tid;  // this thread's timestep
+    const bool valid = t < T;
+    const int unit = NWAVES == 1 ? (int)blockIdx.x * 4 + wid : (int)blockIdx.x;
+    const double x0 = state[a * 3 + 0], y0 = state[a * 3 + 1], th0 = state[a * 3 + 2];
+    const double gx = goal[a * 3 + 0], gy = goal[a * 3 + 1], gth = goal[a * 3 + 2];
+    const double un0 = valid ? unom[(a * 2 + 0) * T + t] : 0.0;
+    const double un1 = valid ? unom[(a * 2 + 1) * T + t] : 0.0;
+    if (blockIdx.x == 0) {  // pre-tick snapshot: prev = {unom [A][2][T], state [A][3], goal [A][3]}
+        double* pv_state = prev + (size_t)P.A * 2 * T;
+        double* pv_goal = pv_state + (size_t)P.A * 3;
+        if ((NWAVES == 4 || wid == 0) && valid) { prev[(a * 2 + 0) * T + t] = un0; prev[(a * 2 + 1) * T + t] = un1; }
+        if (tid < 3) { pv_state[a * 3 + tid] = state[a * 3 + tid]; pv_goal[a * 3 + tid] = goal[a * 3 + tid]; }
+    }
+    const double half_uru = 0.5 * (P.r0 * un0 * un0 + P.r1 * un1 * un1);
+    const double ls = P.lambda * P.sigma, w0 = ls * un0, w1 = ls * un1;
+    uint32_t key0 = 0, key1 = 0, tick = 0;
+    float sigf = 0.f;
+    if (PHILOX) {
+        key0 = (uint32_t)seed; key1 = (uint32_t)(seed >> 32);
+        tick = tick_ptr ? *tick_ptr : tick_arg;
+        sigf = (float)P.sigma;
+    }
+    double m = INFINITY, D = 0.0, N0 = 0.0, N1 = 0.0, E0 = 0.0, E1 = 0.0, cnt = 0.0;
+    const int k_lo = unit * spw, k_hi = min(K, k_lo + spw);  // uniform per unit (NWAVES 4: per block)
+    for (int k = k_lo; k < k_hi; ++k) {
+        double e0 = 0.0, e1 = 0.0;
+        if (valid) {
+            if (PHILOX) {
+                float e[6];
+                philox_normals(P.sample_offset + (uint32_t)k, (uint32_t)(t / kStepsPerDraw), tick, (uint32_t)a, key0, key1,
+                               sigf, e);
+                const int j = t % kStepsPerDraw;
+                e0 = (double)(S)(j == 0 ? e[0] : (j == 1 ? e[2] : e[4]));
+                e1 = (double)(S)(j == 0 ? e[1] : (j == 1 ? e[3] : e[5]));
+            } else {
+                const S* ep = eps + ((size_t)a * T + t) * 2 * (size_t)P.Ks + k;
+                e0 = (double)ep[0];
+                e1 = (double)ep[(size_t)P.Ks];
+            }
+        }
+        // EXPLORE + CLIP (control/src/mppi:147-152), then rk4 (:39-54) / euler (:57-58) as scans over t
+        const double u0 = clampd(un0 + e0, P.u_max), u1 = clampd(un1 + e1, P.u_max);
+        const double h = valid ? (P.model == 1 ? P.dt * u1 : P.kth * P.dt * (u1 - u0)) : 0.0;
+        double tot_;
+        const double th = th0 + (lanes_scan_incl<NWAVES>(h, t, sh_scan, tot_) - h);
+        double s0, c0, ix, iy;
+        sincos(th, &s0, &c0);
+        if (P.model == 1) {
+            ix = P.dt * (c0 * u0); iy = P.dt * (s0 * u0);
+        } else {
+            double s1, c1, s2, c2;
+            if (fabs(h) <= 0.5) {
+                double sp, cp;
+                small_sincos<7>(0.5 * h, sp, cp);
+                c1 = c0 * cp - s0 * sp; s1 = s0 * cp + c0 * sp;
+                c2 = c1 * cp - s1 * sp; s2 = s1 * cp + c1 * sp;
+            } else {
+                sincos(th + 0.5 * h, &s1, &c1);
+                sincos(th + h, &s2, &c2);
+            }
+            const double aa = P.dt * P.rhalf * (u0 + u1) * (1.0 / 6.0);
+            ix = aa * (c0 + 4.0 * c1 + c2); iy = aa * (s0 + 4.0 * s1 + s2);
+        }
+        const double X = x0 + lanes_scan_incl<NWAVES>(valid ? ix : 0.0, t, sh_scan, tot_);
+        const double Y = y0 + lanes_scan_incl<NWAVES>(valid ? iy : 0.0, t, sh_scan, tot_);
+        double cst = 0.0;
+        if (valid) {  // get_cost (:180-184): u = NOMINAL, eps = UNCLIPPED; terminal cost (:165-173) at T-1
+            const double thn = (P.model == 1) ? th + h : wrap_theta(th + h);
+            const double dx = X - gx, dy = Y - gy, dth = thn - gth;
+            cst = 0.5 * (P.q0 * dx * dx + P.q1 * dy * dy + P.q2 * dth * dth) + half_uru + (w0 * e0 + w1 * e1);
+            if (P.grid_weight != 0.0) cst += obstacle_cost(P, X, Y);
+            if (t == T - 1) cst += P.p0 * dx * dx + P.p1 * dy * dy + P.p2 * dth * dth;
+        }
+        double tot;
+        const double inc = lanes_scan_incl<NWAVES>(cst, t, sh_scan, tot);
+        const double V = tot - (inc - cst);  // value_fcn[t, k] (:175)
+        if (valid) {  // fold the sample into this timestep's tuple (update_action :187-196, online form)
+            if (V < m) {
+                const double r = exp((V - m) * P.inv_lambda);  // exp(-inf) = 0 on the first sample
+                D = fma(D, r, 1.0); N0 = fma(N0, r, e0); N1 = fma(N1, r, e1); m = V;
+            } else {
+                const double w = exp((m - V) * P.inv_lambda);
+                D += w; N0 = fma(w, e0, N0); N1 = fma(w, e1, N1);
+            }
+            E0 += e0; E1 += e1; cnt += 1.0;
+        }
+    }
+    if (NWAVES == 1) {  // the block's four waves hold four tuples per timestep: merge them (exact rescaling)
+        double* mine = sh_tup + (wid * 64 + lane) * 7;
+        mine[0] = m; mine[1] = D; mine[2] = N0; mine[3] = N1; mine[4] = E0; mine[5] = E1; mine[6] = cnt;
+        __syncthreads();
+        if (wid != 0) return;
+        double M = INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const double* q = sh_tup + (w * 64 + lane) * 7; if (q[6] > 0.0) M = fmin(M, q[0]); }
+        D = N0 = N1 = E0 = E1 = cnt = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const double* q = sh_tup + (w * 64 + lane) * 7;
+            if (q[6] > 0.0) {
+                const double sc = (q[0] == M) ? 1.0 : exp((M - q[0]) * P.inv_lambda);
+                D += sc * q[1]; N0 += sc * q[2]; N1 += sc * q[3]; E0 += q[4]; E1 += q[5]; cnt += q[6];
+            }
+        }
+        m = M;
+    }
+    if (valid) {
+        double* o = part + (((size_t)a * T + t) * NB + blockIdx.x) * kTupleW;
+        o[0] = m; o[1] = D; o[2] = N0; o[3] = N1; o[4] = E0; o[5] = E1; o[6] = cnt; o[7] = 0.0;
+    }
+}
+
 // exact rk4 step in the reference's operation order (control/src/mppi:39-54), used for the plant
 __device__ __forceinline__ void rk4_exact(const DevParams& P, const double x0[3], double u0, double u1,
                                           double out[3]) {

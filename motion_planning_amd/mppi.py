@@ -7,6 +7,7 @@ method names, argument meaning and array layouts, so the reference's ``Controlle
 logic runs against it unmodified -- but every K x T loop runs in the HIP kernels.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -60,6 +61,9 @@ _MODELS = {"rk4": _capi.MPPI_MODEL_DIFFDRIVE_RK4, "euler": _capi.MPPI_MODEL_UNIC
            _capi.MPPI_MODEL_DIFFDRIVE_RK4: _capi.MPPI_MODEL_DIFFDRIVE_RK4,
            _capi.MPPI_MODEL_UNICYCLE_EULER: _capi.MPPI_MODEL_UNICYCLE_EULER}
 
+# which kernels a tick runs (include/mppi_hip.h MPPI_TICK_*): "lanes" = lane per sample (throughput),
+# "scan" = lanes are timesteps, one kernel (small-K latency), "auto" = scan while A * K <= 2048
+_TICK_PATHS = {"auto": _capi.MPPI_TICK_AUTO, "lanes": _capi.MPPI_TICK_LANES, "scan": _capi.MPPI_TICK_SCAN}
 _STORAGE = {"f32": MPPI_STORE_F32, "f64": MPPI_STORE_F64, MPPI_STORE_F32: MPPI_STORE_F32,
             MPPI_STORE_F64: MPPI_STORE_F64}
 
@@ -75,7 +79,7 @@ class Engine(object):
     """One libmppi_hip engine: A agents x K samples (this GPU's shard) x T horizon."""
 
     def __init__(self, samples, horizon, n_agents=1, storage="f32", device=0, sample_offset=0,
-                 dt=None, sigma=0.9, lam=0.001, model="rk4", **overrides):
+                 dt=None, sigma=0.9, lam=0.001, model="rk4", tick_path=None, **overrides):
         self._lib = _capi.load()
         cfg = _capi.default_config()
         cfg.n_agents, cfg.samples, cfg.horizon = int(n_agents), int(samples), int(horizon)
@@ -83,6 +87,8 @@ class Engine(object):
         cfg.device = int(device)
         cfg.sample_offset = int(sample_offset)
         cfg.model = _MODELS[model]
+        # (the environment default lets the test-suite run every case on both paths)
+        cfg.tick_path = _TICK_PATHS[tick_path if tick_path is not None else os.environ.get("MPPI_TICK_PATH", "auto")]
         cfg.dt = 0.0 if dt is None else float(dt)
         cfg.sigma, cfg.lambda_ = float(sigma), float(lam)
         for key, val in overrides.items():
@@ -276,7 +282,7 @@ class MPPI(object):
     """
 
     def __init__(self, model=rk4, horizon=100, samples=10, thresh=0.05, rng="numpy", seed=0,
-                 storage="f32", device=0):
+                 storage="f32", device=0, tick_path=None):
         if model is rk4 or model == "rk4":
             model_id = "rk4"
         elif model is euler or model == "euler":
@@ -300,7 +306,8 @@ class MPPI(object):
         self.rng = rng
         self.seed = int(seed)
         self._tick = 0
-        self._eng = Engine(self.samples, self.horizon, 1, storage=storage, device=device, model=model_id)
+        self._eng = Engine(self.samples, self.horizon, 1, storage=storage, device=device, model=model_id,
+                           tick_path=tick_path)
         self.initialize()
 
     # control/src/mppi:79-83

@@ -15,6 +15,16 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["lanes", "scan"])
+def tick_path(request, monkeypatch):
+    """Every case runs twice: ticks on the lane-per-sample kernels (the throughput path) and on the scan
+    kernel (lanes = timesteps, the small-K latency path; it applies to T <= 256 with the rk4 model and
+    falls back to the lane kernels elsewhere).  Engines pick the default up from the environment."""
+    monkeypatch.setenv("MPPI_TICK_PATH", request.param)
+    return request.param
+
+
 SIG, LAM = 0.9, 0.001
 C2G = ["c2g_zero", "c2g_warm", "c2g_wrap", "c2g_clip", "c2g_tiny"]
 
@@ -628,7 +638,7 @@ def test_bench_under_torchrun_uses_the_rccl_path():
     ("park", [], 0.05, 30),
     ("pentagon", [[1, 0], [2, 1], [1, 2], [0, 2], [0, 0]], 0.97, 40),
 ])
-def test_cpp_node_matches_the_python_shim(tmp_path, task, waypoints, thresh, n_cb):
+def test_cpp_node_matches_the_python_shim(tmp_path, tick_path, task, waypoints, thresh, n_cb):
     """examples/mppi_node.cpp -- a compiled, Python-free caller of the C ABI with the node shell of
     control/src/mppi:296-389 -- publishes the same twists as motion_planning_amd.Controller (itself
     pinned to the reference's Controller by the ctl_* goldens) on the same device-Philox noise."""
@@ -641,7 +651,7 @@ def test_cpp_node_matches_the_python_shim(tmp_path, task, waypoints, thresh, n_c
     subprocess.run(["make", "-B", "-C", os.path.join(root, "examples"), "OUT=" + exe], check=True, capture_output=True)
     K, T, seed = 2048, 50, 5
     out = subprocess.run([exe, "--task", task, "--samples", str(K), "--horizon", str(T), "--callbacks", str(n_cb),
-                          "--thresh", str(thresh), "--seed", str(seed), "--storage", "f64"],
+                          "--thresh", str(thresh), "--seed", str(seed), "--storage", "f64", "--tick-path", tick_path],
                          capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr[-2000:]
     rows = np.array([[float(x) for x in ln.split()] for ln in out.stdout.strip().splitlines()])
