@@ -306,7 +306,7 @@ struct mppi_engine {
     }
     void launch_merge(int nch) {
         Scope sc(this, MPPI_KERNEL_MERGE);
-        hipLaunchKernelGGL(mppi::merge_kernel, dim3(cfg.horizon, cfg.n_agents), dim3(64), 0, stream, P, d_part, nch, d_merged);
+        hipLaunchKernelGGL(mppi::merge_kernel, dim3(cfg.horizon, cfg.n_agents), dim3(nch > 128 ? 256 : 64), 0, stream, P, d_part, nch, d_merged);
         HIPCHK(hipGetLastError());
     }
     void check_noise_mode(int noise_mode) {
@@ -444,9 +444,10 @@ struct mppi_engine {
         d_state = dev_alloc<double>((size_t)A * 3, hbm_bytes);
         d_goal = dev_alloc<double>((size_t)A * 3, hbm_bytes);
         {   // small-K path: lanes = timesteps, one wave (T <= 64) or one block (T <= 256) per sample
-            // AUTO: the scan kernel wins below ~2000 samples (K = 1000: 18.5 vs 29.4 us per tick), loses above 4000
+            // AUTO: measured ticks, scan vs lane kernels: K = 1000 16.8 vs 28.7 us, 4000 22.4 vs 29.7, 10000 28.8 vs 31.0, 16000 32.4 vs 32.0 (T = 50, a wave per sample);
+            // T = 100 (a block per sample): K = 500 20.1 vs 39.8, 2000 29.4 vs 40.4, 5000 40.7 vs 41.3, 10000 59.0 vs 43.4
             const bool applies = T <= 256 && cfg.model == MPPI_MODEL_DIFFDRIVE_RK4;
-            const bool want = cfg.tick_path == MPPI_TICK_SCAN || (cfg.tick_path == MPPI_TICK_AUTO && (long)A * K <= 2048);
+            const bool want = cfg.tick_path == MPPI_TICK_SCAN || (cfg.tick_path == MPPI_TICK_AUTO && (long)A * K <= (T <= 64 ? 12288 : 4096));
             if (applies && want) {
                 small_nw = T <= 64 ? 1 : 4;
                 const long unit_cap = small_nw == 1 ? 4096 : 1024;  // units the chip keeps resident at once

@@ -311,14 +311,26 @@ __device__ __forceinline__ double wave_sum16(const double (&v)[16], int lane) { 
 }
 
 
-// 64-lane inclusive prefix sum by shuffles (no LDS, no barriers)
-__device__ __forceinline__ double wave_scan_incl(double v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const double y = __shfl_up(v, off, 64);
-        if (lane >= off) v += y;
-    }
+// 64-lane inclusive prefix sum on the DPP network (no LDS crossbar, no barriers): Kogge-Stone inside each
+// 16-lane row (row_shr 1, 2, 4, 8), then the row totals chained by row_bcast:15 (rows 1, 3) and
+// row_bcast:31 (rows 2, 3).  A double moves as two dwords; lanes without a source add 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_scan_incl(double v, int /*lane*/) {
+    v += dpp_mov_f64<0x111, 0xF>(v);
+    v += dpp_mov_f64<0x112, 0xF>(v);
+    v += dpp_mov_f64<0x114, 0xF>(v);
+    v += dpp_mov_f64<0x118, 0xF>(v);
+    v += dpp_mov_f64<0x142, 0xA>(v);
+    v += dpp_mov_f64<0x143, 0xC>(v);
     return v;
+}
+__device__ __forceinline__ double wave_last(double v) {  // lane 63's value, through the scalar unit
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
 // inclusive prefix sum over NWAVES * 64 consecutive lanes: shuffles inside each wave, the wave totals
@@ -327,7 +339,7 @@ template <int NWAVES>
 __device__ __forceinline__ double lanes_scan_incl(double v, int t, double* sh, double& total) {
     const int lane = t & 63;
     v = wave_scan_incl(v, lane);
-    if (NWAVES == 1) { total = __shfl(v, 63, 64); return v; }
+    if (NWAVES == 1) { total = wave_last(v); return v; }
     const int wid = t >> 6;
     if (lane == 63) sh[wid] = v;
     __syncthreads();
@@ -404,7 +416,8 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;  // v_mad_u64_u32
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
         const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        // three-input xor in one instruction (v_bitop3_b32, truth table 0x96 -- a gfx950 addition)
+        const uint32_t n0 = __builtin_amdgcn_bitop3_b32(hi1, c1, k0, 0x96), n2 = __builtin_amdgcn_bitop3_b32(hi0, c3, k1, 0x96);
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
@@ -445,6 +458,18 @@ __device__ __forceinline__ void philox_normals(uint32_t gk, uint32_t triple, uin
     box_muller(o[2] >> 11, (o[3] >> 9) & 0x7FFFFCu, nscale, e[2], e[3]);
     box_muller(((o[0] & 0x7FFu) << 10) | ((o[1] & 0x7FFu) >> 1), ((o[2] & 0x7FFu) << 12) | ((o[3] & 0x7FEu) << 1),
                nscale, e[4], e[5]);
+}
+
+// the same stream addressed by (sample, t): only step t's pair of its draw's three
+__device__ __forceinline__ void philox_normal_pair(uint32_t gk, uint32_t t, uint32_t tick, uint32_t a, uint32_t key0,
+                                                   uint32_t key1, float sigf, float& e0, float& e1) {
+    uint32_t o[4];
+    philox4x32_10(gk, t / kStepsPerDraw, tick, a, key0, key1, o);
+    const uint32_t j = t % kStepsPerDraw;
+    const uint32_t a21 = j == 0 ? o[0] >> 11 : (j == 1 ? o[2] >> 11 : ((o[0] & 0x7FFu) << 10) | ((o[1] & 0x7FFu) >> 1));
+    const uint32_t mant = j == 0 ? (o[1] >> 9) & 0x7FFFFCu
+                                 : (j == 1 ? (o[3] >> 9) & 0x7FFFFCu : ((o[2] & 0x7FFu) << 12) | ((o[3] & 0x7FEu) << 1));
+    box_muller(a21, mant, -1.3862943611198906f * (sigf * sigf), e0, e1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -903,16 +928,26 @@ __global__ __launch_bounds__(256) void eps_regen_kernel(DevParams P, S* __restri
 // merge_kernel: one wave per (t, a) reduces the NCH chunk tuples of this shard.
 // ---------------------------------------------------------------------------------------------
 #ifndef MPPI_ROLLOUT_TU  // non-template kernels are emitted by the engine translation unit only
-__global__ __launch_bounds__(64) void merge_kernel(DevParams P, const double* __restrict__ part, int NCH,
-                                                  double* __restrict__ merged) {
-    const int t = blockIdx.x, a = blockIdx.y, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void merge_kernel(DevParams P, const double* __restrict__ part, int NCH,
+                                                   double* __restrict__ merged) {
+    // block = 64 threads (few chunk tuples) or 256 (the scan kernel's many block tuples)
+    __shared__ double sh[4][7];
+    const int t = blockIdx.x, a = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int nw = (int)blockDim.x >> 6;
     const double* src = part + ((size_t)a * P.T + t) * NCH * kTupleW;
     double m = INFINITY;
-    for (int i = lane; i < NCH; i += 64)
+    for (int i = tid; i < NCH; i += (int)blockDim.x)
         if (src[i * kTupleW + 6] > 0.0) m = fmin(m, src[i * kTupleW]);
-    const double M = wave_min(m);
+    double M = wave_min(m);
+    if (nw > 1) {
+        if (lane == 0) sh[wid][0] = M;
+        __syncthreads();
+        M = sh[0][0];
+        for (int w = 1; w < nw; ++w) M = fmin(M, sh[w][0]);
+        __syncthreads();
+    }
     double d = 0, n0 = 0, n1 = 0, e0 = 0, e1 = 0, cnt = 0;
-    for (int i = lane; i < NCH; i += 64) {
+    for (int i = tid; i < NCH; i += (int)blockDim.x) {
         const double* q = src + i * kTupleW;
         if (q[6] > 0.0) {
             const double sc = exp((M - q[0]) * P.inv_lambda);
@@ -921,7 +956,13 @@ __global__ __launch_bounds__(64) void merge_kernel(DevParams P, const double* __
     }
     d = wave_sum(d); n0 = wave_sum(n0); n1 = wave_sum(n1);
     e0 = wave_sum(e0); e1 = wave_sum(e1); cnt = wave_sum(cnt);
-    if (lane == 0) {
+    if (nw > 1) {
+        if (lane == 0) { sh[wid][1] = d; sh[wid][2] = n0; sh[wid][3] = n1; sh[wid][4] = e0; sh[wid][5] = e1; sh[wid][6] = cnt; }
+        __syncthreads();
+        if (tid == 0)
+            for (int w = 1; w < nw; ++w) { d += sh[w][1]; n0 += sh[w][2]; n1 += sh[w][3]; e0 += sh[w][4]; e1 += sh[w][5]; cnt += sh[w][6]; }
+    }
+    if (tid == 0) {
         double* o = merged + ((size_t)a * P.T + t) * kTupleW;
         o[0] = M; o[1] = d; o[2] = n0; o[3] = n1; o[4] = e0; o[5] = e1; o[6] = cnt; o[7] = 0.0;
     }
@@ -982,12 +1023,10 @@ __global__ __launch_bounds__(256) void scan_tick_kernel(DevParams P, const doubl
         double e0 = 0.0, e1 = 0.0;
         if (valid) {
             if (PHILOX) {
-                float e[6];
-                philox_normals(P.sample_offset + (uint32_t)k, (uint32_t)(t / kStepsPerDraw), tick, (uint32_t)a, key0, key1,
-                               sigf, e);
-                const int j = t % kStepsPerDraw;
-                e0 = (double)(S)(j == 0 ? e[0] : (j == 1 ? e[2] : e[4]));
-                e1 = (double)(S)(j == 0 ? e[1] : (j == 1 ? e[3] : e[5]));
+                float f0, f1;  // only this step's pair of the draw's three
+                philox_normal_pair(P.sample_offset + (uint32_t)k, (uint32_t)t, tick, (uint32_t)a, key0, key1, sigf, f0, f1);
+                e0 = (double)(S)f0;
+                e1 = (double)(S)f1;
             } else {
                 const S* ep = eps + ((size_t)a * T + t) * 2 * (size_t)P.Ks + k;
                 e0 = (double)ep[0];
@@ -1021,7 +1060,8 @@ __global__ __launch_bounds__(256) void scan_tick_kernel(DevParams P, const doubl
         const double Y = y0 + lanes_scan_incl<NWAVES>(valid ? iy : 0.0, t, sh_scan, tot_);
         double cst = 0.0;
         if (valid) {  // get_cost (:180-184): u = NOMINAL, eps = UNCLIPPED; terminal cost (:165-173) at T-1
-            const double thn = (P.model == 1) ? th + h : wrap_theta(th + h);
+            const double the = th + h;  // the wrap (:52-53) is the identity on (-pi, pi]
+            const double thn = (P.model == 0 && (the > M_PI || the <= -M_PI)) ? wrap_theta(the) : the;
             const double dx = X - gx, dy = Y - gy, dth = thn - gth;
             cst = 0.5 * (P.q0 * dx * dx + P.q1 * dy * dy + P.q2 * dth * dth) + half_uru + (w0 * e0 + w1 * e1);
             if (P.grid_weight != 0.0) cst += obstacle_cost(P, X, Y);
@@ -1034,7 +1074,7 @@ __global__ __launch_bounds__(256) void scan_tick_kernel(DevParams P, const doubl
             if (V < m) {
                 const double r = exp((V - m) * P.inv_lambda);  // exp(-inf) = 0 on the first sample
                 D = fma(D, r, 1.0); N0 = fma(N0, r, e0); N1 = fma(N1, r, e1); m = V;
-            } else {
+            } else if ((V - m) * P.inv_lambda < 750.0) {  // beyond that exp() is exactly 0 in fp64
                 const double w = exp((m - V) * P.inv_lambda);
                 D += w; N0 = fma(w, e0, N0); N1 = fma(w, e1, N1);
             }
