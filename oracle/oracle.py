@@ -2,7 +2,7 @@
 
 TEST INFRASTRUCTURE: only tests/, __graft_entry__.smoke() and bench.py's
 cpu_baseline leg may import this module.  Nothing under motion_planning_amd/
-does (tests/test_layout.py enforces it).
+does (tests/test_abi_cpu.py::test_product_never_touches_the_oracle enforces it).
 """
 import ctypes as C
 import os
