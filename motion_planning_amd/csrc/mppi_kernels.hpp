@@ -221,6 +221,44 @@ __device__ __forceinline__ R wave_sum(R v) {
     return v;
 }
 
+// fp64 over the DPP network instead of the LDS crossbar (ds_bpermute): a double moves as two dwords.
+// dpp_mov_f64: lanes without a source (or in a masked-off row) read 0; dpp_mov_f64_keep: they read v itself.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov_f64_keep(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_last(double v) {  // lane 63's value, through the scalar unit
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+// butterfly inside each 16-lane row (every lane gets its row's result), rows chained by row_bcast:15 / :31,
+// lane 63 holds the wave's result and hands it to everyone through the scalar unit
+template <> __device__ __forceinline__ double wave_sum<double>(double v) {
+    v += dpp_mov_f64<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov_f64<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov_f64<0x141, 0xF>(v);  // row_half_mirror
+    v += dpp_mov_f64<0x140, 0xF>(v);  // row_mirror
+    v += dpp_mov_f64<0x142, 0xA>(v);  // row_bcast:15 -> rows 1, 3
+    v += dpp_mov_f64<0x143, 0xC>(v);  // row_bcast:31 -> rows 2, 3
+    return wave_last(v);
+}
+template <> __device__ __forceinline__ double wave_min<double>(double v) {
+    v = fmin(v, dpp_mov_f64_keep<0xB1, 0xF>(v));
+    v = fmin(v, dpp_mov_f64_keep<0x4E, 0xF>(v));
+    v = fmin(v, dpp_mov_f64_keep<0x141, 0xF>(v));
+    v = fmin(v, dpp_mov_f64_keep<0x140, 0xF>(v));
+    v = fmin(v, dpp_mov_f64_keep<0x142, 0xA>(v));
+    v = fmin(v, dpp_mov_f64_keep<0x143, 0xC>(v));
+    return wave_last(v);
+}
+
 
 // 64-lane sum with DPP adds only (no LDS traffic): after the four row steps every lane of a
 // 16-lane row holds its row sum, row_bcast15 / row_bcast31 chain the rows; LANE 63 holds the total.
@@ -238,6 +276,18 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
     return v;
 }
 __device__ __forceinline__ double wave_sum_lane63(double v) { return wave_sum(v); }
+// the fp32 reductions of the update kernel on the same network
+template <> __device__ __forceinline__ float wave_sum<float>(float v) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum_lane63(v)), 63));
+}
+template <> __device__ __forceinline__ float wave_min<float>(float v) {
+#define MPPI_MIN_STEP(CTRL, MASK) \
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, MASK, 0xF, false)))
+    MPPI_MIN_STEP(0xB1, 0xF); MPPI_MIN_STEP(0x4E, 0xF); MPPI_MIN_STEP(0x141, 0xF); MPPI_MIN_STEP(0x140, 0xF);
+    MPPI_MIN_STEP(0x142, 0xA); MPPI_MIN_STEP(0x143, 0xC);
+#undef MPPI_MIN_STEP
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 
 // Sixteen 64-lane sums at once (the eps sums of one 6-step chunk use the first 12 of them) as a
 // reduce-scatter: each exchange halves the values a lane still carries.  The partner of a halving must
@@ -314,12 +364,6 @@ __device__ __forceinline__ double wave_sum16(const double (&v)[16], int lane) { 
 // 64-lane inclusive prefix sum on the DPP network (no LDS crossbar, no barriers): Kogge-Stone inside each
 // 16-lane row (row_shr 1, 2, 4, 8), then the row totals chained by row_bcast:15 (rows 1, 3) and
 // row_bcast:31 (rows 2, 3).  A double moves as two dwords; lanes without a source add 0.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_mov_f64(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, true);
-    return __hiloint2double(hi, lo);
-}
 __device__ __forceinline__ double wave_scan_incl(double v, int /*lane*/) {
     v += dpp_mov_f64<0x111, 0xF>(v);
     v += dpp_mov_f64<0x112, 0xF>(v);
@@ -328,9 +372,6 @@ __device__ __forceinline__ double wave_scan_incl(double v, int /*lane*/) {
     v += dpp_mov_f64<0x142, 0xA>(v);
     v += dpp_mov_f64<0x143, 0xC>(v);
     return v;
-}
-__device__ __forceinline__ double wave_last(double v) {  // lane 63's value, through the scalar unit
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
 // inclusive prefix sum over NWAVES * 64 consecutive lanes: shuffles inside each wave, the wave totals
