@@ -365,7 +365,13 @@ struct mppi_engine {
         }
         if (G < 1) fail(MPPI_E_INVALID, "n_shards must be >= 1");
         Scope sc(this, MPPI_KERNEL_FINALIZE);
-        hipLaunchKernelGGL(mppi::finalize_kernel, dim3(cfg.n_agents), dim3(256), (size_t)4 * cfg.horizon * sizeof(double),
+        const int T = cfg.horizon;
+        size_t lds = (size_t)4 * T * sizeof(double);
+        if (lds + (size_t)T * T * sizeof(double) <= 64 * 1024) {  // S_T fits next to the control rows: stage it
+            lds += (size_t)T * T * sizeof(double);
+            flags |= 8;
+        }
+        hipLaunchKernelGGL(mppi::finalize_kernel, dim3(cfg.n_agents), dim3(256), lds,
                            stream, P, gathered, G, d_S, d_unom, d_ufilt, d_state, d_out, d_tick, flags);
         HIPCHK(hipGetLastError());
         partials_ready = false;

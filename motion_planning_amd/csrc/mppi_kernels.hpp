@@ -1169,9 +1169,9 @@ __device__ __forceinline__ void rk4_exact(const DevParams& P, const double x0[3]
 // (:91-101) for one agent per block.
 //   gathered [G][A][T][8] shard partials (G = 1: this engine's own)
 //   flags: bit0 plant step (perform_action :210-213), bit1 receding-horizon shift (:100-101),
-//          bit2 bump the device tick counter (graph replay)
+//          bit2 bump the device tick counter (graph replay), bit3 S_T staged in LDS (T*T more doubles)
 //   ufilt [A][2][T] filtered controls (un-shifted), outv [A][8] = {next_state[3], u_applied[2]}
-// dynamic LDS = 4*T doubles.
+// dynamic LDS = 4*T doubles (+ T*T with bit3).
 // ---------------------------------------------------------------------------------------------
 #ifndef MPPI_ROLLOUT_TU  // non-template kernels are emitted by the engine translation unit only
 __global__ __launch_bounds__(256) void finalize_kernel(DevParams P, const double* __restrict__ gathered, int G,
@@ -1181,8 +1181,14 @@ __global__ __launch_bounds__(256) void finalize_kernel(DevParams P, const double
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* un = reinterpret_cast<double*>(smem_raw);  // [2][T] updated + clipped
     double* uf = un + 2 * P.T;                          // [2][T] filtered + clipped
+    double* Sl = uf + 2 * P.T;                          // [T][T] staged copy of the filter (flags bit3)
     __shared__ double trig[3][2];
     const int a = blockIdx.x, tid = threadIdx.x, T = P.T;
+    // the filter operator does not depend on anything this kernel waits for: fetch it now, all loads in
+    // flight at once, and read it from LDS when the updated controls are ready
+    const bool staged = (flags & 8) != 0;
+    if (staged)
+        for (int i = tid; i < T * T; i += blockDim.x) Sl[i] = Smat[i];
     for (int t = tid; t < T; t += blockDim.x) {
         double M = INFINITY;
         for (int g = 0; g < G; ++g) {
@@ -1208,7 +1214,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(DevParams P, const double
         const int c = idx >= T, j = idx - c * T;
         const double* ur = un + c * T;
         double acc = 0.0;
-        for (int t = 0; t < T; ++t) acc = fma(ur[t], Smat[(size_t)t * T + j], acc);
+        const double* Sm = staged ? Sl : Smat;
+        for (int t = 0; t < T; ++t) acc = fma(ur[t], Sm[(size_t)t * T + j], acc);
         uf[idx] = clampd(acc, P.u_max);
     }
     __syncthreads();
