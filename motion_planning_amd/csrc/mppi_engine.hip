@@ -205,8 +205,9 @@ struct mppi_engine {
         a.P = P; a.stream = st; a.k0 = k0; a.k1 = k1; a.philox = ph; a.store_eps = store;
         a.model = cfg.model;
         a.inline_nominal = !inline_nominal() ? 0 : (cfg.horizon <= 64 ? 1 : 2);
-        // the lean instantiation is written for the node's cost: Q = diag(q, q, 0), q > 0, no obstacle grid
-        a.general = P.q2 != 0.0 || P.grid_weight != 0.0 || P.q0 != P.q1 || !(P.q0 > 0.0);
+        // the lean instantiation is written for the node's cost: Q = diag(q, q, 0), q > 0 (and sane: it scales
+        // positions by sqrt(q/2)), no obstacle grid
+        a.general = P.q2 != 0.0 || P.grid_weight != 0.0 || P.q0 != P.q1 || !(P.q0 > 1e-100 && P.q0 < 1e100);
         a.seed = seed; a.tick = tick; a.tick_ptr = tick_ptr;
         a.state = ro_state ? ro_state : d_state; a.goal = ro_goal ? ro_goal : d_goal;
         a.unom = ro_unom ? ro_unom : d_unom; a.tc = d_tc; a.base = d_base;
