@@ -38,6 +38,11 @@ def _round_eps(eps, storage):
     return eps.astype(np.float32).astype(np.float64) if storage == "f32" else eps
 
 
+def _vtol_params(orc, state, u0, goal, V, T, params):
+    Vn = orc.get_cost2go(state, u0, goal, LAM, SIG, np.zeros((T, 2, 1)), params=params)
+    return 3e-7 * max(1.0, np.abs(V - Vn).max())
+
+
 def _vtol(orc, state, u0, goal, V, T, K):
     """3e-7 * max(1, max |V - V_nominal|): the fp32-offset storage tolerance."""
     Vn = orc.get_cost2go(state, u0, goal, LAM, SIG, np.zeros((T, 2, 1)))
@@ -167,6 +172,34 @@ def test_config1_k1000(orc, golden, nom, storage):
     assert np.abs(u - golden["c1_%s_unew" % nom]).max() < tu
     assert np.abs(nxt[0] - golden["c1_%s_next_state" % nom]).max() < (1e-12 if storage == "f64" else 1e-8)
     assert np.abs(ua[0] - golden["c1_%s_u_applied" % nom]).max() < tu
+
+
+@pytest.mark.parametrize("weights", ["anisotropic", "heading", "all"])
+@pytest.mark.parametrize("storage", ["f64", "f32"])
+def test_general_cost_weights(orc, weights, storage):
+    """Q, R, P1 other than the node's (control/src/mppi:69-73 are constructor constants there, configuration
+    here): anisotropic position weights and a heading weight leave the scaled-variable instantiation of
+    the rollout kernel and must still agree with the oracle running the reference's formulas."""
+    K, T = 3000, 50
+    q, r, p1 = {"anisotropic": ((700.0, 1300.0, 0.0), (1.0, 1.0), (1000.0, 1000.0, 1000.0)),
+                "heading": ((1000.0, 1000.0, 40.0), (1.0, 1.0), (1000.0, 1000.0, 1000.0)),
+                "all": ((350.0, 900.0, 15.0), (0.5, 2.0), (800.0, 1200.0, 300.0))}[weights]
+    params = orc.default_params()
+    params.q[:], params.r[:], params.p1[:] = q, r, p1
+    eps = _round_eps(orc.reference_noise(11, SIG, T, K), storage)
+    u0 = np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
+    state, goal = [0.1, -0.05, 2.9], [0.4, -1.0, -2.8]   # heading error across the +-pi cut
+    with _engine(K, T, storage, q=q, r=r, p1=p1) as e:
+        e.set_nominal(u0)
+        e.upload_noise(eps)
+        nxt, ua = e.tick(state, goal, noise="injected")
+        V = e.download_value()[0]
+    Vo = orc.get_cost2go(state, u0, goal, LAM, SIG, eps, params=params)
+    so, uo, _ = orc.get_path(state, goal, u0, eps, LAM, SIG, params=params)
+    tv = 1e-9 * np.abs(Vo).max() if storage == "f64" else _vtol_params(orc, state, u0, goal, Vo, T, params)
+    assert np.abs(V - Vo).max() <= tv
+    assert np.abs(ua[0] - uo).max() < (1e-9 if storage == "f64" else 1e-5)
+    assert np.abs(nxt[0] - so).max() < (1e-12 if storage == "f64" else 1e-8)
 
 
 @pytest.mark.parametrize("storage", ["f64", "f32"])
