@@ -249,7 +249,7 @@ def main():
                                            for k, v in phases.items()}
         kernels_us = {name: (dtimes[name][0] * 1e3 / dtimes[name][1] if dtimes[name][1] else None) for name in dtimes}
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             cpu = cpu_baseline(T, goal if goal is not None else [0.0, -1.0, 0.0])
         value = units_total / (elapsed / args.steps)
         line = {
@@ -263,7 +263,7 @@ def main():
                        "state_steps_per_tick": units_total * T, "storage": args.storage,
                        "noise": "device Philox4x32-10", "sigma": 0.9, "lambda": 0.001,
                        "parallelism": ("K-sharded x%d + all-gather" % world) if args.workload != "c5" else "agent replicas",
-                       "graph": bool(args.graph)},
+                       "graph": bool(args.graph), "tick_kernels": eng.info()["tick_kernels"]},
             "state_steps_per_s": value * T,
             "final_state": [float(x) for x in final_nxt[0]], "final_u": [float(x) for x in final_ua[0]],
             "sync_tick_us": sync_tick_us,

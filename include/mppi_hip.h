@@ -220,7 +220,8 @@ int mppi_kernel_timing_period(mppi_engine *h, int period);
 int mppi_kernel_times(mppi_engine *h, double *ms /*[MPPI_KERNEL_COUNT]*/,
                       int64_t *launches /*[MPPI_KERNEL_COUNT]*/);
 
-/* Bytes of HBM held by the engine, and launch geometry (blocks) of rollout / update kernels. */
+/* Bytes of HBM held by the engine, and the launch geometry (blocks) of a tick's kernels: rollout +
+ * update on the lane-per-sample path; the scan kernel and update_blocks = 0 on the small-K path. */
 int mppi_engine_info(mppi_engine *h, size_t *hbm_bytes, int32_t *rollout_blocks,
                      int32_t *update_blocks);
 

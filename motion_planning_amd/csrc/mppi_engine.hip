@@ -874,8 +874,10 @@ int mppi_kernel_times(mppi_engine* h, double* ms, int64_t* launches) {
 int mppi_engine_info(mppi_engine* h, size_t* hbm_bytes, int32_t* rollout_blocks, int32_t* update_blocks) {
     API_BEGIN(h)
     if (hbm_bytes) *hbm_bytes = h->hbm_bytes;
-    if (rollout_blocks) *rollout_blocks = h->roll_blocks * h->cfg.n_agents;
-    if (update_blocks) *update_blocks = h->NCH * h->cfg.horizon * h->cfg.n_agents;
+    // what a tick launches: the scan kernel alone (no update kernel), or rollout + update
+    const bool scan = h->small_nb > 0;
+    if (rollout_blocks) *rollout_blocks = (scan ? h->small_nb : h->roll_blocks) * h->cfg.n_agents;
+    if (update_blocks) *update_blocks = scan ? 0 : h->NCH * h->cfg.horizon * h->cfg.n_agents;
     API_END(h)
 }
 

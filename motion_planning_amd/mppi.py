@@ -256,7 +256,8 @@ class Engine(object):
     def info(self):
         b, r, u = C.c_size_t(), C.c_int32(), C.c_int32()
         self._ck(self._lib.mppi_engine_info(self._h, C.byref(b), C.byref(r), C.byref(u)))
-        return {"hbm_bytes": b.value, "rollout_blocks": r.value, "update_blocks": u.value}
+        return {"hbm_bytes": b.value, "rollout_blocks": r.value, "update_blocks": u.value,
+                "tick_kernels": "scan" if u.value == 0 else "lanes"}
 
 
 def savgol_matrix(horizon):
