@@ -20,6 +20,10 @@
 #include <string>
 #include <vector>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
 #include "mppi_hip.h"
 
 namespace {
@@ -177,7 +181,23 @@ int main(int argc, char** argv) {
         wp = {{1.0, 0.0}, {2.0, 1.0}, {1.0, 2.0}, {0.0, 2.0}, {0.0, 0.0}};
     else if (task != "park") { std::fprintf(stderr, "unknown task %s\n", task.c_str()); return 1; }
 
+    // MPPI_NODE_TRACE=<file>: a progress word in a memory-mapped file (no system call per update), so that
+    // a watchdog can tell where a run stopped: -1 creating, -2 created, i >= 0 callback i done, -3 destroying,
+    // -4 destroyed
+    volatile int* progress = nullptr;
+    if (const char* path = std::getenv("MPPI_NODE_TRACE")) {
+        const int fd = open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);
+        if (fd >= 0 && ftruncate(fd, 64) == 0) {
+            void* m = mmap(nullptr, 64, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            if (m != MAP_FAILED) progress = static_cast<volatile int*>(m);
+        }
+        if (fd >= 0) close(fd);
+    }
+    const bool trace = progress != nullptr;
+    if (trace) *progress = -1;
+    {
     Controller node(cfg, wp, thresh, seed);
+    if (trace) *progress = -2;
     Pose plant{0.0, 0.0, 0.0};
     for (int i = 0; i < callbacks; ++i) {
         double twist[2], u[2];
@@ -187,6 +207,10 @@ int main(int argc, char** argv) {
                     node.start().x, node.start().y, node.start().th, node.goal().x, node.goal().y, node.goal().th,
                     u[0], u[1], twist[0], twist[1], node.idx(), (int)node.done(), (int)node.init());
         plant = rk4(node.cfg(), plant, u, node.dt());
+        if (trace) *progress = i;
     }
+    if (trace) *progress = -3;
+    }
+    if (trace) *progress = -4;
     return 0;
 }

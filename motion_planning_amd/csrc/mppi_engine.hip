@@ -372,7 +372,9 @@ struct mppi_engine {
             lds += (size_t)T * T * sizeof(double);
             flags |= 8;
         }
-        hipLaunchKernelGGL(mppi::finalize_kernel, dim3(cfg.n_agents), dim3(256), lds,
+        // as many threads as the 2T filter outputs can use in slices (T = 50: 1000), at least 256
+        const int fin_threads = std::min(1024, std::max(256, ((2 * T * std::max(1, 1024 / (2 * T)) + 63) / 64) * 64));
+        hipLaunchKernelGGL(mppi::finalize_kernel, dim3(cfg.n_agents), dim3(fin_threads), lds,
                            stream, P, gathered, G, d_S, d_unom, d_ufilt, d_state, d_out, d_tick, flags);
         HIPCHK(hipGetLastError());
         partials_ready = false;

@@ -1174,7 +1174,7 @@ __device__ __forceinline__ void rk4_exact(const DevParams& P, const double x0[3]
 // dynamic LDS = 4*T doubles (+ T*T with bit3).
 // ---------------------------------------------------------------------------------------------
 #ifndef MPPI_ROLLOUT_TU  // non-template kernels are emitted by the engine translation unit only
-__global__ __launch_bounds__(256) void finalize_kernel(DevParams P, const double* __restrict__ gathered, int G,
+__global__ __launch_bounds__(1024) void finalize_kernel(DevParams P, const double* __restrict__ gathered, int G,
                                                       const double* __restrict__ Smat, double* __restrict__ unom,
                                                       double* __restrict__ ufilt, double* __restrict__ state,
                                                       double* __restrict__ outv, uint32_t* tick_ptr, int flags) {
@@ -1210,13 +1210,39 @@ __global__ __launch_bounds__(256) void finalize_kernel(DevParams P, const double
         un[T + t] = clampd(unom[((size_t)a * 2 + 1) * T + t] + du1, P.u_max);
     }
     __syncthreads();
-    for (int idx = tid; idx < 2 * T; idx += blockDim.x) {  // savgol_filter as u @ S (:202), clip (:205-206)
-        const int c = idx >= T, j = idx - c * T;
-        const double* ur = un + c * T;
-        double acc = 0.0;
+    {   // savgol_filter as u @ S (:202), clip (:205-206).  The 2T dot products of length T are cut into
+        // `parts` interleaved slices each so that the whole block works and the S loads of one output run as
+        // `parts` independent streams; the partial sums meet in LDS (uf doubles as scratch: parts <= 2 there,
+        // more go to psum).
+        __shared__ double psum[1024];
+        const int n_out = 2 * T;
+        const int parts = max(1, min((int)blockDim.x / n_out, 1024 / n_out));
         const double* Sm = staged ? Sl : Smat;
-        for (int t = 0; t < T; ++t) acc = fma(ur[t], Sm[(size_t)t * T + j], acc);
-        uf[idx] = clampd(acc, P.u_max);
+        if (tid < n_out * parts) {
+            const int o = tid % n_out, part = tid / n_out, c = o >= T, j = o - c * T;
+            const double* ur = un + c * T;
+            double acc = 0.0;
+            for (int t = part; t < T; t += parts) acc = fma(ur[t], Sm[(size_t)t * T + j], acc);
+            if (parts == 1) uf[o] = clampd(acc, P.u_max);
+            else psum[part * n_out + o] = acc;
+        }
+        if (parts > 1) {
+            __syncthreads();
+            if (tid < n_out) {
+                double acc = 0.0;
+                for (int q = 0; q < parts; ++q) acc += psum[q * n_out + tid];
+                uf[tid] = clampd(acc, P.u_max);
+            }
+        }
+        if (n_out > (int)blockDim.x) {  // T > blockDim.x / 2: the plain loop for the outputs not covered above
+            for (int idx = tid + (int)blockDim.x; idx < n_out; idx += blockDim.x) {
+                const int c = idx >= T, j = idx - c * T;
+                const double* ur = un + c * T;
+                double acc = 0.0;
+                for (int t = 0; t < T; ++t) acc = fma(ur[t], Sm[(size_t)t * T + j], acc);
+                uf[idx] = clampd(acc, P.u_max);
+            }
+        }
     }
     __syncthreads();
     // perform_action (:210-213): the three distinct stage angles of rk4 evaluated by three lanes

@@ -683,9 +683,20 @@ def test_cpp_node_matches_the_python_shim(tmp_path, tick_path, task, waypoints, 
     exe = str(tmp_path / "mppi_node")
     subprocess.run(["make", "-B", "-C", os.path.join(root, "examples"), "OUT=" + exe], check=True, capture_output=True)
     K, T, seed = 2048, 50, 5
-    out = subprocess.run([exe, "--task", task, "--samples", str(K), "--horizon", str(T), "--callbacks", str(n_cb),
-                          "--thresh", str(thresh), "--seed", str(seed), "--storage", "f64", "--tick-path", tick_path],
-                         capture_output=True, text=True, timeout=120)
+    cmd = [exe, "--task", task, "--samples", str(K), "--horizon", str(T), "--callbacks", str(n_cb),
+           "--thresh", str(thresh), "--seed", str(seed), "--storage", "f64", "--tick-path", tick_path]
+    env = dict(os.environ, MPPI_NODE_TRACE=str(tmp_path / "progress.bin"))
+    for attempt in (1, 2):
+        try:
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=30, env=env)
+            break
+        except subprocess.TimeoutExpired:
+            # a run takes 0.3 s.  On some boxes about one fresh process in 200 never returned (none in 900 on
+            # others; tools/hang_hunt.sh); the progress word says where it stopped.  One retry, then fail.
+            word = np.fromfile(str(tmp_path / "progress.bin"), dtype=np.int32, count=1)
+            print("mppi_node attempt %d timed out, progress word %s" % (attempt, word))
+            if attempt == 2:
+                raise
     assert out.returncode == 0, out.stderr[-2000:]
     rows = np.array([[float(x) for x in ln.split()] for ln in out.stdout.strip().splitlines()])
     assert rows.shape == (n_cb, 14)
