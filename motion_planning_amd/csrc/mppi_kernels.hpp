@@ -15,9 +15,13 @@
 //   (nominal_kernel  1 block / agent    the same nominal rollout by block scans, only for T > 256)
 //   update_kernel    1 block / (chunk,t,a)  per-timestep softmax over K: reads the cost prefix back
 //                                       (4 B/step) and eps only for the few samples with weight
-//   merge_kernel     1 wave / (t,a)     merges chunk partials -> shard partial [A][T][8]
+//   merge_kernel     1 block / (t,a)    merges chunk partials -> shard partial [A][T][8]
 //   finalize_kernel  1 block / agent    merges shard partials (after the RCCL all-gather),
 //                                       control update, clip, Savitzky-Golay, clip, plant step, shift
+// Small K (the node's own K = 10 ... ~10^4 samples) takes the latency path instead of rollout + update:
+//   scan_tick_kernel 1 wave|block / sample   lanes = TIMESTEPS: the trajectory as prefix scans over t,
+//                                       cost-to-go as a fourth scan, each timestep's lane folds the
+//                                       sample into its running softmax tuple -- V never leaves registers
 //
 // No MFMA: there is no dense contraction on this path.  All state / cost arithmetic is
 // fp64 (lambda = 1e-3 amplifies cost error 1000x inside exp(), fp32 accumulation of V ~ 1e4
