@@ -687,7 +687,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                         eps_a[(size_t)(t * 2 + 0) * Ks] = cur[j][0];
                         eps_a[(size_t)(t * 2 + 1) * Ks] = cur[j][1];
                     }
-                    dp[(size_t)t * Ks] = (S)pre;
+                    if (sizeof(S) == 4 && FULL) {
+                        // row t of dP as its own buffer: the descriptor is scalar arithmetic (base + t * pitch on
+                        // the SALU), the lane offset k * 4 is loop-invariant -- no per-store 64-bit VALU address
+                        const __amdgpu_buffer_rsrc_t row = __builtin_amdgcn_make_buffer_rsrc(
+                            dP + ((size_t)a * T + t) * Ks, 0, (int)(Ks * sizeof(S)), 0x00020000);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)pre), row, (unsigned)k * 4u, 0, 0);
+                    } else {
+                        dp[(size_t)t * Ks] = (S)pre;
+                    }
                 }
                 // EXPLORE + CLIP (control/src/mppi:147-152)
                 if (LEAN) {
