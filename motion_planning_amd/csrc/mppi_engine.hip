@@ -453,13 +453,15 @@ struct mppi_engine {
         d_state = dev_alloc<double>((size_t)A * 3, hbm_bytes);
         d_goal = dev_alloc<double>((size_t)A * 3, hbm_bytes);
         {   // small-K path: lanes = timesteps, one wave (T <= 64) or one block (T <= 256) per sample
-            // AUTO: measured ticks, scan vs lane kernels: K = 1000 16.8 vs 28.7 us, 4000 22.4 vs 29.7, 10000 28.8 vs 31.0, 16000 32.4 vs 32.0 (T = 50, a wave per sample);
-            // T = 100 (a block per sample): K = 500 20.1 vs 39.8, 2000 29.4 vs 40.4, 5000 40.7 vs 41.3, 10000 59.0 vs 43.4
+            // AUTO: measured ticks, scan vs lane kernels: K = 1000 16.1 vs 27.0 us, 4000 20.0 vs 28.4, 10000 26.8 vs 30.6, 16000 31.5 vs 31.3 (T = 50, a wave per sample);
+            // T = 100 (a block per sample): K = 500 19.0 vs 39.8, 2000 26.1 vs 40.4, 5000 36.9 vs 41.3, 10000 54.8 vs 43.4
             const bool applies = T <= 256 && cfg.model == MPPI_MODEL_DIFFDRIVE_RK4;
-            const bool want = cfg.tick_path == MPPI_TICK_SCAN || (cfg.tick_path == MPPI_TICK_AUTO && (long)A * K <= (T <= 64 ? 12288 : 4096));
+            const bool want = cfg.tick_path == MPPI_TICK_SCAN || (cfg.tick_path == MPPI_TICK_AUTO && (long)A * K <= (T <= 64 ? 12288 : 6144));
             if (applies && want) {
                 small_nw = T <= 64 ? 1 : 4;
-                const long unit_cap = small_nw == 1 ? 4096 : 1024;  // units the chip keeps resident at once
+                // units the chip keeps resident at once (152 VGPRs: 3 waves per SIMD x 1024 SIMDs): the kernel is
+                // latency-bound (46 % VALU-busy at K = 10^4), so a second round of waves would double its time
+                const long unit_cap = small_nw == 1 ? 3072 : 768;
                 small_spw = (int)std::max(1L, ((long)A * K + unit_cap - 1) / unit_cap);
                 const int units = (K + small_spw - 1) / small_spw;
                 small_nb = small_nw == 1 ? (units + 3) / 4 : units;

@@ -368,6 +368,26 @@ __device__ __forceinline__ double wave_sum16(const double (&v)[16], int lane) { 
 // 64-lane inclusive prefix sum on the DPP network (no LDS crossbar, no barriers): Kogge-Stone inside each
 // 16-lane row (row_shr 1, 2, 4, 8), then the row totals chained by row_bcast:15 (rows 1, 3) and
 // row_bcast:31 (rows 2, 3).  A double moves as two dwords; lanes without a source add 0.
+// one Kogge-Stone step of a 64-lane inclusive scan of unit complex numbers (rotations) under multiplication:
+// (c, s) *= the partner's (c, s); lanes without a source lane, or in a masked-off row, multiply by (1, 0)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void dpp_rotate_by_partner(double& c, double& s) {
+    const double pc = __hiloint2double(__builtin_amdgcn_update_dpp(0x3FF00000, __double2hiint(c), CTRL, ROW_MASK, 0xF, false),
+                                       __builtin_amdgcn_update_dpp(0, __double2loint(c), CTRL, ROW_MASK, 0xF, false));
+    const double ps = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(s), CTRL, ROW_MASK, 0xF, false),
+                                       __builtin_amdgcn_update_dpp(0, __double2loint(s), CTRL, ROW_MASK, 0xF, false));
+    const double cn = c * pc - s * ps;
+    s = s * pc + c * ps;
+    c = cn;
+}
+__device__ __forceinline__ void wave_scan_rotations(double& c, double& s) {
+    dpp_rotate_by_partner<0x111, 0xF>(c, s);
+    dpp_rotate_by_partner<0x112, 0xF>(c, s);
+    dpp_rotate_by_partner<0x114, 0xF>(c, s);
+    dpp_rotate_by_partner<0x118, 0xF>(c, s);
+    dpp_rotate_by_partner<0x142, 0xA>(c, s);
+    dpp_rotate_by_partner<0x143, 0xC>(c, s);
+}
 __device__ __forceinline__ double wave_scan_incl(double v, int /*lane*/) {
     v += dpp_mov_f64<0x111, 0xF>(v);
     v += dpp_mov_f64<0x112, 0xF>(v);
@@ -1063,6 +1083,8 @@ __global__ __launch_bounds__(256) void scan_tick_kernel(DevParams P, const doubl
     }
     const double half_uru = 0.5 * (P.r0 * un0 * un0 + P.r1 * un1 * un1);
     const double ls = P.lambda * P.sigma, w0 = ls * un0, w1 = ls * un1;
+    double sth0, cth0;
+    sincos(th0, &sth0, &cth0);
     uint32_t key0 = 0, key1 = 0, tick = 0;
     float sigf = 0.f;
     if (PHILOX) {
@@ -1092,6 +1114,20 @@ __global__ __launch_bounds__(256) void scan_tick_kernel(DevParams P, const doubl
         double tot_;
         const double th = th0 + (lanes_scan_incl<NWAVES>(h, t, sh_scan, tot_) - h);
         double s0, c0, ix, iy;
+        if (NWAVES == 1 && P.model == 0 && __all(fabs(h) <= 0.5)) {
+            // headings without a sincos per lane: every step is a small rotation (series), the heading at the
+            // END of step t is the running product of the rotations (lane 0's carries the initial heading), the
+            // heading at its start is that product turned back by the step's own rotation
+            double sp, cp;
+            small_sincos<7>(0.5 * h, sp, cp);
+            const double hc = fma(-2.0 * sp, sp, 1.0), hs = 2.0 * sp * cp;  // (cos h, sin h)
+            double c2 = lane == 0 ? hc * cth0 - hs * sth0 : hc, s2 = lane == 0 ? hs * cth0 + hc * sth0 : hs;
+            wave_scan_rotations(c2, s2);
+            c0 = c2 * hc + s2 * hs; s0 = s2 * hc - c2 * hs;
+            const double c1 = c0 * cp - s0 * sp, s1 = s0 * cp + c0 * sp;
+            const double aa = P.dt * P.rhalf * (u0 + u1) * (1.0 / 6.0);
+            ix = aa * (c0 + 4.0 * c1 + c2); iy = aa * (s0 + 4.0 * s1 + s2);
+        } else {
         sincos(th, &s0, &c0);
         if (P.model == 1) {
             ix = P.dt * (c0 * u0); iy = P.dt * (s0 * u0);
@@ -1108,6 +1144,7 @@ __global__ __launch_bounds__(256) void scan_tick_kernel(DevParams P, const doubl
             }
             const double aa = P.dt * P.rhalf * (u0 + u1) * (1.0 / 6.0);
             ix = aa * (c0 + 4.0 * c1 + c2); iy = aa * (s0 + 4.0 * s1 + s2);
+        }
         }
         const double X = x0 + lanes_scan_incl<NWAVES>(valid ? ix : 0.0, t, sh_scan, tot_);
         const double Y = y0 + lanes_scan_incl<NWAVES>(valid ? iy : 0.0, t, sh_scan, tot_);
