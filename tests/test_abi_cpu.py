@@ -46,14 +46,19 @@ def test_config_struct_layout_matches_header():
     from motion_planning_amd import _capi
     with tempfile.TemporaryDirectory() as d:
         src = os.path.join(d, "sz.c")
-        open(src, "w").write('#include <stdio.h>\n#include <stddef.h>\n#include "mppi_hip.h"\n'
-                             'int main(){printf("%zu %zu %zu", sizeof(mppi_config), offsetof(mppi_config, dt),'
-                             ' offsetof(mppi_config, floor_w));return 0;}')
+        fields = [name for name, _ in _capi.MppiConfig._fields_]
+        c_names = [("lambda" if f == "lambda_" else f) for f in fields]
+        prog = ('#include <stdio.h>\n#include <stddef.h>\n#include "mppi_hip.h"\nint main(){printf("%zu", sizeof(mppi_config));'
+                + "".join('printf(" %%zu", offsetof(mppi_config, %s));' % n for n in c_names)
+                + 'printf(" %d %d %d", MPPI_TICK_AUTO, MPPI_TICK_LANES, MPPI_TICK_SCAN);return 0;}')
+        open(src, "w").write(prog)
         exe = os.path.join(d, "sz")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
-        size, off_dt, off_floor = [int(x) for x in subprocess.check_output([exe]).split()]
-    assert size == C.sizeof(_capi.MppiConfig)
-    assert off_dt == _capi.MppiConfig.dt.offset and off_floor == _capi.MppiConfig.floor_w.offset
+        nums = [int(x) for x in subprocess.check_output([exe]).split()]
+    assert nums[0] == C.sizeof(_capi.MppiConfig)
+    for f, off in zip(fields, nums[1:1 + len(fields)]):  # every field, by name, at the offset the C compiler uses
+        assert getattr(_capi.MppiConfig, f).offset == off, f
+    assert tuple(nums[-3:]) == (_capi.MPPI_TICK_AUTO, _capi.MPPI_TICK_LANES, _capi.MPPI_TICK_SCAN)
 
 
 @pytest.mark.parametrize("T", [6, 10, 20, 50, 100, 200])
