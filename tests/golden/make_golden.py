@@ -291,6 +291,35 @@ def main():
     out["euler_seq_meta"] = np.array([K, T, seed, nt], dtype=np.int64)
     kat["euler_step"] = ref.euler(np.array([[0.3], [-0.2], [3.1]]), np.array([[1.25], [-0.5]]), 0.25)[:, 0].tolist()
 
+    # ---------------- H: the reference's own cost formulas with OTHER weights: Q, R, P1 are instance
+    # attributes (:69-73); overwriting them after construction runs get_cost / the terminal cost
+    # (:165-173, :180-184) unmodified on an anisotropic Q with a heading weight
+    K, T, seed = 48, 50, 13
+    mp = ref.MPPI(horizon=T, samples=K)
+    mp.Q = np.diag([350.0, 900.0, 15.0])
+    mp.R = np.diag([0.5, 2.0])
+    mp.P1 = np.diag([800.0, 1200.0, 300.0])
+    u0 = nominal_warm(T)
+    state, goal = np.array([0.1, -0.05, 2.9]), np.array([0.4, -1.0, -2.8])
+    np.random.seed(seed)
+    V, eps = mp.get_cost2go(state, u0.copy(), goal, LAM, sig)
+    assert np.array_equal(np.array(eps), np.random.RandomState(seed).normal(0.0, SIG, (T, 2, K)))
+    out["wts_c2g_V"] = V.copy()
+    out["wts_c2g_unew"] = mp.update_action(u0.copy(), eps, V.copy(), sig, LAM)
+    out["wts_c2g_meta"] = np.array([K, T, seed], dtype=np.int64)
+    out["wts_c2g_state"], out["wts_c2g_goal"], out["wts_c2g_u0"] = state, goal, u0
+    out["wts_q"], out["wts_r"], out["wts_p1"] = np.diag(mp.Q).copy(), np.diag(mp.R).copy(), np.diag(mp.P1).copy()
+    nt = 5
+    mp.initialize()
+    np.random.seed(seed + 1)
+    st, states, us = state.copy(), [], []
+    for _ in range(nt):
+        st = mp.get_path(st, goal)
+        states.append(st.copy())
+        us.append(mp.uvec[-1].copy())
+    out["wts_seq_states"], out["wts_seq_u"] = np.array(states), np.array(us)
+    out["wts_seq_meta"] = np.array([K, T, seed + 1, nt], dtype=np.int64)
+
     np.savez_compressed(os.path.join(HERE, "mppi_golden.npz"), **out)
     with open(os.path.join(HERE, "mppi_kat.json"), "w") as f:
         json.dump(kat, f, indent=1, sort_keys=True)

@@ -174,6 +174,35 @@ def test_config1_k1000(orc, golden, nom, storage):
     assert np.abs(ua[0] - golden["c1_%s_u_applied" % nom]).max() < tu
 
 
+@pytest.mark.parametrize("storage", ["f64", "f32"])
+def test_general_weights_golden(golden, storage):
+    """Q, R, P1 other than the node's constants against the reference itself (golden section H: the
+    reference's MPPI instance with its Q / R / P1 attributes overwritten)."""
+    q, r, p1 = [tuple(float(x) for x in golden[k]) for k in ("wts_q", "wts_r", "wts_p1")]
+    K, T, seed = [int(x) for x in golden["wts_c2g_meta"]]
+    eps = np.random.RandomState(seed).normal(0.0, SIG, (T, 2, K))
+    state, goal, u0 = golden["wts_c2g_state"], golden["wts_c2g_goal"], golden["wts_c2g_u0"]
+    with _engine(K, T, storage, q=q, r=r, p1=p1) as e:
+        e.set_nominal(u0)
+        e.upload_noise(eps)
+        e.rollout(state, goal, noise="injected")
+        V = e.download_value()[0]
+        u = e.update()[0]
+        K2, T2, seed2, nt = [int(x) for x in golden["wts_seq_meta"]]
+        noise = np.random.RandomState(seed2).normal(0.0, SIG, (nt, T, 2, K))
+        e.reset()
+        st = state.copy()
+        for i in range(nt):
+            e.upload_noise(noise[i])
+            nxt, ua = e.tick(st, goal, noise="injected")
+            st = nxt[0]
+            assert np.abs(st - golden["wts_seq_states"][i]).max() < (1e-10 if storage == "f64" else 1e-8), i
+            assert np.abs(ua[0] - golden["wts_seq_u"][i]).max() < (1e-9 if storage == "f64" else 1e-5), i
+    Vg = golden["wts_c2g_V"]
+    assert np.abs(V - Vg).max() < (1e-9 * np.abs(Vg).max() if storage == "f64" else 3e-3)
+    assert np.abs(u - golden["wts_c2g_unew"]).max() < (1e-9 if storage == "f64" else 1e-5)
+
+
 @pytest.mark.parametrize("weights", ["anisotropic", "heading", "all"])
 @pytest.mark.parametrize("storage", ["f64", "f32"])
 def test_general_cost_weights(orc, weights, storage):

@@ -169,6 +169,26 @@ def test_euler_unicycle_model(orc, golden, kat):
         assert np.abs(ua - golden["euler_seq_u"][i]).max() < 1e-9
 
 
+def test_general_weights_golden(orc, golden):
+    """Q, R, P1 other than the node's constants, pinned by the reference itself (its MPPI instance with the
+    attributes of control/src/mppi:69-73 overwritten; tests/golden/make_golden.py section H)."""
+    p = orc.default_params()
+    p.q[:], p.r[:], p.p1[:] = golden["wts_q"], golden["wts_r"], golden["wts_p1"]
+    K, T, seed = [int(x) for x in golden["wts_c2g_meta"]]
+    eps = orc.reference_noise(seed, SIG, T, K)
+    state, goal, u0 = golden["wts_c2g_state"], golden["wts_c2g_goal"], golden["wts_c2g_u0"]
+    V = orc.get_cost2go(state, u0, goal, LAM, SIG, eps, params=p)
+    assert np.abs(V - golden["wts_c2g_V"]).max() < 1e-9 * np.abs(golden["wts_c2g_V"]).max()
+    assert np.abs(orc.update_action(u0, eps, V, LAM, params=p) - golden["wts_c2g_unew"]).max() < 1e-9
+    K, T, seed, nt = [int(x) for x in golden["wts_seq_meta"]]
+    noise = orc.reference_noise(seed, SIG, T, K, n_ticks=nt)
+    st, lat = state.copy(), np.zeros((2, T))
+    for i in range(nt):
+        st, ua, lat = orc.get_path(st, goal, lat, noise[i], LAM, SIG, params=p)
+        assert np.abs(st - golden["wts_seq_states"][i]).max() < 1e-10
+        assert np.abs(ua - golden["wts_seq_u"][i]).max() < 1e-9
+
+
 def test_obstacle_grid_extension_is_off_by_default(orc, golden):
     """The obstacle-grid stage cost is NOT in the reference: weight 0 / no grid must
     leave the golden results untouched, a weighted grid must add exactly weight*value/100 per step."""
