@@ -320,6 +320,23 @@ def main():
     out["wts_seq_states"], out["wts_seq_u"] = np.array(states), np.array(us)
     out["wts_seq_meta"] = np.array([K, T, seed + 1, nt], dtype=np.int64)
 
+    # ---------------- I: another temperature and noise level (the sig / lam arguments of get_path, :88-89)
+    K, T, seed, nt = 40, 50, 21, 5
+    sig2, lam2 = 0.4, 0.02
+    mp = ref.MPPI(horizon=T, samples=K)
+    np.random.seed(seed)
+    st, goal = np.array([0.2, 0.1, -0.4]), np.array([-0.3, -0.8, 1.0])
+    states, us = [], []
+    for _ in range(nt):
+        st = mp.get_path(st, goal, sig=np.array([[sig2, 0.0], [0.0, sig2]]), lam=lam2)
+        states.append(st.copy())
+        us.append(mp.uvec[-1].copy())
+    out["lamsig_seq_states"], out["lamsig_seq_u"] = np.array(states), np.array(us)
+    out["lamsig_seq_latest_uvec"] = mp.latest_uvec.copy()
+    out["lamsig_seq_meta"] = np.array([K, T, seed, nt], dtype=np.int64)
+    out["lamsig_params"] = np.array([sig2, lam2])
+    out["lamsig_state0"], out["lamsig_goal"] = np.array([0.2, 0.1, -0.4]), goal
+
     np.savez_compressed(os.path.join(HERE, "mppi_golden.npz"), **out)
     with open(os.path.join(HERE, "mppi_kat.json"), "w") as f:
         json.dump(kat, f, indent=1, sort_keys=True)

@@ -203,6 +203,24 @@ def test_general_weights_golden(golden, storage):
     assert np.abs(u - golden["wts_c2g_unew"]).max() < (1e-9 if storage == "f64" else 1e-5)
 
 
+@pytest.mark.parametrize("storage", ["f64", "f32"])
+def test_other_sigma_and_lambda_golden(golden, storage):
+    """MPPI.get_path with other sig / lam arguments (control/src/mppi:88-89) against the reference (golden
+    section I), through the reference-mirror class with numpy's RNG stream."""
+    from motion_planning_amd import MPPI
+    K, T, seed, nt = [int(x) for x in golden["lamsig_seq_meta"]]
+    sig2, lam2 = [float(x) for x in golden["lamsig_params"]]
+    m = MPPI(horizon=T, samples=K, storage=storage)
+    np.random.seed(seed)
+    st = golden["lamsig_state0"].copy()
+    tol_s, tol_u = (1e-10, 1e-9) if storage == "f64" else (1e-7, 2e-5)  # lam = 0.02: 20x flatter softmax than the node's
+    for i in range(nt):
+        st = m.get_path(st, golden["lamsig_goal"], sig=np.array([[sig2, 0.0], [0.0, sig2]]), lam=lam2)
+        assert np.abs(st - golden["lamsig_seq_states"][i]).max() < tol_s, i
+        assert np.abs(m.uvec[-1] - golden["lamsig_seq_u"][i]).max() < tol_u, i
+    assert np.abs(m.latest_uvec - golden["lamsig_seq_latest_uvec"]).max() < tol_u
+
+
 @pytest.mark.parametrize("weights", ["anisotropic", "heading", "all"])
 @pytest.mark.parametrize("storage", ["f64", "f32"])
 def test_general_cost_weights(orc, weights, storage):

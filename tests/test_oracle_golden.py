@@ -189,6 +189,19 @@ def test_general_weights_golden(orc, golden):
         assert np.abs(ua - golden["wts_seq_u"][i]).max() < 1e-9
 
 
+def test_other_sigma_and_lambda_golden(orc, golden):
+    """get_path with the sig / lam arguments the node never changes (control/src/mppi:88-89), golden section I."""
+    K, T, seed, nt = [int(x) for x in golden["lamsig_seq_meta"]]
+    sig2, lam2 = [float(x) for x in golden["lamsig_params"]]
+    noise = orc.reference_noise(seed, sig2, T, K, n_ticks=nt)
+    st, lat = golden["lamsig_state0"].copy(), np.zeros((2, T))
+    for i in range(nt):
+        st, ua, lat = orc.get_path(st, golden["lamsig_goal"], lat, noise[i], lam2, sig2)
+        assert np.abs(st - golden["lamsig_seq_states"][i]).max() < 1e-10
+        assert np.abs(ua - golden["lamsig_seq_u"][i]).max() < 1e-9
+    assert np.abs(lat - golden["lamsig_seq_latest_uvec"]).max() < 1e-9
+
+
 def test_obstacle_grid_extension_is_off_by_default(orc, golden):
     """The obstacle-grid stage cost is NOT in the reference: weight 0 / no grid must
     leave the golden results untouched, a weighted grid must add exactly weight*value/100 per step."""
