@@ -337,6 +337,15 @@ def main():
     out["lamsig_params"] = np.array([sig2, lam2])
     out["lamsig_state0"], out["lamsig_goal"] = np.array([0.2, 0.1, -0.4]), goal
 
+    # ---------------- J: the offline harness solve_path (:104-125): ticks until within thresh of the goal
+    K, T, seed = 32, 20, 31
+    mp = ref.MPPI(horizon=T, samples=K, thresh=0.8)
+    np.random.seed(seed)
+    mp.solve_path(np.array([0.0, 0.0, 0.0]), np.array([1.0, 0.2, 0.0]))
+    out["solve_path_path"] = mp.path.copy()          # [iterations + 1][3]
+    out["solve_path_uvec"] = mp.uvec.copy()
+    out["solve_path_meta"] = np.array([K, T, seed, mp.path.shape[0] - 1], dtype=np.int64)
+
     np.savez_compressed(os.path.join(HERE, "mppi_golden.npz"), **out)
     with open(os.path.join(HERE, "mppi_kat.json"), "w") as f:
         json.dump(kat, f, indent=1, sort_keys=True)

@@ -202,6 +202,20 @@ def test_other_sigma_and_lambda_golden(orc, golden):
     assert np.abs(lat - golden["lamsig_seq_latest_uvec"]).max() < 1e-9
 
 
+def test_solve_path_golden(orc, golden):
+    """The offline harness (control/src/mppi:104-125, sig = I, lam = 0.01): tick until within thresh of the goal."""
+    K, T, seed, n_it = [int(x) for x in golden["solve_path_meta"]]
+    path = golden["solve_path_path"]
+    noise = orc.reference_noise(seed, 1.0, T, K, n_ticks=n_it)
+    st, goal, lat = np.zeros(3), np.array([1.0, 0.2, 0.0]), np.zeros((2, T))
+    i = 0
+    while np.linalg.norm(st[:2] - goal[:2]) > 0.8:
+        st, ua, lat = orc.get_path(st, goal, lat, noise[i], 0.01, 1.0)
+        i += 1
+        assert np.abs(st - path[i]).max() < 1e-10 and np.abs(ua - golden["solve_path_uvec"][i]).max() < 1e-9
+    assert i == n_it
+
+
 def test_obstacle_grid_extension_is_off_by_default(orc, golden):
     """The obstacle-grid stage cost is NOT in the reference: weight 0 / no grid must
     leave the golden results untouched, a weighted grid must add exactly weight*value/100 per step."""
