@@ -650,13 +650,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
             buf[j][1] = ok ? eps_a[(size_t)(t * 2 + 1) * Ks] : (S)0;
         }
     };
-    auto draw_chunk = [&](int t0, S (&buf)[U][2]) {  // two Philox calls, three steps each
+    auto draw_chunk = [&](int t0, S (&buf)[U][2], auto tail_tag) {  // two Philox calls, three steps each
+        constexpr bool TAIL = decltype(tail_tag)::value;  // ragged tail: skip the draws that lie wholly beyond T
 #pragma unroll
         for (int j = 0; j < U; j += kStepsPerDraw) {
-            float e[6];
-            philox_normals(ctr0, (uint32_t)((t0 + j) / kStepsPerDraw), tick, (uint32_t)a, key0, key1, sigf, e);
+            if (!TAIL || t0 + j < T) {  // (uniform)
+                float e[6];
+                philox_normals(ctr0, (uint32_t)((t0 + j) / kStepsPerDraw), tick, (uint32_t)a, key0, key1, sigf, e);
 #pragma unroll
-            for (int i = 0; i < kStepsPerDraw; ++i) { buf[j + i][0] = (S)e[2 * i]; buf[j + i][1] = (S)e[2 * i + 1]; }
+                for (int i = 0; i < kStepsPerDraw; ++i) { buf[j + i][0] = (S)e[2 * i]; buf[j + i][1] = (S)e[2 * i + 1]; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < kStepsPerDraw; ++i) { buf[j + i][0] = (S)0; buf[j + i][1] = (S)0; }
+            }
         }
     };
     if (!PHILOX) load_chunk(0, cur);
@@ -812,7 +818,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     const int T4 = T - T % U;  // steps covered by full chunks
     auto run = [&](auto full_tag) {
         for (int t0 = 0; t0 < T4; t0 += U) {  // full chunks: straight-line code
-            if (PHILOX) draw_chunk(t0, cur);
+            if (PHILOX) draw_chunk(t0, cur, std::false_type{});
             else load_chunk(t0 + U, nxt);  // prefetch: HBM latency hides under this chunk's math
             eps_sums(t0, full_tag);
             integrate(t0, std::false_type{}, full_tag);
@@ -822,7 +828,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
             }
         }
         if (T4 < T) {  // ragged tail
-            if (PHILOX) draw_chunk(T4, cur);
+            if (PHILOX) draw_chunk(T4, cur, std::true_type{});
             eps_sums(T4, full_tag);
             integrate(T4, std::true_type{}, full_tag);
         }
