@@ -131,3 +131,30 @@ def test_cpp_node_links_against_the_c_abi(tmp_path):
         return
     out = subprocess.run([exe, "--callbacks", "2"], capture_output=True, text=True, timeout=60)
     assert out.returncode == 2 and "mppi_create" in out.stderr and out.stdout == ""
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    """profiles/r1_bench_c4.json is the line bench.py printed on the GPU box: every field the bench contract
+    names is there, the roofline arithmetic is self-consistent and names the workload of BASELINE.json."""
+    import json
+    line = json.load(open(os.path.join(ROOT, "profiles", "r1_bench_c4.json")))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["higher_is_better"] is True and line["vs_baseline"] is None
+    assert line["unit"] == "rollouts/s" and line["data"] == "synthetic" and line["dtype"] == "f64"
+    assert "K=1000000 T=50" in line["config"]["workload"] and "model" not in line["config"]
+    roof = line["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in roof, key
+    assert roof["bound"] in ("hbm", "mfma") and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
+    # achieved = algorithmic bytes per launch / the event-measured average launch duration
+    assert abs(roof["achieved"] - roof["algorithmic_bytes_per_launch"] / (roof["avg_launch_us"] * 1e-6) / 1e9) < 1e-6 * roof["achieved"]
+    assert roof["algorithmic_bytes_per_launch"] == 12 * line["config"]["state_steps_per_tick"]
+    # value = whole-job rollouts per tick / tick time
+    assert abs(line["value"] - line["config"]["samples_total"] / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+    cpu = line["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cpu, key
+    assert cpu["kind"] in ("reference", "port") and cpu["cores"] >= 1
