@@ -229,9 +229,13 @@ class Engine(object):
         return nxt, ua
 
     def tick(self, state=None, goal=None, noise="philox", seed=0, tick_id=0):
-        self.tick_begin(state, goal, noise, seed, tick_id)
-        self.tick_finish()
-        return self.get_outputs()
+        """One blocking control tick: mppi_tick (= tick_begin + tick_finish + get_outputs in one call)."""
+        s, g = self._sg(state, goal)
+        mode = MPPI_NOISE_PHILOX if noise == "philox" else MPPI_NOISE_INJECTED
+        nxt, ua = np.empty((self.A, 3)), np.empty((self.A, 2))
+        self._ck(self._lib.mppi_tick(self._h, _capi.dptr(s), _capi.dptr(g), mode, int(seed), int(tick_id),
+                                     _capi.dptr(nxt), _capi.dptr(ua)))
+        return nxt, ua
 
     def tick_graph(self, seed=0):
         self._ck(self._lib.mppi_tick_graph(self._h, int(seed)))
