@@ -1,22 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- MPPI rollouts/s per control tick on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c2|c3|c5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c2|c3|c5] [--storage f32|f64]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one full control tick (MPPI.get_path, control/src/mppi:85-102) on synthetic
-inputs, device Philox noise, closed loop on the model (the predicted state feeds the next
-tick), everything resident in HBM: nominal baseline -> rollout+cost -> per-timestep softmax
-partials -> [RCCL all-gather of the [A][T][8] partials when K is sharded] -> control update,
-clip, Savitzky-Golay, clip, plant step, shift.
+A "step" is one full control tick (MPPI.get_path, control/src/mppi:85-102) on synthetic inputs, device
+Philox noise, closed loop on the model (the predicted state feeds the next tick), everything resident in
+HBM: nominal baseline -> rollout+cost -> per-timestep softmax partials -> [exchange of the [A][T][8]
+partials when K is sharded] -> control update, clip, Savitzky-Golay, clip, plant step, shift.
 
-Default workload = BASELINE config 4, the one the north-star target is quoted on:
-parallel park, K = 1 000 000 rollouts, T = 50, K split over the N GPUs (strong scaling: the
-north star "2/4/8-GPU runs split K").  It fits one GPU, so N = 1 runs all of it.
---workload c2 / c3 / c5 select the other BASELINE configs (single-GPU cases; c5 = 64 agents).
+Default workload = BASELINE config 4, the one the north-star target is quoted on: parallel park,
+K = 1 000 000 rollouts, T = 50, K split over the N GPUs (strong scaling: the north star "2/4/8-GPU runs
+split K").  It fits one GPU, so N = 1 runs all of it.  --workload c2 / c5 select other BASELINE configs;
+--workload c3 is config 3 as SURVEY 8d-3 specifies it: the node shell driven through the five waypoints of
+control/config/waypoints.yaml with blocking ticks (goal switches need the pose on the host every tick).
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -28,15 +29,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-BYTES_PER_STEP_PER_KERNEL = 12  # eps 2 x fp32 + V 1 x fp32, written once (rollout) / read once (update)
+CLOCK_PEAK_HZ = 2.4e9  # max shader clock, same guide
+N_SIMD = 1024          # 256 CUs x 4 SIMDs
+BYTES_PER_STEP_PER_KERNEL = 12  # eps 2 x fp32 + V 1 x fp32, written once (rollout) / read once (update): SURVEY 8(d)
+PROFILE_ROUND = "r2"
 
 WORKLOADS = {
     # name: (description, agents, K_total, T, goal)
     "c4": ("parallel-park K=1000000 T=50 (BASELINE config 4; K split over the GPUs)", 1, 1000000, 50, [0.0, -1.0, 0.0]),
     "c2": ("parallel-park K=10000 T=50 (BASELINE config 2)", 1, 10000, 50, [0.0, -1.0, 0.0]),
-    "c3": ("pentagon waypoint-follow K=100000 T=100 (BASELINE config 3, first waypoint)", 1, 100000, 100, [1.0, 0.0, 0.0]),
+    "c3": ("pentagon waypoint-follow K=100000 T=100 (BASELINE config 3: the node shell through the five waypoints "
+           "of control/config/waypoints.yaml, blocking ticks)", 1, 100000, 100, [1.0, 0.0, 0.0]),
     "c5": ("64 agents x K=16384 T=50 (BASELINE config 5; agents split over the GPUs)", 64, 16384, 50, None),
 }
+PENTAGON = [[1, 0], [2, 1], [1, 2], [0, 2], [0, 0]]   # control/config/waypoints.yaml:1
 
 
 def nominal_warm(T):
@@ -61,11 +67,12 @@ def host_cores():
     return n
 
 
-def cpu_baseline(T, goal, budget_s=12.0):
-    """The oracle (C restatement of the reference loop, oracle/mppi_oracle.c) timed on this box's
-    host cores on a bounded sample of the same workload: K_cpu rollouts of the same T, once on
-    1 thread (the scalar port) and once with OpenMP over K on every usable core; the better
-    of the two is `value` (with its thread count in `cores`)."""
+def cpu_baseline(T, goal, budget_s=14.0):
+    """The oracle (C restatement of the reference loop, oracle/mppi_oracle.c) timed on this box's host cores.
+    `value`: a bounded sample of the SAME workload (K_cpu rollouts of the same T, goal and nominal), on 1 thread
+    (the scalar port) and with OpenMP over K on every usable core; the better one is `value`.
+    `baseline_md_inputs`: BASELINE.md section 3's own inputs -- config 1 (K = 1000) and config 2 (K = 10 000), T = 50,
+    noise RandomState(0), zero and warm nominal controls -- median and p99 tick time at 1 thread and at all cores."""
     from oracle import oracle as orc
     orc.build()
     cores = host_cores()
@@ -82,14 +89,104 @@ def cpu_baseline(T, goal, budget_s=12.0):
             orc.get_path([0, 0, 0], goal, u0, eps, 0.001, 0.9, S=S)
             n += 1
             el = time.perf_counter() - t0
-            if el > budget_s / 2 or n >= 20:
+            if el > budget_s / 4 or n >= 20:
                 break
         out[used] = K_cpu * n / el
     best = max(out, key=lambda k: out[k])
+    # configs 1 and 2, closed loop on the model, >= 20 warm-up and up to 200 timed ticks (time-capped)
+    md = {}
+    S50 = orc.savgol_matrix(50)
+    for name, K in (("c1_K1000", 1000), ("c2_K10000", 10000)):
+        noise = np.random.RandomState(0).normal(0.0, 0.9, (50, 2, K))
+        for nom_name, nom in (("zero", np.zeros((2, 50))), ("warm", nominal_warm(50))):
+            for nthr in sorted({1, cores}):
+                used = orc.set_threads(nthr)
+                st, lat, ts = np.zeros(3), nom.copy(), []
+                cap = time.perf_counter() + budget_s / 16
+                for i in range(220):
+                    t0 = time.perf_counter()
+                    st, _, lat = orc.get_path(st, [0.0, -1.0, 0.0], lat, noise, 0.001, 0.9, S=S50)
+                    if i >= 20:
+                        ts.append(time.perf_counter() - t0)
+                    if time.perf_counter() > cap and len(ts) >= 10:
+                        break
+                ts = np.sort(np.array(ts))
+                md["%s_%s_%dthr" % (name, nom_name, used)] = {
+                    "median_ms": float(1e3 * np.median(ts)), "p99_ms": float(1e3 * ts[min(len(ts) - 1, int(0.99 * len(ts)))]),
+                    "rollouts_per_s": float(K / np.median(ts)), "ticks": len(ts)}
+    orc.set_threads(cores)
     return {"value": out[best], "unit": "rollouts/s", "cores": best, "kind": "port",
             "by_threads": {str(k): v for k, v in out.items()}, "usable_cores": cores,
             "sample": "oracle get_path ticks (fp64, injected noise, OpenMP over K), K=%d T=%d, same goal/nominal as the "
-                      "GPU workload; noise generation excluded" % (K_cpu, T)}
+                      "GPU workload; noise generation excluded" % (K_cpu, T),
+            "baseline_md_inputs": md}
+
+
+class HipEvents(object):
+    """HIP events on an arbitrary stream through ctypes (torch.cuda.Event only sees torch's current stream)."""
+
+    def __init__(self):
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+        self.hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+        self.hip.hipEventSynchronize.argtypes = [C.c_void_p]
+        self.pool = []
+
+    def record(self, stream):
+        ev = C.c_void_p()
+        assert self.hip.hipEventCreate(C.byref(ev)) == 0
+        assert self.hip.hipEventRecord(ev, C.c_void_p(stream)) == 0
+        self.pool.append(ev)
+        return ev
+
+    def elapsed_us(self, a, b):
+        ms = C.c_float()
+        assert self.hip.hipEventSynchronize(b) == 0
+        assert self.hip.hipEventElapsedTime(C.byref(ms), a, b) == 0
+        return 1e3 * ms.value
+
+    def free(self):
+        for ev in self.pool:
+            self.hip.hipEventDestroy(ev)
+        self.pool = []
+
+
+def dist_stats(us):
+    us = np.sort(np.asarray(us, dtype=np.float64))
+    return {"mean": float(us.mean()), "median": float(np.median(us)),
+            "p99": float(us[min(len(us) - 1, int(0.99 * len(us)))]), "ticks": int(len(us))}
+
+
+def load_profile(name):
+    path = os.path.join(ROOT, "profiles", name)
+    return json.load(open(path)) if os.path.exists(path) else None
+
+
+def run_pentagon(args, K, T, local_rank):
+    """Config 3: Controller (control/src/mppi:296-389) through the pentagon with blocking ticks; a step is a callback
+    that runs a control tick (goal-switch callbacks only reset the nominal controls, :356-375)."""
+    from motion_planning_amd import MPPI, Controller, rk4
+    m = MPPI(horizon=T, samples=K, rng="philox", seed=0, storage=args.storage, device=local_rank)
+    c = Controller(PENTAGON, mppi=m)
+    plant = np.array([0.0, 0.0, 0.0])
+    lat, switches, ticks, t_start = [], 0, 0, time.perf_counter()
+    want = args.warmup + args.steps
+    warm_until = t_start + args.min_warmup_s
+    timed, elapsed = [], None
+    while len(timed) < args.steps:
+        tick_before, idx_before = m._tick, c.idx
+        t0 = time.perf_counter()
+        c.pos_cb(plant[0], plant[1], plant[2])
+        dt = time.perf_counter() - t0
+        if m._tick > tick_before:
+            ticks += 1
+            if ticks > args.warmup and time.perf_counter() > warm_until:
+                timed.append(dt)
+        switches += int(c.idx != idx_before)
+        u = np.array([0.0, 0.0]) if c.done else m.uvec[-1, :].copy()
+        plant = rk4(plant, u, m.dt)
+    return m._eng, np.array(timed), {"waypoint_switches": switches, "ticks_total": ticks, "final_pose": [float(x) for x in plant],
+                                     "wanted": want}
 
 
 def main():
@@ -97,10 +194,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--min-warmup-s", type=float, default=0.35,
+                    help="keep warming up until this much wall time has passed as well (clocks ramp by time, not by count)")
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--storage", default="f32", choices=["f32", "f64"])
     ap.add_argument("--samples", type=int, default=0, help="override K_total")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "rccl", "p2p"],
+                    help="N > 1: how the [A][T][8] partials cross GPUs (auto = p2p over IPC-mapped mailboxes when the probe passes, else RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f64-line", action="store_true", help="skip the extra all-fp64 measurement (N = 1, c4)")
     ap.add_argument("--graph", action="store_true", help="replay the tick as one hipGraph (N=1 only)")
     args = ap.parse_args()
 
@@ -124,31 +226,7 @@ def main():
     desc, A_total, K_total, T, goal = WORKLOADS[args.workload]
     if args.samples:
         K_total = args.samples
-    if args.workload == "c5":  # independent agents: replicas, no collective
-        lo, hi = sharded.shard_range(A_total, world, rank)
-        A = hi - lo
-        from motion_planning_amd.mppi import Engine
-        eng = Engine(K_total, T, n_agents=A, storage=args.storage, device=local_rank)
-        ticker = sharded.ShardedTicker.__new__(sharded.ShardedTicker)
-        ticker.shard = sharded.HipShard(eng, torch.device("cuda", local_rank), use_torch_stream=False)
-        ticker.world, ticker.rank, ticker.dist, ticker.group, ticker._gathered = 1, 0, None, None, None
-        states = np.array([[0.05 * a, 0.0, 0.0] for a in range(lo, hi)])
-        goals = np.array([[0.05 * a, -1.0, 0.0] for a in range(lo, hi)])
-        K_local, units_total = K_total, A_total * K_total
-    else:
-        ticker, eng = sharded.make_hip_ticker(K_total, T, n_agents=1, storage=args.storage, local_rank=local_rank)
-        A = 1
-        states, goals = np.zeros((1, 3)), np.array([goal])
-        K_local, units_total = eng.K, K_total
-    for a in range(A):
-        eng.set_nominal(nominal_warm(T), agent=a)
-
-    seed = 0
-    def tick(i, first=False):
-        if args.graph and not in_group and not first:
-            eng.tick_graph(seed)
-        else:
-            ticker.tick_async(states if first else None, goals if first else None, "philox", seed, i)
+    extra = {}
 
     def sync():
         torch.cuda.synchronize()
@@ -156,59 +234,176 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    tick(0, first=True)
-    for i in range(1, args.warmup + 1):
-        tick(i)
-    # Timed region: exactly --steps ticks between barrier + synchronize pairs.  The dominant kernel
-    # (rollout) is timed live with HIP events that ride on its own launch (hipExtLaunchKernelGGL start /
-    # stop events on the engine's stream = the dispatch's begin / end timestamps, the clock rocprofv3
-    # --kernel-trace reads); no marker packets enter the stream, so every EVENT_PERIOD-th launch is sampled
-    # only to keep the event pool small.
-    EVENT_PERIOD = int(os.environ.get("MPPI_EVENT_PERIOD", "4"))
-    eng.kernel_timing(("rollout",), period=EVENT_PERIOD)
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        tick(args.warmup + 1 + i)
-    sync()
-    elapsed = time.perf_counter() - t0
-    ktimes = eng.kernel_times()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms_per_step = 1e3 * elapsed / args.steps
-
-    # Diagnostic pass (not the headline clock): every kernel bracketed on every launch.
-    n_diag = min(args.steps, 20)
-    eng.kernel_timing(("nominal", "rollout", "update", "merge", "finalize"), period=1)
-    sync()
-    for i in range(n_diag):
-        tick(args.warmup + 1 + args.steps + i)
-    sync()
-    dtimes = eng.kernel_times()
-    eng.kernel_timing(())
-    nxt, ua = eng.get_outputs()
-    assert np.isfinite(nxt).all() and np.isfinite(ua).all()
-    final_nxt, final_ua = nxt.copy(), ua.copy()
-
-    # Diagnostic: the node's own call pattern -- host state in, blocking, host controls out
-    # (mppi_tick; what Controller.pos_cb pays per odometry message), N = 1 only.
-    sync_tick_us = None
-    btimes = None
-    if not in_group:
-        n_lat = min(args.steps, 200)
-        eng.kernel_timing(("rollout",), period=1)
-        st, lat = nxt, []
-        for i in range(n_lat):
-            t0 = time.perf_counter()
-            st, _ = eng.tick(st, goals, noise="philox", seed=seed, tick_id=10_000_000 + i)
-            lat.append(1e6 * (time.perf_counter() - t0))
-        btimes = eng.kernel_times()
+    if args.workload == "c3":
+        if world > 1:
+            raise SystemExit("config 3 is a single-GPU configuration")
+        eng, timed, extra["pentagon"] = run_pentagon(args, K_total, T, local_rank)
+        A, K_local, units_total = 1, K_total, K_total
+        elapsed = float(timed.sum())
+        ms_per_step = 1e3 * elapsed / args.steps
+        tick_us = dist_stats(1e6 * timed)
+        ktimes = dtimes = {k: (0.0, 0) for k in ("nominal", "rollout", "update", "merge", "finalize")}
+        btimes, sync_tick_us, exchange_us, exch_kind = None, tick_us, None, "none"
+        # one more leg of diagnostic ticks with every kernel bracketed
+        eng.kernel_timing(("nominal", "rollout", "update", "merge", "finalize"), period=1)
+        st = np.array([extra["pentagon"]["final_pose"]])
+        for i in range(20):
+            st, _ = eng.tick(st, np.array([[1.0, 0.0, 0.0]]), noise="philox", seed=0, tick_id=20_000_000 + i)
+        dtimes = eng.kernel_times()
+        ktimes = dtimes
         eng.kernel_timing(())
-        lat = np.sort(np.array(lat))
-        sync_tick_us = {"mean": float(lat.mean()), "median": float(np.median(lat)),
-                        "p99": float(lat[min(len(lat) - 1, int(0.99 * len(lat)))]), "ticks": n_lat}
+        final_nxt, final_ua = eng.get_outputs()
+    else:
+        if args.workload == "c5":  # independent agents: replicas, no collective
+            lo, hi = sharded.shard_range(A_total, world, rank)
+            A = hi - lo
+            ticker, eng = sharded.make_replica_ticker(K_total, T, n_agents=A, storage=args.storage, local_rank=local_rank)
+            states = np.array([[0.05 * a, 0.0, 0.0] for a in range(lo, hi)])
+            goals = np.array([[0.05 * a, -1.0, 0.0] for a in range(lo, hi)])
+            K_local, units_total = K_total, A_total * K_total
+        else:
+            ticker, eng = sharded.make_hip_ticker(K_total, T, n_agents=1, storage=args.storage, local_rank=local_rank,
+                                                  exchange=args.exchange)
+            A = 1
+            states, goals = np.zeros((1, 3)), np.array([goal])
+            K_local, units_total = eng.K, K_total
+        exch_kind = ticker.exchange
+        for a in range(A):
+            eng.set_nominal(nominal_warm(T), agent=a)
+
+        seed = 0
+        counter = [0]
+
+        def tick(first=False):
+            i = counter[0]
+            counter[0] += 1
+            if args.graph and not in_group and not first:
+                eng.tick_graph(seed)
+            else:
+                ticker.tick_async(states if first else None, goals if first else None, "philox", seed, i)
+
+        # warm-up: at least --warmup ticks AND at least --min-warmup-s of wall time (a 20-tick warm-up of this
+        # workload is 4 ms: the clocks have not ramped yet and the first timed ticks run slow)
+        tick(first=True)
+        t_w = time.perf_counter()
+        n_w = 0
+        while True:
+            tick()
+            n_w += 1
+            if n_w % 16 == 0:
+                torch.cuda.synchronize()
+            if n_w >= args.warmup and time.perf_counter() - t_w >= args.min_warmup_s:
+                break
+        if world > 1:  # every rank leaves the warm-up after the same number of ticks (the exchange is collective)
+            t = torch.tensor([n_w], dtype=torch.int64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            for _ in range(int(t.item()) - n_w):
+                tick()
+            n_w = int(t.item())
+        extra["warmup_ticks_run"] = n_w
+        # Timed region: exactly --steps ticks between barrier + synchronize pairs.  The dominant kernel (rollout) is
+        # timed live with HIP events that ride on its own launch (hipExtLaunchKernelGGL start / stop events on the
+        # engine's stream = the dispatch's begin / end timestamps, the clock rocprofv3 --kernel-trace reads); no
+        # marker packets enter the stream, every EVENT_PERIOD-th launch is sampled only to keep the event pool small.
+        EVENT_PERIOD = int(os.environ.get("MPPI_EVENT_PERIOD", "4"))
+        eng.kernel_timing(("rollout",), period=EVENT_PERIOD)
+        sync()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            tick()
+        sync()
+        elapsed = time.perf_counter() - t0
+        ktimes = eng.kernel_times()
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        ms_per_step = 1e3 * elapsed / args.steps
+
+        # Distribution pass (not the headline clock): one event between consecutive ticks on the engine's stream
+        # gives every tick's own duration -> median and p99 of the back-to-back tick.
+        eng.kernel_timing(())
+        evs = HipEvents()
+        stream = eng.get_stream()
+        sync()
+        marks = [evs.record(stream)]
+        for i in range(args.steps):
+            tick()
+            marks.append(evs.record(stream))
+        sync()
+        tick_us = dist_stats([evs.elapsed_us(marks[i], marks[i + 1]) for i in range(args.steps)])
+        evs.free()
+
+        # Diagnostic pass: every kernel bracketed on every launch; N > 1: the exchange bracketed as well.
+        n_diag = min(args.steps, 20)
+        eng.kernel_timing(("nominal", "rollout", "update", "merge", "finalize"), period=1)
+        ticker.time_exchange(True)
+        sync()
+        for i in range(n_diag):
+            tick()
+        sync()
+        dtimes = eng.kernel_times()
+        exchange_us = ticker.exchange_times_us()
+        ticker.time_exchange(False)
+        eng.kernel_timing(())
+        nxt, ua = eng.get_outputs()
+        assert np.isfinite(nxt).all() and np.isfinite(ua).all()
+        final_nxt, final_ua = nxt.copy(), ua.copy()
+
+        # Diagnostic: the node's own call pattern -- host state in, blocking, host controls out
+        # (mppi_tick; what Controller.pos_cb pays per odometry message), N = 1 only.
+        sync_tick_us, btimes = None, None
+        if not in_group:
+            n_lat = min(args.steps, 200)
+            eng.kernel_timing(("rollout",), period=1)
+            st, lat = nxt, []
+            for i in range(n_lat):
+                t0 = time.perf_counter()
+                st, _ = eng.tick(st, goals, noise="philox", seed=seed, tick_id=10_000_000 + i)
+                lat.append(1e6 * (time.perf_counter() - t0))
+            btimes = eng.kernel_times()
+            eng.kernel_timing(())
+            sync_tick_us = dist_stats(lat)
+
+    info = eng.info()
+    # per-rank kernel times (N > 1): gathered on rank 0
+    kernels_us = {name: (dtimes[name][0] * 1e3 / dtimes[name][1] if dtimes[name][1] else None) for name in dtimes}
+    per_rank = None
+    if world > 1:
+        objs = [None] * world
+        dist.all_gather_object(objs, {"rank": rank, "kernels_us": kernels_us, "exchange_us": exchange_us,
+                                      "samples": int(eng.K)})
+        per_rank = objs
+
+    # All-fp64 line next to the fp32-storage one (the reference is float64 end to end): N = 1, config 4 only.
+    f64_line = None
+    if (rank == 0 and world == 1 and args.workload == "c4" and args.storage == "f32" and not args.no_f64_line
+            and not args.samples):
+        eng.close()
+        t64, e64 = sharded.make_hip_ticker(K_total, T, n_agents=1, storage="f64", local_rank=local_rank)
+        e64.set_nominal(nominal_warm(T))
+        t64.tick_async(np.zeros((1, 3)), np.array([goal]), "philox", 0, 0)
+        t_w, i = time.perf_counter(), 1
+        while time.perf_counter() - t_w < 0.3 or i < 20:
+            t64.tick_async(None, None, "philox", 0, i)
+            i += 1
+            if i % 16 == 0:
+                torch.cuda.synchronize()
+        e64.kernel_timing(("rollout", "update"), period=4)
+        torch.cuda.synchronize()
+        e64.synchronize()
+        n64 = 100
+        t0 = time.perf_counter()
+        for j in range(n64):
+            t64.tick_async(None, None, "philox", 0, i + j)
+        e64.synchronize()
+        el64 = time.perf_counter() - t0
+        k64 = e64.kernel_times()
+        f64_line = {"storage": "f64", "dtype": "f64", "ms_per_step": 1e3 * el64 / n64, "value": K_total / (el64 / n64), "steps": n64,
+                    "rollout_us": k64["rollout"][0] * 1e3 / max(k64["rollout"][1], 1),
+                    "update_us": k64["update"][0] * 1e3 / max(k64["update"][1], 1),
+                    "note": "eps / V stored as fp64, softmax in fp64 (exp2 in fp64): the reference's own precision end to end"}
+        e64.close()
 
     if rank == 0:
         steps_per_launch = A * K_local * T
@@ -221,54 +416,88 @@ def main():
         roofline = {"kernel": "rollout_kernel", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
                     "algorithmic_bytes_per_launch": BYTES_PER_STEP_PER_KERNEL * steps_per_launch,
-                    "avg_launch_us": avg_s * 1e6, "launches_timed": n, "event_period": EVENT_PERIOD,
-                    "note": "algorithmic = 12 B/state-step per kernel (eps 2xfp32 + V fp32, SURVEY 8d: 24 B/step per tick, "
-                            "written once by rollout, read once by update); the kernel itself is VALU-bound (fp64 state "
-                            "+ Philox) and, in the tick path, writes only 4 of those 12 B (eps is regenerated, not stored)",
+                    "avg_launch_us": avg_s * 1e6, "launches_timed": n,
+                    "actual_bound": "valu-issue",
+                    "note": "SURVEY 8(d) accounting: algorithmic = 12 B/state-step per kernel (eps 2 x fp32 + V fp32; 24 B/step per "
+                            "tick, written once by the rollout, read once by the update).  The kernel is NOT on the HBM roof: it "
+                            "regenerates eps instead of storing it (writes 4.4 of the 12 B/step, see `traffic`) and is bound by "
+                            "VALU issue -- see `valu` for that roofline.",
                     "tick_level": {"algorithmic_bytes": 2 * BYTES_PER_STEP_PER_KERNEL * steps_per_launch,
                                    "achieved": 2 * BYTES_PER_STEP_PER_KERNEL * steps_per_launch / tick_s / 1e9,
                                    "frac": 2 * BYTES_PER_STEP_PER_KERNEL * steps_per_launch / tick_s / 1e9 / HBM_PEAK_GBS}}
+        # VALU-issue roofline of the same kernel: wave-instructions per launch from the compiler's assembly of the
+        # steady-state loop (tools/valu_mix.py; agrees with the SQ_INSTS_VALU PMC count), each priced with its class's
+        # measured issue cost (tools/ubench.hip), against 1024 SIMDs at the 2.4 GHz peak clock.
+        mix = load_profile(PROFILE_ROUND + "_valu_mix.json") or load_profile("r1_valu_mix.json")
+        if mix and info.get("tick_kernels", "lanes") == "lanes" and args.storage == "f32":
+            wave_steps = steps_per_launch / 64.0
+            insts = mix["valu_per_step"] * wave_steps
+            t_min = mix["issue_cycles_per_step"] * wave_steps / N_SIMD / CLOCK_PEAK_HZ
+            roofline["valu"] = {"bound": "valu-issue", "unit": "G wave-inst/s",
+                                "insts_per_launch": insts, "achieved": insts / avg_s / 1e9,
+                                "peak": N_SIMD * CLOCK_PEAK_HZ / mix["avg_cycles_per_valu"] / 1e9,
+                                "frac": t_min / avg_s, "min_launch_us_at_peak_clock": t_min * 1e6,
+                                "valu_per_step": mix["valu_per_step"], "issue_cycles_per_step": mix["issue_cycles_per_step"],
+                                "by_class_per_step": {k: v / mix["steps_per_iteration"] for k, v in mix["by_class_per_iteration"].items()},
+                                "source": "profiles/%s_valu_mix.json" % PROFILE_ROUND}
         # HBM bytes actually moved per launch of that kernel: rocprofv3 --pmc passes of this same command
         # (tools/pmc.sh), summary committed under profiles/ -- bench.py itself cannot host the profiler
-        pmc_file = os.path.join(ROOT, "profiles", "r1_pmc_summary_bench_c4.json")
-        if args.workload == "c4" and args.storage == "f32" and world == 1 and not args.samples and os.path.exists(pmc_file):
-            pm = json.load(open(pmc_file))
+        pmc_name = PROFILE_ROUND + "_pmc_summary_bench_c4.json"
+        pm = load_profile(pmc_name)
+        if pm is None:
+            pmc_name = "r1_pmc_summary_bench_c4.json"
+            pm = load_profile(pmc_name)
+        if args.workload == "c4" and args.storage == "f32" and world == 1 and not args.samples and pm:
             for kname, c in pm.items():
-                if "rollout_kernel" in kname:
+                if "rollout_kernel" in kname or "rollout_pk_kernel" in kname:
                     rd = [v for k, v in c.items() if k.startswith("hbm_read_bytes")]
                     wr = [v for k, v in c.items() if k.startswith("hbm_write_bytes")]
                     if rd and wr:
                         roofline["traffic"] = rd[0] + wr[0]
-                        roofline["traffic_source"] = "profiles/r1_pmc_summary_bench_c4.json (FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)"
+                        roofline["traffic_source"] = "profiles/%s (FETCH_SIZE x2 + WRITE_SIZE, bytes/launch; separate --pmc passes of this command)" % pmc_name
+                        if "SQ_INSTS_VALU" in c and "valu" in roofline:
+                            roofline["valu"]["insts_per_launch_pmc"] = c["SQ_INSTS_VALU"]
         # the rollout launch in each phase of this command (what a rocprofv3 --kernel-trace --stats of the whole
-        # command averages over): back-to-back ticks run ~8 % longer than launches behind an idle gap
+        # command averages over): back-to-back ticks run a few % longer than launches behind an idle gap
         phases = {"timed": ktimes["rollout"], "diagnostic": dtimes["rollout"]}
         if btimes:
             phases["blocking"] = btimes["rollout"]
         roofline["rollout_us_by_phase"] = {k: {"avg_us": (v[0] * 1e3 / v[1] if v[1] else None), "launches_timed": v[1]}
                                            for k, v in phases.items()}
-        kernels_us = {name: (dtimes[name][0] * 1e3 / dtimes[name][1] if dtimes[name][1] else None) for name in dtimes}
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             cpu = cpu_baseline(T, goal if goal is not None else [0.0, -1.0, 0.0])
         value = units_total / (elapsed / args.steps)
+        lanes = info.get("tick_kernels", "lanes") == "lanes"
+        if args.storage == "f64":
+            dtype, detail = "f64", "fp64 state, cost, storage and softmax (the reference's precision end to end)"
+        else:
+            dtype = "f64"
+            detail = ("rollout state + cost arithmetic fp64; noise drawn in fp32 (Philox + Box-Muller); HBM-resident cost prefix "
+                      "fp32 offsets from the nominal trajectory; softmax weights (exp, sums) fp32; merge / control update / "
+                      "filter / plant step fp64" if lanes else
+                      "scan kernel: all arithmetic fp64 (noise drawn in fp32), nothing stored")
         line = {
             "metric": "MPPI rollouts/sec per control tick (K x T state steps)",
             "value": value, "unit": "rollouts/s", "n_gpus": args.gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": dtype, "dtype_detail": detail, "data": "synthetic",
             "config": {"workload": desc, "agents": A_total, "samples_total": K_total, "horizon": T,
                        "samples_per_gpu": K_local if args.workload != "c5" else K_total,
                        "state_steps_per_tick": units_total * T, "storage": args.storage,
                        "noise": "device Philox4x32-10", "sigma": 0.9, "lambda": 0.001,
-                       "parallelism": ("K-sharded x%d + all-gather" % world) if args.workload != "c5" else "agent replicas",
-                       "graph": bool(args.graph), "tick_kernels": eng.info()["tick_kernels"]},
+                       "parallelism": ("K-sharded x%d, exchange: %s" % (world, exch_kind)) if args.workload != "c5" else "agent replicas",
+                       "graph": bool(args.graph), "tick_kernels": info.get("tick_kernels", "lanes"),
+                       "min_warmup_s": args.min_warmup_s},
             "state_steps_per_s": value * T,
+            "tick_us": tick_us,
             "final_state": [float(x) for x in final_nxt[0]], "final_u": [float(x) for x in final_ua[0]],
             "sync_tick_us": sync_tick_us,
-            "kernels_us": kernels_us, "roofline": roofline, "cpu_baseline": cpu,
+            "kernels_us": kernels_us, "exchange_us": exchange_us, "per_rank": per_rank,
+            "roofline": roofline, "cpu_baseline": cpu, "f64_storage": f64_line,
         }
+        line.update(extra)
         print(json.dumps(line))
     if in_group:
         dist.destroy_process_group()

@@ -23,9 +23,19 @@
  *   - every function returns 0 on success or a negative MPPI_E_* code, never throws or
  *     aborts across the ABI; mppi_last_error() gives the message;
  *   - one handle is not re-entrant; it may be driven from any single thread;
- *   - all work is enqueued on the handle's HIP stream (mppi_set_stream; default: the
- *     null stream).  Calls that return host data synchronise that stream, the rest are
- *     asynchronous.
+ *   - all work is enqueued on the handle's HIP stream.  DEFAULT: a stream the engine creates for
+ *     itself with hipStreamNonBlocking -- it does NOT synchronise with the legacy null stream, so a
+ *     caller that touches engine-owned device memory (mppi_partials_ptr, the `gathered_dev` buffer
+ *     it passes to mppi_tick_finish) from another stream must order the two: either run the engine
+ *     on that stream (mppi_set_stream), or use mppi_stream_wait_partials / mppi_wait_for_stream,
+ *     or call mppi_synchronize.  Calls that return host data wait for the engine's stream, the rest
+ *     are asynchronous.
+ *   - every blocking wait is bounded: if the device does not finish within the sync timeout
+ *     (mppi_set_sync_timeout, default 10 s; env MPPI_SYNC_TIMEOUT_MS) the call returns
+ *     MPPI_E_TIMEOUT instead of blocking the control thread forever; the engine must then be
+ *     destroyed.
+ *   - a call makes the engine's device current only for its own duration and restores the caller's
+ *     current device before returning.
  *   - K is the number of samples owned by THIS handle (one GPU's shard); sample_offset is
  *     the global index of its first sample (device-RNG streams are keyed by global index,
  *     so results do not depend on the shard count).
@@ -40,7 +50,7 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 1
+#define MPPI_ABI_VERSION 2
 
 /* error codes */
 #define MPPI_OK 0
@@ -48,6 +58,7 @@ extern "C" {
 #define MPPI_E_HIP (-2)       /* a HIP runtime call failed (no device, OOM, launch error) */
 #define MPPI_E_STATE (-3)     /* call order violated (e.g. update before rollout) */
 #define MPPI_E_INTERNAL (-4)
+#define MPPI_E_TIMEOUT (-5)   /* a bounded wait expired: the device did not finish in time */
 
 /* storage type of the per-(t,k) intermediates eps and V kept in HBM */
 #define MPPI_STORE_F32 0 /* eps fp32, V as fp32 offset from the nominal cost-to-go */
@@ -119,9 +130,18 @@ int mppi_destroy(mppi_engine *h);
 
 /* Use an existing hipStream_t (e.g. torch's current stream) for all later work. */
 int mppi_set_stream(mppi_engine *h, void *hip_stream);
+/* The hipStream_t the engine enqueues on (its own non-blocking stream unless mppi_set_stream changed it). */
+int mppi_get_stream(mppi_engine *h, void **hip_stream);
 
-/* Per-call sig / lam of get_path (control/src/mppi:88-89). */
+/* Per-call sig / lam of get_path (control/src/mppi:88-89), sig = sigma * I. */
 int mppi_set_sigma_lambda(mppi_engine *h, double sigma, double lambda);
+/* The same with sig as the full row-major 2 x 2 matrix the reference accepts: the noise of BOTH
+ * wheels is drawn with std-dev sig[0][0] (control/src/mppi:143-146), the stage cost uses the whole
+ * matrix, lam * u . sig . eps (:184). */
+int mppi_set_sig_matrix(mppi_engine *h, const double *sig /*[4]*/, double lambda);
+
+/* Deadline of the blocking waits, in milliseconds (0 = wait forever).  See MPPI_E_TIMEOUT. */
+int mppi_set_sync_timeout(mppi_engine *h, int milliseconds);
 
 /*
  * EXTENSION (not in the reference's cost; off unless called with weight != 0):
@@ -178,8 +198,8 @@ int mppi_shift(mppi_engine *h);
 /*
  * MPPI.get_path, control/src/mppi:85-102, split at the only cross-GPU exchange:
  *   tick_begin : nominal baseline -> rollout+cost -> softmax partials -> per-(agent,t)
- *                merged partials of THIS shard, left in a device buffer of
- *                mppi_partials_bytes() bytes, float64 [A][T][8] =
+ *                merged partials of THIS shard, left in the device buffer mppi_partials_ptr
+ *                reports (pointer and size in bytes), float64 [A][T][8] =
  *                {min V, sum e, sum e*eps0, sum e*eps1, sum eps0, sum eps1, K_shard, 0};
  *   (host side all-gathers those buffers over RCCL when K is sharded over GPUs)
  *   tick_finish: merges n_shards such buffers (device pointer, [n_shards][A][T][8];
@@ -191,14 +211,26 @@ int mppi_tick_begin(mppi_engine *h, const double *state, const double *goal, int
                     uint64_t seed, uint32_t tick_id);
 int mppi_partials_ptr(mppi_engine *h, void **dev_ptr, size_t *bytes);
 int mppi_tick_finish(mppi_engine *h, const void *gathered_dev, int n_shards);
+/* Cross-stream ordering for callers that run the exchange on a stream of their own:
+ *   mppi_stream_wait_partials: work enqueued on `other_stream` after this call starts only when
+ *       everything the engine has enqueued so far (e.g. tick_begin's partials) is complete;
+ *   mppi_wait_for_stream: everything the engine enqueues after this call starts only when the work
+ *       `other_stream` holds now (e.g. the all-gather into gathered_dev) is complete.
+ * other_stream is a hipStream_t (NULL = the legacy null stream). */
+int mppi_stream_wait_partials(mppi_engine *h, void *other_stream);
+int mppi_wait_for_stream(mppi_engine *h, void *other_stream);
 /* Synchronises; next_state [A][3], u_applied [A][2] (either may be NULL). */
 int mppi_get_outputs(mppi_engine *h, double *next_state, double *u_applied);
 int mppi_tick(mppi_engine *h, const double *state, const double *goal, int noise_mode,
               uint64_t seed, uint32_t tick_id, double *next_state, double *u_applied);
 
 /* Capture begin+finish (device RNG, resident state/goal) into a hipGraph and replay it:
- * one launch per tick for the launch-bound small-K case.  tick_id advances per replay. */
+ * one launch per tick for the launch-bound small-K case.  The tick id of a replay is read from a
+ * device-resident counter that every replay advances; eager ticks (mppi_tick, mppi_tick_finish)
+ * leave it at their own tick_id + 1, so a node that mixes the two keeps drawing fresh noise.
+ * mppi_set_tick_counter overrides it (the id the NEXT replay uses). */
 int mppi_tick_graph(mppi_engine *h, uint64_t seed);
+int mppi_set_tick_counter(mppi_engine *h, uint32_t next_tick_id);
 
 int mppi_synchronize(mppi_engine *h);
 

@@ -11,8 +11,9 @@ MPPI_STORE_F32, MPPI_STORE_F64 = 0, 1
 MPPI_NOISE_INJECTED, MPPI_NOISE_PHILOX = 0, 1
 MPPI_MODEL_DIFFDRIVE_RK4, MPPI_MODEL_UNICYCLE_EULER = 0, 1
 MPPI_TICK_AUTO, MPPI_TICK_LANES, MPPI_TICK_SCAN = 0, 1, 2
+MPPI_E_TIMEOUT = -5
 KERNELS = ("nominal", "rollout", "update", "merge", "finalize")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class MppiConfig(C.Structure):
@@ -42,7 +43,13 @@ SIGNATURES = {
     "mppi_create": (C.c_int, [C.POINTER(MppiConfig), C.POINTER(_H)]),
     "mppi_destroy": (C.c_int, [_H]),
     "mppi_set_stream": (C.c_int, [_H, C.c_void_p]),
+    "mppi_get_stream": (C.c_int, [_H, C.POINTER(C.c_void_p)]),
     "mppi_set_sigma_lambda": (C.c_int, [_H, C.c_double, C.c_double]),
+    "mppi_set_sig_matrix": (C.c_int, [_H, _dp, C.c_double]),
+    "mppi_set_sync_timeout": (C.c_int, [_H, C.c_int]),
+    "mppi_set_tick_counter": (C.c_int, [_H, C.c_uint32]),
+    "mppi_stream_wait_partials": (C.c_int, [_H, C.c_void_p]),
+    "mppi_wait_for_stream": (C.c_int, [_H, C.c_void_p]),
     "mppi_reset": (C.c_int, [_H, C.c_int]),
     "mppi_set_obstacle_grid": (C.c_int, [_H, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double,
                                          C.c_double]),

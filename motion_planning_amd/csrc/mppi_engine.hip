@@ -5,7 +5,10 @@
 // `latest_uvec` lives on the device between ticks exactly like the Python attribute does.
 #include <hip/hip_runtime.h>
 
+#include <time.h>
+
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -45,6 +48,22 @@ struct EngineError {
     } while (0)
 
 thread_local std::string g_create_error = "";
+
+// Makes the engine's device current for the duration of one ABI call and puts the caller's device back
+// afterwards (a process may drive engines on several GPUs, or run torch on another device, from one thread).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev == dev) return;
+        hipError_t e = hipSetDevice(dev);
+        if (e != hipSuccess) fail(MPPI_E_HIP, "hipSetDevice(%d): %s", dev, hipGetErrorString(e));
+        switched = prev >= 0;
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
 
 template <typename T>
 T* dev_alloc(size_t n, size_t& tally) {
@@ -111,6 +130,39 @@ struct mppi_engine {
     int ring_pos = 0;
 
     bool noise_ready = false, value_ready = false, partials_ready = false, have_state = false, have_goal = false;
+    bool injected_ready = false;   // d_eps holds noise a MPPI_NOISE_INJECTED rollout may read (uploaded, or stored by a rollout)
+    double sig_cost[4] = {0, 0, 0, 0};  // the sig matrix of the stage cost (sigma * I unless mppi_set_sig_matrix)
+    bool sig_is_matrix = false;
+    uint32_t last_tick_id = 0;     // id of the last eager tick (its successor is written to d_tick by tick_finish)
+    bool last_tick_eager = false;
+    hipEvent_t ev_partials = nullptr, ev_foreign = nullptr;  // cross-stream ordering helpers (mppi_stream_wait_*)
+
+    // Blocking waits are polls with a deadline: a control thread must get an error back, not hang, if the
+    // device stops answering (MPPI_E_TIMEOUT; mppi_set_sync_timeout, default 10 s, 0 = wait forever).
+    int sync_timeout_ms = 10000;
+    template <typename Query>
+    void bounded_wait(Query query, const char* what) {
+        using clock = std::chrono::steady_clock;
+        const auto t0 = clock::now();
+        for (unsigned spins = 1;; ++spins) {
+            const hipError_t e = query();
+            if (e == hipSuccess) return;
+            if (e != hipErrorNotReady) fail(MPPI_E_HIP, "%s: %s", what, hipGetErrorString(e));
+            if ((spins & 31u) == 0) {
+                const auto us = std::chrono::duration_cast<std::chrono::microseconds>(clock::now() - t0).count();
+                if (sync_timeout_ms > 0 && us > (long long)sync_timeout_ms * 1000)
+                    fail(MPPI_E_TIMEOUT, "%s: the device did not finish within %d ms (the engine must be destroyed)", what, sync_timeout_ms);
+                if (us > 2000) { struct timespec ts = {0, 50000}; nanosleep(&ts, nullptr); }  // long waits: stop burning the core
+            }
+        }
+    }
+    void wait_stream(const char* what) {
+        hipStream_t st = stream;
+        bounded_wait([st] { return hipStreamQuery(st); }, what);
+    }
+    void wait_event(hipEvent_t ev, const char* what) {
+        bounded_wait([ev] { return hipEventQuery(ev); }, what);
+    }
 
     // kernel timing
     uint32_t time_mask = 0;
@@ -138,7 +190,7 @@ struct mppi_engine {
     }
     void drain_timing() {
         if (pending.empty()) return;
-        HIPCHK(hipStreamSynchronize(stream));
+        wait_stream("kernel-timing drain");
         for (auto& p : pending) {
             float ms = 0.f;
             HIPCHK(hipEventElapsedTime(&ms, p.a, p.b));
@@ -172,7 +224,7 @@ struct mppi_engine {
 
     void ensure_tmp(size_t elems) {
         if (elems <= tmp_elems) return;
-        if (d_tmp) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(d_tmp)); hbm_bytes -= tmp_elems * 8; d_tmp = nullptr; tmp_elems = 0; }
+        if (d_tmp) { wait_stream("staging-buffer regrow"); HIPCHK(hipFree(d_tmp)); hbm_bytes -= tmp_elems * 8; d_tmp = nullptr; tmp_elems = 0; }
         d_tmp = dev_alloc<double>(elems, hbm_bytes);
         tmp_elems = elems;
     }
@@ -180,7 +232,7 @@ struct mppi_engine {
     void stage_upload(const double* src, double* dst, size_t n) {
         const int slot = ring_pos;
         ring_pos = (ring_pos + 1) % kRing;
-        if (ring_used[slot]) HIPCHK(hipEventSynchronize(ring_ev[slot]));
+        if (ring_used[slot]) wait_event(ring_ev[slot], "state/goal staging ring");
         double* h = h_stage + (size_t)slot * cfg.n_agents * 6;
         std::memcpy(h, src, n * sizeof(double));
         HIPCHK(hipMemcpyAsync(dst, h, n * sizeof(double), hipMemcpyHostToDevice, stream));
@@ -230,7 +282,7 @@ struct mppi_engine {
         uint32_t tick = lazy_tick;
         if (lazy_from_counter) {
             HIPCHK(hipMemcpyAsync(&tick, d_tick, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-            HIPCHK(hipStreamSynchronize(stream));
+            wait_stream("tick counter read-back");
             if (lazy_counter_bumped) tick -= 1u;
         }
         return tick;
@@ -238,7 +290,7 @@ struct mppi_engine {
     void materialise_eps() {
         if (!eps_lazy) return;
         launch_regen(stream, lazy_seed, lazy_tick_now(), nullptr);
-        eps_lazy = false;
+        eps_lazy = false; injected_ready = true;
     }
     // The small-K tick keeps V in registers.  When a caller asks for it afterwards (mppi_download_value,
     // mppi_update), the lane-per-sample rollout kernel re-runs the tick's rollout from the pre-tick
@@ -258,7 +310,7 @@ struct mppi_engine {
             throw;
         }
         ro_unom = ro_state = ro_goal = nullptr;
-        if (ph) eps_lazy = false;
+        if (ph) { eps_lazy = false; injected_ready = true; }
         value_lazy = false; value_ready = true; epart_ready = true;
     }
     void launch_scan_tick(bool ph, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
@@ -311,8 +363,8 @@ struct mppi_engine {
         HIPCHK(hipGetLastError());
     }
     void check_noise_mode(int noise_mode) {
-        if (noise_mode == MPPI_NOISE_INJECTED && !noise_ready)
-            fail(MPPI_E_STATE, "MPPI_NOISE_INJECTED but mppi_upload_noise was never called");
+        if (noise_mode == MPPI_NOISE_INJECTED && !injected_ready)
+            fail(MPPI_E_STATE, "MPPI_NOISE_INJECTED but no noise is resident (mppi_upload_noise, or a rollout that stored its noise)");
         if (noise_mode != MPPI_NOISE_INJECTED && noise_mode != MPPI_NOISE_PHILOX)
             fail(MPPI_E_INVALID, "unknown noise_mode %d", noise_mode);
     }
@@ -322,10 +374,13 @@ struct mppi_engine {
         const bool ph = noise_mode == MPPI_NOISE_PHILOX;
         const bool store = !ph || store_eps_always;
         eps_lazy = ph && !store;
+        if (ph && store) injected_ready = true;   // this rollout leaves its noise in d_eps
         lazy_seed = seed; lazy_tick = tick; lazy_from_counter = tick_ptr != nullptr; lazy_counter_bumped = false;
+        last_tick_id = tick; last_tick_eager = tick_ptr == nullptr;
         epart_ready = true;  // every rollout launch below writes its waves' eps sums
         if (small_nb > 0) {  // small K: rollout + cost-to-go + softmax partials in one kernel, V stays in registers
             eps_lazy = ph;
+            if (ph) injected_ready = false;  // the scan kernel never writes d_eps
             launch_scan_tick(ph, seed, tick, tick_ptr);
             launch_merge(small_nb);
             noise_ready = true; value_ready = false; value_lazy = true; partials_ready = true; epart_ready = false;
@@ -348,7 +403,7 @@ struct mppi_engine {
     void run_rollout(int noise_mode, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
         check_noise_mode(noise_mode);
         launch_rollout(stream, 0, cfg.samples, noise_mode == MPPI_NOISE_PHILOX, true, seed, tick, tick_ptr);
-        eps_lazy = false;
+        eps_lazy = false; injected_ready = true;
         noise_ready = true; value_ready = true; value_lazy = false; partials_ready = false; epart_ready = true;
     }
     void run_update() {
@@ -374,19 +429,31 @@ struct mppi_engine {
         }
         // as many threads as the 2T filter outputs can use in slices (T = 50: 1000), at least 256
         const int fin_threads = std::min(1024, std::max(256, ((2 * T * std::max(1, 1024 / (2 * T)) + 63) / 64) * 64));
+        uint32_t tick_set = 0;
+        if ((flags & 1) && !(flags & 4) && last_tick_eager) { flags |= 16; tick_set = last_tick_id + 1u; }
         hipLaunchKernelGGL(mppi::finalize_kernel, dim3(cfg.n_agents), dim3(fin_threads), lds,
-                           stream, P, gathered, G, d_S, d_unom, d_ufilt, d_state, d_out, d_tick, flags);
+                           stream, P, gathered, G, d_S, d_unom, d_ufilt, d_state, d_out, d_tick, flags, tick_set);
         HIPCHK(hipGetLastError());
         partials_ready = false;
     }
 
     void refresh_params() {
         P.sigma = cfg.sigma; P.lambda = cfg.lambda; P.inv_lambda = 1.0 / cfg.lambda;
+        if (!sig_is_matrix) { sig_cost[0] = sig_cost[3] = cfg.sigma; sig_cost[1] = sig_cost[2] = 0.0; }
+        P.sg00 = sig_cost[0]; P.sg01 = sig_cost[1]; P.sg10 = sig_cost[2]; P.sg11 = sig_cost[3];
+    }
+    // The last tick's noise / V may exist only as "re-draw with these parameters" (eps_lazy, value_lazy):
+    // anything that changes what a re-draw or re-run would produce must materialise them first, so that
+    // mppi_download_noise / _value keep returning what the last rollout really used.
+    void settle_lazy_state() {
+        if (value_lazy && have_state && have_goal) materialise_value();
+        materialise_eps();
     }
 
     void init(const mppi_config& c) {
         cfg = c;
         if (const char* v = std::getenv("MPPI_STORE_EPS")) store_eps_always = std::atoi(v) != 0;
+        if (const char* v = std::getenv("MPPI_SYNC_TIMEOUT_MS")) sync_timeout_ms = std::atoi(v);
         if (cfg.n_agents < 1 || cfg.samples < 1) fail(MPPI_E_INVALID, "n_agents and samples must be >= 1");
         if (cfg.horizon < 5 || ((cfg.horizon - 1) % 2) == 0)
             fail(MPPI_E_INVALID, "horizon=%d: the Savitzky-Golay window horizon-1 must be odd and > 3 "
@@ -488,7 +555,9 @@ struct mppi_engine {
         std::vector<double> S;
         if (!mppi::savgol_operator(T, S)) fail(MPPI_E_INVALID, "cannot build the Savitzky-Golay operator for horizon %d", T);
         HIPCHK(hipMemcpyAsync(d_S, S.data(), S.size() * sizeof(double), hipMemcpyHostToDevice, stream));
-        HIPCHK(hipStreamSynchronize(stream));
+        wait_stream("engine initialisation");
+        HIPCHK(hipEventCreateWithFlags(&ev_partials, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ev_foreign, hipEventDisableTiming));
 
         HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_stage), (size_t)kRing * A * 6 * sizeof(double), hipHostMallocDefault));
         for (int i = 0; i < kRing; ++i) HIPCHK(hipEventCreateWithFlags(&ring_ev[i], hipEventDisableTiming));
@@ -501,8 +570,13 @@ struct mppi_engine {
     }
 
     ~mppi_engine() {
+        int prev = -1;
+        const bool back = hipGetDevice(&prev) == hipSuccess && prev != device;
         hipSetDevice(device);
-        if (stream) hipStreamSynchronize(stream);
+        struct Restore { bool on; int dev; ~Restore() { if (on) (void)hipSetDevice(dev); } } restore{back, prev};
+        try { wait_stream("engine teardown"); } catch (...) {}  // a dead device must not hang the destructor either
+        if (ev_partials) hipEventDestroy(ev_partials);
+        if (ev_foreign) hipEventDestroy(ev_foreign);
         destroy_graph();
         for (auto& p : pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
         for (auto e : ev_pool) hipEventDestroy(e);
@@ -521,8 +595,7 @@ struct mppi_engine {
 #define API_BEGIN(h)                                   \
     if (!(h)) return MPPI_E_INVALID;                   \
     try {                                              \
-        hipError_t sd__ = hipSetDevice((h)->device);   \
-        if (sd__ != hipSuccess) fail(MPPI_E_HIP, "hipSetDevice(%d): %s", (h)->device, hipGetErrorString(sd__));
+        DeviceGuard dev_guard__((h)->device);
 #define API_END(h)                                                                  \
         return MPPI_OK;                                                             \
     } catch (const EngineError& e) { (h)->err = e.msg; return e.code; }             \
@@ -564,6 +637,9 @@ int mppi_create(const mppi_config* cfg, mppi_engine** out) {
     if (!cfg || !out) { g_create_error = "mppi_create: NULL argument"; return MPPI_E_INVALID; }
     *out = nullptr;
     mppi_engine* e = nullptr;
+    int prev_dev = -1;
+    const bool have_prev = hipGetDevice(&prev_dev) == hipSuccess;
+    struct Restore { bool on; int dev; ~Restore() { if (on) (void)hipSetDevice(dev); } } restore{have_prev, prev_dev};
     try {
         e = new mppi_engine();
         e->init(*cfg);
@@ -576,32 +652,84 @@ int mppi_create(const mppi_config* cfg, mppi_engine** out) {
 
 int mppi_destroy(mppi_engine* h) {
     if (!h) return MPPI_E_INVALID;
-    delete h;
+    delete h;  // the destructor restores the caller's current device
     return MPPI_OK;
 }
 
 int mppi_set_stream(mppi_engine* h, void* hip_stream) {
     API_BEGIN(h)
     h->drain_timing();
-    HIPCHK(hipStreamSynchronize(h->stream));
+    h->wait_stream(__func__);
     h->destroy_graph();
     h->stream = static_cast<hipStream_t>(hip_stream);
+    API_END(h)
+}
+
+int mppi_get_stream(mppi_engine* h, void** hip_stream) {
+    API_BEGIN(h)
+    if (!hip_stream) fail(MPPI_E_INVALID, "hip_stream is NULL");
+    *hip_stream = static_cast<void*>(h->stream);
     API_END(h)
 }
 
 int mppi_set_sigma_lambda(mppi_engine* h, double sigma, double lambda) {
     API_BEGIN(h)
     if (!(lambda > 0.0) || !(sigma >= 0.0)) fail(MPPI_E_INVALID, "lambda must be > 0 and sigma >= 0");
+    h->settle_lazy_state();
     h->cfg.sigma = sigma; h->cfg.lambda = lambda;
+    h->sig_is_matrix = false;
     h->refresh_params();
     h->destroy_graph();
+    API_END(h)
+}
+
+int mppi_set_sig_matrix(mppi_engine* h, const double* sig, double lambda) {
+    API_BEGIN(h)
+    if (!sig) fail(MPPI_E_INVALID, "sig is NULL");
+    if (!(lambda > 0.0) || !(sig[0] >= 0.0)) fail(MPPI_E_INVALID, "lambda must be > 0 and sig[0][0] >= 0");
+    for (int i = 0; i < 4; ++i) if (!std::isfinite(sig[i])) fail(MPPI_E_INVALID, "sig[%d] is not finite", i);
+    h->settle_lazy_state();
+    h->cfg.sigma = sig[0]; h->cfg.lambda = lambda;  // the noise of BOTH wheels is drawn with sig[0,0] (control/src/mppi:145)
+    for (int i = 0; i < 4; ++i) h->sig_cost[i] = sig[i];
+    h->sig_is_matrix = true;
+    h->refresh_params();
+    h->destroy_graph();
+    API_END(h)
+}
+
+int mppi_set_sync_timeout(mppi_engine* h, int milliseconds) {
+    API_BEGIN(h)
+    if (milliseconds < 0) fail(MPPI_E_INVALID, "timeout must be >= 0 (0 = wait forever)");
+    h->sync_timeout_ms = milliseconds;
+    API_END(h)
+}
+
+int mppi_set_tick_counter(mppi_engine* h, uint32_t next_tick_id) {
+    API_BEGIN(h)
+    HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->d_tick), (int)next_tick_id, 1, h->stream));
+    h->last_tick_eager = false;  // the counter now holds what the caller put there
+    API_END(h)
+}
+
+int mppi_stream_wait_partials(mppi_engine* h, void* other_stream) {
+    API_BEGIN(h)
+    HIPCHK(hipEventRecord(h->ev_partials, h->stream));
+    HIPCHK(hipStreamWaitEvent(static_cast<hipStream_t>(other_stream), h->ev_partials, 0));
+    API_END(h)
+}
+
+int mppi_wait_for_stream(mppi_engine* h, void* other_stream) {
+    API_BEGIN(h)
+    HIPCHK(hipEventRecord(h->ev_foreign, static_cast<hipStream_t>(other_stream)));
+    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_foreign, 0));
     API_END(h)
 }
 
 int mppi_set_obstacle_grid(mppi_engine* h, const int8_t* cells, int32_t width, int32_t height, double resolution,
                            double origin_x, double origin_y, double weight) {
     API_BEGIN(h)
-    HIPCHK(hipStreamSynchronize(h->stream));
+    h->settle_lazy_state();
+    h->wait_stream(__func__);
     h->destroy_graph();
     if (!cells || weight == 0.0) {
         h->P.grid = nullptr; h->P.grid_weight = 0.0;
@@ -634,7 +762,7 @@ int mppi_set_nominal(mppi_engine* h, int agent, const double* uvec) {
     if (!uvec || agent < 0 || agent >= h->cfg.n_agents) fail(MPPI_E_INVALID, "bad agent/uvec");
     const size_t n = (size_t)2 * h->cfg.horizon;
     HIPCHK(hipMemcpyAsync(h->d_unom + agent * n, uvec, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    h->wait_stream(__func__);
     API_END(h)
 }
 
@@ -643,7 +771,7 @@ int mppi_get_nominal(mppi_engine* h, int agent, double* uvec) {
     if (!uvec || agent < 0 || agent >= h->cfg.n_agents) fail(MPPI_E_INVALID, "bad agent/uvec");
     const size_t n = (size_t)2 * h->cfg.horizon;
     HIPCHK(hipMemcpyAsync(uvec, h->d_unom + agent * n, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    h->wait_stream(__func__);
     API_END(h)
 }
 
@@ -658,8 +786,8 @@ int mppi_upload_noise(mppi_engine* h, const double* eps) {
     if (h->f64()) hipLaunchKernelGGL(mppi::pack_rows_kernel<double>, grid, dim3(256), 0, h->stream, h->d_tmp, static_cast<double*>(h->d_eps), K, h->P.Ks, (const double*)nullptr, 1);
     else hipLaunchKernelGGL(mppi::pack_rows_kernel<float>, grid, dim3(256), 0, h->stream, h->d_tmp, static_cast<float*>(h->d_eps), K, h->P.Ks, (const double*)nullptr, 1);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(h->stream));
-    h->noise_ready = true;
+    h->wait_stream(__func__);
+    h->noise_ready = true; h->injected_ready = true;
     h->epart_ready = false;
     h->eps_lazy = false;
     h->value_lazy = false;  // the snapshot no longer matches the resident noise
@@ -679,7 +807,7 @@ int mppi_download_noise(mppi_engine* h, double* eps) {
     else hipLaunchKernelGGL(mppi::unpack_rows_kernel<float>, grid, dim3(256), 0, h->stream, static_cast<const float*>(h->d_eps), h->d_tmp, K, h->P.Ks, (const double*)nullptr, 1);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(eps, h->d_tmp, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    h->wait_stream(__func__);
     API_END(h)
 }
 
@@ -704,7 +832,7 @@ int mppi_download_value(mppi_engine* h, double* V) {
     else hipLaunchKernelGGL(mppi::value_unpack_kernel<float>, grid, dim3(256), 0, h->stream, static_cast<const float*>(h->d_dP), static_cast<const float*>(h->d_stot), (const double*)h->d_base, h->d_tmp, K, h->P.Ks, T);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(V, h->d_tmp, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    h->wait_stream(__func__);
     API_END(h)
 }
 
@@ -722,7 +850,7 @@ int mppi_upload_value(mppi_engine* h, const double* V) {
     if (h->f64()) hipLaunchKernelGGL(mppi::value_pack_kernel<double>, grid, dim3(256), 0, h->stream, (const double*)h->d_tmp, (const double*)h->d_base, static_cast<double*>(h->d_dP), static_cast<double*>(h->d_stot), K, h->P.Ks, T);
     else hipLaunchKernelGGL(mppi::value_pack_kernel<float>, grid, dim3(256), 0, h->stream, (const double*)h->d_tmp, (const double*)h->d_base, static_cast<float*>(h->d_dP), static_cast<float*>(h->d_stot), K, h->P.Ks, T);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(h->stream));
+    h->wait_stream(__func__);
     h->value_ready = true; h->value_lazy = false;
     API_END(h)
 }
@@ -734,7 +862,7 @@ int mppi_update(mppi_engine* h, double* uvec_out) {
     if (uvec_out) {
         const size_t n = (size_t)h->cfg.n_agents * 2 * h->cfg.horizon;
         HIPCHK(hipMemcpyAsync(uvec_out, h->d_ufilt, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        h->wait_stream(__func__);
     }
     API_END(h)
 }
@@ -749,7 +877,7 @@ int mppi_plant_step(mppi_engine* h, const double* state, double* next_state) {
     if (next_state) {
         const double* o = h->h_out;
         HIPCHK(hipMemcpyAsync(h->h_out, h->d_out, (size_t)A * 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        h->wait_stream(__func__);
         for (int a = 0; a < A; ++a) for (int i = 0; i < 3; ++i) next_state[a * 3 + i] = o[(size_t)a * 8 + i];
     }
     API_END(h)
@@ -788,7 +916,7 @@ int mppi_get_outputs(mppi_engine* h, double* next_state, double* u_applied) {
     const int A = h->cfg.n_agents;
     const double* o = h->h_out;
     HIPCHK(hipMemcpyAsync(h->h_out, h->d_out, (size_t)A * 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    h->wait_stream(__func__);
     for (int a = 0; a < A; ++a) {
         if (next_state) for (int i = 0; i < 3; ++i) next_state[a * 3 + i] = o[(size_t)a * 8 + i];
         if (u_applied) for (int i = 0; i < 2; ++i) u_applied[a * 2 + i] = o[(size_t)a * 8 + 3 + i];
@@ -835,12 +963,13 @@ int mppi_tick_graph(mppi_engine* h, uint64_t seed) {
     const bool small = h->small_nb > 0;
     h->noise_ready = true; h->value_ready = !small; h->value_lazy = small; h->partials_ready = false; h->epart_ready = !small;
     h->eps_lazy = small || !h->store_eps_always; h->lazy_seed = seed; h->lazy_from_counter = true; h->lazy_counter_bumped = true;
+    h->injected_ready = !h->eps_lazy; h->last_tick_eager = false;
     API_END(h)
 }
 
 int mppi_synchronize(mppi_engine* h) {
     API_BEGIN(h)
-    HIPCHK(hipStreamSynchronize(h->stream));
+    h->wait_stream(__func__);
     API_END(h)
 }
 

@@ -48,6 +48,9 @@ struct DevParams {
     double dt, sigma, lambda, inv_lambda;
     double q0, q1, q2, r0, r1, p0, p1, p2;
     double u_max, kth, rhalf, floor_w;  // kth = wheel_radius / wheel_base, rhalf = wheel_radius / 2
+    // the `sig` matrix of get_cost (control/src/mppi:184: lam * u . sig . eps), row-major; sigma above is the
+    // std-dev the noise is drawn with (= sig[0,0], :143-146).  sigma * I unless mppi_set_sig_matrix was called.
+    double sg00, sg01, sg10, sg11;
     int model;                          // 0: rk4 + dd_dynamics, 1: euler + unicycle_dynamics
     // optional obstacle-grid stage cost (extension, include/mppi_hip.h mppi_set_obstacle_grid)
     const signed char* grid;
@@ -60,6 +63,12 @@ __device__ __forceinline__ double obstacle_cost(const DevParams& P, double x, do
     const int ix = (int)floor((x - P.grid_ox) / P.grid_res), iy = (int)floor((y - P.grid_oy) / P.grid_res);
     if (ix < 0 || iy < 0 || ix >= P.grid_w || iy >= P.grid_h) return 0.0;
     return P.grid_weight * ((double)P.grid[ix + iy * P.grid_w] / 100.0);
+}
+
+// lam * (u . sig): the row vector that multiplies the (unclipped) noise in get_cost, control/src/mppi:184
+__device__ __forceinline__ void cost_noise_weights(const DevParams& P, double un0, double un1, double& w0, double& w1) {
+    w0 = P.lambda * (un0 * P.sg00 + un1 * P.sg10);
+    w1 = P.lambda * (un0 * P.sg01 + un1 * P.sg11);
 }
 
 __device__ __forceinline__ double clampd(double v, double lim) { return fmin(fmax(v, -lim), lim); }
@@ -149,7 +158,6 @@ __global__ __launch_bounds__(kNomThreads) void nominal_kernel(DevParams P, const
     const int a = blockIdx.x, tid = threadIdx.x, T = P.T;
     const double gx = goal[a * 3 + 0], gy = goal[a * 3 + 1], gth = goal[a * 3 + 2];
     double car_x = state[a * 3 + 0], car_y = state[a * 3 + 1], car_th = state[a * 3 + 2];
-    const double ls = P.lambda * P.sigma;
     for (int b0 = 0; b0 < T; b0 += kNomThreads) {
         const int t = b0 + tid;
         const bool valid = t < T;
@@ -183,7 +191,8 @@ __global__ __launch_bounds__(kNomThreads) void nominal_kernel(DevParams P, const
             double cst = 0.5 * (xqx + uru);
             if (t == T - 1) cst += P.p0 * dx * dx + P.p1 * dy * dy + P.p2 * dth * dth;
             double* o = tc + ((size_t)a * T + t) * kTcW;
-            o[0] = un0; o[1] = un1; o[2] = ls * un0; o[3] = ls * un1;
+            o[0] = un0; o[1] = un1;
+            cost_noise_weights(P, un0, un1, o[2], o[3]);
             o[4] = 0.5 * uru - cst; o[5] = 0.0; o[6] = 0.0; o[7] = 0.0;
             cstage[t] = cst;
         }
@@ -461,8 +470,8 @@ __device__ __forceinline__ void nominal_lanes(const DevParams& P, const double* 
         const double uru = P.r0 * un0 * un0 + P.r1 * un1 * un1;
         cst = 0.5 * (xqx + uru);
         if (t == T - 1) cst += P.p0 * dx * dx + P.p1 * dy * dy + P.p2 * dth * dth;
-        const double ls = P.lambda * P.sigma;
-        row[2] = ls * un0; row[3] = ls * un1; row[4] = 0.5 * uru - cst;
+        cost_noise_weights(P, un0, un1, row[2], row[3]);
+        row[4] = 0.5 * uru - cst;
     }
     double tot;
     const double inc = lanes_scan_incl<NWAVES>(cst, t, sh, tot);
@@ -1088,7 +1097,8 @@ __global__ __launch_bounds__(256) void scan_tick_kernel(DevParams P, const doubl
         if (tid < 3) { pv_state[a * 3 + tid] = state[a * 3 + tid]; pv_goal[a * 3 + tid] = goal[a * 3 + tid]; }
     }
     const double half_uru = 0.5 * (P.r0 * un0 * un0 + P.r1 * un1 * un1);
-    const double ls = P.lambda * P.sigma, w0 = ls * un0, w1 = ls * un1;
+    double w0, w1;
+    cost_noise_weights(P, un0, un1, w0, w1);
     double sth0, cth0;
     sincos(th0, &sth0, &cth0);
     uint32_t key0 = 0, key1 = 0, tick = 0;
@@ -1224,7 +1234,9 @@ __device__ __forceinline__ void rk4_exact(const DevParams& P, const double x0[3]
 // (:91-101) for one agent per block.
 //   gathered [G][A][T][8] shard partials (G = 1: this engine's own)
 //   flags: bit0 plant step (perform_action :210-213), bit1 receding-horizon shift (:100-101),
-//          bit2 bump the device tick counter (graph replay), bit3 S_T staged in LDS (T*T more doubles)
+//          bit2 bump the device tick counter (graph replay), bit3 S_T staged in LDS (T*T more doubles),
+//          bit4 set the device tick counter to tick_set (eager ticks: the id after the one just run, so a
+//          later mppi_tick_graph continues the stream instead of re-drawing it)
 //   ufilt [A][2][T] filtered controls (un-shifted), outv [A][8] = {next_state[3], u_applied[2]}
 // dynamic LDS = 4*T doubles (+ T*T with bit3).
 // ---------------------------------------------------------------------------------------------
@@ -1232,7 +1244,8 @@ __device__ __forceinline__ void rk4_exact(const DevParams& P, const double x0[3]
 __global__ __launch_bounds__(1024) void finalize_kernel(DevParams P, const double* __restrict__ gathered, int G,
                                                       const double* __restrict__ Smat, double* __restrict__ unom,
                                                       double* __restrict__ ufilt, double* __restrict__ state,
-                                                      double* __restrict__ outv, uint32_t* tick_ptr, int flags) {
+                                                      double* __restrict__ outv, uint32_t* tick_ptr, int flags,
+                                                      uint32_t tick_set) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* un = reinterpret_cast<double*>(smem_raw);  // [2][T] updated + clipped
     double* uf = un + 2 * P.T;                          // [2][T] filtered + clipped
@@ -1343,6 +1356,7 @@ __global__ __launch_bounds__(1024) void finalize_kernel(DevParams P, const doubl
             state[a * 3 + 0] = xn[0]; state[a * 3 + 1] = xn[1]; state[a * 3 + 2] = xn[2];
         }
         if ((flags & 4) && a == 0 && tick_ptr) *tick_ptr = *tick_ptr + 1u;
+        if ((flags & 16) && a == 0 && tick_ptr) *tick_ptr = tick_set;
     }
 }
 #endif

@@ -7,7 +7,6 @@ method names, argument meaning and array layouts, so the reference's ``Controlle
 logic runs against it unmodified -- but every K x T loop runs in the HIP kernels.
 """
 import ctypes as C
-import os
 
 import numpy as np
 
@@ -20,41 +19,40 @@ WHEEL_RADIUS = 0.033
 WHEEL_BASE = 0.16
 
 
-def dd_dynamics(x, u):
-    """Diff-drive kinematics, control/src/mppi:23-30 (x [3,N], u [2,N]).  Host utility for
-    callers that want the model itself (e.g. a simulated plant); the engine never calls it."""
-    x = np.asarray(x, dtype=np.float64)
-    u = np.asarray(u, dtype=np.float64)
-    v = u[0, :] + u[1, :]
-    return np.array([(WHEEL_RADIUS / 2.0) * np.cos(x[2, :]) * v,
-                     (WHEEL_RADIUS / 2.0) * np.sin(x[2, :]) * v,
-                     (WHEEL_RADIUS / WHEEL_BASE) * (u[1, :] - u[0, :])])
+class _Model(object):
+    """One of the two integrator / dynamics pairs ``control/src/mppi`` defines, usable exactly like the
+    reference's module-level functions: as the ``model=`` constructor argument (:62) and as a callable
+    ``model(x0 [3,N], u [2,N], dt) -> [3,N]`` (how perform_action uses it, :210-213).  A call runs the
+    engine's own plant kernel (the reference's operation order, theta wrap included) -- there is no
+    host-side copy of the dynamics in this package."""
+
+    def __init__(self, name, doc):
+        self.name = name
+        self.__doc__ = doc
+        self._engines = {}
+
+    def __repr__(self):
+        return "<motion_planning_amd model %s>" % self.name
+
+    def __call__(self, x0, u, dt):
+        x0 = np.asarray(x0, dtype=np.float64)
+        u = np.asarray(u, dtype=np.float64)
+        single = x0.ndim == 1
+        xs = x0.reshape(3, -1)
+        us = u.reshape(2, -1)
+        n = xs.shape[1]
+        key = (n, float(dt))
+        eng = self._engines.get(key)
+        if eng is None:
+            eng = self._engines[key] = Engine(1, 6, n_agents=n, dt=float(dt), model=self.name, storage="f64")
+        for a in range(n):
+            eng.set_nominal(np.repeat(us[:, a:a + 1], 6, axis=1), agent=a)
+        out = eng.plant_step(np.ascontiguousarray(xs.T)).T
+        return out[:, 0] if single else out
 
 
-def rk4(x0, u, dt):
-    """Runge-Kutta 4 step + theta wrap, control/src/mppi:39-54.  Host utility (see dd_dynamics);
-    passing it as ``model=`` selects the engine's built-in RK4 rollout."""
-    x0 = np.asarray(x0, dtype=np.float64)
-    k1 = dt * dd_dynamics(x0, u)
-    k2 = dt * dd_dynamics(x0 + k1 / 2, u)
-    k3 = dt * dd_dynamics(x0 + k2 / 2, u)
-    k4 = dt * dd_dynamics(x0 + k3, u)
-    xnew = x0 + (1.0 / 6.0) * (k1 + 2 * k2 + 2 * k3 + k4)
-    xnew[2, :] = xnew[2, :] - (np.ceil((xnew[2, :] + np.pi) / (2.0 * np.pi)) - 1.0) * 2.0 * np.pi
-    return xnew
-
-
-def unicycle_dynamics(x, u):
-    """control/src/mppi:33-36.  Host utility (see dd_dynamics)."""
-    x = np.asarray(x, dtype=np.float64)
-    u = np.asarray(u, dtype=np.float64)
-    return np.array([np.cos(x[2, :]) * u[0, :], np.sin(x[2, :]) * u[0, :], u[1, :]])
-
-
-def euler(x0, u, dt):
-    """control/src/mppi:57-58.  Host utility; passing it as ``model=`` selects the engine's
-    euler + unicycle rollout (the reference's alternative to the default rk4 + diff drive)."""
-    return np.asarray(x0, dtype=np.float64) + dt * unicycle_dynamics(x0, u)
+rk4 = _Model("rk4", "rk4 over dd_dynamics, control/src/mppi:23-30, :39-54 (the node's model)")
+euler = _Model("euler", "euler over unicycle_dynamics, control/src/mppi:33-36, :57-58")
 
 
 _MODELS = {"rk4": _capi.MPPI_MODEL_DIFFDRIVE_RK4, "euler": _capi.MPPI_MODEL_UNICYCLE_EULER,
@@ -78,6 +76,9 @@ def _f64(a, shape=None):
 class Engine(object):
     """One libmppi_hip engine: A agents x K samples (this GPU's shard) x T horizon."""
 
+    # which kernels a tick runs when the constructor is not told (include/mppi_hip.h MPPI_TICK_*)
+    default_tick_path = "auto"
+
     def __init__(self, samples, horizon, n_agents=1, storage="f32", device=0, sample_offset=0,
                  dt=None, sigma=0.9, lam=0.001, model="rk4", tick_path=None, **overrides):
         self._lib = _capi.load()
@@ -87,8 +88,7 @@ class Engine(object):
         cfg.device = int(device)
         cfg.sample_offset = int(sample_offset)
         cfg.model = _MODELS[model]
-        # (the environment default lets the test-suite run every case on both paths)
-        cfg.tick_path = _TICK_PATHS[tick_path if tick_path is not None else os.environ.get("MPPI_TICK_PATH", "auto")]
+        cfg.tick_path = _TICK_PATHS[tick_path if tick_path is not None else self.default_tick_path]
         cfg.dt = 0.0 if dt is None else float(dt)
         cfg.sigma, cfg.lambda_ = float(sigma), float(lam)
         for key, val in overrides.items():
@@ -135,10 +135,42 @@ class Engine(object):
     def set_stream(self, stream_ptr):
         self._ck(self._lib.mppi_set_stream(self._h, C.c_void_p(int(stream_ptr))))
 
+    def get_stream(self):
+        """The hipStream_t (as an integer) the engine enqueues on."""
+        st = C.c_void_p()
+        self._ck(self._lib.mppi_get_stream(self._h, C.byref(st)))
+        return st.value or 0
+
     def set_sigma_lambda(self, sigma, lam):
         if sigma != self.sigma or lam != self.lam:
             self._ck(self._lib.mppi_set_sigma_lambda(self._h, float(sigma), float(lam)))
             self.sigma, self.lam = float(sigma), float(lam)
+
+    def set_sig(self, sig, lam):
+        """sig as get_path accepts it (control/src/mppi:88): a scalar sigma (= sigma * I) or any 2 x 2
+        matrix -- the noise is drawn with sig[0,0] (:143-146), the stage cost uses the whole matrix (:184)."""
+        sig = np.asarray(sig, dtype=np.float64)
+        if sig.ndim == 0:
+            return self.set_sigma_lambda(float(sig), lam)
+        if sig.shape != (2, 2):
+            raise ValueError("sig must be a scalar or a 2 x 2 matrix")
+        if sig[0, 1] == 0.0 and sig[1, 0] == 0.0 and sig[0, 0] == sig[1, 1]:
+            return self.set_sigma_lambda(float(sig[0, 0]), lam)
+        m = _f64(sig, (2, 2))
+        self._ck(self._lib.mppi_set_sig_matrix(self._h, _capi.dptr(m), float(lam)))
+        self.sigma, self.lam = None, float(lam)   # not a scalar any more: the next set_sigma_lambda always applies
+
+    def set_sync_timeout(self, milliseconds):
+        self._ck(self._lib.mppi_set_sync_timeout(self._h, int(milliseconds)))
+
+    def set_tick_counter(self, next_tick_id):
+        self._ck(self._lib.mppi_set_tick_counter(self._h, int(next_tick_id)))
+
+    def stream_wait_partials(self, other_stream_ptr):
+        self._ck(self._lib.mppi_stream_wait_partials(self._h, C.c_void_p(int(other_stream_ptr))))
+
+    def wait_for_stream(self, other_stream_ptr):
+        self._ck(self._lib.mppi_wait_for_stream(self._h, C.c_void_p(int(other_stream_ptr))))
 
     def set_obstacle_grid(self, cells, resolution, origin, weight):
         """EXTENSION (not in the reference cost): occupancy grid in map::Grid's export format,
@@ -264,6 +296,26 @@ class Engine(object):
                 "tick_kernels": "scan" if u.value == 0 else "lanes"}
 
 
+class _NominalView(np.ndarray):
+    """Host copy of the device-resident nominal controls whose assignments write through."""
+
+    def __new__(cls, arr, engine):
+        obj = np.asarray(arr, dtype=np.float64).view(cls)
+        obj._engine = engine
+        obj._root = obj
+        return obj
+
+    def __array_finalize__(self, obj):
+        self._engine = getattr(obj, "_engine", None)
+        self._root = getattr(obj, "_root", None)
+
+    def __setitem__(self, key, value):
+        super().__setitem__(key, value)
+        root = self._root
+        if root is not None and self._engine is not None and np.may_share_memory(self, root):
+            self._engine.set_nominal(np.asarray(root))
+
+
 def savgol_matrix(horizon):
     """The operator S with savgol_filter(u, T-1, 3, axis=1) == u @ S (control/src/mppi:202)."""
     S = np.empty((horizon, horizon))
@@ -288,10 +340,10 @@ class MPPI(object):
 
     def __init__(self, model=rk4, horizon=100, samples=10, thresh=0.05, rng="numpy", seed=0,
                  storage="f32", device=0, tick_path=None):
-        if model is rk4 or model == "rk4":
-            model_id = "rk4"
-        elif model is euler or model == "euler":
-            model_id = "euler"
+        if isinstance(model, _Model):
+            model_id = model.name
+        elif model in ("rk4", "euler"):
+            model_id = model
         else:
             raise NotImplementedError("model must be rk4 (diff drive, the node's default) or euler (unicycle): "
                                       "the two integrators control/src/mppi defines")
@@ -324,20 +376,22 @@ class MPPI(object):
 
     @property
     def latest_uvec(self):
-        return self._eng.get_nominal()
+        """The nominal control sequence [2, T] (control/src/mppi:81).  It lives on the device; what comes
+        back is an array whose item / slice assignments write through (``m.latest_uvec[:, 0] = 0`` works
+        like it does on the reference's attribute)."""
+        return _NominalView(self._eng.get_nominal(), self._eng)
 
     @latest_uvec.setter
     def latest_uvec(self, u):
         self._eng.set_nominal(u)
 
-    @staticmethod
-    def _sigma(sig):
+    def _set_sig(self, sig, lam):
+        """Hands sig / lam to the engine; returns the std-dev the noise is drawn with = sig[0,0] (:145)."""
         sig = np.asarray(sig, dtype=np.float64)
-        if sig.ndim == 0:
-            return float(sig)
-        if sig.shape != (2, 2) or sig[0, 1] != 0.0 or sig[1, 0] != 0.0 or sig[0, 0] != sig[1, 1]:
-            raise ValueError("sig must be sigma * I (the reference draws N(0, sig[0,0]) for both wheels)")
-        return float(sig[0, 0])
+        if sig.ndim not in (0, 2) or (sig.ndim == 2 and sig.shape != (2, 2)):
+            raise ValueError("sig must be a scalar or the 2 x 2 matrix get_path takes (control/src/mppi:88)")
+        self._eng.set_sig(sig, lam)
+        return float(sig) if sig.ndim == 0 else float(sig[0, 0])
 
     def _draw(self, sigma):
         # one legacy-RNG call per timestep, exactly the reference's consumption (:143-146)
@@ -345,8 +399,7 @@ class MPPI(object):
 
     # control/src/mppi:85-102
     def get_path(self, state, goal, sig=np.array([[.9, 0.0], [0.0, .9]]), lam=.001):
-        sigma = self._sigma(sig)
-        self._eng.set_sigma_lambda(sigma, lam)
+        sigma = self._set_sig(sig, lam)
         if self.rng == "numpy":
             self._eng.upload_noise(self._draw(sigma))
             nxt, ua = self._eng.tick(state, goal, noise="injected")
@@ -374,8 +427,7 @@ class MPPI(object):
 
     # control/src/mppi:127-178
     def get_cost2go(self, state, uvec, goal, lam, sig):
-        sigma = self._sigma(sig)
-        self._eng.set_sigma_lambda(sigma, lam)
+        sigma = self._set_sig(sig, lam)
         self._eng.set_nominal(uvec)
         if self.rng == "numpy":
             self._eng.upload_noise(self._draw(sigma))
@@ -395,7 +447,7 @@ class MPPI(object):
 
     # control/src/mppi:186-208
     def update_action(self, uvec, eps, value_fcn, sig, lam):
-        self._eng.set_sigma_lambda(self._sigma(sig), lam)
+        self._set_sig(sig, lam)
         self._eng.set_nominal(uvec)
         self._eng.upload_noise(np.asarray(eps, dtype=np.float64))
         self._eng.upload_value(value_fcn)

@@ -1,13 +1,21 @@
-"""K sharded over GPUs: one process per GPU, one tiny RCCL exchange per control tick.
+"""K sharded over GPUs: one process per GPU, one tiny exchange per control tick.
 
 The reference is single-process (control/src/mppi); its only cross-sample coupling is the
 per-timestep softmax of update_action (:187-196).  Splitting K over G ranks therefore needs
 exactly one exchange per tick: each rank reduces its samples to the tuple
 {min V, sum e, sum e*eps, sum eps, count} per (agent, t) -- [A][T][8] float64, 3.2 KB at
-T=50 -- the ranks all-gather those tuples (torch.distributed, backend "nccl" = RCCL over
-xGMI; "gloo" on CPU in the tests) and every rank finishes the tick identically
+T=50 -- the ranks all-gather those tuples and every rank finishes the tick identically
 (merge, control update, clip, filter, clip, plant step, shift).  The message is
-latency-bound, so it is ONE collective of the whole [A][T][8] block, not one per timestep.
+latency-bound, so it is ONE exchange of the whole [A][T][8] block, not one per timestep.
+
+Exchange back-ends (``exchange=``):
+  "rccl"  torch.distributed.all_gather_into_tensor (backend "nccl" = RCCL over xGMI; "gloo" on
+          CPU in the tests) on the stream the engine runs on;
+  "p2p"   the engine's own one-shot all-gather (mppi_p2p_*): every rank's publish kernel stores its
+          tuples straight into each peer's IPC-mapped mailbox over xGMI and raises a flag; the
+          finalize kernel waits for the G flags.  No collective launch, no host involvement per tick.
+  "auto"  p2p when its probe passes on every rank (sharded.probe_p2p), else rccl.
+Independent agents (BASELINE config 5) are replicas: no exchange at all (make_replica_ticker).
 """
 TUPLE_W = 8
 
@@ -58,32 +66,60 @@ def shard_range(samples_total, world_size, rank):
 
 
 class ShardedTicker(object):
-    """Drives one shard per rank through tick_begin -> all-gather -> tick_finish.
+    """Drives one shard per rank through tick_begin -> exchange -> tick_finish.
 
     ``shard`` is anything with the HipShard interface (the CPU tests plug the oracle in);
-    ``group`` a torch.distributed process group (None: the default group, or single process).
+    ``group`` a torch.distributed process group (None: the default group, or single process);
+    ``exchange``: "rccl" (the collective), "p2p" (the engine's own mailbox all-gather, set up by
+    make_hip_ticker), "none" (replicas / single process: every shard finishes on its own partials).
     """
 
-    def __init__(self, shard, group=None):
+    def __init__(self, shard, group=None, exchange="rccl"):
         import torch
         import torch.distributed as dist
         self.shard = shard
         self.group = group
-        self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
+        self.dist = dist if (exchange != "none" and dist.is_available() and dist.is_initialized()) else None
         self.world = self.dist.get_world_size(group) if self.dist else 1
         self.rank = self.dist.get_rank(group) if self.dist else 0
-        part = shard.partials_tensor()
-        # flat [world * A*T*8] receive buffer (rank-major), the layout mppi_tick_finish expects
-        # (a 1-rank process group still goes through the collective: same code path as N ranks)
-        self._gathered = torch.empty(self.world * part.numel(), dtype=part.dtype,
-                                     device=part.device) if self.dist else None
+        self.exchange = exchange if self.dist else "none"
+        self._gathered = None
+        if self.exchange == "rccl":
+            part = shard.partials_tensor()
+            # flat [world * A*T*8] receive buffer (rank-major), the layout mppi_tick_finish expects
+            # (a 1-rank process group still goes through the collective: same code path as N ranks)
+            self._gathered = torch.empty(self.world * part.numel(), dtype=part.dtype, device=part.device)
+        self._timing = False
+        self._ev = []
+
+    # -- optional timing of the exchange step (bench.py diagnostics) ----------------------------------
+    def time_exchange(self, on):
+        self._timing = bool(on) and self.exchange == "rccl"
+        self._ev = []
+
+    def exchange_times_us(self):
+        """Mean duration of the exchange step over the ticks run since time_exchange(True); None when there is
+        no bracketable exchange (no group; or p2p, whose wait lives inside the finalize kernel)."""
+        if not self._ev:
+            return None
+        self._ev[-1][1].synchronize()
+        return float(sum(1e3 * a.elapsed_time(b) for a, b in self._ev) / len(self._ev))
 
     def tick_async(self, state=None, goal=None, noise="philox", seed=0, tick_id=0):
         self.shard.tick_begin(state, goal, noise, seed, tick_id)
-        if self.dist:
+        if self.exchange == "rccl":
+            if self._timing:
+                import torch
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
             # one all-gather of [A][T][8] f64 per tick (RCCL over xGMI on GPUs)
             self.dist.all_gather_into_tensor(self._gathered, self.shard.partials_tensor(), group=self.group)
+            if self._timing:
+                b.record()
+                self._ev.append((a, b))
             self.shard.tick_finish(self._gathered, self.world)
+        elif self.exchange == "p2p":
+            self.shard.engine.tick_exchange_p2p()   # publish into every peer's mailbox + finalize behind the flags
         else:
             self.shard.tick_finish(None, 1)
 
@@ -92,19 +128,35 @@ class ShardedTicker(object):
         return self.shard.get_outputs()
 
 
-def make_hip_ticker(samples_total, horizon, n_agents=1, storage="f32", local_rank=0, group=None, **engine_kw):
+def make_hip_ticker(samples_total, horizon, n_agents=1, storage="f32", local_rank=0, group=None, exchange="auto",
+                    **engine_kw):
     """Engine for this rank's slice of the samples + the ticker around it."""
     import torch
     import torch.distributed as dist
     from .mppi import Engine
-    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-    rank = dist.get_rank(group) if world > 1 else 0
+    in_group = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if in_group else 1
+    rank = dist.get_rank(group) if in_group else 0
     lo, hi = shard_range(samples_total, world, rank)
     torch.cuda.set_device(local_rank)
     eng = Engine(hi - lo, horizon, n_agents=n_agents, storage=storage, device=local_rank,
                  sample_offset=lo, **engine_kw)
     # a single process has no collective to order with: keep the engine's own stream (which is
     # also what hipGraph capture needs -- the null stream cannot be captured)
-    in_group = dist.is_available() and dist.is_initialized()
     shard = HipShard(eng, torch.device("cuda", local_rank), use_torch_stream=in_group)
-    return ShardedTicker(shard, group), eng
+    kind = "none" if not in_group else "rccl"
+    if in_group and world > 1 and exchange in ("auto", "p2p"):
+        from . import p2p
+        if p2p.setup(eng, group, rank, world, local_rank, required=(exchange == "p2p")):
+            kind = "p2p"
+    return ShardedTicker(shard, group, exchange=kind), eng
+
+
+def make_replica_ticker(samples, horizon, n_agents, storage="f32", local_rank=0, **engine_kw):
+    """Independent agents (BASELINE config 5): this rank's agents in one engine, no exchange."""
+    import torch
+    from .mppi import Engine
+    torch.cuda.set_device(local_rank)
+    eng = Engine(samples, horizon, n_agents=n_agents, storage=storage, device=local_rank, **engine_kw)
+    shard = HipShard(eng, torch.device("cuda", local_rank), use_torch_stream=False)
+    return ShardedTicker(shard, None, exchange="none"), eng

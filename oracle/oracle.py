@@ -22,7 +22,7 @@ class OrcParams(C.Structure):
                 ("wheel_base", C.c_double), ("floor_w", C.c_double), ("model", C.c_int),
                 ("grid", C.c_void_p), ("grid_w", C.c_int), ("grid_h", C.c_int),
                 ("grid_res", C.c_double), ("grid_ox", C.c_double), ("grid_oy", C.c_double),
-                ("grid_weight", C.c_double)]
+                ("grid_weight", C.c_double), ("use_sig", C.c_int), ("sig", C.c_double * 4)]
 
 
 def build(force=False):
@@ -69,6 +69,15 @@ def set_obstacle_grid(params, cells, resolution, origin, weight):
     params.grid_h, params.grid_w = cells.shape
     params.grid_res, params.grid_ox, params.grid_oy = float(resolution), float(origin[0]), float(origin[1])
     params.grid_weight = float(weight)
+    return params
+
+
+def set_sig_matrix(params, sig):
+    """sig [2,2] as the reference's get_path accepts it: stage cost lam * u . sig . eps (control/src/mppi:184);
+    the noise is still drawn with sig[0,0] (:143-146) -- pass that as the scalar `sigma`."""
+    sig = np.asarray(sig, dtype=np.float64).reshape(2, 2)
+    params.use_sig = 1
+    params.sig[:] = [sig[0, 0], sig[0, 1], sig[1, 0], sig[1, 1]]
     return params
 
 

@@ -346,6 +346,33 @@ def main():
     out["solve_path_uvec"] = mp.uvec.copy()
     out["solve_path_meta"] = np.array([K, T, seed, mp.path.shape[0] - 1], dtype=np.int64)
 
+    # ---------------- K: sig that is NOT sigma * I.  The reference draws every wheel's noise with sig[0,0] (:143-146)
+    # but its stage cost multiplies the FULL matrix, lam * u . sig . eps (:184): a diagonal with two different
+    # entries, and a matrix with off-diagonal terms (the reference accepts both).
+    K, T, seed, nt = 56, 50, 41, 4
+    for tag, sm in (("sigdiag", np.array([[0.9, 0.0], [0.0, 0.5]])), ("sigfull", np.array([[0.8, 0.15], [-0.1, 0.5]]))):
+        mp = ref.MPPI(horizon=T, samples=K)
+        u0 = nominal_warm(T)
+        state, goal = np.array([0.05, -0.1, 0.3]), np.array([0.5, -0.7, -0.2])
+        np.random.seed(seed)
+        V, eps = mp.get_cost2go(state, u0.copy(), goal, 0.02, sm)
+        assert np.array_equal(np.array(eps), np.random.RandomState(seed).normal(0.0, sm[0, 0], (T, 2, K)))
+        out[tag + "_c2g_V"] = V.copy()
+        out[tag + "_c2g_unew"] = mp.update_action(u0.copy(), eps, V.copy(), sm, 0.02)
+        mp.initialize()
+        np.random.seed(seed + 1)
+        st, states, us = state.copy(), [], []
+        for _ in range(nt):
+            st = mp.get_path(st, goal, sig=sm, lam=0.02)
+            states.append(st.copy())
+            us.append(mp.uvec[-1].copy())
+        out[tag + "_seq_states"], out[tag + "_seq_u"] = np.array(states), np.array(us)
+        out[tag + "_seq_latest_uvec"] = mp.latest_uvec.copy()
+        out[tag + "_sig"] = sm
+    out["sigmat_meta"] = np.array([K, T, seed, nt], dtype=np.int64)
+    out["sigmat_state"], out["sigmat_goal"], out["sigmat_u0"] = state, goal, nominal_warm(T)
+    out["sigmat_lam"] = np.array(0.02)
+
     np.savez_compressed(os.path.join(HERE, "mppi_golden.npz"), **out)
     with open(os.path.join(HERE, "mppi_kat.json"), "w") as f:
         json.dump(kat, f, indent=1, sort_keys=True)

@@ -25,7 +25,7 @@ def test_header_symbols_all_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), "libmppi_hip.so does not export %s" % n
     assert sorted(_capi.SIGNATURES) == names  # the ctypes binding covers exactly the header
-    assert lib.mppi_abi_version() == 1
+    assert lib.mppi_abi_version() == 2
 
 
 def test_default_config_is_the_reference_node(kat):
@@ -76,14 +76,20 @@ def test_savgol_rejects_even_window():
         savgol_matrix(4)
 
 
-def test_host_kinematics_helpers(kat):
-    from motion_planning_amd import dd_dynamics, rk4, wheels_to_twist
-    x, u = np.array([[0.3], [-0.2], [0.7]]), np.array([[1.25], [-0.5]])
-    assert np.allclose(dd_dynamics(x, u)[:, 0], kat["dd_dynamics"], rtol=0, atol=1e-17)
-    assert np.allclose(rk4(x, u, 0.01)[:, 0], kat["rk4_plain"], rtol=0, atol=1e-16)
-    assert np.allclose(rk4(np.array([[0.0], [0.0], [3.1]]), np.array([[-6.35492], [6.35492]]), 0.02)[:, 0],
-                       kat["rk4_wrap"], rtol=0, atol=1e-15)
-    assert np.allclose(wheels_to_twist([1.0, 2.0]), kat["wheelsToTwist_1_2"], rtol=0, atol=1e-17)
+def test_host_helpers(kat):
+    """The only arithmetic the host side keeps: wheelsToTwist.  The models (`rk4`, `euler`) are tokens for
+    the `model=` argument whose calls run the engine's plant kernel (GPU test: test_model_tokens_run_the_plant_kernel)."""
+    import motion_planning_amd as pkg
+    assert np.allclose(pkg.wheels_to_twist([1.0, 2.0]), kat["wheelsToTwist_1_2"], rtol=0, atol=1e-17)
+    assert pkg.rk4.name == "rk4" and pkg.euler.name == "euler" and callable(pkg.rk4)
+    assert not hasattr(pkg, "dd_dynamics") and not hasattr(pkg.mppi, "dd_dynamics")   # no host copy of the dynamics
+
+
+def test_product_reads_no_test_hooks_from_the_environment():
+    """Engine construction is configured by arguments only (the test-suite picks the tick path through
+    Engine.default_tick_path, not through an environment variable read in the product)."""
+    src = open(os.path.join(ROOT, "motion_planning_amd", "mppi.py")).read()
+    assert "os.environ" not in src and "MPPI_TICK_PATH" not in src
 
 
 def test_create_fails_loudly_without_gpu():

@@ -232,3 +232,28 @@ def test_obstacle_grid_extension_is_off_by_default(orc, golden):
     V0, c0, _ = orc.get_cost2go(*args, want_costs=True)
     extra = c - c0
     assert extra.min() >= 0 and set(np.unique(np.round(extra, 9))) <= {0.0, 150.0, 300.0} and extra.max() > 0
+
+
+@pytest.mark.parametrize("tag", ["sigdiag", "sigfull"])
+def test_sig_matrix_not_isotropic(orc, golden, tag):
+    """sig != sigma * I (golden section K): the noise is drawn with sig[0,0] for both wheels
+    (control/src/mppi:143-146) while the stage cost uses the full matrix, lam * u . sig . eps (:184)."""
+    K, T, seed, nt = [int(x) for x in golden["sigmat_meta"]]
+    sm, lam = golden[tag + "_sig"], float(golden["sigmat_lam"])
+    p = orc.set_sig_matrix(orc.default_params(), sm)
+    state, goal, u0 = golden["sigmat_state"], golden["sigmat_goal"], golden["sigmat_u0"]
+    eps = orc.reference_noise(seed, sm[0, 0], T, K)
+    V = orc.get_cost2go(state, u0, goal, lam, sm[0, 0], eps, params=p)
+    assert np.abs(V - golden[tag + "_c2g_V"]).max() < 1e-9
+    u = orc.update_action(u0, eps, V, lam, params=p)
+    assert np.abs(u - golden[tag + "_c2g_unew"]).max() < 1e-9
+    # the isotropic shortcut would be wrong here: the goldens really exercise the matrix
+    Viso = orc.get_cost2go(state, u0, goal, lam, sm[0, 0], eps)
+    assert np.abs(Viso - golden[tag + "_c2g_V"]).max() > 1e-4
+    noise = orc.reference_noise(seed + 1, sm[0, 0], T, K, n_ticks=nt)
+    st, lat = state.copy(), np.zeros((2, T))
+    for i in range(nt):
+        st, ua, lat = orc.get_path(st, goal, lat, noise[i], lam, sm[0, 0], params=p)
+        assert np.abs(st - golden[tag + "_seq_states"][i]).max() < 1e-10, i
+        assert np.abs(ua - golden[tag + "_seq_u"][i]).max() < 1e-9, i
+    assert np.abs(lat - golden[tag + "_seq_latest_uvec"]).max() < 1e-9
