@@ -148,7 +148,7 @@ struct mppi_engine {
             const hipError_t e = query();
             if (e == hipSuccess) return;
             if (e != hipErrorNotReady) fail(MPPI_E_HIP, "%s: %s", what, hipGetErrorString(e));
-            if ((spins & 31u) == 0) {
+            if ((spins & 7u) == 0) {
                 const auto us = std::chrono::duration_cast<std::chrono::microseconds>(clock::now() - t0).count();
                 if (sync_timeout_ms > 0 && us > (long long)sync_timeout_ms * 1000)
                     fail(MPPI_E_TIMEOUT, "%s: the device did not finish within %d ms (the engine must be destroyed)", what, sync_timeout_ms);

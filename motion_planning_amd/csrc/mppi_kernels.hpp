@@ -937,6 +937,25 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
     const R scale = (R)(P.inv_lambda * 1.4426950408889634);  // log2(e) / lambda
     const R cand = (R)(sizeof(S) == 4 ? -80.0 : -100.0);     // log2 of the smallest weight that is kept
     R D = 0, N0 = 0, N1 = 0;
+    // REGEN (eps was never stored): a sample that carries weight needs its noise re-drawn -- one Philox call.
+    // Far from the goal a row has a handful of such samples; parked AT the goal 1-5 % of a row carry weight, and a
+    // re-draw inside this loop would run (wave-uniformly) for almost every one of the 32 values a lane walks through.
+    // So the loop only NOTES its weighted samples -- (index, weight) in the thread's own LDS slots, no atomics, no
+    // cross-lane traffic -- and the re-draws happen afterwards, once per slot: max-per-lane (~5) Philox rounds per
+    // wave instead of 32.  A lane that runs out of slots (sigma = 0, or every sample on the same cost) walks its
+    // values again from L2 in a rolled loop and re-draws the ones beyond its slots (rare, kept out of the hot loop).
+    constexpr int kSlots = 6;
+    __shared__ uint32_t q_k[REGEN ? kSlots : 1][256];
+    __shared__ R q_e[REGEN ? kSlots : 1][256];
+    int qn = 0;
+    const uint32_t tick_now = REGEN ? (tick_ptr ? *tick_ptr : tick_arg) : 0u;
+    auto redraw = [&](uint32_t kk, R e) {
+        float f0, f1;  // the same Philox counter the rollout used for this (sample, step)
+        philox_normal_pair(P.sample_offset + kk, (uint32_t)t, tick_now, (uint32_t)a, (uint32_t)seed, (uint32_t)(seed >> 32),
+                           (float)P.sigma, f0, f1);
+        N0 = fma(e, (R)(S)f0, N0);
+        N1 = fma(e, (R)(S)f1, N1);
+    };
 #pragma unroll
     for (int j = 0; j < kUpdNV; ++j) {
         const int k = k_begin + (j * 256 + tid) * VEC;
@@ -945,22 +964,32 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
             const R x = (M - v[j][i]) * scale;  // <= 0; -inf for the padding
             const R e = Exp2<R>::f(x);
             D += e;
-            if (x > cand) {  // rare: wave-uniformly skipped for almost every vector
-                R a0, a1;
-                if (REGEN) {  // eps was never stored: re-draw this sample's step (same Philox counter)
-                    float ev[6];
-                    philox_normals(P.sample_offset + (uint32_t)(k + i), (uint32_t)(t / kStepsPerDraw),
-                                   tick_ptr ? *tick_ptr : tick_arg, (uint32_t)a, (uint32_t)seed,
-                                   (uint32_t)(seed >> 32), (float)P.sigma, ev);
-                    const int sel = t % kStepsPerDraw;
-                    a0 = (R)(sel == 0 ? ev[0] : (sel == 1 ? ev[2] : ev[4]));
-                    a1 = (R)(sel == 0 ? ev[1] : (sel == 1 ? ev[3] : ev[5]));
+            if (x > cand) {  // wave-uniformly skipped for almost every vector while the robot is far from its goal
+                if (REGEN) {
+                    if (qn < kSlots) { q_k[qn][tid] = (uint32_t)(k + i); q_e[qn][tid] = e; }
+                    ++qn;
                 } else {
-                    a0 = (R)e0_row[k + i];
-                    a1 = (R)e1_row[k + i];
+                    N0 = fma(e, (R)e0_row[k + i], N0);
+                    N1 = fma(e, (R)e1_row[k + i], N1);
                 }
-                N0 = fma(e, a0, N0);
-                N1 = fma(e, a1, N1);
+            }
+        }
+    }
+    if (REGEN) {
+#pragma unroll 1
+        for (int j = 0; j < kSlots; ++j) {
+            if (!__any(j < qn)) break;  // (uniform)
+            if (j < qn) redraw(q_k[j][tid], q_e[j][tid]);
+        }
+        if (__any(qn > kSlots)) {  // (uniform, rare) same walk, same order: skip what the slots already covered
+            int seen = 0;
+#pragma unroll 1
+            for (int idx = 0; idx < kUpdNV * VEC; ++idx) {
+                const int k = k_begin + ((idx / VEC) * 256 + tid) * VEC + idx % VEC;
+                if (k < k_end && qn > kSlots) {
+                    const R x = (M - (s_row[k] - v_row[k])) * scale;
+                    if (x > cand && ++seen > kSlots) redraw((uint32_t)k, Exp2<R>::f(x));
+                }
             }
         }
     }

@@ -735,6 +735,41 @@ def test_f32_storage_against_f64_storage_at_config4(orc, tick_path):
         eV_rows.max(), np.abs(out["f32"][2] - out["f64"][2]).max(), tol.max()))
 
 
+@pytest.mark.parametrize("regime", ["parked", "flat"])
+def test_many_weighted_samples(orc, tick_path, regime):
+    """The other regime of the update: the robot parked AT its goal with zero nominal controls -- 1-5 % of every
+    row's samples carry softmax weight ("parked"); and a nearly flat cost landscape (sigma = 1e-3: essentially every sample
+    carries weight, the per-lane candidate slots of the update kernel overflow into its fallback walk, "flat").
+    Device noise, full oracle replay, K = 200 000."""
+    if tick_path == "scan":
+        pytest.skip("lane kernels (the update kernel) are the subject")
+    K, T = 200000, 50
+    state, goal = [0.0, -1.0, 0.0], [0.0, -1.0, 0.0]
+    u0 = np.zeros((2, T))
+    sigma = SIG if regime == "parked" else 1e-3
+    for storage in ("f32", "f64"):
+        with _engine(K, T, storage, sigma=sigma) as e:
+            e.set_nominal(u0)
+            nxt, ua = e.tick(state, goal, noise="philox", seed=12, tick_id=5)
+            V = e.download_value()[0]
+            eps = e.download_noise()[0]
+            lat = e.get_nominal()
+        Vo = orc.get_cost2go(state, u0, goal, LAM, sigma, eps)
+        frac = ((Vo - Vo.min(axis=1, keepdims=True)) < 0.0554).mean()
+        assert frac > (5e-3 if regime == "parked" else 0.5), frac          # the regime is what the test says it is
+        errV = np.abs(V - Vo)
+        assert errV.max() <= (1e-9 * max(1.0, np.abs(Vo).max()) if storage == "f64" else 3e-7 * max(1.0, np.abs(Vo).max()))
+        mean, mad = _softmax_rows(Vo, eps)
+        S = orc.savgol_matrix(T)
+        uf = np.clip(np.clip(u0 + mean.T, -6.35492, 6.35492) @ S, -6.35492, 6.35492)
+        # fp32 mode: the weights themselves are fp32 (v_exp_f32 of an fp32 argument: ~1e-6 relative each)
+        tol = _u_bound(mad, errV.max(axis=1), S) + (1e-9 if storage == "f64" else 2e-6 * np.abs(S).T.sum(axis=1)[None, :] * mad.max())
+        assert (np.abs(ua[0] - uf[:, 0]) <= tol[:, 0]).all(), (storage, np.abs(ua[0] - uf[:, 0]), tol[:, 0])
+        assert (np.abs(lat[:, :-1] - uf[:, 1:]) <= tol[:, 1:]).all(), storage
+        print("many weighted samples (%s, %s): %.2f %% of (t, k) carry weight, max |du| %.3g" % (
+            regime, storage, 100 * frac, max(np.abs(ua[0] - uf[:, 0]).max(), np.abs(lat[:, :-1] - uf[:, 1:]).max())))
+
+
 def test_config5_64_agents_full_size(orc, tick_path):
     """BASELINE config 5 at full size: 64 agents x K = 16384, T = 50 in ONE engine (device RNG).  Agents are
     independent controllers: EVERY agent's tick equals the full oracle replay of that agent alone on the noise
@@ -817,8 +852,9 @@ def test_tick_graph_equals_eager():
         for i in range(1, 4):
             a.tick(None, None, noise="philox", seed=seed, tick_id=i)
         ea = a.get_outputs()
-        # graph path on b: prime state/goal without running a tick
+        # graph path on b: prime state/goal without running a tick; the replays count ticks from 0 again
         b.rollout([0, 0, 0], [0, -1, 0], noise="philox", seed=seed, tick_id=0)
+        b.set_tick_counter(0)
         for i in range(4):
             b.tick_graph(seed)
         eb = b.get_outputs()
@@ -877,13 +913,16 @@ def test_eager_ticks_advance_the_graph_tick_counter():
 
 def test_blocking_waits_are_bounded():
     """A blocking call gives up with MPPI_E_TIMEOUT (-5) instead of hanging the control thread: a 1 ms deadline
-    against a tick that takes several (K = 10^6 on the scan kernel)."""
+    against 40 queued ticks of K = 10^6 on the scan kernel (tens of milliseconds of work)."""
     from motion_planning_amd._capi import MppiError, MPPI_E_TIMEOUT
     with _engine(1000000, 50, "f32", tick_path="scan") as e:
         e.tick([0, 0, 0], [0, -1, 0], noise="philox", seed=1, tick_id=0)   # default deadline: fine
         e.set_sync_timeout(1)
+        for i in range(40):
+            e.tick_begin(None, None, noise="philox", seed=1, tick_id=1 + i)
+            e.tick_finish()
         with pytest.raises(MppiError) as ei:
-            e.tick(None, None, noise="philox", seed=1, tick_id=1)
+            e.get_outputs()
         assert ei.value.code == MPPI_E_TIMEOUT and "did not finish" in str(ei.value)
         e.set_sync_timeout(0)      # wait forever: drains what is still running
         e.synchronize()

@@ -45,6 +45,29 @@ KERNEL32(k_mul_lo_u32, "v_mul_lo_u32 %0, %0, %8\nv_mul_lo_u32 %1, %1, %8\nv_mul_
 KERNEL32(k_mul_hi_u32, "v_mul_hi_u32 %0, %0, %8\nv_mul_hi_u32 %1, %1, %8\nv_mul_hi_u32 %2, %2, %8\nv_mul_hi_u32 %3, %3, %8\nv_mul_hi_u32 %4, %4, %8\nv_mul_hi_u32 %5, %5, %8\nv_mul_hi_u32 %6, %6, %8\nv_mul_hi_u32 %7, %7, %8")
 KERNEL32(k_xor_b32, "v_xor_b32 %0, %0, %8\nv_xor_b32 %1, %1, %8\nv_xor_b32 %2, %2, %8\nv_xor_b32 %3, %3, %8\nv_xor_b32 %4, %4, %8\nv_xor_b32 %5, %5, %8\nv_xor_b32 %6, %6, %8\nv_xor_b32 %7, %7, %8")
 KERNEL64(k_pk_fma_f32, "v_pk_fma_f32 %0, %0, %8, %9\nv_pk_fma_f32 %1, %1, %8, %9\nv_pk_fma_f32 %2, %2, %8, %9\nv_pk_fma_f32 %3, %3, %8, %9\nv_pk_fma_f32 %4, %4, %8, %9\nv_pk_fma_f32 %5, %5, %8, %9\nv_pk_fma_f32 %6, %6, %8, %9\nv_pk_fma_f32 %7, %7, %8, %9", "")
+// packed / VOP2 fp32 forms the two-samples-per-lane rollout would use
+#define PK8(OP) OP " %0, %0, %8\n" OP " %1, %1, %8\n" OP " %2, %2, %8\n" OP " %3, %3, %8\n" OP " %4, %4, %8\n" OP " %5, %5, %8\n" OP " %6, %6, %8\n" OP " %7, %7, %8"
+KERNEL64(k_pk_mul_f32, PK8("v_pk_mul_f32"), "")
+KERNEL64(k_pk_add_f32, PK8("v_pk_add_f32"), "")
+KERNEL32(k_add_f32, PK8("v_add_f32"))
+KERNEL32(k_mul_f32, PK8("v_mul_f32"))
+KERNEL32(k_max_f32, PK8("v_max_f32"))
+KERNEL32(k_fmac_f32, PK8("v_fmac_f32"))
+KERNEL32(k_med3_f32, "v_med3_f32 %0, %0, %8, %9\nv_med3_f32 %1, %1, %8, %9\nv_med3_f32 %2, %2, %8, %9\nv_med3_f32 %3, %3, %8, %9\nv_med3_f32 %4, %4, %8, %9\nv_med3_f32 %5, %5, %8, %9\nv_med3_f32 %6, %6, %8, %9\nv_med3_f32 %7, %7, %8, %9")
+KERNEL32(k_add_f32_dpp, "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\nv_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\nv_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\nv_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\nv_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\nv_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\nv_add_f32_dpp %6, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\nv_add_f32_dpp %7, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+KERNEL32(k_bitop3, "v_bitop3_b32 %0, %0, %8, %9 bitop3:0x96\nv_bitop3_b32 %1, %1, %8, %9 bitop3:0x96\nv_bitop3_b32 %2, %2, %8, %9 bitop3:0x96\nv_bitop3_b32 %3, %3, %8, %9 bitop3:0x96\nv_bitop3_b32 %4, %4, %8, %9 bitop3:0x96\nv_bitop3_b32 %5, %5, %8, %9 bitop3:0x96\nv_bitop3_b32 %6, %6, %8, %9 bitop3:0x96\nv_bitop3_b32 %7, %7, %8, %9 bitop3:0x96")
+KERNEL32(k_cndmask, "v_cndmask_b32 %0, %0, %8, vcc\nv_cndmask_b32 %1, %1, %8, vcc\nv_cndmask_b32 %2, %2, %8, vcc\nv_cndmask_b32 %3, %3, %8, vcc\nv_cndmask_b32 %4, %4, %8, vcc\nv_cndmask_b32 %5, %5, %8, vcc\nv_cndmask_b32 %6, %6, %8, vcc\nv_cndmask_b32 %7, %7, %8, vcc")
+__global__ void k_cvt_f32_f64(double* out, int iters) {
+    float d0 = threadIdx.x, d1 = d0 + 1, d2 = d0 + 2, d3 = d0 + 3, d4 = d0 + 4, d5 = d0 + 5, d6 = d0 + 6, d7 = d0 + 7;
+    double k = 1.5 + threadIdx.x;
+    for (int i = 0; i < iters; ++i) {
+        for (int j = 0; j < 8; ++j) {
+            asm volatile("v_cvt_f32_f64 %0, %8\nv_cvt_f32_f64 %1, %8\nv_cvt_f32_f64 %2, %8\nv_cvt_f32_f64 %3, %8\nv_cvt_f32_f64 %4, %8\nv_cvt_f32_f64 %5, %8\nv_cvt_f32_f64 %6, %8\nv_cvt_f32_f64 %7, %8"
+                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(k));
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7;
+}
 __global__ void k_mad_u64_u32(double* out, int iters) {
     unsigned long long d0 = threadIdx.x, d1 = d0 + 1, d2 = d0 + 2, d3 = d0 + 3, d4 = d0 + 4, d5 = d0 + 5, d6 = d0 + 6, d7 = d0 + 7;
     const unsigned k = 0xD2511F53u, m = 0xCD9E8D57u + threadIdx.x;
@@ -82,9 +105,12 @@ int main() {
         {"v_fma_f64", k_fma_f64}, {"v_mul_f64", k_mul_f64}, {"v_add_f64", k_add_f64}, {"v_max_f64", k_max_f64},
         {"v_fma_f32", k_fma_f32}, {"v_pk_fma_f32", k_pk_fma_f32}, {"v_exp_f32", k_exp_f32}, {"v_log_f32", k_log_f32},
         {"v_sin_f32", k_sin_f32}, {"v_sqrt_f32", k_sqrt_f32}, {"v_mul_lo_u32", k_mul_lo_u32}, {"v_mul_hi_u32", k_mul_hi_u32},
-        {"v_xor_b32", k_xor_b32}, {"v_mad_u64_u32", k_mad_u64_u32}, {"v_cvt_f64_f32", k_cvt_f64_f32}};
+        {"v_xor_b32", k_xor_b32}, {"v_mad_u64_u32", k_mad_u64_u32}, {"v_cvt_f64_f32", k_cvt_f64_f32},
+        {"v_pk_mul_f32", k_pk_mul_f32}, {"v_pk_add_f32", k_pk_add_f32}, {"v_add_f32", k_add_f32}, {"v_mul_f32", k_mul_f32},
+        {"v_max_f32", k_max_f32}, {"v_fmac_f32", k_fmac_f32}, {"v_med3_f32", k_med3_f32}, {"v_add_f32_dpp", k_add_f32_dpp},
+        {"v_bitop3_b32", k_bitop3}, {"v_cndmask_b32", k_cndmask}, {"v_cvt_f32_f64", k_cvt_f32_f64}};
     printf("device %s, %d CUs, clockRate %.0f MHz\n", prop.name, cus, mhz);
-    for (int wps : {1, 2, 4}) {   // waves per SIMD
+    for (int wps : {2, 4}) {   // waves per SIMD
         for (auto& c : cases) {
             const int iters = 2000;
             const int blocks = cus * wps;  // 256-thread blocks: 4 waves = 1 per SIMD

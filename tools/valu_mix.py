@@ -70,7 +70,12 @@ def main():
     inner = [l for l in loops if not any(o is not l and o[0] >= l[0] and o[1] <= l[1] for o in loops)]
     if not inner:
         sys.exit("no loop found")
-    best = max(inner, key=lambda l: l[1] - l[0])
+    # the steady-state loop of FULL blocks is the one whose stores are raw buffer stores (the ragged-block variant of
+    # the same chunk guards plain global stores with exec masks); ties -> the larger body
+    def key(l):
+        ops = [i.split()[0] for i in insts[l[0]:l[1] + 1]]
+        return (sum(o.startswith("buffer_store") for o in ops), l[1] - l[0])
+    best = max(inner, key=key)
     n, body = best[2], insts[best[0]:best[1] + 1]
     counts = {}
     n_salu = n_vmem = n_lds = n_other = 0
