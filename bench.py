@@ -305,9 +305,15 @@ def main():
         # at its goal -- a different workload (1-5 % of a row carry softmax weight there, a handful do on the way).
         # The measured ticks must not depend on how long the clocks took to ramp: put the controller back at the start
         # (state, nominal controls) so that the timed region is always ticks 1..K of the same parallel-park run.
+        phase = [0]
+
         def restart():
             for a in range(A):
                 eng.set_nominal(nominal_warm(T), agent=a)
+            phase[0] += 1
+            counter[0] = 1_000_000 * phase[0]      # tick ids (= noise streams) of a phase do not depend on the warm-up's length
+            if args.graph and not in_group:
+                eng.set_tick_counter(counter[0] + 1)
             tick(first=True)
         restart()
         # Timed region: exactly --steps ticks between barrier + synchronize pairs.  The dominant kernel (rollout) is

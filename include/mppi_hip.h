@@ -219,6 +219,32 @@ int mppi_tick_finish(mppi_engine *h, const void *gathered_dev, int n_shards);
  * other_stream is a hipStream_t (NULL = the legacy null stream). */
 int mppi_stream_wait_partials(mppi_engine *h, void *other_stream);
 int mppi_wait_for_stream(mppi_engine *h, void *other_stream);
+/*
+ * One-shot peer-to-peer exchange of the partials for K sharded over the (<= 8) GPUs of ONE node -- the alternative
+ * to an RCCL all-gather between tick_begin and tick_finish (the message is 3.2 KB: latency is everything):
+ *   mppi_p2p_create   allocates this rank's mailbox (fine-grained device memory, [2][n_ranks] slots + flags) and
+ *                     returns its HIP IPC handle in ipc_handle_out (MPPI_IPC_HANDLE_BYTES bytes; NULL: not wanted);
+ *   mppi_p2p_connect  maps the peers' mailboxes: ipc_handles = n_ranks handles, rank-major (other processes), and / or
+ *                     local_ptrs[g] = mppi_p2p_mailbox_ptr of an engine in THIS process (non-NULL entries win);
+ *   mppi_tick_exchange_p2p   replaces mppi_tick_finish after mppi_tick_begin: a publish kernel stores this rank's
+ *                     tuples into every peer's mailbox over xGMI and raises a flag; the finalize kernel waits for its
+ *                     own mailbox's n_ranks flags and finishes the tick.  Asynchronous, no host involvement, no collective;
+ *                     a peer that never delivers surfaces as MPPI_E_TIMEOUT from mppi_get_outputs.
+ *                     = mppi_p2p_publish + mppi_tick_finish_p2p, which a caller driving SEVERAL engines from one
+ *                     thread calls separately (publish on all of them first: a finalize kernel that waits for a
+ *                     publish enqueued after it can starve it when the runtime maps both streams to one hardware queue);
+ *   mppi_p2p_selftest collective round trips of a known pattern (set-up time check before trusting the path).
+ * Every rank must run the same sequence of exchanges (epochs are counted per rank).
+ */
+#define MPPI_IPC_HANDLE_BYTES 64
+int mppi_p2p_create(mppi_engine *h, int n_ranks, int rank, void *ipc_handle_out);
+int mppi_p2p_connect(mppi_engine *h, const void *ipc_handles, void *const *local_ptrs);
+int mppi_p2p_mailbox_ptr(mppi_engine *h, void **dev_ptr);
+int mppi_p2p_selftest(mppi_engine *h, int rounds);
+int mppi_p2p_destroy(mppi_engine *h);
+int mppi_p2p_publish(mppi_engine *h);
+int mppi_tick_finish_p2p(mppi_engine *h);
+int mppi_tick_exchange_p2p(mppi_engine *h);
 /* Synchronises; next_state [A][3], u_applied [A][2] (either may be NULL). */
 int mppi_get_outputs(mppi_engine *h, double *next_state, double *u_applied);
 int mppi_tick(mppi_engine *h, const double *state, const double *goal, int noise_mode,

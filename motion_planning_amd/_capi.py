@@ -12,6 +12,7 @@ MPPI_NOISE_INJECTED, MPPI_NOISE_PHILOX = 0, 1
 MPPI_MODEL_DIFFDRIVE_RK4, MPPI_MODEL_UNICYCLE_EULER = 0, 1
 MPPI_TICK_AUTO, MPPI_TICK_LANES, MPPI_TICK_SCAN = 0, 1, 2
 MPPI_E_TIMEOUT = -5
+IPC_HANDLE_BYTES = 64
 KERNELS = ("nominal", "rollout", "update", "merge", "finalize")
 ABI_VERSION = 2
 
@@ -66,6 +67,14 @@ SIGNATURES = {
     "mppi_tick_begin": (C.c_int, [_H, _dp, _dp, C.c_int, C.c_uint64, C.c_uint32]),
     "mppi_partials_ptr": (C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "mppi_tick_finish": (C.c_int, [_H, C.c_void_p, C.c_int]),
+    "mppi_p2p_create": (C.c_int, [_H, C.c_int, C.c_int, C.c_void_p]),
+    "mppi_p2p_connect": (C.c_int, [_H, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mppi_p2p_mailbox_ptr": (C.c_int, [_H, C.POINTER(C.c_void_p)]),
+    "mppi_p2p_selftest": (C.c_int, [_H, C.c_int]),
+    "mppi_p2p_destroy": (C.c_int, [_H]),
+    "mppi_p2p_publish": (C.c_int, [_H]),
+    "mppi_tick_finish_p2p": (C.c_int, [_H]),
+    "mppi_tick_exchange_p2p": (C.c_int, [_H]),
     "mppi_get_outputs": (C.c_int, [_H, _dp, _dp]),
     "mppi_tick": (C.c_int, [_H, _dp, _dp, C.c_int, C.c_uint64, C.c_uint32, _dp, _dp]),
     "mppi_tick_graph": (C.c_int, [_H, C.c_uint64]),

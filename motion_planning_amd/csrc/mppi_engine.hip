@@ -123,8 +123,16 @@ struct mppi_engine {
 
     // pinned staging ring for state/goal uploads
     static constexpr int kRing = 16;
-    double* h_stage = nullptr;  // [kRing][A*6]
-    double* h_out = nullptr;    // [A][8] pinned landing zone of mppi_get_outputs / mppi_plant_step
+    double* h_stage = nullptr;  // [kRing][A*6]  pinned AND device-mapped: the scan tick reads its inputs straight from here
+    double* d_stage_view = nullptr;  // the same ring as the device sees it
+    double* h_out = nullptr;    // [A][8] pinned landing zone of mppi_get_outputs / mppi_plant_step (device-mapped: finalize writes it)
+    double* d_out_view = nullptr;
+    uint32_t* h_seq = nullptr;  // [A] sequence words finalize raises behind its host-side outputs
+    uint32_t* d_seq_view = nullptr;
+    uint32_t out_seq = 0;       // sequence number of the last finalize that wrote the host-side outputs
+    bool out_via_host = false;  // mppi_get_outputs: poll h_seq instead of copying d_out
+    const double *in_state = nullptr, *in_goal = nullptr;  // what the FIRST kernel of this tick reads (pinned slot or d_state / d_goal)
+    int in_slot = -1;
     hipEvent_t ring_ev[kRing]{};
     bool ring_used[kRing]{};
     int ring_pos = 0;
@@ -174,10 +182,51 @@ struct mppi_engine {
     double t_ms[MPPI_KERNEL_COUNT]{};
     int64_t t_n[MPPI_KERNEL_COUNT]{};
 
+    // peer-to-peer exchange of the shard tuples (mppi_p2p_*): see P2PWait in mppi_kernels.hpp
+    int p2p_n = 0, p2p_rank = 0;
+    char* p2p_mbox = nullptr;            // this rank's mailbox (fine-grained device memory)
+    size_t p2p_bytes = 0, p2p_slot = 0;  // total size; bytes of one [n] slot
+    char* p2p_peer[8] = {};              // every rank's mailbox as this process sees it ([rank] = own)
+    bool p2p_peer_ipc[8] = {};
+    bool p2p_connected = false;
+    uint32_t p2p_epoch = 0;
+    bool p2p_published = false;          // this epoch's tuples are on their way; mppi_tick_finish_p2p may follow
+    mppi::P2PWait p2p_wait{};
+    size_t p2p_n_f64() const { return (size_t)cfg.n_agents * cfg.horizon * mppi::kTupleW; }
+    double* p2p_data(char* base, int parity, int slot) const {
+        return reinterpret_cast<double*>(base + ((size_t)parity * p2p_n + slot) * p2p_slot);
+    }
+    uint32_t* p2p_flag(char* base, int parity, int slot) const {
+        return reinterpret_cast<uint32_t*>(base + (size_t)2 * p2p_n * p2p_slot) + ((size_t)parity * p2p_n + slot) * mppi::kFlagStride;
+    }
+    void p2p_release() {
+        for (int g = 0; g < 8; ++g) {
+            if (p2p_peer[g] && p2p_peer_ipc[g]) hipIpcCloseMemHandle(p2p_peer[g]);
+            p2p_peer[g] = nullptr; p2p_peer_ipc[g] = false;
+        }
+        if (p2p_mbox) { hipFree(p2p_mbox); hbm_bytes -= p2p_bytes; p2p_mbox = nullptr; }
+        p2p_connected = false; p2p_n = 0;
+    }
+    // publish this rank's tuples `src` [A][T][8] for the next epoch and return the wait descriptor for the consumer
+    mppi::P2PWait p2p_publish(const double* src) {
+        if (!p2p_connected) fail(MPPI_E_STATE, "p2p exchange is not connected (mppi_p2p_create + mppi_p2p_connect)");
+        p2p_epoch += 1u;
+        const int par = (int)(p2p_epoch & 1u);
+        mppi::P2PPeers peers{};
+        for (int g = 0; g < p2p_n; ++g) { peers.data[g] = p2p_data(p2p_peer[g], par, p2p_rank); peers.flag[g] = p2p_flag(p2p_peer[g], par, p2p_rank); }
+        hipLaunchKernelGGL(mppi::p2p_publish_kernel, dim3(p2p_n), dim3(256), 0, stream, src, (int)p2p_n_f64(), peers, p2p_epoch);
+        HIPCHK(hipGetLastError());
+        mppi::P2PWait w{};
+        w.flags = p2p_flag(p2p_mbox, par, 0); w.n = p2p_n; w.epoch = p2p_epoch;
+        w.timeout_ticks = sync_timeout_ms > 0 ? (unsigned long long)sync_timeout_ms * 100000ull : 0ull;  // wall_clock64: 100 MHz
+        return w;
+    }
+
     // hipGraph of a whole tick
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     uint64_t graph_seed = 0;
+    bool capturing = false;
 
     bool f64() const { return cfg.storage == MPPI_STORE_F64; }
     size_t esz() const { return f64() ? 8 : 4; }
@@ -240,11 +289,30 @@ struct mppi_engine {
         ring_used[slot] = true;
     }
 
-    void set_inputs(const double* state, const double* goal) {
+    // zero_copy: the caller's state / goal are written into a pinned, device-mapped ring slot and the tick's first
+    // kernel (scan_tick_kernel) reads them from there over PCIe -- no H2D copy in front of a latency-bound tick
+    // (two copies were 14 of the 47 us of a K = 10 tick); that kernel refreshes d_state / d_goal for the later ones.
+    void set_inputs(const double* state, const double* goal, bool zero_copy = false) {
         const size_t n = (size_t)cfg.n_agents * 3;
-        if (state) { stage_upload(state, d_state, n); have_state = true; }
-        if (goal) { stage_upload(goal, d_goal, n); have_goal = true; }
+        in_state = d_state; in_goal = d_goal; in_slot = -1;
+        if (zero_copy && (state || goal)) {
+            const int slot = ring_pos;
+            ring_pos = (ring_pos + 1) % kRing;
+            if (ring_used[slot]) wait_event(ring_ev[slot], "state/goal staging ring");
+            double* h = h_stage + (size_t)slot * cfg.n_agents * 6;
+            const double* dv = d_stage_view + (size_t)slot * cfg.n_agents * 6;
+            if (state) { std::memcpy(h, state, n * sizeof(double)); in_state = dv; have_state = true; }
+            if (goal) { std::memcpy(h + n, goal, n * sizeof(double)); in_goal = dv + n; have_goal = true; }
+            in_slot = slot;
+        } else {
+            if (state) { stage_upload(state, d_state, n); have_state = true; }
+            if (goal) { stage_upload(goal, d_goal, n); have_goal = true; }
+        }
         if (!have_state || !have_goal) fail(MPPI_E_STATE, "state/goal passed as NULL before ever being set");
+    }
+    void inputs_consumed() {  // the kernel that reads the pinned slot has been enqueued: the slot is free once it has run
+        if (in_slot >= 0) { HIPCHK(hipEventRecord(ring_ev[in_slot], stream)); ring_used[in_slot] = true; in_slot = -1; }
+        in_state = d_state; in_goal = d_goal;
     }
 
     void launch_rollout(hipStream_t st, int k0, int k1, bool ph, bool store, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
@@ -317,9 +385,9 @@ struct mppi_engine {
         Scope sc(this, MPPI_KERNEL_ROLLOUT);
         dim3 grid(small_nb, cfg.n_agents);
 #define LAUNCH_SCAN(TYPE, NW, PH)                                                                                       \
-    hipLaunchKernelGGL((mppi::scan_tick_kernel<TYPE, NW, PH>), grid, dim3(256), 0, stream, P, (const double*)d_state,   \
-                       (const double*)d_goal, (const double*)d_unom, static_cast<const TYPE*>(d_eps), seed, tick,      \
-                       tick_ptr, small_spw, d_part, small_nb, d_prev)
+    hipLaunchKernelGGL((mppi::scan_tick_kernel<TYPE, NW, PH>), grid, dim3(256), 0, stream, P, in_state ? in_state : (const double*)d_state, \
+                       in_goal ? in_goal : (const double*)d_goal, (const double*)d_unom, static_cast<const TYPE*>(d_eps), seed, tick,      \
+                       tick_ptr, small_spw, d_part, small_nb, d_prev, d_state, d_goal)
 #define LAUNCH_SCAN_T(TYPE)                                                                \
     do {                                                                                   \
         if (small_nw == 1) { if (ph) LAUNCH_SCAN(TYPE, 1, true); else LAUNCH_SCAN(TYPE, 1, false); } \
@@ -329,6 +397,7 @@ struct mppi_engine {
 #undef LAUNCH_SCAN_T
 #undef LAUNCH_SCAN
         HIPCHK(hipGetLastError());
+        inputs_consumed();
     }
     void launch_regen(hipStream_t st, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
         dim3 g((cfg.samples + 255) / 256, (cfg.horizon + mppi::kStepsPerDraw - 1) / mppi::kStepsPerDraw, cfg.n_agents);
@@ -369,7 +438,11 @@ struct mppi_engine {
             fail(MPPI_E_INVALID, "unknown noise_mode %d", noise_mode);
     }
     // rollout + update + merge of one tick
-    void run_pipeline(int noise_mode, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
+    // skip_small_merge: the caller finishes the tick on this engine's own tuples (no exchange): with a handful of scan
+    // blocks the finalize kernel merges their tuples itself (one launch and one boundary less on the latency path)
+    bool merge_skipped = false;
+    static constexpr int kDirectTuples = 16;
+    void run_pipeline(int noise_mode, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr, bool skip_small_merge = false) {
         check_noise_mode(noise_mode);
         const bool ph = noise_mode == MPPI_NOISE_PHILOX;
         const bool store = !ph || store_eps_always;
@@ -382,10 +455,12 @@ struct mppi_engine {
             eps_lazy = ph;
             if (ph) injected_ready = false;  // the scan kernel never writes d_eps
             launch_scan_tick(ph, seed, tick, tick_ptr);
-            launch_merge(small_nb);
+            merge_skipped = skip_small_merge && small_nb <= kDirectTuples;
+            if (!merge_skipped) launch_merge(small_nb);
             noise_ready = true; value_ready = false; value_lazy = true; partials_ready = true; epart_ready = false;
             return;
         }
+        merge_skipped = false;
         launch_rollout(stream, 0, cfg.samples, ph, store, seed, tick, tick_ptr);
         launch_update(stream, 0, NCH, tick_ptr);
         launch_merge(NCH);
@@ -414,10 +489,18 @@ struct mppi_engine {
         launch_merge(NCH);
         partials_ready = true;
     }
-    void run_finalize(const double* gathered, int G, int flags) {
+    void run_finalize(const double* gathered, int G, int flags, mppi::P2PWait wait = mppi::P2PWait{}) {
+        const int A_ = cfg.n_agents, T_ = cfg.horizon;
+        mppi::TupleLayout lay{(unsigned)(A_ * T_ * mppi::kTupleW), (unsigned)(T_ * mppi::kTupleW), (unsigned)mppi::kTupleW};
         if (!gathered) {
             if (!partials_ready) fail(MPPI_E_STATE, "no partials: call mppi_tick_begin first");
             gathered = d_merged; G = 1;
+            if (merge_skipped) {  // the scan kernel's block tuples, merged by the finalize kernel itself
+                gathered = d_part; G = small_nb;
+                lay = mppi::TupleLayout{(unsigned)mppi::kTupleW, (unsigned)(T_ * small_nb * mppi::kTupleW), (unsigned)(small_nb * mppi::kTupleW)};
+            }
+        } else if (merge_skipped) {
+            fail(MPPI_E_STATE, "this tick's partials were not merged (fused mppi_tick): nothing to exchange");
         }
         if (G < 1) fail(MPPI_E_INVALID, "n_shards must be >= 1");
         Scope sc(this, MPPI_KERNEL_FINALIZE);
@@ -431,8 +514,14 @@ struct mppi_engine {
         const int fin_threads = std::min(1024, std::max(256, ((2 * T * std::max(1, 1024 / (2 * T)) + 63) / 64) * 64));
         uint32_t tick_set = 0;
         if ((flags & 1) && !(flags & 4) && last_tick_eager) { flags |= 16; tick_set = last_tick_id + 1u; }
+        // eager ticks also drop their outputs into the pinned host buffer (a graph replay cannot: its sequence number
+        // would be frozen at capture time -- it keeps the D2H copy)
+        const bool host_out = (flags & 1) && !(flags & 4) && !capturing;
+        if (host_out) out_seq += 1u;
         hipLaunchKernelGGL(mppi::finalize_kernel, dim3(cfg.n_agents), dim3(fin_threads), lds,
-                           stream, P, gathered, G, d_S, d_unom, d_ufilt, d_state, d_out, d_tick, flags, tick_set);
+                           stream, P, gathered, G, lay, d_S, d_unom, d_ufilt, d_state, d_out, d_tick, flags, tick_set,
+                           host_out ? d_out_view : nullptr, d_seq_view, out_seq, wait);
+        if (flags & 1) out_via_host = host_out;
         HIPCHK(hipGetLastError());
         partials_ready = false;
     }
@@ -559,9 +648,17 @@ struct mppi_engine {
         HIPCHK(hipEventCreateWithFlags(&ev_partials, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&ev_foreign, hipEventDisableTiming));
 
-        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_stage), (size_t)kRing * A * 6 * sizeof(double), hipHostMallocDefault));
+        // pinned + mapped + coherent: the device reads inputs from / writes outputs to these buffers directly
+        const unsigned pin = hipHostMallocMapped | hipHostMallocCoherent;
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_stage), (size_t)kRing * A * 6 * sizeof(double), pin));
+        HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_stage_view), h_stage, 0));
         for (int i = 0; i < kRing; ++i) HIPCHK(hipEventCreateWithFlags(&ring_ev[i], hipEventDisableTiming));
-        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_out), (size_t)A * 8 * sizeof(double), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_out), (size_t)A * 8 * sizeof(double), pin));
+        HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_out_view), h_out, 0));
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_seq), (size_t)A * sizeof(uint32_t), pin));
+        HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_seq_view), h_seq, 0));
+        std::memset(h_out, 0, (size_t)A * 8 * sizeof(double));
+        std::memset(h_seq, 0, (size_t)A * sizeof(uint32_t));
     }
 
     void destroy_graph() {
@@ -575,6 +672,7 @@ struct mppi_engine {
         hipSetDevice(device);
         struct Restore { bool on; int dev; ~Restore() { if (on) (void)hipSetDevice(dev); } } restore{back, prev};
         try { wait_stream("engine teardown"); } catch (...) {}  // a dead device must not hang the destructor either
+        p2p_release();
         if (ev_partials) hipEventDestroy(ev_partials);
         if (ev_foreign) hipEventDestroy(ev_foreign);
         destroy_graph();
@@ -583,6 +681,7 @@ struct mppi_engine {
         for (int i = 0; i < kRing; ++i) if (ring_ev[i]) hipEventDestroy(ring_ev[i]);
         if (h_stage) hipHostFree(h_stage);
         if (h_out) hipHostFree(h_out);
+        if (h_seq) hipHostFree(h_seq);
         void* bufs[] = {d_eps, d_dP, d_stot, d_epart, d_tc, d_base, d_unom, d_ufilt, d_state, d_goal, d_part, d_merged, d_S, d_out, d_tick, d_tmp, d_grid, d_prev};
         for (void* b : bufs) if (b) hipFree(b);
         if (own_stream) hipStreamDestroy(own_stream);
@@ -874,8 +973,10 @@ int mppi_plant_step(mppi_engine* h, const double* state, double* next_state) {
     if (!h->have_state) fail(MPPI_E_STATE, "no state resident");
     hipLaunchKernelGGL(mppi::plant_kernel, dim3((A + 63) / 64), dim3(64), 0, h->stream, h->P, h->d_state, h->d_unom, h->d_out);
     HIPCHK(hipGetLastError());
+    h->out_via_host = false;  // d_out now holds the plant step's result, not the last tick's
     if (next_state) {
         const double* o = h->h_out;
+        if (h->out_seq) h->wait_stream("mppi_plant_step");  // a finalize still in flight may write h_out: let it land first
         HIPCHK(hipMemcpyAsync(h->h_out, h->d_out, (size_t)A * 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         h->wait_stream(__func__);
         for (int a = 0; a < A; ++a) for (int i = 0; i < 3; ++i) next_state[a * 3 + i] = o[(size_t)a * 8 + i];
@@ -892,7 +993,7 @@ int mppi_shift(mppi_engine* h) {
 
 int mppi_tick_begin(mppi_engine* h, const double* state, const double* goal, int noise_mode, uint64_t seed, uint32_t tick_id) {
     API_BEGIN(h)
-    h->set_inputs(state, goal);
+    h->set_inputs(state, goal, /*zero_copy=*/h->small_nb > 0);
     h->run_nominal();
     h->run_pipeline(noise_mode, seed, tick_id, nullptr);
     API_END(h)
@@ -911,12 +1012,138 @@ int mppi_tick_finish(mppi_engine* h, const void* gathered_dev, int n_shards) {
     API_END(h)
 }
 
+int mppi_p2p_create(mppi_engine* h, int n_ranks, int rank, void* ipc_handle_out) {
+    API_BEGIN(h)
+    if (n_ranks < 1 || n_ranks > 8 || rank < 0 || rank >= n_ranks) fail(MPPI_E_INVALID, "p2p: 1 <= n_ranks <= 8, 0 <= rank < n_ranks");
+    static_assert(sizeof(hipIpcMemHandle_t) <= MPPI_IPC_HANDLE_BYTES, "IPC handle does not fit the ABI's buffer");
+    h->wait_stream(__func__);
+    h->p2p_release();
+    h->p2p_n = n_ranks; h->p2p_rank = rank;
+    h->p2p_slot = (h->p2p_n_f64() * sizeof(double) + 255) / 256 * 256;
+    h->p2p_bytes = (size_t)2 * n_ranks * h->p2p_slot + (size_t)2 * n_ranks * mppi::kFlagStride * sizeof(uint32_t);
+    void* p = nullptr;
+    // fine-grained: stores from a peer GPU become visible to a kernel that is already running here
+    HIPCHK(hipExtMallocWithFlags(&p, h->p2p_bytes, hipDeviceMallocFinegrained));
+    h->p2p_mbox = static_cast<char*>(p); h->hbm_bytes += h->p2p_bytes;
+    HIPCHK(hipMemset(p, 0, h->p2p_bytes));
+    h->p2p_epoch = 0;
+    if (ipc_handle_out) {
+        hipIpcMemHandle_t hd;
+        HIPCHK(hipIpcGetMemHandle(&hd, p));
+        std::memset(ipc_handle_out, 0, MPPI_IPC_HANDLE_BYTES);
+        std::memcpy(ipc_handle_out, &hd, sizeof(hd));
+    }
+    API_END(h)
+}
+
+int mppi_p2p_connect(mppi_engine* h, const void* ipc_handles, void* const* local_ptrs) {
+    API_BEGIN(h)
+    if (!h->p2p_mbox) fail(MPPI_E_STATE, "mppi_p2p_create first");
+    if (!ipc_handles && !local_ptrs) fail(MPPI_E_INVALID, "p2p connect needs IPC handles or mailbox pointers");
+    for (int g = 0; g < h->p2p_n; ++g) {
+        if (g == h->p2p_rank) { h->p2p_peer[g] = h->p2p_mbox; continue; }
+        if (local_ptrs && local_ptrs[g]) { h->p2p_peer[g] = static_cast<char*>(local_ptrs[g]); continue; }  // same process
+        if (!ipc_handles) fail(MPPI_E_INVALID, "p2p connect: no handle for rank %d", g);
+        hipIpcMemHandle_t hd;
+        std::memcpy(&hd, static_cast<const char*>(ipc_handles) + (size_t)g * MPPI_IPC_HANDLE_BYTES, sizeof(hd));
+        void* p = nullptr;
+        HIPCHK(hipIpcOpenMemHandle(&p, hd, hipIpcMemLazyEnablePeerAccess));
+        h->p2p_peer[g] = static_cast<char*>(p); h->p2p_peer_ipc[g] = true;
+    }
+    h->p2p_connected = true;
+    API_END(h)
+}
+
+int mppi_p2p_mailbox_ptr(mppi_engine* h, void** dev_ptr) {
+    API_BEGIN(h)
+    if (!dev_ptr) fail(MPPI_E_INVALID, "dev_ptr is NULL");
+    *dev_ptr = h->p2p_mbox;
+    API_END(h)
+}
+
+int mppi_p2p_destroy(mppi_engine* h) {
+    API_BEGIN(h)
+    h->wait_stream(__func__);
+    h->p2p_release();
+    API_END(h)
+}
+
+int mppi_p2p_publish(mppi_engine* h) {
+    API_BEGIN(h)
+    if (!h->partials_ready) fail(MPPI_E_STATE, "no partials: call mppi_tick_begin first");
+    if (h->p2p_published) fail(MPPI_E_STATE, "this tick's partials were already published");
+    h->p2p_wait = h->p2p_publish(h->d_merged);
+    h->p2p_published = true;
+    API_END(h)
+}
+
+int mppi_tick_finish_p2p(mppi_engine* h) {
+    API_BEGIN(h)
+    if (!h->p2p_published) fail(MPPI_E_STATE, "mppi_p2p_publish first");
+    const int par = (int)(h->p2p_epoch & 1u);
+    h->p2p_published = false;
+    h->run_finalize(h->p2p_data(h->p2p_mbox, par, 0), h->p2p_n, 1 | 2, h->p2p_wait);
+    API_END(h)
+}
+
+int mppi_tick_exchange_p2p(mppi_engine* h) {
+    const int rc = mppi_p2p_publish(h);
+    return rc ? rc : mppi_tick_finish_p2p(h);
+}
+
+// Round trips of a known pattern through the mailboxes (no rollouts): every rank publishes, every rank checks what it
+// received from every peer.  Collective: all ranks must call it with the same `rounds`.
+int mppi_p2p_selftest(mppi_engine* h, int rounds) {
+    API_BEGIN(h)
+    if (!h->p2p_connected) fail(MPPI_E_STATE, "p2p exchange is not connected");
+    const size_t n = h->p2p_n_f64();
+    std::vector<double> pat(n), got((size_t)h->p2p_n * n);
+    h->ensure_tmp(n);
+    for (int r = 0; r < rounds; ++r) {
+        const uint32_t e = h->p2p_epoch + 1u;
+        for (size_t i = 0; i < n; ++i) pat[i] = 1e6 * (h->p2p_rank + 1) + 1e3 * e + (double)(i % 997);
+        HIPCHK(hipMemcpyAsync(h->d_tmp, pat.data(), n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        const mppi::P2PWait w = h->p2p_publish(h->d_tmp);
+        // consumer side without a kernel of its own: poll this rank's flags from the host, then read the slots back
+        const int par = (int)(h->p2p_epoch & 1u);
+        h->wait_stream("p2p selftest publish");
+        for (int g = 0; g < h->p2p_n; ++g) {
+            const uint32_t* f = h->p2p_flag(h->p2p_mbox, par, g);
+            uint32_t v = 0;
+            h->bounded_wait([&] {
+                if (hipMemcpy(&v, f, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return hipErrorUnknown;
+                return v == w.epoch ? hipSuccess : hipErrorNotReady;
+            }, "p2p selftest: waiting for a peer's flag");
+        }
+        HIPCHK(hipMemcpy(got.data(), h->p2p_data(h->p2p_mbox, par, 0), got.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int g = 0; g < h->p2p_n; ++g)
+            for (size_t i = 0; i < n; ++i)
+                if (got[(size_t)g * n + i] != 1e6 * (g + 1) + 1e3 * e + (double)(i % 997))
+                    fail(MPPI_E_INTERNAL, "p2p selftest: round %d, slot %d, element %zu holds %.17g", r, g, i, got[(size_t)g * n + i]);
+    }
+    API_END(h)
+}
+
 int mppi_get_outputs(mppi_engine* h, double* next_state, double* u_applied) {
     API_BEGIN(h)
     const int A = h->cfg.n_agents;
     const double* o = h->h_out;
-    HIPCHK(hipMemcpyAsync(h->h_out, h->d_out, (size_t)A * 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    h->wait_stream(__func__);
+    if (h->out_via_host) {
+        // the last finalize wrote its results into h_out itself and raised h_seq[a] behind them: wait for the words
+        const uint32_t want = h->out_seq;
+        const uint32_t* seqw = h->h_seq;
+        h->bounded_wait([seqw, want, A] {
+            for (int a = 0; a < A; ++a)
+                if (__atomic_load_n(seqw + a, __ATOMIC_ACQUIRE) != want) return hipErrorNotReady;
+            return hipSuccess;
+        }, "mppi_get_outputs");
+    } else {
+        HIPCHK(hipMemcpyAsync(h->h_out, h->d_out, (size_t)A * 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        h->wait_stream(__func__);
+    }
+    for (int a = 0; a < A; ++a)
+        if (o[(size_t)a * 8 + 7] != 0.0)
+            fail(MPPI_E_TIMEOUT, "p2p exchange: a peer's tuples did not arrive within %d ms (the engine must be destroyed)", h->sync_timeout_ms);
     for (int a = 0; a < A; ++a) {
         if (next_state) for (int i = 0; i < 3; ++i) next_state[a * 3 + i] = o[(size_t)a * 8 + i];
         if (u_applied) for (int i = 0; i < 2; ++i) u_applied[a * 2 + i] = o[(size_t)a * 8 + 3 + i];
@@ -924,9 +1151,18 @@ int mppi_get_outputs(mppi_engine* h, double* next_state, double* u_applied) {
     API_END(h)
 }
 
+// mppi_tick_begin with the knowledge that no exchange follows (the fused call)
+static int tick_begin_fused(mppi_engine* h, const double* state, const double* goal, int noise_mode, uint64_t seed, uint32_t tick_id) {
+    API_BEGIN(h)
+    h->set_inputs(state, goal, /*zero_copy=*/h->small_nb > 0);
+    h->run_nominal();
+    h->run_pipeline(noise_mode, seed, tick_id, nullptr, /*skip_small_merge=*/true);
+    API_END(h)
+}
+
 int mppi_tick(mppi_engine* h, const double* state, const double* goal, int noise_mode, uint64_t seed, uint32_t tick_id,
               double* next_state, double* u_applied) {
-    int rc = mppi_tick_begin(h, state, goal, noise_mode, seed, tick_id);
+    int rc = tick_begin_fused(h, state, goal, noise_mode, seed, tick_id);
     if (rc) return rc;
     rc = mppi_tick_finish(h, nullptr, 1);
     if (rc) return rc;
@@ -943,23 +1179,27 @@ int mppi_tick_graph(mppi_engine* h, uint64_t seed) {
         const uint32_t saved = h->time_mask;
         h->time_mask = 0;
         HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        h->capturing = true;
         try {
             h->run_nominal();
-            h->run_pipeline(MPPI_NOISE_PHILOX, seed, 0, h->d_tick);
+            h->run_pipeline(MPPI_NOISE_PHILOX, seed, 0, h->d_tick, /*skip_small_merge=*/true);
             h->run_finalize(nullptr, 1, 1 | 2 | 4);
         } catch (...) {
             hipGraph_t g = nullptr;
             hipStreamEndCapture(h->stream, &g);
             if (g) hipGraphDestroy(g);
             h->time_mask = saved;
+            h->capturing = false;
             throw;
         }
+        h->capturing = false;
         HIPCHK(hipStreamEndCapture(h->stream, &h->graph));
         HIPCHK(hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
         h->graph_seed = seed;
         h->time_mask = saved;
     }
     HIPCHK(hipGraphLaunch(h->graph_exec, h->stream));
+    h->out_via_host = false;
     const bool small = h->small_nb > 0;
     h->noise_ready = true; h->value_ready = !small; h->value_lazy = small; h->partials_ready = false; h->epart_ready = !small;
     h->eps_lazy = small || !h->store_eps_always; h->lazy_seed = seed; h->lazy_from_counter = true; h->lazy_counter_bumped = true;

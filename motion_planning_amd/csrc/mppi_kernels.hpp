@@ -1101,13 +1101,15 @@ __global__ __launch_bounds__(256) void merge_kernel(DevParams P, const double* _
 // unit u walks samples [u * spw, (u + 1) * spw).  part[a][t][block] = the block's tuple; block 0 also
 // snapshots (state, goal, nominal) so that V can be materialised later (mppi_download_value).
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
 template <typename S, int NWAVES, bool PHILOX>
 __global__ __launch_bounds__(256) void scan_tick_kernel(DevParams P, const double* __restrict__ state,
                                                        const double* __restrict__ goal,
                                                        const double* __restrict__ unom, const S* __restrict__ eps,
                                                        uint64_t seed, uint32_t tick_arg,
                                                        const uint32_t* __restrict__ tick_ptr, int spw,
-                                                       double* __restrict__ part, int NB, double* __restrict__ prev) {
+                                                       double* __restrict__ part, int NB, double* __restrict__ prev,
+                                                       double* __restrict__ state_keep, double* __restrict__ goal_keep) {
     __shared__ double sh_scan[4];
     __shared__ double sh_tup[NWAVES == 1 ? 4 * 64 * 7 : 1];
     const int tid = threadIdx.x, a = blockIdx.y, T = P.T, K = P.K;
@@ -1115,15 +1117,22 @@ __global__ __launch_bounds__(256) void scan_tick_kernel(DevParams P, const doubl
     const int t = NWAVES == 1 ? lane : tid;  // this thread's timestep
     const bool valid = t < T;
     const int unit = NWAVES == 1 ? (int)blockIdx.x * 4 + wid : (int)blockIdx.x;
+    const bool first_block = blockIdx.x == 0;
     const double x0 = state[a * 3 + 0], y0 = state[a * 3 + 1], th0 = state[a * 3 + 2];
     const double gx = goal[a * 3 + 0], gy = goal[a * 3 + 1], gth = goal[a * 3 + 2];
     const double un0 = valid ? unom[(a * 2 + 0) * T + t] : 0.0;
     const double un1 = valid ? unom[(a * 2 + 1) * T + t] : 0.0;
-    if (blockIdx.x == 0) {  // pre-tick snapshot: prev = {unom [A][2][T], state [A][3], goal [A][3]}
+    if (first_block) {  // pre-tick snapshot: prev = {unom [A][2][T], state [A][3], goal [A][3]}
         double* pv_state = prev + (size_t)P.A * 2 * T;
         double* pv_goal = pv_state + (size_t)P.A * 3;
         if ((NWAVES == 4 || wid == 0) && valid) { prev[(a * 2 + 0) * T + t] = un0; prev[(a * 2 + 1) * T + t] = un1; }
-        if (tid < 3) { pv_state[a * 3 + tid] = state[a * 3 + tid]; pv_goal[a * 3 + tid] = goal[a * 3 + tid]; }
+        if (tid < 3) {
+            pv_state[a * 3 + tid] = state[a * 3 + tid]; pv_goal[a * 3 + tid] = goal[a * 3 + tid];
+            // `state` / `goal` may be the caller's pinned host slot (zero-copy input: no H2D copy in front of the
+            // tick); the device-resident copies the later kernels (finalize's plant step) read are refreshed here
+            if (state_keep != state) state_keep[a * 3 + tid] = state[a * 3 + tid];
+            if (goal_keep != goal) goal_keep[a * 3 + tid] = goal[a * 3 + tid];
+        }
     }
     const double half_uru = 0.5 * (P.r0 * un0 * un0 + P.r1 * un1 * un1);
     double w0, w1;
@@ -1269,18 +1278,77 @@ __device__ __forceinline__ void rk4_exact(const DevParams& P, const double x0[3]
 //   ufilt [A][2][T] filtered controls (un-shifted), outv [A][8] = {next_state[3], u_applied[2]}
 // dynamic LDS = 4*T doubles (+ T*T with bit3).
 // ---------------------------------------------------------------------------------------------
+// One-shot peer-to-peer all-gather of the shard tuples (K sharded over the GPUs of one node) without a
+// collective launch: every rank owns a MAILBOX in fine-grained device memory that its peers map through HIP IPC,
+//     data [2][G][n] float64   (double-buffered by the parity of the tick's epoch; slot g = rank g's tuples)
+//     flag [2][G] uint32, one 64-byte line each (the epoch of the tick whose tuples the slot holds)
+// p2p_publish_kernel (one block per destination) stores this rank's tuples into slot `rank` of every peer's mailbox
+// over xGMI with system-scope write-through stores, fences, and raises the flag; the finalize kernel of each rank
+// polls its OWN mailbox's G flags (relaxed system-scope loads, one lane each), acquires, and merges.  Double
+// buffering is enough: a peer can only publish epoch e + 2 after its finalize of e + 1, which needed this rank's
+// e + 1 tuples, which this rank published after its own finalize of e had read buffer (e & 1).
+struct P2PWait {  // finalize side: nullptr flags = no wait
+    const uint32_t* flags;   // this rank's flag[parity][0..n): kFlagStride uint32 (64 B) apart
+    int n;
+    uint32_t epoch;
+    unsigned long long timeout_ticks;  // of wall_clock64() (100 MHz); 0 = wait forever
+};
+constexpr int kFlagStride = 16;  // uint32 per flag line
+
 #ifndef MPPI_ROLLOUT_TU  // non-template kernels are emitted by the engine translation unit only
-__global__ __launch_bounds__(1024) void finalize_kernel(DevParams P, const double* __restrict__ gathered, int G,
-                                                      const double* __restrict__ Smat, double* __restrict__ unom,
-                                                      double* __restrict__ ufilt, double* __restrict__ state,
-                                                      double* __restrict__ outv, uint32_t* tick_ptr, int flags,
-                                                      uint32_t tick_set) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+struct P2PPeers { double* data[8]; uint32_t* flag[8]; };  // slot `rank` of each peer's mailbox, for one parity
+__global__ __launch_bounds__(256) void p2p_publish_kernel(const double* __restrict__ src, int n, P2PPeers peers, uint32_t epoch) {
+    double* dst = peers.data[blockIdx.x];
+    for (int i = threadIdx.x; i < n; i += 256) __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope: every store of this wave has left for the peer
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(peers.flag[blockIdx.x], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+#endif
+
+// Where the G tuples of (agent a, row t) sit: element offsets of tuple (g, a, t) = g * gs + a * as + t * ts.
+//   shard tuples after an exchange  [G][A][T][8]:       gs = A*T*8, as = T*8,    ts = 8
+//   the scan kernel's block tuples  part[A][T][NB][8]:  gs = 8,     as = T*NB*8, ts = NB*8   (G = NB: no merge kernel)
+struct TupleLayout { unsigned gs, as, ts; };
+
+// finalize_block: the body of finalize_kernel for one agent `a`, run by all threads of the block.
+// smem: 4*T doubles (+ T*T with flags bit3), 16-byte aligned.
+__device__ __forceinline__ void finalize_block(const DevParams& P, int a, const double* gathered, int G, TupleLayout lay,
+                                               const double* __restrict__ Smat, double* unom, double* ufilt, double* state,
+                                               double* outv, uint32_t* tick_ptr, int flags, uint32_t tick_set,
+                                               double* host_out, uint32_t* host_seq, uint32_t seq, char* smem_raw,
+                                               P2PWait wait) {
+    __shared__ int p2p_late;
+    if (wait.flags) {  // peer-to-peer exchange: `gathered` is this rank's mailbox; wait until every peer's tuples are in
+        if (threadIdx.x == 0) p2p_late = 0;
+        __syncthreads();
+        if ((int)threadIdx.x < wait.n) {
+            const uint32_t* f = wait.flags + (size_t)threadIdx.x * kFlagStride;
+            const unsigned long long t0 = wall_clock64();
+            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != wait.epoch) {
+                if (wait.timeout_ticks && wall_clock64() - t0 > wait.timeout_ticks) { p2p_late = 1; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope: drop whatever this CU cached of the mailbox
+        if (p2p_late) {  // a peer never delivered: poison the outputs (mppi_get_outputs reports MPPI_E_TIMEOUT), touch nothing else
+            if (threadIdx.x == 0) {
+                outv[(size_t)a * 8 + 7] = 1.0;
+                if (host_out) {
+                    __hip_atomic_store(host_out + (size_t)a * 8 + 7, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(host_seq + a, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+            return;
+        }
+    }
     double* un = reinterpret_cast<double*>(smem_raw);  // [2][T] updated + clipped
     double* uf = un + 2 * P.T;                          // [2][T] filtered + clipped
     double* Sl = uf + 2 * P.T;                          // [T][T] staged copy of the filter (flags bit3)
     __shared__ double trig[3][2];
-    const int a = blockIdx.x, tid = threadIdx.x, T = P.T;
+    const int tid = threadIdx.x, T = P.T;
     // the filter operator does not depend on anything this kernel waits for: fetch it now, all loads in
     // flight at once, and read it from LDS when the updated controls are ready
     const bool staged = (flags & 8) != 0;
@@ -1288,13 +1356,14 @@ __global__ __launch_bounds__(1024) void finalize_kernel(DevParams P, const doubl
         for (int i = tid; i < T * T; i += blockDim.x) Sl[i] = Smat[i];
     for (int t = tid; t < T; t += blockDim.x) {
         double M = INFINITY;
+        const double* row = gathered + (size_t)a * lay.as + (size_t)t * lay.ts;
         for (int g = 0; g < G; ++g) {
-            const double* q = gathered + (((size_t)g * P.A + a) * T + t) * kTupleW;
+            const double* q = row + (size_t)g * lay.gs;
             if (q[6] > 0.0) M = fmin(M, q[0]);
         }
         double d = 0, n0 = 0, n1 = 0, e0 = 0, e1 = 0, cnt = 0;
         for (int g = 0; g < G; ++g) {
-            const double* q = gathered + (((size_t)g * P.A + a) * T + t) * kTupleW;
+            const double* q = row + (size_t)g * lay.gs;
             if (q[6] > 0.0) {
                 const double sc = (q[0] == M) ? 1.0 : exp((M - q[0]) * P.inv_lambda);
                 d += sc * q[1]; n0 += sc * q[2]; n1 += sc * q[3]; e0 += q[4]; e1 += q[5]; cnt += q[6];
@@ -1383,10 +1452,30 @@ __global__ __launch_bounds__(1024) void finalize_kernel(DevParams P, const doubl
             double* o = outv + (size_t)a * 8;
             o[0] = xn[0]; o[1] = xn[1]; o[2] = xn[2]; o[3] = uf[0]; o[4] = uf[T];
             state[a * 3 + 0] = xn[0]; state[a * 3 + 1] = xn[1]; state[a * 3 + 2] = xn[2];
+            if (host_out) {
+                // zero-copy output: the five results go straight into the caller's pinned host buffer, then the
+                // sequence word (system-scope release) -- mppi_get_outputs polls that word instead of issuing a D2H copy
+                double* ho = host_out + (size_t)a * 8;
+#pragma unroll
+                for (int i = 0; i < 5; ++i) __hip_atomic_store(ho + i, o[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(host_seq + a, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
         if ((flags & 4) && a == 0 && tick_ptr) *tick_ptr = *tick_ptr + 1u;
         if ((flags & 16) && a == 0 && tick_ptr) *tick_ptr = tick_set;
     }
+}
+
+#ifndef MPPI_ROLLOUT_TU  // non-template kernels are emitted by the engine translation unit only
+__global__ __launch_bounds__(1024) void finalize_kernel(DevParams P, const double* __restrict__ gathered, int G, TupleLayout lay,
+                                                      const double* __restrict__ Smat, double* __restrict__ unom,
+                                                      double* __restrict__ ufilt, double* __restrict__ state,
+                                                      double* __restrict__ outv, uint32_t* tick_ptr, int flags,
+                                                      uint32_t tick_set, double* host_out, uint32_t* host_seq, uint32_t seq,
+                                                      P2PWait wait) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    finalize_block(P, blockIdx.x, gathered, G, lay, Smat, unom, ufilt, state, outv, tick_ptr, flags, tick_set, host_out, host_seq,
+                   seq, smem_raw, wait);
 }
 #endif
 

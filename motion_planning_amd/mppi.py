@@ -255,6 +255,41 @@ class Engine(object):
     def tick_finish(self, gathered_ptr=None, n_shards=1):
         self._ck(self._lib.mppi_tick_finish(self._h, C.c_void_p(gathered_ptr) if gathered_ptr else None, int(n_shards)))
 
+    # -- peer-to-peer exchange (K sharded over the GPUs of one node; include/mppi_hip.h mppi_p2p_*) ------------
+    def p2p_create(self, n_ranks, rank):
+        """Allocates this rank's mailbox; returns its HIP IPC handle (bytes)."""
+        buf = C.create_string_buffer(_capi.IPC_HANDLE_BYTES)
+        self._ck(self._lib.mppi_p2p_create(self._h, int(n_ranks), int(rank), buf))
+        return bytes(buf.raw)
+
+    def p2p_connect(self, handles=None, local_ptrs=None):
+        """handles: one IPC handle (bytes) per rank, rank-major; local_ptrs: mailbox pointers of engines in this process."""
+        blob = b"".join(handles) if handles is not None else None
+        arr = None
+        if local_ptrs is not None:
+            arr = (C.c_void_p * len(local_ptrs))(*[C.c_void_p(p) if p else None for p in local_ptrs])
+        self._ck(self._lib.mppi_p2p_connect(self._h, blob, arr))
+
+    def p2p_mailbox_ptr(self):
+        p = C.c_void_p()
+        self._ck(self._lib.mppi_p2p_mailbox_ptr(self._h, C.byref(p)))
+        return p.value
+
+    def p2p_selftest(self, rounds=4):
+        self._ck(self._lib.mppi_p2p_selftest(self._h, int(rounds)))
+
+    def p2p_destroy(self):
+        self._ck(self._lib.mppi_p2p_destroy(self._h))
+
+    def p2p_publish(self):
+        self._ck(self._lib.mppi_p2p_publish(self._h))
+
+    def tick_finish_p2p(self):
+        self._ck(self._lib.mppi_tick_finish_p2p(self._h))
+
+    def tick_exchange_p2p(self):
+        self._ck(self._lib.mppi_tick_exchange_p2p(self._h))
+
     def get_outputs(self):
         nxt, ua = np.empty((self.A, 3)), np.empty((self.A, 2))
         self._ck(self._lib.mppi_get_outputs(self._h, _capi.dptr(nxt), _capi.dptr(ua)))

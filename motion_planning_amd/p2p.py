@@ -1,14 +1,97 @@
-"""Set-up of the engine's one-shot peer-to-peer all-gather (include/mppi_hip.h mppi_p2p_*) across the ranks
-of a torch.distributed group on ONE node: IPC handles of the mailboxes are exchanged through the group, a probe
-round-trip is checked on every rank, and only if all ranks pass does the ticker switch from RCCL to p2p."""
+"""Set-up of the engine's one-shot peer-to-peer all-gather (include/mppi_hip.h mppi_p2p_*) across the ranks of a
+torch.distributed group on ONE node.
+
+    setup(engine, group, rank, world, local_rank) -> True when every rank has switched to the p2p exchange
+
+Steps, all collective over the group (object collectives only: works on "nccl" and on "gloo"):
+  1. probe (optional, default on real multi-GPU runs): every rank starts a CHILD process that builds a tiny engine
+     on the same GPU, exchanges mailbox handles through the parents and runs the self-test.  A GPU memory fault on
+     a machine whose peer mappings do not work kills the child, not the benchmark; any rank's failure -> RCCL.
+  2. the real engines: mppi_p2p_create -> all-gather of the IPC handles -> mppi_p2p_connect -> mppi_p2p_selftest;
+     again any failure on any rank -> every rank tears the mailboxes down and stays on RCCL.
+"""
+import os
+import subprocess
+import sys
 
 
-def setup(engine, group, rank, world, local_rank, required=False):
-    """Returns True when the p2p exchange is live on every rank (False: keep RCCL)."""
-    lib = engine._lib
-    if not hasattr(lib, "mppi_p2p_create"):
+def _all_gather(dist, group, world, obj):
+    out = [None] * world
+    dist.all_gather_object(out, obj, group=group)
+    return out
+
+
+def _probe(dist, group, rank, world, local_rank, timeout_s=60.0):
+    """Run the handle exchange + self-test in child processes; True when every rank's child passed."""
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    child = subprocess.Popen([sys.executable, "-m", "motion_planning_amd.p2p_probe", str(world), str(rank), str(local_rank)],
+                             cwd=here, env=env, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    ok, handle = True, ""
+    try:
+        line = child.stdout.readline().strip()          # "HANDLE <hex>"
+        ok = line.startswith("HANDLE ")
+        handle = line[7:] if ok else ""
+    except Exception:
+        ok = False
+    handles = _all_gather(dist, group, world, handle if ok else None)
+    if all(h for h in handles):
+        try:
+            child.stdin.write(" ".join(handles) + "\n")
+            child.stdin.flush()
+            out, _ = child.communicate(timeout=timeout_s)
+            ok = child.returncode == 0 and "P2P_OK" in out
+        except Exception:
+            ok = False
+    else:
+        ok = False
+    if child.poll() is None:
+        child.kill()
+    return all(_all_gather(dist, group, world, bool(ok)))
+
+
+def setup(engine, group, rank, world, local_rank, required=False, probe=None, selftest_rounds=8):
+    import torch.distributed as dist
+    if world < 2 or world > 8:
         if required:
-            raise RuntimeError("this libmppi_hip.so has no p2p exchange")
+            raise RuntimeError("the p2p exchange serves 2..8 ranks on one node")
         return False
-    from . import _p2p_impl
-    return _p2p_impl.setup(engine, group, rank, world, local_rank, required)
+    if probe is None:
+        probe = dist.get_backend(group) == "nccl"     # real multi-GPU run: guard the first contact
+    if probe and not _probe(dist, group, rank, world, local_rank):
+        if required:
+            raise RuntimeError("p2p probe failed on at least one rank")
+        return False
+    ok, handle, why = True, None, []
+    try:
+        handle = engine.p2p_create(world, rank)
+    except Exception as e:
+        ok = False
+        why.append("create: %s" % e)
+    handles = _all_gather(dist, group, world, handle)
+    ok = ok and all(h is not None for h in handles)
+    if ok:
+        try:
+            engine.p2p_connect(handles=handles)
+        except Exception as e:
+            ok = False
+            why.append("connect: %s" % e)
+    ok = all(_all_gather(dist, group, world, ok))
+    if ok:
+        try:
+            engine.p2p_selftest(selftest_rounds)      # collective: every rank publishes to every rank
+        except Exception as e:
+            ok = False
+            why.append("selftest: %s" % e)
+        ok = all(_all_gather(dist, group, world, ok))
+    if not ok:
+        try:
+            engine.p2p_destroy()
+        except Exception:
+            pass
+        reasons = _all_gather(dist, group, world, "; ".join(why))
+        if required:
+            raise RuntimeError("p2p exchange could not be established on every rank: %s" % reasons)
+        if rank == 0 and os.environ.get("MPPI_P2P_VERBOSE"):
+            sys.stderr.write("p2p exchange not used: %s\n" % reasons)
+    return ok

@@ -141,14 +141,14 @@ def make_hip_ticker(samples_total, horizon, n_agents=1, storage="f32", local_ran
     torch.cuda.set_device(local_rank)
     eng = Engine(hi - lo, horizon, n_agents=n_agents, storage=storage, device=local_rank,
                  sample_offset=lo, **engine_kw)
-    # a single process has no collective to order with: keep the engine's own stream (which is
-    # also what hipGraph capture needs -- the null stream cannot be captured)
-    shard = HipShard(eng, torch.device("cuda", local_rank), use_torch_stream=in_group)
     kind = "none" if not in_group else "rccl"
     if in_group and world > 1 and exchange in ("auto", "p2p"):
         from . import p2p
         if p2p.setup(eng, group, rank, world, local_rank, required=(exchange == "p2p")):
             kind = "p2p"
+    # only the RCCL collective has to order with torch's stream; a single process and the p2p exchange keep the
+    # engine's own stream (which is also what hipGraph capture needs -- the null stream cannot be captured)
+    shard = HipShard(eng, torch.device("cuda", local_rank), use_torch_stream=(kind == "rccl"))
     return ShardedTicker(shard, group, exchange=kind), eng
 
 

@@ -1,0 +1,102 @@
+"""The peer-to-peer exchange of the shard tuples (include/mppi_hip.h mppi_p2p_*) on the one GPU a test box has:
+ (1) two engines in ONE process, mailboxes connected by pointer;
+ (2) two PROCESSES (K/2 samples each, global sample offsets), mailboxes exchanged as HIP IPC handles through a gloo
+     group, the product's ShardedTicker on the p2p exchange -- RCCL refuses two ranks on one device, IPC does not.
+Both must reproduce the unsharded engine (same device noise: streams are keyed by the global sample index)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+K, T, SEED, NT = 6000, 50, 99, 6
+
+
+def _u0():
+    return np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
+
+
+def _reference():
+    from motion_planning_amd.mppi import Engine
+    out = []
+    with Engine(K, T, storage="f32", tick_path="lanes") as e:
+        e.set_nominal(_u0())
+        for i in range(NT):
+            nxt, ua = e.tick([0, 0, 0] if i == 0 else None, [0, -1, 0] if i == 0 else None, noise="philox", seed=SEED, tick_id=i)
+            out.append(np.concatenate([nxt[0], ua[0]]))
+        lat = e.get_nominal()
+    return np.array(out), lat
+
+
+def test_p2p_two_engines_one_process():
+    from motion_planning_amd.mppi import Engine
+    ref, ref_lat = _reference()
+    G = 2
+    engs = [Engine(K // G, T, storage="f32", sample_offset=g * (K // G), tick_path="lanes") for g in range(G)]
+    try:
+        for g, e in enumerate(engs):
+            e.set_nominal(_u0())
+            e.p2p_create(G, g)
+        ptrs = [e.p2p_mailbox_ptr() for e in engs]
+        for e in engs:
+            e.p2p_connect(local_ptrs=ptrs)
+        for i in range(NT):
+            for e in engs:
+                e.tick_begin([0, 0, 0] if i == 0 else None, [0, -1, 0] if i == 0 else None, noise="philox", seed=SEED, tick_id=i)
+            for e in engs:                      # one thread drives both engines: all publishes first (see the header)
+                e.p2p_publish()
+            for e in engs:                      # finalize behind the flags; nothing blocks on the host
+                e.tick_finish_p2p()
+            for e in engs:
+                nxt, ua = e.get_outputs()
+                assert np.abs(np.concatenate([nxt[0], ua[0]]) - ref[i]).max() < 1e-12, i
+        for e in engs:
+            assert np.abs(e.get_nominal() - ref_lat).max() < 1e-12
+    finally:
+        for e in engs:
+            e.close()
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    from motion_planning_amd import sharded
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ticker, eng = sharded.make_hip_ticker(K, T, storage="f32", local_rank=0, exchange="p2p", tick_path="lanes")
+        assert ticker.exchange == "p2p" and ticker.world == world and eng.K == K // world
+        eng.set_nominal(_u0())
+        outs = []
+        for i in range(NT):
+            nxt, ua = ticker.tick([[0, 0, 0]] if i == 0 else None, [[0, -1, 0]] if i == 0 else None, "philox", SEED, i)
+            outs.append(np.concatenate([nxt[0], ua[0]]))
+        lat = eng.get_nominal()
+        dist.barrier()                         # nobody unmaps a mailbox a peer may still be writing to
+        q.put((rank, np.array(outs), lat))
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_p2p_two_processes_over_ipc():
+    import torch.multiprocessing as mp
+    ref, ref_lat = _reference()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, outs, lat in res:
+        assert np.abs(outs - ref).max() < 1e-12, rank
+        assert np.abs(lat - ref_lat).max() < 1e-12, rank
