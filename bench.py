@@ -312,8 +312,6 @@ def main():
                 eng.set_nominal(nominal_warm(T), agent=a)
             phase[0] += 1
             counter[0] = 1_000_000 * phase[0]      # tick ids (= noise streams) of a phase do not depend on the warm-up's length
-            if args.graph and not in_group:
-                eng.set_tick_counter(counter[0] + 1)
             tick(first=True)
         restart()
         # Timed region: exactly --steps ticks between barrier + synchronize pairs.  The dominant kernel (rollout) is

@@ -189,6 +189,7 @@ struct mppi_engine {
     char* p2p_peer[8] = {};              // every rank's mailbox as this process sees it ([rank] = own)
     bool p2p_peer_ipc[8] = {};
     bool p2p_connected = false;
+    int wall_clock_khz = 100000;         // rate of the device's wall_clock64() (hipDeviceAttributeWallClockRate)
     uint32_t p2p_epoch = 0;
     bool p2p_published = false;          // this epoch's tuples are on their way; mppi_tick_finish_p2p may follow
     mppi::P2PWait p2p_wait{};
@@ -218,7 +219,7 @@ struct mppi_engine {
         HIPCHK(hipGetLastError());
         mppi::P2PWait w{};
         w.flags = p2p_flag(p2p_mbox, par, 0); w.n = p2p_n; w.epoch = p2p_epoch;
-        w.timeout_ticks = sync_timeout_ms > 0 ? (unsigned long long)sync_timeout_ms * 100000ull : 0ull;  // wall_clock64: 100 MHz
+        w.timeout_ticks = sync_timeout_ms > 0 ? (unsigned long long)sync_timeout_ms * (unsigned long long)wall_clock_khz : 0ull;
         return w;
     }
 
@@ -489,9 +490,11 @@ struct mppi_engine {
         launch_merge(NCH);
         partials_ready = true;
     }
-    void run_finalize(const double* gathered, int G, int flags, mppi::P2PWait wait = mppi::P2PWait{}) {
+    // shard_stride: elements between consecutive shards' [A][T][8] blocks in `gathered` (0: packed)
+    void run_finalize(const double* gathered, int G, int flags, mppi::P2PWait wait = mppi::P2PWait{}, size_t shard_stride = 0) {
         const int A_ = cfg.n_agents, T_ = cfg.horizon;
-        mppi::TupleLayout lay{(unsigned)(A_ * T_ * mppi::kTupleW), (unsigned)(T_ * mppi::kTupleW), (unsigned)mppi::kTupleW};
+        mppi::TupleLayout lay{(unsigned)(shard_stride ? shard_stride : (size_t)A_ * T_ * mppi::kTupleW), (unsigned)(T_ * mppi::kTupleW),
+                              (unsigned)mppi::kTupleW};
         if (!gathered) {
             if (!partials_ready) fail(MPPI_E_STATE, "no partials: call mppi_tick_begin first");
             gathered = d_merged; G = 1;
@@ -567,6 +570,10 @@ struct mppi_engine {
         device = cfg.device;
         HIPCHK(hipSetDevice(device));
         HIPCHK(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
+        {
+            int khz = 0;
+            if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) wall_clock_khz = khz;
+        }
         stream = own_stream;
 
         const int A = cfg.n_agents, K = cfg.samples, T = cfg.horizon;
@@ -1082,7 +1089,7 @@ int mppi_tick_finish_p2p(mppi_engine* h) {
     if (!h->p2p_published) fail(MPPI_E_STATE, "mppi_p2p_publish first");
     const int par = (int)(h->p2p_epoch & 1u);
     h->p2p_published = false;
-    h->run_finalize(h->p2p_data(h->p2p_mbox, par, 0), h->p2p_n, 1 | 2, h->p2p_wait);
+    h->run_finalize(h->p2p_data(h->p2p_mbox, par, 0), h->p2p_n, 1 | 2, h->p2p_wait, h->p2p_slot / sizeof(double));  // mailbox slots are padded
     API_END(h)
 }
 
@@ -1097,7 +1104,8 @@ int mppi_p2p_selftest(mppi_engine* h, int rounds) {
     API_BEGIN(h)
     if (!h->p2p_connected) fail(MPPI_E_STATE, "p2p exchange is not connected");
     const size_t n = h->p2p_n_f64();
-    std::vector<double> pat(n), got((size_t)h->p2p_n * n);
+    const size_t slot_f64 = h->p2p_slot / sizeof(double);  // slots are padded to 256 bytes
+    std::vector<double> pat(n), got((size_t)h->p2p_n * slot_f64);
     h->ensure_tmp(n);
     for (int r = 0; r < rounds; ++r) {
         const uint32_t e = h->p2p_epoch + 1u;
@@ -1118,8 +1126,8 @@ int mppi_p2p_selftest(mppi_engine* h, int rounds) {
         HIPCHK(hipMemcpy(got.data(), h->p2p_data(h->p2p_mbox, par, 0), got.size() * sizeof(double), hipMemcpyDeviceToHost));
         for (int g = 0; g < h->p2p_n; ++g)
             for (size_t i = 0; i < n; ++i)
-                if (got[(size_t)g * n + i] != 1e6 * (g + 1) + 1e3 * e + (double)(i % 997))
-                    fail(MPPI_E_INTERNAL, "p2p selftest: round %d, slot %d, element %zu holds %.17g", r, g, i, got[(size_t)g * n + i]);
+                if (got[(size_t)g * slot_f64 + i] != 1e6 * (g + 1) + 1e3 * e + (double)(i % 997))
+                    fail(MPPI_E_INTERNAL, "p2p selftest: round %d, slot %d, element %zu holds %.17g", r, g, i, got[(size_t)g * slot_f64 + i]);
     }
     API_END(h)
 }

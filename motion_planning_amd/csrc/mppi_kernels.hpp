@@ -941,10 +941,10 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
     // Far from the goal a row has a handful of such samples; parked AT the goal 1-5 % of a row carry weight, and a
     // re-draw inside this loop would run (wave-uniformly) for almost every one of the 32 values a lane walks through.
     // So the loop only NOTES its weighted samples -- (index, weight) in the thread's own LDS slots, no atomics, no
-    // cross-lane traffic -- and the re-draws happen afterwards, once per slot: max-per-lane (~5) Philox rounds per
+    // cross-lane traffic -- and the re-draws happen afterwards, once per slot: max-per-lane (~6) Philox rounds per
     // wave instead of 32.  A lane that runs out of slots (sigma = 0, or every sample on the same cost) walks its
     // values again from L2 in a rolled loop and re-draws the ones beyond its slots (rare, kept out of the hot loop).
-    constexpr int kSlots = 6;
+    constexpr int kSlots = 8;
     __shared__ uint32_t q_k[REGEN ? kSlots : 1][256];
     __shared__ R q_e[REGEN ? kSlots : 1][256];
     int qn = 0;

@@ -912,20 +912,29 @@ def test_eager_ticks_advance_the_graph_tick_counter():
 
 
 def test_blocking_waits_are_bounded():
-    """A blocking call gives up with MPPI_E_TIMEOUT (-5) instead of hanging the control thread: a 1 ms deadline
-    against 40 queued ticks of K = 10^6 on the scan kernel (tens of milliseconds of work)."""
+    """A blocking call gives up with MPPI_E_TIMEOUT (-5) instead of hanging the control thread.  Deterministic stall: a
+    two-rank p2p exchange whose second rank never publishes -- the finalize kernel waits for a flag that never comes
+    (its own device-side deadline ends it), mppi_get_outputs runs into the host-side deadline."""
+    import time
     from motion_planning_amd._capi import MppiError, MPPI_E_TIMEOUT
-    with _engine(1000000, 50, "f32", tick_path="scan") as e:
+    with _engine(4096, 50, "f32", tick_path="lanes") as e:
         e.tick([0, 0, 0], [0, -1, 0], noise="philox", seed=1, tick_id=0)   # default deadline: fine
-        e.set_sync_timeout(1)
-        for i in range(40):
-            e.tick_begin(None, None, noise="philox", seed=1, tick_id=1 + i)
-            e.tick_finish()
+        e.p2p_create(2, 0)
+        own = e.p2p_mailbox_ptr()
+        e.p2p_connect(local_ptrs=[own, own])      # "rank 1" is nobody: its slot's flag is never raised
+        e.set_sync_timeout(200)
+        e.tick_begin(None, None, noise="philox", seed=1, tick_id=1)
+        e.tick_exchange_p2p()
+        t0 = time.perf_counter()
         with pytest.raises(MppiError) as ei:
             e.get_outputs()
-        assert ei.value.code == MPPI_E_TIMEOUT and "did not finish" in str(ei.value)
-        e.set_sync_timeout(0)      # wait forever: drains what is still running
+        assert ei.value.code == MPPI_E_TIMEOUT and 0.15 < time.perf_counter() - t0 < 5.0
+        time.sleep(0.3)                            # the kernel's own deadline has passed as well: the stream drains
+        e.set_sync_timeout(0)
         e.synchronize()
+        with pytest.raises(MppiError) as ei:       # and the poisoned outputs keep saying so
+            e.get_outputs()
+        assert ei.value.code == MPPI_E_TIMEOUT and "peer" in str(ei.value)
 
 
 def test_calls_restore_the_callers_device():

@@ -27,7 +27,7 @@ for d in sorted(glob.glob(R+'/gpurun_out/$TAG/pmc*/*/*counter_collection.csv')):
             out[k]['launches_'+c]=len(v)
 summ={}
 for k,c in out.items():
-    if not k.startswith('mppi::'): continue
+    if "mppi::" not in k: continue
     e=dict(c)
     if 'FETCH_SIZE' in c: e['hbm_read_bytes_per_launch (FETCH_SIZE KB x 1024 x 2: gfx950 wide-load correction, MI355X_MICROARCH.md)']=c['FETCH_SIZE']*1024*2
     if 'WRITE_SIZE' in c: e['hbm_write_bytes_per_launch (WRITE_SIZE KB x 1024; calibrated on the 12 B/step stored-eps rollout = 604 MB)']=c['WRITE_SIZE']*1024

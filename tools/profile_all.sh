@@ -1,12 +1,34 @@
+#!/bin/bash
+# Run ON THE GPU BOX (gpurun): the round's full measurement set -> gpurun_out/final/ (what profiles/rN_* is copied from).
+#   tests, the bench line (default and driver-like flags), rocprofv3 kernel stats of the same command, the PMC passes,
+#   the other BASELINE configs, per-shard sizes (what N = 2/4/8 ranks each run), a fresh-process hang hunt.
 set -x
-R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/final
-timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-timeout 300 python bench.py --steps 200 --warmup 20 2>&1 | tail -1 > $R/gpurun_out/final/bench_c4.json
-cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/stats -- python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline > $R/gpurun_out/final/stats.log 2>&1
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final; mkdir -p $O
 cd $R
-timeout 600 bash tools/pmc.sh final/pmc > $R/gpurun_out/final/pmc.log 2>&1
-tail -5 $R/gpurun_out/final/pmc.log
-for w in c2 c3 c5; do timeout 200 python bench.py --workload $w --no-cpu-baseline 2>&1 | tail -1 > $R/gpurun_out/final/bench_$w.json; done
-ls -R $R/gpurun_out/final | head -40
+( time timeout 900 python -m pytest tests -m gpu -q --timeout 300 2>&1 ) > $O/gpu_tests.log 2>&1; tail -4 $O/gpu_tests.log
+timeout 400 python bench.py 2>$O/bench_c4.err | tail -1 > $O/bench_c4.json
+timeout 300 python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_c4_driver_flags.json
+cd /tmp && export TMPDIR=/tmp
+for i in 1 2 3; do
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats$i -- python $R/bench.py --no-cpu-baseline --no-f64-line > $O/stats$i.log 2>&1
+done
+cd $R
+timeout 900 bash tools/pmc.sh final/pmc > $O/pmc.log 2>&1; tail -4 $O/pmc.log
+for w in c2 c3 c5; do timeout 300 python bench.py --workload $w --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_$w.json; done
+for k in 500000 250000 125000; do timeout 200 python bench.py --samples $k --no-cpu-baseline --no-f64-line --steps 100 2>/dev/null | tail -1 > $O/bench_shard_$k.json; done
+timeout 120 python tools/node_latency.py > $O/node_latency.txt 2>&1
+timeout 60 ./tools/ubench > $O/ubench.txt 2>&1
+timeout 300 bash tools/hang_hunt.sh 1000 4 gpurun_out/final/hang 2>&1 | tail -5
+python3 - <<PY
+import csv, glob, json, collections
+rows = collections.defaultdict(list)
+for i in (1, 2, 3):
+    for f in glob.glob("$O/stats%d/*/*kernel_stats.csv" % i):
+        for r in csv.DictReader(open(f)):
+            rows[r["Name"].split("(")[0].replace("void ", "")].append((i, int(r["Calls"]), float(r["AverageNs"]) / 1e3))
+json.dump({k: [{"run": a, "calls": b, "avg_us": c} for a, b, c in v] for k, v in rows.items() if "mppi::" in k},
+          open("$O/kernel_stats_all_runs.json", "w"), indent=1)
+for k, v in rows.items():
+    if "mppi::" in k: print(k[:60], [(b, round(c, 2)) for a, b, c in v])
+PY
+ls $O
