@@ -1,12 +1,44 @@
 #!/usr/bin/env python3
-"""Error budget of the deviation-form rollout: every stage in float64 except the ones named on the command line."""
+"""Design study behind DESIGN.md 4 ("why the rollout's state arithmetic stays fp64"): error budget of a rollout written
+in DEVIATION form -- every per-sample quantity as its difference from the nominal (eps = 0) trajectory, the form that
+would let fp32 / packed-fp32 instructions carry the state (task 4).  Runs on the CPU against the oracle:
+
+    python tools/fp32_error_budget.py
+
+Stages: A heading deviation (clip, d_phi, running sum d_theta), B sin/cos series + rotation of the nominal mid-step
+heading, C wheel-sum / Simpson-weight deviations and the position increments, D running sums dX, dY, E stage cost from
+dX, dY.  Each line switches the named stages to float32 (numpy rounds every operation, no fma) and reports the largest
+error of the cost-to-go V against the float64 oracle, over all samples and over the 1000 best ones -- the ones whose
+softmax weights matter (lambda = 1e-3 turns a V error of 1e-5 into a 1 % weight error)."""
 import sys, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import oracle as orc
-from tools.dev_model import nominal, UMAX
 
 f64 = np.float64
+UMAX, R, WB = 6.35492, 0.033, 0.16
+
+
+def nominal(state, goal, u0, T, dt, q=1e3, p1=(1e3, 1e3, 1e3), lam=1e-3, sig=0.9, rr=(1.0, 1.0)):
+    kth, rhalf = R / WB, R / 2
+    hk = 0.5 * kth * dt
+    ac = np.clip(u0, -UMAX, UMAX)
+    pn = hk * ac
+    phin = pn[1] - pn[0]
+    th = state[2] + np.concatenate([[0.0], np.cumsum(2 * phin)])[:-1]   # start-of-step headings (unwrapped)
+    f = np.sqrt(0.5 * q)
+    rho = f * (dt * rhalf / 6.0) / hk
+    c1n, s1n = np.cos(th + phin), np.sin(th + phin)
+    Wn = 4 + 2 * np.cos(phin)
+    Pn = pn[0] + pn[1]
+    incx, incy = rho * Pn * Wn * c1n, rho * Pn * Wn * s1n
+    Xn = f * (state[0] - goal[0]) + np.cumsum(incx)
+    Yn = f * (state[1] - goal[1]) + np.cumsum(incy)
+    thT = th[-1] + 2 * phin[-1]
+    return dict(hk=hk, ac=ac, a=u0, pn=pn, phin=phin, th=th, f=f, rho=rho, c1n=c1n, s1n=s1n, Wn=Wn, Pn=Pn,
+                Xn=Xn, Yn=Yn, thT=thT, w=lam * sig * u0)
+
+
 
 
 def run(state, goal, u0, eps, T, dt, low, lam=1e-3, sig=0.9):
