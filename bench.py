@@ -163,30 +163,34 @@ def load_profile(name):
 
 
 def run_pentagon(args, K, T, local_rank):
-    """Config 3: Controller (control/src/mppi:296-389) through the pentagon with blocking ticks; a step is a callback
-    that runs a control tick (goal-switch callbacks only reset the nominal controls, :356-375)."""
+    """Config 3: Controller (control/src/mppi:296-389) from the origin through the pentagon with blocking ticks; a step
+    is a callback that runs a control tick (goal-switch callbacks only reset the nominal controls, :356-375).  Warm-up
+    = throw-away ticks of the same engine (count AND wall time), then MPPI.initialize() and a fresh Controller: the
+    timed region is always the first --steps ticks of the same run (4221 ticks cover all five waypoints)."""
     from motion_planning_amd import MPPI, Controller, rk4
     m = MPPI(horizon=T, samples=K, rng="philox", seed=0, storage=args.storage, device=local_rank)
+    st, g = np.zeros(3), np.array([1.0, 0.0, 0.0])
+    t_w, n_w = time.perf_counter(), 0
+    while n_w < args.warmup or time.perf_counter() - t_w < args.min_warmup_s:
+        st = m.get_path(st, g)
+        n_w += 1
+    m.initialize()
+    m._tick = 1_000_000          # the timed run's noise streams do not depend on the warm-up's length
     c = Controller(PENTAGON, mppi=m)
     plant = np.array([0.0, 0.0, 0.0])
-    lat, switches, ticks, t_start = [], 0, 0, time.perf_counter()
-    want = args.warmup + args.steps
-    warm_until = t_start + args.min_warmup_s
-    timed, elapsed = [], None
+    timed, switches = [], 0
     while len(timed) < args.steps:
         tick_before, idx_before = m._tick, c.idx
         t0 = time.perf_counter()
         c.pos_cb(plant[0], plant[1], plant[2])
         dt = time.perf_counter() - t0
         if m._tick > tick_before:
-            ticks += 1
-            if ticks > args.warmup and time.perf_counter() > warm_until:
-                timed.append(dt)
+            timed.append(dt)
         switches += int(c.idx != idx_before)
         u = np.array([0.0, 0.0]) if c.done else m.uvec[-1, :].copy()
         plant = rk4(plant, u, m.dt)
-    return m._eng, np.array(timed), {"waypoint_switches": switches, "ticks_total": ticks, "final_pose": [float(x) for x in plant],
-                                     "wanted": want}
+    return m._eng, np.array(timed), {"waypoint_switches": switches, "warmup_ticks_run": n_w, "final_pose": [float(x) for x in plant],
+                                     "goal": [float(x) for x in m.goal]}
 
 
 def main():
@@ -284,6 +288,7 @@ def main():
 
         # warm-up: at least --warmup ticks AND at least --min-warmup-s of wall time (a 20-tick warm-up of this
         # workload is 4 ms: the clocks have not ramped yet and the first timed ticks run slow)
+        eng.kernel_timing(("rollout", "update"), period=8)   # the warm-up's launches too: rocprofv3 averages over the whole command
         tick(first=True)
         t_w = time.perf_counter()
         n_w = 0
@@ -301,6 +306,7 @@ def main():
                 tick()
             n_w = int(t.item())
         extra["warmup_ticks_run"] = n_w
+        wtimes = eng.kernel_times()
         # The warm-up above is real ticks of the closed loop, and a time-based one is long enough to park the robot
         # at its goal -- a different workload (1-5 % of a row carry softmax weight there, a handful do on the way).
         # The measured ticks must not depend on how long the clocks took to ramp: put the controller back at the start
@@ -498,6 +504,9 @@ def main():
         # the rollout launch in each phase of this command (what a rocprofv3 --kernel-trace --stats of the whole
         # command averages over): back-to-back ticks run a few % longer than launches behind an idle gap
         phases = {"timed": ktimes["rollout"], "diagnostic": dtimes["rollout"]}
+        if args.workload != "c3":
+            phases["warmup (closed loop, parks at the goal after ~600 ticks; sampled 1 in 8)"] = wtimes["rollout"]
+            roofline["update_us_warmup_phase"] = wtimes["update"][0] * 1e3 / wtimes["update"][1] if wtimes["update"][1] else None
         if btimes:
             phases["blocking"] = btimes["rollout"]
         roofline["rollout_us_by_phase"] = {k: {"avg_us": (v[0] * 1e3 / v[1] if v[1] else None), "launches_timed": v[1]}

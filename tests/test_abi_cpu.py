@@ -140,27 +140,43 @@ def test_cpp_node_links_against_the_c_abi(tmp_path):
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    """profiles/r1_bench_c4.json is the line bench.py printed on the GPU box: every field the bench contract
-    names is there, the roofline arithmetic is self-consistent and names the workload of BASELINE.json."""
+    """profiles/r2_bench_c4.json is the line bench.py printed on the GPU box: every field the bench contract names is there,
+    the roofline arithmetic (the 8(d) HBM accounting and the VALU-issue roof) is self-consistent and the line names the
+    workload of BASELINE.json; the line printed with the driver's own flags agrees with it."""
     import json
-    line = json.load(open(os.path.join(ROOT, "profiles", "r1_bench_c4.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r2_bench_c4.json")))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                 "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in line, key
     assert line["n_gpus"] == 1 and line["higher_is_better"] is True and line["vs_baseline"] is None
     assert line["unit"] == "rollouts/s" and line["data"] == "synthetic" and line["dtype"] == "f64"
+    assert "fp32" in line["dtype_detail"] and "softmax" in line["dtype_detail"]      # the label says what is fp32
     assert "K=1000000 T=50" in line["config"]["workload"] and "model" not in line["config"]
     roof = line["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in roof, key
     assert roof["bound"] in ("hbm", "mfma") and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert roof["actual_bound"] == "valu-issue"
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
     # achieved = algorithmic bytes per launch / the event-measured average launch duration
     assert abs(roof["achieved"] - roof["algorithmic_bytes_per_launch"] / (roof["avg_launch_us"] * 1e-6) / 1e9) < 1e-6 * roof["achieved"]
     assert roof["algorithmic_bytes_per_launch"] == 12 * line["config"]["state_steps_per_tick"]
-    # value = whole-job rollouts per tick / tick time
+    assert roof["traffic"] < roof["algorithmic_bytes_per_launch"]        # no wasted re-reads: eps is never stored
+    valu = roof["valu"]    # wave-instructions x issue cost against 1024 SIMDs at 2.4 GHz
+    wave_steps = line["config"]["state_steps_per_tick"] / 64.0
+    assert abs(valu["insts_per_launch"] - valu["valu_per_step"] * wave_steps) < 1.0
+    t_min = valu["issue_cycles_per_step"] * wave_steps / 1024 / 2.4e9
+    assert abs(valu["frac"] - t_min / (roof["avg_launch_us"] * 1e-6)) < 1e-9 and 0.3 < valu["frac"] < 1.0
+    assert abs(valu["insts_per_launch_pmc"] / valu["insts_per_launch"] - 1.0) < 0.2   # SQ_INSTS_VALU agrees with the assembly count
+    # value = whole-job rollouts per tick / tick time; the tick distribution brackets the mean
     assert abs(line["value"] - line["config"]["samples_total"] / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+    assert line["tick_us"]["median"] <= line["tick_us"]["p99"] and abs(line["tick_us"]["median"] / (1e3 * line["ms_per_step"]) - 1) < 0.1
+    assert line["f64_storage"]["storage"] == "f64" and line["f64_storage"]["ms_per_step"] > line["ms_per_step"]
     cpu = line["cpu_baseline"]
-    for key in ("value", "unit", "cores", "kind", "sample"):
+    for key in ("value", "unit", "cores", "kind", "sample", "baseline_md_inputs"):
         assert key in cpu, key
     assert cpu["kind"] in ("reference", "port") and cpu["cores"] >= 1
+    assert any(k.startswith("c1_K1000") for k in cpu["baseline_md_inputs"]) and any(k.startswith("c2_K10000") for k in cpu["baseline_md_inputs"])
+    drv = json.load(open(os.path.join(ROOT, "profiles", "r2_bench_c4_driver_flags.json")))
+    assert drv["steps"] == 20 and drv["warmup"] == 5
+    assert abs(drv["ms_per_step"] / line["ms_per_step"] - 1.0) < 0.03      # a 20-step run is steady-state too
