@@ -126,6 +126,8 @@ class HipEvents(object):
     """HIP events on an arbitrary stream through ctypes (torch.cuda.Event only sees torch's current stream)."""
 
     def __init__(self):
+        # torch is imported before the first engine exists, so libmppi_hip.so is bound to the runtime torch bundles
+        # (same SONAME) and this name resolves to that one runtime as well (sharded._one_hip_runtime checks it)
         self.hip = C.CDLL("libamdhip64.so")
         self.hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
         self.hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]

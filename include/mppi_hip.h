@@ -233,7 +233,9 @@ int mppi_wait_for_stream(mppi_engine *h, void *other_stream);
  *                     = mppi_p2p_publish + mppi_tick_finish_p2p, which a caller driving SEVERAL engines from one
  *                     thread calls separately (publish on all of them first: a finalize kernel that waits for a
  *                     publish enqueued after it can starve it when the runtime maps both streams to one hardware queue);
- *   mppi_p2p_selftest collective round trips of a known pattern (set-up time check before trusting the path).
+ *   mppi_p2p_selftest collective round trips of a known pattern, consumed by a kernel that waits on the flags the way
+ *                     the finalize kernel does (set-up time check before trusting the path; blocking; one caller per
+ *                     rank -- engines of ONE thread cannot run it against each other).
  * Every rank must run the same sequence of exchanges (epochs are counted per rank).
  */
 #define MPPI_IPC_HANDLE_BYTES 64

@@ -1098,36 +1098,38 @@ int mppi_tick_exchange_p2p(mppi_engine* h) {
     return rc ? rc : mppi_tick_finish_p2p(h);
 }
 
-// Round trips of a known pattern through the mailboxes (no rollouts): every rank publishes, every rank checks what it
-// received from every peer.  Collective: all ranks must call it with the same `rounds`.
+// Round trips of a known pattern through the mailboxes (no rollouts): every rank publishes, and a consumer kernel on
+// every rank does exactly what the finalize kernel does -- polls this rank's flags from the device, acquires, reads the
+// slots -- before the host compares what arrived with what every peer must have sent.  Collective: all ranks must call
+// it with the same `rounds`.
 int mppi_p2p_selftest(mppi_engine* h, int rounds) {
     API_BEGIN(h)
     if (!h->p2p_connected) fail(MPPI_E_STATE, "p2p exchange is not connected");
     const size_t n = h->p2p_n_f64();
     const size_t slot_f64 = h->p2p_slot / sizeof(double);  // slots are padded to 256 bytes
-    std::vector<double> pat(n), got((size_t)h->p2p_n * slot_f64);
-    h->ensure_tmp(n);
+    std::vector<double> pat(n), got((size_t)h->p2p_n * n);
+    h->ensure_tmp(n + got.size() + 1);
+    double* d_pat = h->d_tmp;
+    double* d_got = h->d_tmp + n;
+    int* d_status = reinterpret_cast<int*>(h->d_tmp + n + got.size());
     for (int r = 0; r < rounds; ++r) {
         const uint32_t e = h->p2p_epoch + 1u;
         for (size_t i = 0; i < n; ++i) pat[i] = 1e6 * (h->p2p_rank + 1) + 1e3 * e + (double)(i % 997);
-        HIPCHK(hipMemcpyAsync(h->d_tmp, pat.data(), n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        const mppi::P2PWait w = h->p2p_publish(h->d_tmp);
-        // consumer side without a kernel of its own: poll this rank's flags from the host, then read the slots back
+        HIPCHK(hipMemcpyAsync(d_pat, pat.data(), n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        const mppi::P2PWait w = h->p2p_publish(d_pat);
         const int par = (int)(h->p2p_epoch & 1u);
-        h->wait_stream("p2p selftest publish");
-        for (int g = 0; g < h->p2p_n; ++g) {
-            const uint32_t* f = h->p2p_flag(h->p2p_mbox, par, g);
-            uint32_t v = 0;
-            h->bounded_wait([&] {
-                if (hipMemcpy(&v, f, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return hipErrorUnknown;
-                return v == w.epoch ? hipSuccess : hipErrorNotReady;
-            }, "p2p selftest: waiting for a peer's flag");
-        }
-        HIPCHK(hipMemcpy(got.data(), h->p2p_data(h->p2p_mbox, par, 0), got.size() * sizeof(double), hipMemcpyDeviceToHost));
+        hipLaunchKernelGGL(mppi::p2p_check_kernel, dim3(1), dim3(256), 0, h->stream, w,
+                           (const double*)h->p2p_data(h->p2p_mbox, par, 0), (int)n, (int)slot_f64, d_got, d_status);
+        HIPCHK(hipGetLastError());
+        int status = -1;
+        HIPCHK(hipMemcpyAsync(&status, d_status, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(got.data(), d_got, got.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        h->wait_stream("p2p selftest");
+        if (status != 0) fail(MPPI_E_TIMEOUT, "p2p selftest: round %d: a peer's flag did not reach the consumer kernel in time", r);
         for (int g = 0; g < h->p2p_n; ++g)
             for (size_t i = 0; i < n; ++i)
-                if (got[(size_t)g * slot_f64 + i] != 1e6 * (g + 1) + 1e3 * e + (double)(i % 997))
-                    fail(MPPI_E_INTERNAL, "p2p selftest: round %d, slot %d, element %zu holds %.17g", r, g, i, got[(size_t)g * slot_f64 + i]);
+                if (got[(size_t)g * n + i] != 1e6 * (g + 1) + 1e3 * e + (double)(i % 997))
+                    fail(MPPI_E_INTERNAL, "p2p selftest: round %d, slot %d, element %zu holds %.17g", r, g, i, got[(size_t)g * n + i]);
     }
     API_END(h)
 }

@@ -1307,6 +1307,37 @@ __global__ __launch_bounds__(256) void p2p_publish_kernel(const double* __restri
 }
 #endif
 
+// The consumer side of the exchange: wait (bounded) until the n flags of this rank's mailbox carry `epoch`, then make the
+// peers' stores visible to this CU.  Returns false when a flag did not arrive in time.  All threads of the block call it.
+__device__ __forceinline__ bool p2p_wait_block(const P2PWait& wait) {
+    __shared__ int p2p_late;
+    if (threadIdx.x == 0) p2p_late = 0;
+    __syncthreads();
+    if ((int)threadIdx.x < wait.n) {
+        const uint32_t* f = wait.flags + (size_t)threadIdx.x * kFlagStride;
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != wait.epoch) {
+            if (wait.timeout_ticks && wall_clock64() - t0 > wait.timeout_ticks) { p2p_late = 1; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope: drop whatever this CU cached of the mailbox
+    return p2p_late == 0;
+}
+
+#ifndef MPPI_ROLLOUT_TU
+// self-test consumer: the same wait the finalize kernel does, then the G slots copied out for the host to check
+__global__ __launch_bounds__(256) void p2p_check_kernel(P2PWait wait, const double* __restrict__ slots, int n_per_slot,
+                                                       int slot_stride, double* __restrict__ out, int* __restrict__ status) {
+    const bool ok = p2p_wait_block(wait);
+    if (threadIdx.x == 0) *status = ok ? 0 : 1;
+    if (!ok) return;
+    for (int g = 0; g < wait.n; ++g)
+        for (int i = threadIdx.x; i < n_per_slot; i += 256) out[(size_t)g * n_per_slot + i] = slots[(size_t)g * slot_stride + i];
+}
+#endif
+
 // Where the G tuples of (agent a, row t) sit: element offsets of tuple (g, a, t) = g * gs + a * as + t * ts.
 //   shard tuples after an exchange  [G][A][T][8]:       gs = A*T*8, as = T*8,    ts = 8
 //   the scan kernel's block tuples  part[A][T][NB][8]:  gs = 8,     as = T*NB*8, ts = NB*8   (G = NB: no merge kernel)
@@ -1319,21 +1350,8 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
                                                double* outv, uint32_t* tick_ptr, int flags, uint32_t tick_set,
                                                double* host_out, uint32_t* host_seq, uint32_t seq, char* smem_raw,
                                                P2PWait wait) {
-    __shared__ int p2p_late;
     if (wait.flags) {  // peer-to-peer exchange: `gathered` is this rank's mailbox; wait until every peer's tuples are in
-        if (threadIdx.x == 0) p2p_late = 0;
-        __syncthreads();
-        if ((int)threadIdx.x < wait.n) {
-            const uint32_t* f = wait.flags + (size_t)threadIdx.x * kFlagStride;
-            const unsigned long long t0 = wall_clock64();
-            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != wait.epoch) {
-                if (wait.timeout_ticks && wall_clock64() - t0 > wait.timeout_ticks) { p2p_late = 1; break; }
-                __builtin_amdgcn_s_sleep(2);
-            }
-        }
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope: drop whatever this CU cached of the mailbox
-        if (p2p_late) {  // a peer never delivered: poison the outputs (mppi_get_outputs reports MPPI_E_TIMEOUT), touch nothing else
+        if (!p2p_wait_block(wait)) {  // a peer never delivered: poison the outputs (mppi_get_outputs reports MPPI_E_TIMEOUT), touch nothing else
             if (threadIdx.x == 0) {
                 outv[(size_t)a * 8 + 7] = 1.0;
                 if (host_out) {

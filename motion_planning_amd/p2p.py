@@ -29,7 +29,9 @@ def _probe(dist, group, rank, world, local_rank, timeout_s=60.0):
                              cwd=here, env=env, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     ok, handle = True, ""
     try:
-        line = child.stdout.readline().strip()          # "HANDLE <hex>"
+        import select
+        ready, _, _ = select.select([child.stdout], [], [], timeout_s)   # a child that never gets that far is a failed probe
+        line = child.stdout.readline().strip() if ready else ""          # "HANDLE <hex>"
         ok = line.startswith("HANDLE ")
         handle = line[7:] if ok else ""
     except Exception:

@@ -28,11 +28,26 @@ class _DevBuf(object):
                                          "version": 2, "strides": None}
 
 
+def _one_hip_runtime():
+    """torch wheels bundle a libamdhip64.so of their own.  Loaded first, it also serves libmppi_hip.so (same SONAME) and
+    everything is one runtime; but an engine created BEFORE `import torch` binds the system runtime and torch then maps
+    its own copy next to it -- two HIP runtimes whose pointers and streams mean nothing to each other.  This module
+    hands engine memory to torch (zero-copy tensor, collectives on it), so it refuses to run in such a process."""
+    try:
+        paths = sorted(set(l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l))
+    except OSError:
+        return
+    if len(paths) > 1:
+        raise RuntimeError("two HIP runtimes are mapped in this process (%s): import torch before creating the first "
+                           "motion_planning_amd engine, so that libmppi_hip binds the runtime torch uses" % ", ".join(paths))
+
+
 class HipShard(object):
     """Adapter: one libmppi_hip Engine as a shard (partials exposed as a torch CUDA tensor)."""
 
     def __init__(self, engine, torch_device, use_torch_stream=True):
         import torch
+        _one_hip_runtime()
         self.engine = engine
         self.device = torch_device
         ptr, nbytes = engine.partials()

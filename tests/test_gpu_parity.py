@@ -534,7 +534,7 @@ def test_philox_tick_against_oracle_on_device_noise(orc):
     assert np.abs(ua[0] - uo).max() < 1e-6 and np.abs(nxt[0] - so).max() < 1e-8
 
 
-def test_shard_partials_merge_equals_single_engine(orc):
+def test_shard_partials_merge_equals_single_engine(orc, hip_runtime):
     """K split over 2 and 4 engines (= GPUs), partials concatenated as an all-gather would,
     finished on each shard: identical controls to the unsharded engine."""
     import ctypes as C
@@ -546,7 +546,7 @@ def test_shard_partials_merge_equals_single_engine(orc):
         e.set_nominal(u0)
         ref_nxt, ref_u = e.tick(state, goal, noise="philox", seed=seed, tick_id=1)
         ref_lat = e.get_nominal()
-    hip = C.CDLL("libamdhip64.so")
+    hip = hip_runtime
     for G in (2, 4):
         engs = [_engine(K // G, T, "f32", sample_offset=g * (K // G)) for g in range(G)]
         try:
@@ -557,7 +557,8 @@ def test_shard_partials_merge_equals_single_engine(orc):
                 e.synchronize()
                 ptr, nbytes = e.partials()
                 host = np.empty(nbytes // 8)
-                assert hip.hipMemcpy(host.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(nbytes), 2) == 0
+                rc = hip.hipMemcpy(host.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(nbytes), 2)
+                assert rc == 0, "hipMemcpy D2H of the partials -> %d" % rc
                 bufs.append(host)
             gathered = np.concatenate(bufs)
             dev = C.c_void_p()
@@ -937,9 +938,9 @@ def test_blocking_waits_are_bounded():
         assert ei.value.code == MPPI_E_TIMEOUT and "peer" in str(ei.value)
 
 
-def test_calls_restore_the_callers_device():
+def test_calls_restore_the_callers_device(hip_runtime):
     import ctypes as C
-    hip = C.CDLL("libamdhip64.so")
+    hip = hip_runtime
     dev = C.c_int(-1)
     with _engine(64, 10, "f32") as e:
         e.tick([0, 0, 0], [0, -1, 0], noise="philox")

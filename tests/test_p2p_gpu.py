@@ -85,8 +85,8 @@ def _worker(rank, world, port, q):
 
 
 def test_p2p_two_processes_over_ipc():
-    import torch.multiprocessing as mp
-    ref, ref_lat = _reference()
+    import multiprocessing as mp      # (not torch.multiprocessing: this process has engines on the system HIP runtime
+    ref, ref_lat = _reference()       #  and must not map the copy torch bundles next to it; the workers import torch first)
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
