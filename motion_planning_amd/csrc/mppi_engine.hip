@@ -208,14 +208,17 @@ struct mppi_engine {
         if (p2p_mbox) { hipFree(p2p_mbox); hbm_bytes -= p2p_bytes; p2p_mbox = nullptr; }
         p2p_connected = false; p2p_n = 0;
     }
-    // publish this rank's tuples `src` [A][T][8] for the next epoch and return the wait descriptor for the consumer
+    // publish this rank's tuples for the next epoch and return the wait descriptor for the consumer.
+    // src = merged tuples [A][T][8]; src == nullptr: merge d_part's direct_n tuples per row on the way (merge_skipped)
     mppi::P2PWait p2p_publish(const double* src) {
         if (!p2p_connected) fail(MPPI_E_STATE, "p2p exchange is not connected (mppi_p2p_create + mppi_p2p_connect)");
         p2p_epoch += 1u;
         const int par = (int)(p2p_epoch & 1u);
         mppi::P2PPeers peers{};
         for (int g = 0; g < p2p_n; ++g) { peers.data[g] = p2p_data(p2p_peer[g], par, p2p_rank); peers.flag[g] = p2p_flag(p2p_peer[g], par, p2p_rank); }
-        hipLaunchKernelGGL(mppi::p2p_publish_kernel, dim3(p2p_n), dim3(256), 0, stream, src, (int)p2p_n_f64(), peers, p2p_epoch);
+        if (src) hipLaunchKernelGGL(mppi::p2p_publish_kernel, dim3(p2p_n), dim3(256), 0, stream, src, (int)p2p_n_f64(), peers, p2p_epoch);
+        else hipLaunchKernelGGL(mppi::p2p_publish_merge_kernel, dim3(p2p_n), dim3(256), 0, stream, P, (const double*)d_part, direct_n,
+                                cfg.n_agents * cfg.horizon, peers, p2p_epoch);
         HIPCHK(hipGetLastError());
         mppi::P2PWait w{};
         w.flags = p2p_flag(p2p_mbox, par, 0); w.n = p2p_n; w.epoch = p2p_epoch;
@@ -439,9 +442,12 @@ struct mppi_engine {
             fail(MPPI_E_INVALID, "unknown noise_mode %d", noise_mode);
     }
     // rollout + update + merge of one tick
-    // skip_small_merge: the caller finishes the tick on this engine's own tuples (no exchange): with a handful of scan
-    // blocks the finalize kernel merges their tuples itself (one launch and one boundary less on the latency path)
+    // The merge launch is skipped when whoever consumes the tuples can merge a handful per row itself -- one launch and
+    // one boundary less per tick: the finalize kernel (skip_small_merge: the fused mppi_tick, no exchange follows) or the
+    // merging publish kernel of the p2p exchange.  "A handful" = at most kDirectTuples chunk / scan-block tuples per row
+    // (K <= 131072 samples on the lane kernels).
     bool merge_skipped = false;
+    int direct_n = 0;   // tuples per row in d_part when the merge was skipped
     static constexpr int kDirectTuples = 16;
     void run_pipeline(int noise_mode, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr, bool skip_small_merge = false) {
         check_noise_mode(noise_mode);
@@ -456,15 +462,17 @@ struct mppi_engine {
             eps_lazy = ph;
             if (ph) injected_ready = false;  // the scan kernel never writes d_eps
             launch_scan_tick(ph, seed, tick, tick_ptr);
-            merge_skipped = skip_small_merge && small_nb <= kDirectTuples;
+            merge_skipped = (skip_small_merge || p2p_connected) && small_nb <= kDirectTuples;
+            direct_n = small_nb;
             if (!merge_skipped) launch_merge(small_nb);
             noise_ready = true; value_ready = false; value_lazy = true; partials_ready = true; epart_ready = false;
             return;
         }
-        merge_skipped = false;
+        merge_skipped = (skip_small_merge || p2p_connected) && NCH <= kDirectTuples;
+        direct_n = NCH;
         launch_rollout(stream, 0, cfg.samples, ph, store, seed, tick, tick_ptr);
         launch_update(stream, 0, NCH, tick_ptr);
-        launch_merge(NCH);
+        if (!merge_skipped) launch_merge(NCH);
         noise_ready = true; value_ready = true; value_lazy = false; partials_ready = true; epart_ready = true;
     }
     // T <= 256: the nominal rollout runs inside every rollout block (lanes = timesteps)
@@ -498,12 +506,13 @@ struct mppi_engine {
         if (!gathered) {
             if (!partials_ready) fail(MPPI_E_STATE, "no partials: call mppi_tick_begin first");
             gathered = d_merged; G = 1;
-            if (merge_skipped) {  // the scan kernel's block tuples, merged by the finalize kernel itself
-                gathered = d_part; G = small_nb;
-                lay = mppi::TupleLayout{(unsigned)mppi::kTupleW, (unsigned)(T_ * small_nb * mppi::kTupleW), (unsigned)(small_nb * mppi::kTupleW)};
+            if (merge_skipped) {  // the chunk / scan-block tuples, merged by the finalize kernel itself
+                gathered = d_part; G = direct_n;
+                lay = mppi::TupleLayout{(unsigned)mppi::kTupleW, (unsigned)(T_ * direct_n * mppi::kTupleW), (unsigned)(direct_n * mppi::kTupleW)};
             }
-        } else if (merge_skipped) {
-            fail(MPPI_E_STATE, "this tick's partials were not merged (fused mppi_tick): nothing to exchange");
+        } else if (merge_skipped && !wait.flags) {
+            fail(MPPI_E_STATE, "this tick's partials were not merged (fused mppi_tick, or an engine connected to the p2p "
+                               "exchange): nothing for a caller-side exchange to gather");
         }
         if (G < 1) fail(MPPI_E_INVALID, "n_shards must be >= 1");
         Scope sc(this, MPPI_KERNEL_FINALIZE);
@@ -1079,7 +1088,7 @@ int mppi_p2p_publish(mppi_engine* h) {
     API_BEGIN(h)
     if (!h->partials_ready) fail(MPPI_E_STATE, "no partials: call mppi_tick_begin first");
     if (h->p2p_published) fail(MPPI_E_STATE, "this tick's partials were already published");
-    h->p2p_wait = h->p2p_publish(h->d_merged);
+    h->p2p_wait = h->p2p_publish(h->merge_skipped ? nullptr : h->d_merged);
     h->p2p_published = true;
     API_END(h)
 }

@@ -273,6 +273,34 @@ template <> __device__ __forceinline__ double wave_min<double>(double v) {
 }
 
 
+// Sixteen lanes -- one DPP row -- merge the (at most 16) softmax tuples of ONE row: lane g of the row holds tuple g
+// (q = nullptr: none), every lane of the row returns the merged tuple {M, D, N0, N1, E0, E1, count}.  The rescaling
+// exp() of the 16 tuples run side by side and the sums are four row-level DPP butterflies each: what a thread
+// looping over the tuples does in 16 dependent exp() calls (~10 us for a horizon's rows) takes ~1 us.  Every lane of
+// the wave must call it (DPP sources must be active lanes).
+__device__ __forceinline__ void merge_row16(const double* q, double inv_lambda, double (&t)[7]) {
+    const bool has = q != nullptr && q[6] > 0.0;
+    const double m = has ? q[0] : INFINITY;
+    double M = m;
+    M = fmin(M, dpp_mov_f64_keep<0xB1, 0xF>(M));   // quad_perm [1,0,3,2]
+    M = fmin(M, dpp_mov_f64_keep<0x4E, 0xF>(M));   // quad_perm [2,3,0,1]
+    M = fmin(M, dpp_mov_f64_keep<0x141, 0xF>(M));  // row_half_mirror
+    M = fmin(M, dpp_mov_f64_keep<0x140, 0xF>(M));  // row_mirror
+    const double sc = !has ? 0.0 : (m == M ? 1.0 : exp((M - m) * inv_lambda));
+    double v[6] = {0, 0, 0, 0, 0, 0};
+    if (has) { v[0] = sc * q[1]; v[1] = sc * q[2]; v[2] = sc * q[3]; v[3] = q[4]; v[4] = q[5]; v[5] = q[6]; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        v[i] += dpp_mov_f64<0xB1, 0xF>(v[i]);
+        v[i] += dpp_mov_f64<0x4E, 0xF>(v[i]);
+        v[i] += dpp_mov_f64<0x141, 0xF>(v[i]);
+        v[i] += dpp_mov_f64<0x140, 0xF>(v[i]);
+    }
+    t[0] = M;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) t[i + 1] = v[i];
+}
+
 // 64-lane sum with DPP adds only (no LDS traffic): after the four row steps every lane of a
 // 16-lane row holds its row sum, row_bcast15 / row_bcast31 chain the rows; LANE 63 holds the total.
 template <int CTRL, int ROW_MASK>
@@ -1305,6 +1333,26 @@ __global__ __launch_bounds__(256) void p2p_publish_kernel(const double* __restri
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(peers.flag[blockIdx.x], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// The same with the shard's merge folded in: with a handful of chunk (or scan-block) tuples per row the merge kernel is
+// skipped and every publishing block merges the n_rows = A * T rows itself (redundantly per destination, 16 lanes per
+// row: merge_row16) straight into its peer's mailbox -- one launch and one boundary less per tick.
+__global__ __launch_bounds__(256) void p2p_publish_merge_kernel(DevParams P, const double* __restrict__ part, int NCH, int n_rows,
+                                                               P2PPeers peers, uint32_t epoch) {
+    double* dst = peers.data[blockIdx.x];
+    const int r = threadIdx.x >> 4, g = threadIdx.x & 15;   // 16 lanes per row, 16 rows per pass
+    for (int r0 = 0; r0 < n_rows; r0 += 16) {               // (uniform trip count)
+        const int row = r0 + r;
+        const double* q = (row < n_rows && g < NCH) ? part + ((size_t)row * NCH + g) * kTupleW : nullptr;
+        double t[7];
+        merge_row16(q, P.inv_lambda, t);
+        if (row < n_rows && g < kTupleW)   // lanes 0..7 of the row store the eight words of its tuple
+            __hip_atomic_store(dst + (size_t)row * kTupleW + g, g < 7 ? t[g] : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(peers.flag[blockIdx.x], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 #endif
 
 // The consumer side of the exchange: wait (bounded) until the n flags of this rank's mailbox carry `epoch`, then make the
@@ -1372,26 +1420,41 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
     const bool staged = (flags & 8) != 0;
     if (staged)
         for (int i = tid; i < T * T; i += blockDim.x) Sl[i] = Smat[i];
-    for (int t = tid; t < T; t += blockDim.x) {
-        double M = INFINITY;
-        const double* row = gathered + (size_t)a * lay.as + (size_t)t * lay.ts;
-        for (int g = 0; g < G; ++g) {
-            const double* q = row + (size_t)g * lay.gs;
-            if (q[6] > 0.0) M = fmin(M, q[0]);
-        }
-        double d = 0, n0 = 0, n1 = 0, e0 = 0, e1 = 0, cnt = 0;
-        for (int g = 0; g < G; ++g) {
-            const double* q = row + (size_t)g * lay.gs;
-            if (q[6] > 0.0) {
-                const double sc = (q[0] == M) ? 1.0 : exp((M - q[0]) * P.inv_lambda);
-                d += sc * q[1]; n0 += sc * q[2]; n1 += sc * q[3]; e0 += q[4]; e1 += q[5]; cnt += q[6];
-            }
-        }
-        // omg = exp(-V/lam) + 1e-8, normalised; uvec += eps . omg   (control/src/mppi:193-196)
+    // omg = exp(-V/lam) + 1e-8, normalised; uvec += eps . omg   (control/src/mppi:193-196), then clip (:198-199)
+    auto apply = [&](int t, double d, double n0, double n1, double e0, double e1, double cnt) {
         const double den = d + P.floor_w * cnt;
         const double du0 = (n0 + P.floor_w * e0) / den, du1 = (n1 + P.floor_w * e1) / den;
-        un[t] = clampd(unom[((size_t)a * 2 + 0) * T + t] + du0, P.u_max);      // :198-199
+        un[t] = clampd(unom[((size_t)a * 2 + 0) * T + t] + du0, P.u_max);
         un[T + t] = clampd(unom[((size_t)a * 2 + 1) * T + t] + du1, P.u_max);
+    };
+    if (G > 1 && G <= 16) {
+        // several tuples per row (shards after an exchange, or a handful of chunk / scan-block tuples): 16 lanes per row
+        const int rows_per_pass = (int)blockDim.x >> 4, r = tid >> 4, g = tid & 15;
+        for (int t0 = 0; t0 < T; t0 += rows_per_pass) {  // (uniform trip count: every lane takes part in the DPP steps)
+            const int t = t0 + r;
+            const double* q = (t < T && g < G) ? gathered + (size_t)a * lay.as + (size_t)t * lay.ts + (size_t)g * lay.gs : nullptr;
+            double m[7];
+            merge_row16(q, P.inv_lambda, m);
+            if (g == 0 && t < T) apply(t, m[1], m[2], m[3], m[4], m[5], m[6]);
+        }
+    } else {
+        for (int t = tid; t < T; t += blockDim.x) {
+            double M = INFINITY;
+            const double* row = gathered + (size_t)a * lay.as + (size_t)t * lay.ts;
+            for (int g = 0; g < G; ++g) {
+                const double* q = row + (size_t)g * lay.gs;
+                if (q[6] > 0.0) M = fmin(M, q[0]);
+            }
+            double d = 0, n0 = 0, n1 = 0, e0 = 0, e1 = 0, cnt = 0;
+            for (int g = 0; g < G; ++g) {
+                const double* q = row + (size_t)g * lay.gs;
+                if (q[6] > 0.0) {
+                    const double sc = (q[0] == M) ? 1.0 : exp((M - q[0]) * P.inv_lambda);
+                    d += sc * q[1]; n0 += sc * q[2]; n1 += sc * q[3]; e0 += q[4]; e1 += q[5]; cnt += q[6];
+                }
+            }
+            apply(t, d, n0, n1, e0, e1, cnt);
+        }
     }
     __syncthreads();
     {   // savgol_filter as u @ S (:202), clip (:205-206).  The 2T dot products of length T are cut into

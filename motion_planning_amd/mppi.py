@@ -304,6 +304,14 @@ class Engine(object):
                                      _capi.dptr(nxt), _capi.dptr(ua)))
         return nxt, ua
 
+    def tick_async(self, state=None, goal=None, noise="philox", seed=0, tick_id=0):
+        """The fused tick without waiting for its outputs (mppi_tick with NULL outputs): everything is enqueued, nothing
+        blocks; get_outputs() later.  Unlike tick_begin + tick_finish it has no exchange point, so the engine may take
+        its shortcuts (zero-copy inputs, no merge launch for a handful of tuples)."""
+        s, g = self._sg(state, goal)
+        mode = MPPI_NOISE_PHILOX if noise == "philox" else MPPI_NOISE_INJECTED
+        self._ck(self._lib.mppi_tick(self._h, _capi.dptr(s), _capi.dptr(g), mode, int(seed), int(tick_id), None, None))
+
     def tick_graph(self, seed=0):
         self._ck(self._lib.mppi_tick_graph(self._h, int(seed)))
 

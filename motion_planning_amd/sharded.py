@@ -69,6 +69,10 @@ class HipShard(object):
         else:
             self.engine.tick_finish(gathered.data_ptr(), n_shards)
 
+    def tick_fused(self, state, goal, noise, seed, tick_id):
+        """No exchange follows (single process / replicas): the engine's fused tick, asynchronous."""
+        self.engine.tick_async(state, goal, noise=noise, seed=seed, tick_id=tick_id)
+
     def get_outputs(self):
         return self.engine.get_outputs()
 
@@ -121,6 +125,9 @@ class ShardedTicker(object):
         return float(sum(1e3 * a.elapsed_time(b) for a, b in self._ev) / len(self._ev))
 
     def tick_async(self, state=None, goal=None, noise="philox", seed=0, tick_id=0):
+        if self.exchange == "none" and hasattr(self.shard, "tick_fused"):
+            self.shard.tick_fused(state, goal, noise, seed, tick_id)
+            return
         self.shard.tick_begin(state, goal, noise, seed, tick_id)
         if self.exchange == "rccl":
             if self._timing:
