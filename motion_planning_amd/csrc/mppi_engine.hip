@@ -496,6 +496,7 @@ struct mppi_engine {
         materialise_eps();
         launch_update(stream, 0, NCH);
         launch_merge(NCH);
+        merge_skipped = false;  // (an earlier fused tick may have left its tuples unmerged: these are merged)
         partials_ready = true;
     }
     // shard_stride: elements between consecutive shards' [A][T][8] blocks in `gathered` (0: packed)

@@ -348,6 +348,21 @@ def test_config2_k10000_vs_oracle(orc, storage):
     assert np.abs(nxt[0] - so).max() < 1e-9
 
 
+def test_update_after_a_fused_tick_with_unmerged_tuples(orc):
+    """A fused tick of a handful of samples leaves its block tuples unmerged (the finalize kernel merges them); a
+    stand-alone update_action afterwards must not pick that layout up again."""
+    K, T = 24, 50
+    u0 = np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
+    eps = orc.reference_noise(3, SIG, T, K)
+    V = orc.get_cost2go([0, 0, 0], u0, [0, -1, 0], LAM, SIG, eps)
+    with _engine(K, T, "f64") as e:
+        e.set_nominal(u0)
+        e.tick([0, 0, 0], [0, -1, 0], noise="philox", seed=2, tick_id=0)
+        e.set_nominal(u0); e.upload_noise(eps); e.upload_value(V)
+        u = e.update()[0]
+    assert np.abs(u - orc.update_action(u0, eps, V, LAM)).max() < 1e-9
+
+
 def test_odd_sizes_and_ragged_tail(orc):
     """K not a multiple of the lane/vector/block sizes, T not a multiple of the unroll; K=1."""
     for K, T in [(1, 6), (3, 8), (65, 10), (257, 12), (1025, 6), (2049, 20)]:
