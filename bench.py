@@ -295,18 +295,19 @@ def main():
         t_w = time.perf_counter()
         n_w = 0
         while True:
-            tick()
-            n_w += 1
-            if n_w % 16 == 0:
-                torch.cuda.synchronize()
-            if n_w >= args.warmup and time.perf_counter() - t_w >= args.min_warmup_s:
-                break
-        if world > 1:  # every rank leaves the warm-up after the same number of ticks (the exchange is collective)
-            t = torch.tensor([n_w], dtype=torch.int64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            for _ in range(int(t.item()) - n_w):
+            # in rounds of 16 ticks; rank 0's clock decides when the warm-up ends and tells the others, so that every rank
+            # runs the same number of ticks and issues its collectives (the exchange, this broadcast) in the same order
+            for _ in range(16):
                 tick()
-            n_w = int(t.item())
+            n_w += 16
+            torch.cuda.synchronize()
+            done = n_w >= args.warmup and time.perf_counter() - t_w >= args.min_warmup_s
+            if world > 1:
+                t = torch.tensor([1 if done else 0], dtype=torch.int64, device="cuda")
+                dist.broadcast(t, src=0)
+                done = bool(t.item())
+            if done:
+                break
         extra["warmup_ticks_run"] = n_w
         wtimes = eng.kernel_times()
         # The warm-up above is real ticks of the closed loop, and a time-based one is long enough to park the robot

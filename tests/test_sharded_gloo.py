@@ -134,3 +134,71 @@ def test_sharded_ticks_equal_unsharded_gloo(orc, world):
         eps = orc.philox_noise(7, 0, i, 0, K, T, SIG)
         st, ua, lat = orc.get_path(st, [0.0, -1.0, 0.0], lat, eps, LAM, SIG)
         assert np.abs(np.concatenate([st, ua]) - ref[i]).max() < 1e-12
+
+
+class _FakeP2PEngine(object):
+    """What p2p.setup needs of an Engine, without a GPU: records the calls, can be told to fail at a step."""
+
+    def __init__(self, rank, fail_at=None):
+        self.rank, self.fail_at, self.calls, self._lib = rank, fail_at, [], self
+
+    mppi_p2p_create = True   # `hasattr(lib, "mppi_p2p_create")`
+
+    def p2p_create(self, world, rank):
+        self.calls.append("create")
+        if self.fail_at == "create":
+            raise RuntimeError("no fine-grained memory")
+        return bytes([rank]) * 64
+
+    def p2p_connect(self, handles=None, local_ptrs=None):
+        self.calls.append("connect")
+        assert [h[0] for h in handles] == list(range(len(handles)))      # rank-major, every rank's handle
+        if self.fail_at == "connect":
+            raise RuntimeError("hipIpcOpenMemHandle failed")
+
+    def p2p_selftest(self, rounds):
+        self.calls.append("selftest")
+        if self.fail_at == "selftest":
+            raise RuntimeError("a flag never arrived")
+
+    def p2p_destroy(self):
+        self.calls.append("destroy")
+
+
+def _p2p_setup_worker(rank, world, port, fail_rank, fail_at, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from motion_planning_amd import p2p
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        eng = _FakeP2PEngine(rank, fail_at if rank == fail_rank else None)
+        ok = p2p.setup(eng, None, rank, world, 0, required=False, probe=False)
+        q.put((rank, ok, eng.calls))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_at", [None, "create", "connect", "selftest"])
+def test_p2p_setup_is_all_or_nothing(fail_at):
+    """The decision to leave RCCL for the p2p exchange is collective: one rank failing at any step (mailbox allocation,
+    mapping a peer, the self-test) puts EVERY rank back on RCCL with its mailbox torn down; no rank is left waiting in a
+    collective the others skipped."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_p2p_setup_worker, args=(r, 2, port, 1, fail_at, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, calls in res:
+        assert ok == (fail_at is None), (rank, ok, calls)
+        if fail_at is None:
+            assert calls == ["create", "connect", "selftest"]
+        else:
+            assert calls[-1] == "destroy" and "selftest" not in calls[:-1] or fail_at == "selftest"
