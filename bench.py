@@ -205,6 +205,9 @@ def main():
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--storage", default="f32", choices=["f32", "f64"])
     ap.add_argument("--samples", type=int, default=0, help="override K_total")
+    ap.add_argument("--horizon", type=int, default=0, help="override T (sweeps; not a BASELINE config)")
+    ap.add_argument("--tick-path", default="auto", choices=["auto", "lanes", "scan"],
+                    help="which kernels a tick runs (include/mppi_hip.h MPPI_TICK_*; sweeps)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "rccl", "p2p"],
                     help="N > 1: how the [A][T][8] partials cross GPUs (auto = p2p over IPC-mapped mailboxes when the probe passes, else RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -232,6 +235,8 @@ def main():
     desc, A_total, K_total, T, goal = WORKLOADS[args.workload]
     if args.samples:
         K_total = args.samples
+    if args.horizon:
+        T = args.horizon
     extra = {}
 
     def sync():
@@ -263,13 +268,14 @@ def main():
         if args.workload == "c5":  # independent agents: replicas, no collective
             lo, hi = sharded.shard_range(A_total, world, rank)
             A = hi - lo
-            ticker, eng = sharded.make_replica_ticker(K_total, T, n_agents=A, storage=args.storage, local_rank=local_rank)
+            ticker, eng = sharded.make_replica_ticker(K_total, T, n_agents=A, storage=args.storage, local_rank=local_rank,
+                                                      tick_path=args.tick_path)
             states = np.array([[0.05 * a, 0.0, 0.0] for a in range(lo, hi)])
             goals = np.array([[0.05 * a, -1.0, 0.0] for a in range(lo, hi)])
             K_local, units_total = K_total, A_total * K_total
         else:
             ticker, eng = sharded.make_hip_ticker(K_total, T, n_agents=1, storage=args.storage, local_rank=local_rank,
-                                                  exchange=args.exchange)
+                                                  exchange=args.exchange, tick_path=args.tick_path)
             A = 1
             states, goals = np.zeros((1, 3)), np.array([goal])
             K_local, units_total = eng.K, K_total
