@@ -631,9 +631,12 @@ struct mppi_engine {
         d_goal = dev_alloc<double>((size_t)A * 3, hbm_bytes);
         {   // small-K path: lanes = timesteps, one wave (T <= 64) or one block (T <= 256) per sample
             // AUTO: measured ticks, scan vs lane kernels: K = 1000 16.1 vs 27.0 us, 4000 20.0 vs 28.4, 10000 26.8 vs 30.6, 16000 31.5 vs 31.3 (T = 50, a wave per sample);
-            // T = 100 (a block per sample): K = 500 19.0 vs 39.8, 2000 26.1 vs 40.4, 5000 36.9 vs 41.3, 10000 54.8 vs 43.4
+            // T = 100 (a block per sample): K = 500 19.0 vs 39.8, 2000 26.1 vs 40.4, 5000 36.9 vs 41.3, 10000 54.8 vs 43.4.
+            // Round 2 (back to back | blocking call, which only the scan path serves zero-copy), T = 50: K = 8000 24.7 vs 28.4 | 48 vs 61,
+            // 12000 27.5 vs 29.7 | 51 vs 62, 16000 31.8 vs 30.3 | 56 vs 62, 24000 36.4 vs 31.5 | 61 vs 67; T = 100: 4000 34.9 vs 38.1 | 59 vs 75,
+            // 6000 40.5 vs 39.8 | 65 vs 72, 10000 55.5 vs 44.0 | 79 vs 76  ->  16384 / 6144
             const bool applies = T <= 256 && cfg.model == MPPI_MODEL_DIFFDRIVE_RK4;
-            const bool want = cfg.tick_path == MPPI_TICK_SCAN || (cfg.tick_path == MPPI_TICK_AUTO && (long)A * K <= (T <= 64 ? 12288 : 6144));
+            const bool want = cfg.tick_path == MPPI_TICK_SCAN || (cfg.tick_path == MPPI_TICK_AUTO && (long)A * K <= (T <= 64 ? 16384 : 6144));
             if (applies && want) {
                 small_nw = T <= 64 ? 1 : 4;
                 // units the chip keeps resident at once (152 VGPRs: 3 waves per SIMD x 1024 SIMDs): the kernel is
