@@ -1060,6 +1060,12 @@ int mppi_p2p_connect(mppi_engine* h, const void* ipc_handles, void* const* local
     API_BEGIN(h)
     if (!h->p2p_mbox) fail(MPPI_E_STATE, "mppi_p2p_create first");
     if (!ipc_handles && !local_ptrs) fail(MPPI_E_INVALID, "p2p connect needs IPC handles or mailbox pointers");
+    h->wait_stream(__func__);
+    for (int g = 0; g < 8; ++g) {  // connecting again: unmap what an earlier connect opened
+        if (h->p2p_peer[g] && h->p2p_peer_ipc[g]) hipIpcCloseMemHandle(h->p2p_peer[g]);
+        h->p2p_peer[g] = nullptr; h->p2p_peer_ipc[g] = false;
+    }
+    h->p2p_connected = false;
     for (int g = 0; g < h->p2p_n; ++g) {
         if (g == h->p2p_rank) { h->p2p_peer[g] = h->p2p_mbox; continue; }
         if (local_ptrs && local_ptrs[g]) { h->p2p_peer[g] = static_cast<char*>(local_ptrs[g]); continue; }  // same process

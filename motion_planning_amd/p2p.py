@@ -49,6 +49,10 @@ def _probe(dist, group, rank, world, local_rank, timeout_s=60.0):
         ok = False
     if child.poll() is None:
         child.kill()
+    try:
+        child.wait(timeout=10)
+    except Exception:
+        pass
     return all(_all_gather(dist, group, world, bool(ok)))
 
 
