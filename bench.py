@@ -253,7 +253,7 @@ def main():
         elapsed = float(timed.sum())
         ms_per_step = 1e3 * elapsed / args.steps
         tick_us = dist_stats(1e6 * timed)
-        ktimes = dtimes = {k: (0.0, 0) for k in ("nominal", "rollout", "update", "merge", "finalize")}
+        ktimes = dtimes = {k: (0.0, 0) for k in ("nominal", "rollout", "update", "merge", "finalize", "exchange")}
         btimes, sync_tick_us, exchange_us, exch_kind = None, tick_us, None, "none"
         # one more leg of diagnostic ticks with every kernel bracketed
         eng.kernel_timing(("nominal", "rollout", "update", "merge", "finalize"), period=1)
@@ -366,7 +366,7 @@ def main():
         # Diagnostic pass: every kernel bracketed on every launch; N > 1: the exchange bracketed as well.
         n_diag = min(args.steps, 20)
         restart()
-        eng.kernel_timing(("nominal", "rollout", "update", "merge", "finalize"), period=1)
+        eng.kernel_timing(("nominal", "rollout", "update", "merge", "finalize", "exchange"), period=1)
         ticker.time_exchange(True)
         sync()
         for i in range(n_diag):
@@ -374,6 +374,8 @@ def main():
         sync()
         dtimes = eng.kernel_times()
         exchange_us = ticker.exchange_times_us()
+        if exchange_us is None and dtimes["exchange"][1]:   # p2p: the publish kernel; the wait for the peers sits in `finalize`
+            exchange_us = dtimes["exchange"][0] * 1e3 / dtimes["exchange"][1]
         ticker.time_exchange(False)
         eng.kernel_timing(())
         nxt, ua = eng.get_outputs()

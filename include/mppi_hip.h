@@ -90,7 +90,8 @@ extern "C" {
 #define MPPI_KERNEL_UPDATE 2
 #define MPPI_KERNEL_MERGE 3
 #define MPPI_KERNEL_FINALIZE 4
-#define MPPI_KERNEL_COUNT 5
+#define MPPI_KERNEL_EXCHANGE 5 /* the p2p publish kernel (the wait for the peers is inside MPPI_KERNEL_FINALIZE) */
+#define MPPI_KERNEL_COUNT 6
 
 typedef struct mppi_engine mppi_engine;
 

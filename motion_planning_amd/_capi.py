@@ -13,7 +13,7 @@ MPPI_MODEL_DIFFDRIVE_RK4, MPPI_MODEL_UNICYCLE_EULER = 0, 1
 MPPI_TICK_AUTO, MPPI_TICK_LANES, MPPI_TICK_SCAN = 0, 1, 2
 MPPI_E_TIMEOUT = -5
 IPC_HANDLE_BYTES = 64
-KERNELS = ("nominal", "rollout", "update", "merge", "finalize")
+KERNELS = ("nominal", "rollout", "update", "merge", "finalize", "exchange")
 ABI_VERSION = 2
 
 

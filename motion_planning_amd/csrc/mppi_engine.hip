@@ -216,6 +216,7 @@ struct mppi_engine {
         const int par = (int)(p2p_epoch & 1u);
         mppi::P2PPeers peers{};
         for (int g = 0; g < p2p_n; ++g) { peers.data[g] = p2p_data(p2p_peer[g], par, p2p_rank); peers.flag[g] = p2p_flag(p2p_peer[g], par, p2p_rank); }
+        Scope sc(this, MPPI_KERNEL_EXCHANGE);
         if (src) hipLaunchKernelGGL(mppi::p2p_publish_kernel, dim3(p2p_n), dim3(256), 0, stream, src, (int)p2p_n_f64(), peers, p2p_epoch);
         else hipLaunchKernelGGL(mppi::p2p_publish_merge_kernel, dim3(p2p_n), dim3(256), 0, stream, P, (const double*)d_part, direct_n,
                                 cfg.n_agents * cfg.horizon, peers, p2p_epoch);
