@@ -1243,13 +1243,17 @@ __global__ __launch_bounds__(256) void scan_tick_kernel(DevParams P, const doubl
         const double inc = lanes_scan_incl<NWAVES>(cst, t, sh_scan, tot);
         const double V = tot - (inc - cst);  // value_fcn[t, k] (:175)
         if (valid) {  // fold the sample into this timestep's tuple (update_action :187-196, online form)
-            if (V < m) {
-                const double r = exp((V - m) * P.inv_lambda);  // exp(-inf) = 0 on the first sample
-                D = fma(D, r, 1.0); N0 = fma(N0, r, e0); N1 = fma(N1, r, e1); m = V;
-            } else if ((V - m) * P.inv_lambda < 750.0) {  // beyond that exp() is exactly 0 in fp64
-                const double w = exp((m - V) * P.inv_lambda);
-                D += w; N0 = fma(w, e0, N0); N1 = fma(w, e1, N1);
-            }
+            // ONE exponential per sample and step, no divergence: w = exp(-|V - m| / lam) either rescales the running
+            // tuple (V is the new minimum; the sample enters with weight 1) or is the sample's own weight.  The first
+            // sample meets m = +inf: w = exp(-inf) = 0.  fp32-storage mode takes the weight from v_exp_f32 like the
+            // update kernel does (relative error ~1e-7 of the weight), the fp64 mode from exp().
+            const bool lt = V < m;
+            const double arg = -fabs(V - m) * P.inv_lambda;
+            const double w = sizeof(S) == 4 ? (double)__builtin_amdgcn_exp2f((float)(arg * 1.4426950408889634)) : exp(arg);
+            D = lt ? fma(D, w, 1.0) : D + w;
+            N0 = lt ? fma(N0, w, e0) : fma(w, e0, N0);
+            N1 = lt ? fma(N1, w, e1) : fma(w, e1, N1);
+            m = lt ? V : m;
             E0 += e0; E1 += e1; cnt += 1.0;
         }
     }
