@@ -133,6 +133,12 @@ struct mppi_engine {
     bool out_via_host = false;  // mppi_get_outputs: poll h_seq instead of copying d_out
     const double *in_state = nullptr, *in_goal = nullptr;  // what the FIRST kernel of this tick reads (pinned slot or d_state / d_goal)
     int in_slot = -1;
+    // A zero-copy input slot is free again once the tick that read it has finished.  That tick's finalize kernel raises
+    // h_seq anyway, so the slot remembers the sequence number to look for (no event record in the stream of a
+    // latency-bound tick); a tick that never reaches such a finalize falls back to an event.
+    uint32_t slot_seq[kRing]{};
+    bool slot_seq_valid[kRing]{};
+    int slot_unclaimed = -1;   // slot read by a kernel already enqueued, not yet tied to a finalize's sequence number
     hipEvent_t ring_ev[kRing]{};
     bool ring_used[kRing]{};
     int ring_pos = 0;
@@ -283,10 +289,21 @@ struct mppi_engine {
         tmp_elems = elems;
     }
 
+    void wait_slot_free(int slot) {  // whoever used this ring slot last (a copy, or a kernel reading it in place) is done with it
+        if (slot_seq_valid[slot]) {
+            const uint32_t want = slot_seq[slot];
+            const uint32_t* seqw = h_seq;
+            bounded_wait([seqw, want] { return (int32_t)(__atomic_load_n(seqw, __ATOMIC_ACQUIRE) - want) >= 0 ? hipSuccess : hipErrorNotReady; },
+                         "state/goal staging ring");
+            slot_seq_valid[slot] = false;
+        }
+        if (ring_used[slot]) { wait_event(ring_ev[slot], "state/goal staging ring"); ring_used[slot] = false; }
+    }
     void stage_upload(const double* src, double* dst, size_t n) {
+        release_unclaimed_slot();
         const int slot = ring_pos;
         ring_pos = (ring_pos + 1) % kRing;
-        if (ring_used[slot]) wait_event(ring_ev[slot], "state/goal staging ring");
+        wait_slot_free(slot);
         double* h = h_stage + (size_t)slot * cfg.n_agents * 6;
         std::memcpy(h, src, n * sizeof(double));
         HIPCHK(hipMemcpyAsync(dst, h, n * sizeof(double), hipMemcpyHostToDevice, stream));
@@ -301,9 +318,10 @@ struct mppi_engine {
         const size_t n = (size_t)cfg.n_agents * 3;
         in_state = d_state; in_goal = d_goal; in_slot = -1;
         if (zero_copy && (state || goal)) {
+            release_unclaimed_slot();
             const int slot = ring_pos;
             ring_pos = (ring_pos + 1) % kRing;
-            if (ring_used[slot]) wait_event(ring_ev[slot], "state/goal staging ring");
+            wait_slot_free(slot);
             double* h = h_stage + (size_t)slot * cfg.n_agents * 6;
             const double* dv = d_stage_view + (size_t)slot * cfg.n_agents * 6;
             if (state) { std::memcpy(h, state, n * sizeof(double)); in_state = dv; have_state = true; }
@@ -316,8 +334,15 @@ struct mppi_engine {
         if (!have_state || !have_goal) fail(MPPI_E_STATE, "state/goal passed as NULL before ever being set");
     }
     void inputs_consumed() {  // the kernel that reads the pinned slot has been enqueued: the slot is free once it has run
-        if (in_slot >= 0) { HIPCHK(hipEventRecord(ring_ev[in_slot], stream)); ring_used[in_slot] = true; in_slot = -1; }
+        if (in_slot >= 0) { slot_unclaimed = in_slot; in_slot = -1; }
         in_state = d_state; in_goal = d_goal;
+    }
+    void release_unclaimed_slot() {  // no finalize took the slot over: guard it with an event after all
+        if (slot_unclaimed >= 0) {
+            HIPCHK(hipEventRecord(ring_ev[slot_unclaimed], stream));
+            ring_used[slot_unclaimed] = true;
+            slot_unclaimed = -1;
+        }
     }
 
     void launch_rollout(hipStream_t st, int k0, int k1, bool ph, bool store, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
@@ -532,6 +557,10 @@ struct mppi_engine {
         // would be frozen at capture time -- it keeps the D2H copy)
         const bool host_out = (flags & 1) && !(flags & 4) && !capturing;
         if (host_out) out_seq += 1u;
+        if (slot_unclaimed >= 0) {
+            if (host_out) { slot_seq[slot_unclaimed] = out_seq; slot_seq_valid[slot_unclaimed] = true; slot_unclaimed = -1; }
+            else release_unclaimed_slot();
+        }
         hipLaunchKernelGGL(mppi::finalize_kernel, dim3(cfg.n_agents), dim3(fin_threads), lds,
                            stream, P, gathered, G, lay, d_S, d_unom, d_ufilt, d_state, d_out, d_tick, flags, tick_set,
                            host_out ? d_out_view : nullptr, d_seq_view, out_seq, wait);
