@@ -213,6 +213,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f64-line", action="store_true", help="skip the extra all-fp64 measurement (N = 1, c4)")
     ap.add_argument("--graph", action="store_true", help="replay the tick as one hipGraph (N=1 only)")
+    ap.add_argument("--all-ranks-on-gpu0", action="store_true",
+                    help="TEST ONLY: every rank drives cuda:0 and the process group is gloo (RCCL refuses two ranks on one "
+                         "device) -- runs the N > 1 code path of this script on a one-GPU box; use with --exchange p2p")
     args = ap.parse_args()
 
     import torch
@@ -226,11 +229,17 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
         args.gpus = world
+    if args.all_ranks_on_gpu0:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     in_group = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ  # launched by torch.distributed.run
+    coll_dev = "cpu" if args.all_ranks_on_gpu0 else "cuda"       # where the few control collectives of this script live
     if in_group:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.all_ranks_on_gpu0:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     desc, A_total, K_total, T, goal = WORKLOADS[args.workload]
     if args.samples:
@@ -309,7 +318,7 @@ def main():
             torch.cuda.synchronize()
             done = n_w >= args.warmup and time.perf_counter() - t_w >= args.min_warmup_s
             if world > 1:
-                t = torch.tensor([1 if done else 0], dtype=torch.int64, device="cuda")
+                t = torch.tensor([1 if done else 0], dtype=torch.int64, device=coll_dev)
                 dist.broadcast(t, src=0)
                 done = bool(t.item())
             if done:
@@ -343,7 +352,7 @@ def main():
         elapsed = time.perf_counter() - t0
         ktimes = eng.kernel_times()
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         ms_per_step = 1e3 * elapsed / args.steps
