@@ -627,6 +627,9 @@ struct mppi_engine {
         P.kth = cfg.wheel_radius / cfg.wheel_base;
         P.rhalf = cfg.wheel_radius / 2.0;
         P.floor_w = cfg.floor_w;
+        P.lean_f = std::sqrt(0.5 * P.q0);
+        P.lean_rho = P.lean_f * (P.dt * P.rhalf * (1.0 / 6.0)) / (0.5 * P.kth * P.dt);
+        P.lean_inv_f = 1.0 / P.lean_f;
         refresh_params();
 
         roll_bs = 256;

@@ -52,6 +52,9 @@ struct DevParams {
     // std-dev the noise is drawn with (= sig[0,0], :143-146).  sigma * I unless mppi_set_sig_matrix was called.
     double sg00, sg01, sg10, sg11;
     int model;                          // 0: rk4 + dd_dynamics, 1: euler + unicycle_dynamics
+    // constants of the rollout kernel's lean (scaled-variable) step, computed once on the host instead of by every lane:
+    // lean_f = sqrt(q0 / 2), lean_rho = lean_f * (dt * rhalf / 6) / (kth * dt / 2), lean_inv_f = 1 / lean_f
+    double lean_f, lean_rho, lean_inv_f;
     // optional obstacle-grid stage cost (extension, include/mppi_hip.h mppi_set_obstacle_grid)
     const signed char* grid;
     int grid_w, grid_h;
@@ -459,7 +462,8 @@ __device__ __forceinline__ double lanes_scan_incl(double v, int t, double* sh, d
 template <int NWAVES>
 __device__ __forceinline__ void nominal_lanes(const DevParams& P, const double* __restrict__ state,
                                               const double* __restrict__ goal, const double* __restrict__ unom,
-                                              int a, int t, double (&row)[5], double& base_t, double* sh) {
+                                              int a, int t, double (&row)[5], double& base_t, double* sh,
+                                              double* head0 = nullptr) {
     const int T = P.T;
     double tot_;
     const bool valid = t < T;
@@ -471,6 +475,7 @@ __device__ __forceinline__ void nominal_lanes(const DevParams& P, const double* 
     const double th = state[a * 3 + 2] + (lanes_scan_incl<NWAVES>(h, t, sh, tot_) - h);
     double s0, c0, ix, iy;
     sincos(th, &s0, &c0);
+    if (head0 && t == 0) { head0[0] = c0; head0[1] = s0; }  // lane 0: th = the state's theta exactly (its exclusive scan is 0)
     if (P.model == 1) {  // euler + unicycle: x += dt * cos(theta) * u0
         ix = P.dt * (c0 * u0); iy = P.dt * (s0 * u0);
     } else {
@@ -613,6 +618,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     constexpr int NT_ROT = (LEAN && NTERM == 4 && sizeof(S) == 4) ? 3 : NTERM;
     // The per-step table lives in LDS: read back as wave-uniform (broadcast) ds_reads that the
     // scheduler can hoist, instead of an s_load + s_waitcnt round trip on every step.
+    // (cos, sin) of the state's heading: one sincos per block (the nominal rollout's), not one per lane; [2]: 1 / sqrt(q0 / 2),
+    // parked here so that it does not hold a pair of SGPRs through the loop (the kernel sits at the SGPR limit: two more and
+    // the compiler carries the dP row descriptors in VGPRs and wraps every store in a waterfall loop)
+    __shared__ double head_sh[3];
     if (INLINE_NOM) {
         // The block runs the nominal rollout itself, lanes = timesteps: wave 0 alone for T <= 64
         // (INLINE_NOM 1, ~600 instructions, no barrier), all four waves for T <= 256 (INLINE_NOM 2) -- no
@@ -621,7 +630,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         __shared__ double nom_sh[4];
         if (INLINE_NOM == 2 || tid < 64) {
             double row[5], base_t;
-            nominal_lanes<(INLINE_NOM == 2 ? 4 : 1)>(P, state, goal, unom, a, tid, row, base_t, nom_sh);
+            nominal_lanes<(INLINE_NOM == 2 ? 4 : 1)>(P, state, goal, unom, a, tid, row, base_t, nom_sh, head_sh);
+            if (tid == 0) head_sh[2] = P.lean_inv_f;
             if (tid < T) {
 #pragma unroll
                 for (int i = 0; i < 5; ++i) lt[tid * 5 + i] = (LEAN && i < 2) ? row[i] * (0.5 * P.kth * P.dt) : row[i];
@@ -647,19 +657,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     const double gth = goal[a * 3 + 2];
     double x = state[a * 3 + 0], y = state[a * 3 + 1], th = state[a * 3 + 2];
     double c, s;
-    sincos(th, &s, &c);
+    if (INLINE_NOM) { c = head_sh[0]; s = head_sh[1]; }
+    else sincos(th, &s, &c);
     if (LEAN) {
-        const double f = sqrt(0.5 * P.q0), rho = f * (P.dt * P.rhalf * (1.0 / 6.0)) / (0.5 * P.kth * P.dt);
+        const double f = P.lean_f, rho = P.lean_rho;
         x = (x - gx) * f; y = (y - gy) * f;  // position is carried relative to the goal
         gx = 0.0; gy = 0.0;
         c *= rho; s *= rho;  // the Simpson weight of (p0 + p1), in scaled position, rides on the heading vector
     }
     S* eps_a = eps + (size_t)a * T * 2 * Ks + k;
     S* dp = dP + (size_t)a * T * Ks + k;
+    // row 0 of this agent's dP block, pinned to the scalar unit: the row descriptors of the loop are derived from it by
+    // scalar adds.  (Left to itself the compiler may do this 64-bit product on the VALU -- and then has to wrap every
+    // buffer store of the loop in a waterfall loop to get the descriptor back into SGPRs.)
+    const uint64_t dP_a64 = reinterpret_cast<uint64_t>(dP + (size_t)a * T * Ks);
+    S* const dP_a = reinterpret_cast<S*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(dP_a64 >> 32)) << 32) |
+                                         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)dP_a64));
     const double half_kd = 0.5 * P.kth * P.dt;             // phi = half_kd * (u1 - u0) = h / 2
     const double sixth_rd = P.dt * P.rhalf * (1.0 / 6.0);  // Simpson weight of (u0 + u1)
     const double hq0 = 0.5 * P.q0, hq1 = 0.5 * P.q1, hq2 = 0.5 * P.q2;
-    const double sq = LEAN ? sqrt(hq0) : 1.0;                // LEAN: x, y below are sq * position
     const double p_max = half_kd * P.u_max;                 // LEAN: clip bound of the scaled wheel speeds
     const size_t NW = Ks >> 6;  // waves per agent row (Ks is a multiple of 64)
     // raw buffer view of epart (byte-addressed, bounds-checked by the hardware); < 4 GB by construction
@@ -754,7 +770,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                         // row t of dP as its own buffer: the descriptor is scalar arithmetic (base + t * pitch on
                         // the SALU), the lane offset k * 4 is loop-invariant -- no per-store 64-bit VALU address
                         const __amdgpu_buffer_rsrc_t row = __builtin_amdgcn_make_buffer_rsrc(
-                            dP + ((size_t)a * T + t) * Ks, 0, (int)(Ks * sizeof(S)), 0x00020000);
+                            dP_a + (size_t)t * Ks, 0, (int)(Ks * sizeof(S)), 0x00020000);
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)pre), row, (unsigned)k * 4u, 0, 0);
                     } else {
                         dp[(size_t)t * Ks] = (S)pre;
@@ -849,7 +865,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     // sample's terminal cost only enters the total
     auto terminal = [&]() {
         const double thw = (MODEL == 0 && (th > M_PI || th <= -M_PI)) ? wrap_theta(th) : th;
-        const double dx = (x - gx) / sq, dy = (y - gy) / sq, dth = thw - gth;  // sq = 1 unless LEAN
+        const double inv_sq = !LEAN ? 1.0 : (INLINE_NOM ? head_sh[2] : P.lean_inv_f);  // LEAN: x, y are sqrt(q0 / 2) * position
+        const double dx = (x - gx) * inv_sq, dy = (y - gy) * inv_sq, dth = thw - gth;
         pre += P.p0 * dx * dx + P.p1 * dy * dy + P.p2 * dth * dth;
     };
     const int T4 = T - T % U;  // steps covered by full chunks
