@@ -18,7 +18,7 @@ for w in c2 c3 c5; do timeout 300 python bench.py --workload $w --no-cpu-baselin
 for k in 500000 250000 125000; do timeout 200 python bench.py --samples $k --no-cpu-baseline --no-f64-line --steps 100 2>/dev/null | tail -1 > $O/bench_shard_$k.json; done
 timeout 120 python tools/node_latency.py > $O/node_latency.txt 2>&1
 timeout 60 ./tools/ubench > $O/ubench.txt 2>&1
-timeout 300 bash tools/hang_hunt.sh 1000 4 gpurun_out/final/hang 2>&1 | tail -5
+[ -n "$SKIP_HANG_HUNT" ] || timeout 300 bash tools/hang_hunt.sh 1000 4 gpurun_out/final/hang 2>&1 | tail -5
 python3 - <<PY
 import csv, glob, json, collections
 rows = collections.defaultdict(list)
