@@ -66,7 +66,9 @@ extern "C" {
 
 /* noise source for a rollout */
 #define MPPI_NOISE_INJECTED 0 /* use the buffer filled by mppi_upload_noise (reference-RNG parity) */
-#define MPPI_NOISE_PHILOX 1   /* device Philox4x32-10 + Box-Muller keyed by (seed, tick, agent, sample) */
+#define MPPI_NOISE_PHILOX 1   /* device Philox4x32-10 + Box-Muller keyed by (seed, tick, agent, sample): hipRAND's
+                                 HIPRAND_RNG_PSEUDO_PHILOX4_32_10 words at subsequence = agent << 32 | tick,
+                                 offset = 4 * ((t / 3) << 32 | sample_offset + sample) */
 
 /* dynamics + integrator pairs the reference's `model=` argument can select (control/src/mppi:62) */
 #define MPPI_MODEL_DIFFDRIVE_RK4 0   /* rk4 :39-54 over dd_dynamics :23-30 -- what the node runs      */

@@ -533,6 +533,32 @@ def test_philox_matches_cpu_twin_and_is_shard_invariant(orc):
     assert np.abs(two[1] - orc.philox_noise(seed, 1, tick, 0, K, T, SIG)).max() < 2e-6
 
 
+def test_device_noise_is_hiprands_philox_stream(orc, tmp_path):
+    """north_star: "Gaussian control perturbation from hipRAND".  The engine inlines Philox4x32-10 instead of calling the
+    library; this pins the inlined generator to hipRAND's own HIPRAND_RNG_PSEUDO_PHILOX4_32_10 device generator:
+    hiprand_init(seed, subsequence = agent << 32 | tick, offset = 4 * (triple << 32 | global sample)) followed by
+    hiprand4() returns exactly the four words the engine's draw (sample, triple, tick, agent) starts from -- compared
+    through the CPU twin, which test_philox_matches_cpu_twin_and_is_shard_invariant ties to the device noise bit for bit."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "hiprand_philox_words")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", os.path.join(root, "tests", "native", "hiprand_philox_words.hip"),
+                    "-o", exe], check=True, capture_output=True, timeout=300)
+    rng = np.random.RandomState(5)
+    cases = [(0, 0, 0, 0, 0), (1, 0, 0, 0, 0), (7, 999_999, 16, 12345, 63), (2**64 - 1, 2**32 - 1, 2**30 - 1, 2**32 - 1, 2**32 - 1)]
+    cases += [(int(rng.randint(0, 2**63)), int(rng.randint(0, 2**32)), int(rng.randint(0, 2**30)), int(rng.randint(0, 2**32)),
+               int(rng.randint(0, 2**32))) for _ in range(60)]
+    lines = "".join("%d %d %d\n" % (seed, (a << 32) | tick, (triple << 32) | gk) for seed, gk, triple, tick, a in cases)
+    out = subprocess.run([exe], input=lines, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    got = np.array([[int(x) for x in l.split()] for l in out.stdout.splitlines()], dtype=np.uint64)
+    assert got.shape == (len(cases), 4)
+    for (seed, gk, triple, tick, a), words in zip(cases, got):
+        want = orc.philox4x32_10([gk, triple, tick, a], [seed & 0xFFFFFFFF, seed >> 32])
+        assert [int(w) for w in want] == [int(w) for w in words], (seed, gk, triple, tick, a)
+
+
 def test_philox_tick_against_oracle_on_device_noise(orc):
     """Seed parity end to end: run a device-RNG tick, read the noise back, replay on the CPU."""
     K, T = 4096, 50
