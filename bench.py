@@ -213,6 +213,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f64-line", action="store_true", help="skip the extra all-fp64 measurement (N = 1, c4)")
     ap.add_argument("--graph", action="store_true", help="replay the tick as one hipGraph (N=1 only)")
+    ap.add_argument("--no-co-line", action="store_true", help="skip the co-scheduled (two engines on the one GPU) leg of config 4")
     ap.add_argument("--all-ranks-on-gpu0", action="store_true",
                     help="TEST ONLY: every rank drives cuda:0 and the process group is gloo (RCCL refuses two ranks on one "
                          "device) -- runs the N > 1 code path of this script on a one-GPU box; use with --exchange p2p")
@@ -469,6 +470,42 @@ def main():
                     "note": "eps / V stored as fp64, softmax in fp64 (exp2 in fp64): the reference's own precision end to end"}
         e64.close()
 
+    # Co-scheduled shards next to the one-engine line: N = 1, config 4 only.  Two engines on this one GPU, K / 2 samples each,
+    # own streams, coupled only by the p2p mailbox flags: one engine's HBM-bound update kernel runs under the other's
+    # VALU-bound rollout.  Same protocol as the headline (time-based warm-up, controller put back at the start, the same tick
+    # ids timed); reported beside `value`, never as `value`: per-kernel durations of overlapping kernels say nothing about a
+    # roofline, and the headline keeps the one-engine tick that `roofline` describes.
+    co_line = None
+    if (rank == 0 and world == 1 and args.workload == "c4" and args.storage == "f32" and not args.no_co_line
+            and not args.samples and not args.graph):
+        if f64_line is None:
+            eng.close()
+        ct = sharded.make_co_scheduled_ticker(K_total, T, n_shards=2, storage="f32", device=local_rank)
+        ct.set_nominal(nominal_warm(T))
+        ct.tick_async(np.zeros((1, 3)), np.array([goal]), "philox", 0, 0)
+        t_w, i = time.perf_counter(), 1
+        while time.perf_counter() - t_w < args.min_warmup_s or i < args.warmup:
+            ct.tick_async(None, None, "philox", 0, i)
+            i += 1
+            if i % 16 == 0:
+                ct.synchronize()
+        ct.set_nominal(nominal_warm(T))
+        ct.tick_async(np.zeros((1, 3)), np.array([goal]), "philox", 0, 1_000_000)
+        ct.synchronize()
+        n_co = max(args.steps, 200)
+        t0 = time.perf_counter()
+        for j in range(n_co):
+            ct.tick_async(None, None, "philox", 0, 1_000_001 + j)
+        ct.synchronize()
+        el_co = time.perf_counter() - t0
+        nxt_co, ua_co = ct.get_outputs()
+        assert np.isfinite(nxt_co).all() and np.isfinite(ua_co).all()
+        co_line = {"engines_per_gpu": 2, "samples_per_engine": [int(e.K) for e in ct.engines], "exchange": "p2p mailboxes (in-process pointers)",
+                   "ms_per_step": 1e3 * el_co / n_co, "value": K_total / (el_co / n_co), "steps": n_co,
+                   "note": "two engines on the one GPU, K/2 samples each, own streams, coupled by the finalize kernels' mailbox flags; "
+                           "one engine's update (HBM-bound) overlaps the other's rollout (VALU-bound)"}
+        ct.close()
+
     if rank == 0:
         steps_per_launch = A * K_local * T
         ms, n = ktimes["rollout"]
@@ -562,7 +599,7 @@ def main():
             "final_state": [float(x) for x in final_nxt[0]], "final_u": [float(x) for x in final_ua[0]],
             "sync_tick_us": sync_tick_us,
             "kernels_us": kernels_us, "exchange_us": exchange_us, "per_rank": per_rank,
-            "roofline": roofline, "cpu_baseline": cpu, "f64_storage": f64_line,
+            "roofline": roofline, "cpu_baseline": cpu, "f64_storage": f64_line, "co_scheduled": co_line,
         }
         line.update(extra)
         print(json.dumps(line))

@@ -16,6 +16,9 @@ Exchange back-ends (``exchange=``):
           finalize kernel waits for the G flags.  No collective launch, no host involvement per tick.
   "auto"  p2p when its probe passes on every rank (sharded.probe_p2p), else rccl.
 Independent agents (BASELINE config 5) are replicas: no exchange at all (make_replica_ticker).
+Co-scheduled shards (make_co_scheduled_ticker): the same K-split with the shards on ONE GPU in one process, each engine on
+its own stream, coupled only by the p2p mailboxes -- one shard's HBM-bound update kernel runs under the other's
+VALU-bound rollout (+5 % rollouts/s at K = 10^6 on one MI355X).
 """
 TUPLE_W = 8
 
@@ -182,3 +185,80 @@ def make_replica_ticker(samples, horizon, n_agents, storage="f32", local_rank=0,
     eng = Engine(samples, horizon, n_agents=n_agents, storage=storage, device=local_rank, **engine_kw)
     shard = HipShard(eng, torch.device("cuda", local_rank), use_torch_stream=False)
     return ShardedTicker(shard, None, exchange="none"), eng
+
+
+class CoScheduledTicker(object):
+    """G engines on one GPU in this process, the samples split between them (global sample offsets, so the noise streams
+    are those of the unsharded controller), every engine on its own stream; the only coupling is the p2p mailbox
+    exchange, i.e. flags polled by the finalize kernels -- no event, no host wait between the engines.  Every engine
+    finishes every tick identically; outputs are read from the first."""
+
+    def __init__(self, engines):
+        self.engines = list(engines)
+        self.exchange = "p2p (co-scheduled x%d)" % len(self.engines)
+        for g, e in enumerate(self.engines):
+            e.p2p_create(len(self.engines), g)
+        ptrs = [e.p2p_mailbox_ptr() for e in self.engines]
+        for e in self.engines:
+            e.p2p_connect(local_ptrs=ptrs)
+
+    def set_nominal(self, uvec, agent=0):
+        for e in self.engines:
+            e.set_nominal(uvec, agent=agent)
+
+    def tick_async(self, state=None, goal=None, noise="philox", seed=0, tick_id=0):
+        for e in self.engines:
+            e.tick_begin(state, goal, noise=noise, seed=seed, tick_id=tick_id)
+        for e in self.engines:   # one thread drives all engines: every publish is enqueued before any finalize that waits for it
+            e.p2p_publish()
+        for e in self.engines:
+            e.tick_finish_p2p()
+
+    def tick(self, state=None, goal=None, noise="philox", seed=0, tick_id=0):
+        self.tick_async(state, goal, noise, seed, tick_id)
+        return self.engines[0].get_outputs()
+
+    def get_outputs(self):
+        return self.engines[0].get_outputs()
+
+    def get_nominal(self, agent=0):
+        return self.engines[0].get_nominal(agent)
+
+    def synchronize(self):
+        for e in self.engines:
+            e.synchronize()
+
+    def close(self):
+        for e in self.engines:
+            e.close()
+        self.engines = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def make_co_scheduled_ticker(samples_total, horizon, n_shards=2, n_agents=1, storage="f32", device=0, chunk=8192, **engine_kw):
+    """K split into n_shards engines on one GPU (boundaries on multiples of `chunk`, the update kernel's chunk of
+    fp32-storage samples, so that no shard ends in a ragged chunk)."""
+    from .mppi import Engine
+    if not 2 <= n_shards <= 8:
+        raise ValueError("2..8 co-scheduled shards")
+    cuts = [0]
+    for g in range(1, n_shards):
+        cuts.append(min(int(samples_total), max(cuts[-1] + 1, int(round(g * samples_total / n_shards / chunk)) * chunk)))
+    cuts.append(int(samples_total))
+    if any(b <= a for a, b in zip(cuts, cuts[1:])):
+        raise ValueError("%d samples do not split into %d shards" % (samples_total, n_shards))
+    engines = []
+    try:
+        for g in range(n_shards):
+            engines.append(Engine(cuts[g + 1] - cuts[g], horizon, n_agents=n_agents, storage=storage, device=device,
+                                  sample_offset=cuts[g], tick_path="lanes", **engine_kw))
+        return CoScheduledTicker(engines)
+    except Exception:
+        for e in engines:
+            e.close()
+        raise

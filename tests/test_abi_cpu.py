@@ -172,6 +172,10 @@ def test_committed_bench_line_has_the_contract_fields():
     assert abs(line["value"] - line["config"]["samples_total"] / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
     assert line["tick_us"]["median"] <= line["tick_us"]["p99"] and abs(line["tick_us"]["median"] / (1e3 * line["ms_per_step"]) - 1) < 0.1
     assert line["f64_storage"]["storage"] == "f64" and line["f64_storage"]["ms_per_step"] > line["ms_per_step"]
+    co = line["co_scheduled"]     # two engines on the one GPU: reported beside `value`, never as `value`
+    assert co["engines_per_gpu"] == 2 and sum(co["samples_per_engine"]) == line["config"]["samples_total"]
+    assert abs(co["value"] - line["config"]["samples_total"] / (co["ms_per_step"] * 1e-3)) < 1e-6 * co["value"]
+    assert 0.8 < co["ms_per_step"] / line["ms_per_step"] < 1.1
     cpu = line["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample", "baseline_md_inputs"):
         assert key in cpu, key

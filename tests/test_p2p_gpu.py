@@ -129,3 +129,28 @@ def test_bench_with_two_ranks_on_the_one_gpu():
     ref = json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][-1])
     assert np.abs(np.array(line["final_state"]) - np.array(ref["final_state"])).max() < 1e-10
     assert np.abs(np.array(line["final_u"]) - np.array(ref["final_u"])).max() < 1e-10
+
+
+@pytest.mark.parametrize("n_shards,K_total", [(2, 6000), (3, 50000), (2, 300000)])
+def test_co_scheduled_shards_equal_the_single_engine(n_shards, K_total):
+    """sharded.make_co_scheduled_ticker: the K-split with all shards on this one GPU, every engine on its own stream,
+    nothing but mailbox flags between them -- closed loop, equal to the unsharded engine (fp32 chunk sums associate
+    differently: 1e-10), and every engine of the set ends with the same nominal controls."""
+    from motion_planning_amd import sharded
+    from motion_planning_amd.mppi import Engine
+    ref = []
+    with Engine(K_total, T, storage="f32", tick_path="lanes") as e:
+        e.set_nominal(_u0())
+        for i in range(NT):
+            nxt, ua = e.tick([0, 0, 0] if i == 0 else None, [0, -1, 0] if i == 0 else None, noise="philox", seed=SEED, tick_id=i)
+            ref.append(np.concatenate([nxt[0], ua[0]]))
+        ref_lat = e.get_nominal()
+    with sharded.make_co_scheduled_ticker(K_total, T, n_shards=n_shards, storage="f32") as ct:
+        assert sum(e.K for e in ct.engines) == K_total and len(ct.engines) == n_shards
+        ct.set_nominal(_u0())
+        for i in range(NT):
+            nxt, ua = ct.tick([[0, 0, 0]] if i == 0 else None, [[0, -1, 0]] if i == 0 else None, "philox", SEED, i)
+            assert np.abs(np.concatenate([nxt[0], ua[0]]) - ref[i]).max() < 1e-10, i
+        ct.synchronize()
+        for e in ct.engines:
+            assert np.abs(e.get_nominal() - ref_lat).max() < 1e-10
