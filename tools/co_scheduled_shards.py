@@ -7,8 +7,9 @@ import numpy as np
 sys.path.insert(0, ".")
 from motion_planning_amd.mppi import Engine
 
-K, T = 1_000_000, 50
+T = 50
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
 u0 = np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
 
 
