@@ -252,11 +252,12 @@ def make_co_scheduled_ticker(samples_total, horizon, n_shards=2, n_agents=1, sto
     cuts.append(int(samples_total))
     if any(b <= a for a, b in zip(cuts, cuts[1:])):
         raise ValueError("%d samples do not split into %d shards" % (samples_total, n_shards))
+    engine_kw.setdefault("tick_path", "lanes")
     engines = []
     try:
         for g in range(n_shards):
             engines.append(Engine(cuts[g + 1] - cuts[g], horizon, n_agents=n_agents, storage=storage, device=device,
-                                  sample_offset=cuts[g], tick_path="lanes", **engine_kw))
+                                  sample_offset=cuts[g], **engine_kw))
         return CoScheduledTicker(engines)
     except Exception:
         for e in engines:
