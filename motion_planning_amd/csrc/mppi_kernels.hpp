@@ -350,9 +350,32 @@ template <> __device__ __forceinline__ float wave_min<float>(float v) {
 __device__ __forceinline__ int sum16_index(int lane) {
     return ((lane & 4) << 1) | ((lane & 8) >> 1) | ((lane & 1) << 1) | ((lane >> 1) & 1);
 }
+template <bool FULL16 = false>   // FULL16: values 12..15 are real too (four more overwrites in the first halving)
 __device__ __forceinline__ float wave_sum16(const float (&v)[16], int lane) {
     const bool b1 = lane & 1, b2 = lane & 2;
     float u[8], w[4], x[2];
+    if (FULL16)
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %9, %9 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %10, %10 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %11, %11 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %12, %12 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %5, %13, %13 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %6, %14, %14 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %7, %15, %15 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %16, %16 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %1, %17, %17 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %2, %18, %18 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %3, %19, %19 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %4, %20, %20 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %5, %21, %21 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %6, %22, %22 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %7, %23, %23 row_half_mirror row_mask:0xf bank_mask:0xa"
+        : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]), "=&v"(u[4]), "=&v"(u[5]), "=&v"(u[6]), "=&v"(u[7])
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]),
+          "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]));
+    else
     asm("s_nop 1\n\t"
         "v_add_f32_dpp %0, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
         "v_add_f32_dpp %1, %9, %9 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
@@ -396,6 +419,7 @@ __device__ __forceinline__ float wave_sum16(const float (&v)[16], int lane) {
     }
     return y;
 }
+template <bool FULL16 = false>
 __device__ __forceinline__ double wave_sum16(const double (&v)[16], int lane) {  // exact-parity mode: plain sums
     double r = 0.0;
     const int mine = sum16_index(lane);
@@ -721,8 +745,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     if (!PHILOX) load_chunk(0, cur);
 
     double pre = 0.0;  // sum_{tau < t} (c[tau] - c_nom[tau])
-    auto eps_sums = [&](int t0, auto full_tag) {
+    S tl[kStepsPerDraw][2];  // the one or two steps behind the last full chunk when they ride along with it (see `run`)
+    auto eps_sums = [&](int t0, auto full_tag, auto extra_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
+        constexpr bool EXTRA = decltype(extra_tag)::value;  // slots 12..15 carry steps t0 + 6, t0 + 7 (from tl)
         {   // sum_k eps per wave for the chunk's 6 steps x 2 wheels (the E of the softmax floor term,
             // control/src/mppi:193): saves the update kernel from reading eps at all (8 of its 12 B/step)
             S ev[16];
@@ -732,10 +758,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                 ev[2 * j + 1] = (FULL || active) ? cur[j][1] : (S)0;
             }
 #pragma unroll
-            for (int j = 2 * U; j < 16; ++j) ev[j] = (S)0;
-            const S tot = wave_sum16(ev, tid & 63);
+            for (int j = 2 * U; j < 16; ++j) ev[j] = !EXTRA ? (S)0 : ((FULL || active) ? tl[(j - 2 * U) >> 1][j & 1] : (S)0);
+            const S tot = wave_sum16<EXTRA>(ev, tid & 63);
             const int idx = sum16_index(tid & 63), te = t0 + (idx >> 1);
-            const bool mine = (tid & 63) < 16 && idx < 2 * U && te < T && (size_t)(k >> 6) < NW;
+            const bool mine = (tid & 63) < 16 && idx < (EXTRA ? 16 : 2 * U) && te < T && (size_t)(k >> 6) < NW;
             const size_t at = (((size_t)a * T + te) * 2 + (idx & 1)) * NW + (k >> 6);
             if (sizeof(S) == 4) {
                 // predication by address instead of by branch: a buffer store whose offset lies beyond
@@ -870,20 +896,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         pre += P.p0 * dx * dx + P.p1 * dy * dy + P.p2 * dth * dth;
     };
     const int T4 = T - T % U;  // steps covered by full chunks
+    // T = 6 n + 1 or 6 n + 2 (the node's T = 50, 20): the one or two steps behind the last full chunk do not get a chunk of their
+    // own -- their draw is made with that chunk's two and their eps sums ride in wave_sum16's four spare slots (whose lanes map
+    // to steps t0 + 6, t0 + 7 as it is); only the steps themselves remain.
+    const bool ride = PHILOX && T4 >= U && (T - T4 == 1 || T - T4 == 2);  // (uniform)
     auto run = [&](auto full_tag) {
-        for (int t0 = 0; t0 < T4; t0 += U) {  // full chunks: straight-line code
+        const int t_loop = ride ? T4 - U : T4;
+        for (int t0 = 0; t0 < t_loop; t0 += U) {  // full chunks: straight-line code
             if (PHILOX) draw_chunk(t0, cur, std::false_type{});
             else load_chunk(t0 + U, nxt);  // prefetch: HBM latency hides under this chunk's math
-            eps_sums(t0, full_tag);
+            eps_sums(t0, full_tag, std::false_type{});
             integrate(t0, std::false_type{}, full_tag);
             if (!PHILOX) {
 #pragma unroll
                 for (int j = 0; j < U; ++j) { cur[j][0] = nxt[j][0]; cur[j][1] = nxt[j][1]; }
             }
         }
-        if (T4 < T) {  // ragged tail
+        if (PHILOX && ride) {
+            const int t0 = T4 - U;
+            draw_chunk(t0, cur, std::false_type{});
+            {
+                float e[6];
+                philox_normals(ctr0, (uint32_t)(T4 / kStepsPerDraw), tick, (uint32_t)a, key0, key1, sigf, e);
+#pragma unroll
+                for (int i = 0; i < kStepsPerDraw; ++i) {  // steps at or beyond T: no noise (they are never integrated)
+                    tl[i][0] = T4 + i < T ? (S)e[2 * i] : (S)0;
+                    tl[i][1] = T4 + i < T ? (S)e[2 * i + 1] : (S)0;
+                }
+            }
+            eps_sums(t0, full_tag, std::true_type{});
+            integrate(t0, std::false_type{}, full_tag);
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                cur[j][0] = j < kStepsPerDraw ? tl[j][0] : (S)0;
+                cur[j][1] = j < kStepsPerDraw ? tl[j][1] : (S)0;
+            }
+            integrate(T4, std::true_type{}, full_tag);
+        } else if (T4 < T) {  // ragged tail
             if (PHILOX) draw_chunk(T4, cur, std::true_type{});
-            eps_sums(T4, full_tag);
+            eps_sums(T4, full_tag, std::false_type{});
             integrate(T4, std::true_type{}, full_tag);
         }
     };
