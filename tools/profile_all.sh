@@ -10,7 +10,7 @@ timeout 400 python bench.py 2>$O/bench_c4.err | tail -1 > $O/bench_c4.json
 timeout 300 python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_c4_driver_flags.json
 cd /tmp && export TMPDIR=/tmp
 for i in 1 2 3; do
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats$i -- python $R/bench.py --no-cpu-baseline --no-f64-line > $O/stats$i.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats$i -- python $R/bench.py --no-cpu-baseline --no-f64-line --no-co-line > $O/stats$i.log 2>&1
 done
 cd $R
 timeout 900 bash tools/pmc.sh final/pmc > $O/pmc.log 2>&1; tail -4 $O/pmc.log
