@@ -240,18 +240,30 @@ class CoScheduledTicker(object):
         self.close()
 
 
+def co_scheduled_cuts(samples_total, n_shards, chunk=8192):
+    """Shard boundaries [0, c1, ..., K]: as equal as multiples of `chunk` allow (equal halves measured best), every shard
+    non-empty; interior boundaries are multiples of `chunk` whenever K has room for them."""
+    K = int(samples_total)
+    if not 2 <= n_shards <= 8:
+        raise ValueError("2..8 co-scheduled shards")
+    if K < n_shards:
+        raise ValueError("%d samples do not split into %d shards" % (K, n_shards))
+    cuts = [0]
+    for g in range(1, n_shards):
+        c = int(round(g * K / n_shards / chunk)) * chunk
+        lo, hi = cuts[-1] + 1, K - (n_shards - g)      # leave at least one sample for every shard before and behind
+        if not lo <= c <= hi:                          # K too small for chunk-aligned boundaries: plain balanced split
+            c = min(hi, max(lo, (g * K) // n_shards))
+        cuts.append(c)
+    cuts.append(K)
+    return cuts
+
+
 def make_co_scheduled_ticker(samples_total, horizon, n_shards=2, n_agents=1, storage="f32", device=0, chunk=8192, **engine_kw):
     """K split into n_shards engines on one GPU (boundaries on multiples of `chunk`, the update kernel's chunk of
     fp32-storage samples, so that no shard ends in a ragged chunk)."""
     from .mppi import Engine
-    if not 2 <= n_shards <= 8:
-        raise ValueError("2..8 co-scheduled shards")
-    cuts = [0]
-    for g in range(1, n_shards):
-        cuts.append(min(int(samples_total), max(cuts[-1] + 1, int(round(g * samples_total / n_shards / chunk)) * chunk)))
-    cuts.append(int(samples_total))
-    if any(b <= a for a, b in zip(cuts, cuts[1:])):
-        raise ValueError("%d samples do not split into %d shards" % (samples_total, n_shards))
+    cuts = co_scheduled_cuts(samples_total, n_shards, chunk)
     engine_kw.setdefault("tick_path", "lanes")
     engines = []
     try:

@@ -202,3 +202,23 @@ def test_p2p_setup_is_all_or_nothing(fail_at):
             assert calls == ["create", "connect", "selftest"]
         else:
             assert calls[-1] == "destroy" and "selftest" not in calls[:-1] or fail_at == "selftest"
+
+
+def test_co_scheduled_cuts_partition_the_samples():
+    from motion_planning_amd.sharded import co_scheduled_cuts
+    for K in (2, 3, 9, 6000, 8192, 50000, 300000, 1000000, 1048576, 2**24 + 5):
+        for n in (2, 3, 4, 8):
+            if K < n:
+                with pytest.raises(ValueError):
+                    co_scheduled_cuts(K, n)
+                continue
+            cuts = co_scheduled_cuts(K, n)
+            assert cuts[0] == 0 and cuts[-1] == K and len(cuts) == n + 1
+            assert all(b > a for a, b in zip(cuts, cuts[1:])), (K, n, cuts)      # every shard has samples
+            if K >= 4 * n * 8192:                                                 # room for chunk-aligned boundaries
+                assert all(c % 8192 == 0 for c in cuts[1:-1]), (K, n, cuts)
+                sizes = [b - a for a, b in zip(cuts, cuts[1:])]
+                assert max(sizes) - min(sizes) <= 2 * 8192
+    assert co_scheduled_cuts(1000000, 2) == [0, 499712, 1000000]
+    with pytest.raises(ValueError):
+        co_scheduled_cuts(100, 9)
