@@ -667,6 +667,27 @@ def test_floor_term_uses_sum_of_eps(orc, storage):
         assert np.abs(ua[0] - uo).max() < tol
 
 
+@pytest.mark.parametrize("storage", ["f64", "f32"])
+@pytest.mark.parametrize("K,T", [(1, 8), (300, 8), (777, 14), (2049, 26), (640, 12), (515, 10)])
+def test_device_noise_ticks_at_every_tail_length(orc, K, T, storage):
+    """Horizons 6n + 2 (the steps behind the last full 6-step chunk ride along with it: 8 = no full chunk in the loop at
+    all, 14, 26, like the node's 50 and 20), 6n (12) and 6n + 4 (10: a tail chunk of its own), ragged K, device noise,
+    floor raised to 1.0 so that the per-wave eps sums of every step carry weight in the result."""
+    u0 = 0.5 * np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
+    state, goal = [0.0, 0.0, 0.2], [0.4, -0.3, 0.0]
+    p = orc.default_params()
+    p.floor_w = 1.0
+    with _engine(K, T, storage, floor_w=1.0) as e:
+        e.set_nominal(u0)
+        nxt, ua = e.tick(state, goal, noise="philox", seed=11, tick_id=4)
+        dev = e.download_noise()[0]
+        V = e.download_value()[0]
+    Vo = orc.get_cost2go(state, u0, goal, LAM, SIG, dev)
+    assert np.abs(V - Vo).max() <= (1e-9 * max(1.0, np.abs(Vo).max()) if storage == "f64" else _vtol(orc, state, u0, goal, Vo, T, K))
+    so, uo, _ = orc.get_path(state, goal, u0, dev, LAM, SIG, params=p)
+    assert np.abs(ua[0] - uo).max() < (1e-9 if storage == "f64" else 2e-6), (K, T)
+
+
 def _softmax_rows(V, eps, lam=LAM, floor=1e-8):
     """Row-wise softmax statistics of update_action (control/src/mppi:187-196) in float64 on the host:
     mean[t, c] = sum_k w eps (the control increment) and mad[t, c] = sum_k w |eps - mean| for w = the
