@@ -590,8 +590,8 @@ struct mppi_engine {
         if (cfg.horizon < 5 || ((cfg.horizon - 1) % 2) == 0)
             fail(MPPI_E_INVALID, "horizon=%d: the Savitzky-Golay window horizon-1 must be odd and > 3 "
                  "(scipy.signal.savgol_filter at control/src/mppi:202)", cfg.horizon);
-        if ((size_t)cfg.horizon * 40 > 64 * 1024)
-            fail(MPPI_E_INVALID, "horizon %d: the per-step table (40 B/step) must fit 64 KB of LDS (horizon <= 1638)", cfg.horizon);
+        if ((size_t)cfg.horizon * 40 + 128 > 64 * 1024)   // + the rollout kernel's few static LDS words
+            fail(MPPI_E_INVALID, "horizon %d: the per-step table (40 B/step) must fit 64 KB of LDS (horizon <= 1634)", cfg.horizon);
         if (cfg.storage != MPPI_STORE_F32 && cfg.storage != MPPI_STORE_F64) fail(MPPI_E_INVALID, "bad storage %d", cfg.storage);
         // one row of dP / eps is addressed through a 32-bit buffer descriptor and 32-bit lane offsets
         if ((size_t)cfg.samples * (cfg.storage == MPPI_STORE_F64 ? 8 : 4) >= ((size_t)1 << 31))
