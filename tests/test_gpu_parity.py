@@ -380,10 +380,11 @@ def test_odd_sizes_and_ragged_tail(orc):
         assert np.abs(ua[0] - uo).max() < 1e-9 and np.abs(nxt[0] - so).max() < 1e-12, (K, T)
 
 
-@pytest.mark.parametrize("T", [64, 66, 130, 300, 1000])
+@pytest.mark.parametrize("T", [64, 66, 130, 300, 1000, 1634])
 def test_long_horizons(orc, T):
     """T = 64 is the last horizon whose nominal rollout runs inside the rollout kernel (one wave);
-    above it the block-scan nominal kernel takes over (T > 256: several scan chunks with carries)."""
+    above it the block-scan nominal kernel takes over (T > 256: several scan chunks with carries).
+    1634 is the largest horizon mppi_create accepts (the per-step table + the kernel's static words fill the 64 KB of LDS)."""
     K = 96
     eps = orc.reference_noise(T, SIG, T, K)
     u0 = 0.4 * np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
