@@ -597,6 +597,10 @@ struct mppi_engine {
         if ((size_t)cfg.samples * (cfg.storage == MPPI_STORE_F64 ? 8 : 4) >= ((size_t)1 << 31))
             fail(MPPI_E_INVALID, "samples %d: a row of %d-byte elements must stay below 2 GiB", cfg.samples,
                  cfg.storage == MPPI_STORE_F64 ? 8 : 4);
+        // the per-wave eps sums [A][T][2][Ks/64] are written through ONE 32-bit buffer descriptor (2 GiB of records)
+        if ((size_t)cfg.n_agents * cfg.horizon * 2 * (((size_t)cfg.samples + 63) / 64) * (cfg.storage == MPPI_STORE_F64 ? 8 : 4) >= ((size_t)1 << 31))
+            fail(MPPI_E_INVALID, "n_agents * horizon * samples = %d * %d * %d: the per-wave noise sums must stay below 2 GiB", cfg.n_agents,
+                 cfg.horizon, cfg.samples);
         if (cfg.model != MPPI_MODEL_DIFFDRIVE_RK4 && cfg.model != MPPI_MODEL_UNICYCLE_EULER)
             fail(MPPI_E_INVALID, "unknown model %d (rk4 + dd_dynamics = 0, euler + unicycle_dynamics = 1)", cfg.model);
         if (cfg.tick_path != MPPI_TICK_AUTO && cfg.tick_path != MPPI_TICK_LANES && cfg.tick_path != MPPI_TICK_SCAN)

@@ -1018,6 +1018,11 @@ def test_error_behaviour():
     assert ei.value.code == -1
     with pytest.raises(MppiError):
         Engine(0, 50)
+    # sizes the 32-bit buffer addressing cannot serve are refused at creation (before any allocation), not truncated
+    for K, T, A in ((2**29, 50, 1), (2**28, 1000, 1), (2**26, 50, 64), (64, 1636, 1)):
+        with pytest.raises(MppiError) as ei:
+            Engine(K, T, n_agents=A)
+        assert ei.value.code == -1, (K, T, A)
     with _engine(16, 10, "f32") as e:
         with pytest.raises(MppiError) as ei:
             e.rollout([0, 0, 0], [0, 0, 0], noise="injected")  # no noise uploaded
