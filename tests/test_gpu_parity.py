@@ -1019,7 +1019,7 @@ def test_error_behaviour():
     with pytest.raises(MppiError):
         Engine(0, 50)
     # sizes the 32-bit buffer addressing cannot serve are refused at creation (before any allocation), not truncated
-    for K, T, A in ((2**29, 50, 1), (2**28, 1000, 1), (2**26, 50, 64), (64, 1636, 1)):
+    for K, T, A in ((2**29, 50, 1), (2**28, 1000, 1), (2**26, 50, 64), (64, 1636, 1), (64, 50, 65536)):
         with pytest.raises(MppiError) as ei:
             Engine(K, T, n_agents=A)
         assert ei.value.code == -1, (K, T, A)
