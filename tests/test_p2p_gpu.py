@@ -154,3 +154,30 @@ def test_co_scheduled_shards_equal_the_single_engine(n_shards, K_total):
         ct.synchronize()
         for e in ct.engines:
             assert np.abs(e.get_nominal() - ref_lat).max() < 1e-10
+
+
+@pytest.mark.parametrize("log2_k", [24, 27])
+def test_large_k_single_engine_equals_four_small_ones(log2_k):
+    """Maximum-size edge: K = 2^24 samples in ONE engine -- its noise buffer (6.7 GB) and cost-prefix buffer (3.4 GB)
+    run past every 32-bit byte offset -- against the same samples in four engines of 2^22 (every buffer below 4 GB),
+    co-scheduled on this GPU; and K = 2^27 (134 million samples, 80 GB of HBM, rows of 512 MB: a quarter of the largest
+    row mppi_create accepts) against four engines of 2^25.  Split invariance is a size-independent property: the
+    controls must agree.  (The single engine is closed before the four are built: peak 80 GB of the 288.)"""
+    from motion_planning_amd import sharded
+    from motion_planning_amd.mppi import Engine
+    K_big, n_ticks = 1 << log2_k, 3
+    ref = []
+    with Engine(K_big, T, storage="f32", tick_path="lanes") as e:
+        e.set_nominal(_u0())
+        for i in range(n_ticks):
+            nxt, ua = e.tick([0, 0, 0] if i == 0 else None, [0, -1, 0] if i == 0 else None, noise="philox", seed=SEED, tick_id=i)
+            ref.append(np.concatenate([nxt[0], ua[0]]))
+        ref_lat = e.get_nominal()
+        assert e.info()["hbm_bytes"] > 9 * 2**30 * (K_big >> 24)
+    with sharded.make_co_scheduled_ticker(K_big, T, n_shards=4, storage="f32") as ct:
+        assert [e.K for e in ct.engines] == [K_big // 4] * 4
+        ct.set_nominal(_u0())
+        for i in range(n_ticks):
+            nxt, ua = ct.tick([[0, 0, 0]] if i == 0 else None, [[0, -1, 0]] if i == 0 else None, "philox", SEED, i)
+            assert np.abs(np.concatenate([nxt[0], ua[0]]) - ref[i]).max() < 1e-10, i
+        assert np.abs(ct.get_nominal() - ref_lat).max() < 1e-10
