@@ -102,11 +102,14 @@ def test_p2p_two_processes_over_ipc():
         assert np.abs(lat - ref_lat).max() < 1e-10, rank
 
 
-def test_bench_with_two_ranks_on_the_one_gpu():
-    """bench.py's N > 1 code path -- K split over the ranks, the p2p exchange, the warm-up rounds agreed by broadcast,
+@pytest.mark.parametrize("exchange", ["p2p", "rccl"])
+def test_bench_with_two_ranks_on_the_one_gpu(exchange):
+    """bench.py's N > 1 code path -- K split over the ranks, the exchange, the warm-up rounds agreed by broadcast,
     max-over-ranks timing, per-rank kernel times gathered on rank 0 -- launched the way the driver launches it
     (torch.distributed.run, one process per rank), but with both ranks on this box's one GPU (--all-ranks-on-gpu0: gloo
-    group, since RCCL refuses two ranks on a device).  Must agree with the single-process run of the same total K."""
+    group, since RCCL refuses two ranks on a device).  "p2p": the engines' mailboxes over HIP IPC; "rccl": the collective
+    path -- mppi_tick_begin, all_gather_into_tensor of the two ranks' tuples on the engine's device buffers (gloo moves them
+    here, RCCL on N GPUs), mppi_tick_finish(gathered, 2).  Must agree with the single-process run of the same total K."""
     import json
     import subprocess
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
@@ -116,11 +119,11 @@ def test_bench_with_two_ranks_on_the_one_gpu():
     def run(cmd):
         return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     out = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-               "--master-port", str(port)] + common + ["--gpus", "2", "--all-ranks-on-gpu0", "--exchange", "p2p"])
+               "--master-port", str(port)] + common + ["--gpus", "2", "--all-ranks-on-gpu0", "--exchange", exchange])
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["samples_total"] == 50000 and line["config"]["samples_per_gpu"] == 25000
-    assert line["config"]["parallelism"] == "K-sharded x2, exchange: p2p" and line["scaling"] == "strong"
+    assert line["config"]["parallelism"] == "K-sharded x2, exchange: %s" % exchange and line["scaling"] == "strong"
     assert [r["rank"] for r in line["per_rank"]] == [0, 1] and all(r["samples"] == 25000 for r in line["per_rank"])
     assert all(r["kernels_us"]["rollout"] > 0 and r["exchange_us"] > 0 for r in line["per_rank"])
     assert line["value"] == pytest.approx(50000 / (line["ms_per_step"] * 1e-3))   # whole-job samples / max-over-ranks time
