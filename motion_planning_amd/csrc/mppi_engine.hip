@@ -327,9 +327,21 @@ struct mppi_engine {
             if (state) { std::memcpy(h, state, n * sizeof(double)); in_state = dv; have_state = true; }
             if (goal) { std::memcpy(h + n, goal, n * sizeof(double)); in_goal = dv + n; have_goal = true; }
             in_slot = slot;
-        } else {
-            if (state) { stage_upload(state, d_state, n); have_state = true; }
-            if (goal) { stage_upload(goal, d_goal, n); have_goal = true; }
+        } else if (state || goal) {
+            // lane-per-sample tick: the inputs go into a pinned slot as well, and ONE small kernel moves them to d_state /
+            // d_goal (two H2D copies cost ~10 us more in front of a blocking tick)
+            release_unclaimed_slot();
+            const int slot = ring_pos;
+            ring_pos = (ring_pos + 1) % kRing;
+            wait_slot_free(slot);
+            double* h = h_stage + (size_t)slot * cfg.n_agents * 6;
+            const double* dv = d_stage_view + (size_t)slot * cfg.n_agents * 6;
+            if (state) { std::memcpy(h, state, n * sizeof(double)); have_state = true; }
+            if (goal) { std::memcpy(h + n, goal, n * sizeof(double)); have_goal = true; }
+            hipLaunchKernelGGL(mppi::fetch_inputs_kernel, dim3(((int)n + 63) / 64), dim3(64), 0, stream, state ? dv : nullptr,
+                               goal ? dv + n : nullptr, d_state, d_goal, (int)n);
+            HIPCHK(hipGetLastError());
+            slot_unclaimed = slot;   // free once that kernel has run: tied to this tick's finalize, or to an event
         }
         if (!have_state || !have_goal) fail(MPPI_E_STATE, "state/goal passed as NULL before ever being set");
     }

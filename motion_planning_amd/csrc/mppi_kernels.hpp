@@ -1632,8 +1632,20 @@ __global__ __launch_bounds__(1024) void finalize_kernel(DevParams P, const doubl
 }
 #endif
 
-// perform_action alone (control/src/mppi:210-213): next = rk4(state, unom[:,0])
 #ifndef MPPI_ROLLOUT_TU  // non-template kernels are emitted by the engine translation unit only
+// state / goal from the caller's pinned, device-mapped staging slot into their device-resident homes: one tiny launch in
+// front of a lane-per-sample tick instead of two H2D copies (the thousands of rollout blocks must not each read the slot
+// over PCIe; the scan tick's few blocks do read it in place).  nullptr = keep what is resident.
+__global__ void fetch_inputs_kernel(const double* __restrict__ src_state, const double* __restrict__ src_goal,
+                                    double* __restrict__ state, double* __restrict__ goal, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        if (src_state) state[i] = src_state[i];
+        if (src_goal) goal[i] = src_goal[i];
+    }
+}
+
+// perform_action alone (control/src/mppi:210-213): next = rk4(state, unom[:,0])
 __global__ void plant_kernel(DevParams P, const double* __restrict__ state, const double* __restrict__ unom,
                              double* __restrict__ outv) {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
