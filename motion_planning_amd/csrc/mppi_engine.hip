@@ -557,11 +557,11 @@ struct mppi_engine {
         Scope sc(this, MPPI_KERNEL_FINALIZE);
         const int T = cfg.horizon;
         size_t lds = (size_t)4 * T * sizeof(double);
-        if (lds + (size_t)T * T * sizeof(double) <= 64 * 1024) {  // S_T fits next to the control rows: stage it
-            lds += (size_t)T * T * sizeof(double);
+        if (lds + (size_t)4 * (T - 1) * sizeof(double) + 1024 <= 64 * 1024) {  // the filter's basis fits next to the control rows: stage it
+            lds += (size_t)4 * (T - 1) * sizeof(double);
             flags |= 8;
         }
-        // as many threads as the 2T filter outputs can use in slices (T = 50: 1000), at least 256
+        // 16 lanes per row for the tuple merge, one wave per filter coefficient (16 of them): T = 50 -> 1024 threads; at least 256
         const int fin_threads = std::min(1024, std::max(256, ((2 * T * std::max(1, 1024 / (2 * T)) + 63) / 64) * 64));
         uint32_t tick_set = 0;
         if ((flags & 1) && !(flags & 4) && last_tick_eager) { flags |= 16; tick_set = last_tick_id + 1u; }
@@ -702,7 +702,7 @@ struct mppi_engine {
         d_part = dev_alloc<double>((size_t)A * T * std::max(NCH, small_nb) * mppi::kTupleW, hbm_bytes);
         d_prev = dev_alloc<double>((size_t)A * (2 * T + 6), hbm_bytes);
         d_merged = dev_alloc<double>((size_t)A * T * mppi::kTupleW, hbm_bytes);
-        d_S = dev_alloc<double>((size_t)T * T, hbm_bytes);
+        d_S = dev_alloc<double>((size_t)4 * (T - 1), hbm_bytes);   // the Savitzky-Golay operator's orthonormal basis [4][T-1]
         d_out = dev_alloc<double>((size_t)A * 8, hbm_bytes);
         d_tick = dev_alloc<uint32_t>(1, hbm_bytes);
         HIPCHK(hipMemsetAsync(d_unom, 0, (size_t)A * 2 * T * sizeof(double), stream));  // uvec_init, :65
@@ -714,7 +714,7 @@ struct mppi_engine {
         HIPCHK(hipMemsetAsync(d_stot, 0, (size_t)A * Ks * esz(), stream));
 
         std::vector<double> S;
-        if (!mppi::savgol_operator(T, S)) fail(MPPI_E_INVALID, "cannot build the Savitzky-Golay operator for horizon %d", T);
+        if (!mppi::savgol_basis(T, S)) fail(MPPI_E_INVALID, "cannot build the Savitzky-Golay operator for horizon %d", T);
         HIPCHK(hipMemcpyAsync(d_S, S.data(), S.size() * sizeof(double), hipMemcpyHostToDevice, stream));
         wait_stream("engine initialisation");
         HIPCHK(hipEventCreateWithFlags(&ev_partials, hipEventDisableTiming));

@@ -1372,7 +1372,7 @@ __device__ __forceinline__ void rk4_exact(const DevParams& P, const double x0[3]
 // (:91-101) for one agent per block.
 //   gathered [G][A][T][8] shard partials (G = 1: this engine's own)
 //   flags: bit0 plant step (perform_action :210-213), bit1 receding-horizon shift (:100-101),
-//          bit2 bump the device tick counter (graph replay), bit3 S_T staged in LDS (T*T more doubles),
+//          bit2 bump the device tick counter (graph replay), bit3 the filter's basis staged in LDS (4*(T-1) more doubles),
 //          bit4 set the device tick counter to tick_set (eager ticks: the id after the one just run, so a
 //          later mppi_tick_graph continues the stream instead of re-drawing it)
 //   ufilt [A][2][T] filtered controls (un-shifted), outv [A][8] = {next_state[3], u_applied[2]}
@@ -1484,14 +1484,15 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
     }
     double* un = reinterpret_cast<double*>(smem_raw);  // [2][T] updated + clipped
     double* uf = un + 2 * P.T;                          // [2][T] filtered + clipped
-    double* Sl = uf + 2 * P.T;                          // [T][T] staged copy of the filter (flags bit3)
+    double* Sl = uf + 2 * P.T;                          // [4][T-1] staged copy of the filter's basis (flags bit3)
     __shared__ double trig[3][2];
     const int tid = threadIdx.x, T = P.T;
     // the filter operator does not depend on anything this kernel waits for: fetch it now, all loads in
     // flight at once, and read it from LDS when the updated controls are ready
     const bool staged = (flags & 8) != 0;
+    const int nb = T - 1;  // basis length = the filter window
     if (staged)
-        for (int i = tid; i < T * T; i += blockDim.x) Sl[i] = Smat[i];
+        for (int i = tid; i < 4 * nb; i += blockDim.x) Sl[i] = Smat[i];
     // omg = exp(-V/lam) + 1e-8, normalised; uvec += eps . omg   (control/src/mppi:193-196), then clip (:198-199)
     auto apply = [&](int t, double d, double n0, double n1, double e0, double e1, double cnt) {
         const double den = d + P.floor_w * cnt;
@@ -1529,38 +1530,31 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
         }
     }
     __syncthreads();
-    {   // savgol_filter as u @ S (:202), clip (:205-206).  The 2T dot products of length T are cut into
-        // `parts` interleaved slices each so that the whole block works and the S loads of one output run as
-        // `parts` independent streams; the partial sums meet in LDS (uf doubles as scratch: parts <= 2 there,
-        // more go to psum).
-        __shared__ double psum[1024];
-        const int n_out = 2 * T;
-        const int parts = max(1, min((int)blockDim.x / n_out, 1024 / n_out));
-        const double* Sm = staged ? Sl : Smat;
-        if (tid < n_out * parts) {
-            const int o = tid % n_out, part = tid / n_out, c = o >= T, j = o - c * T;
-            const double* ur = un + c * T;
+    {   // savgol_filter (:202) as u @ S, clip (:205-206).  With window T-1 the operator has rank 8 (savgol.hpp):
+        //   (u @ S)[j] = sum_d p_d(e_j) c_d[shift_j],   c_d[s] = sum_i p_d(i) u[i + s]
+        // so per wheel eight dot products against the orthonormal basis -- one wave each, sixteen in all -- and four
+        // multiply-adds per output, instead of 2 T^2 multiply-adds over an operator of 8 T^2 bytes.
+        __shared__ double coef[2][2][4];
+        const double* Pb = staged ? Sl : Smat;
+        const int lane = tid & 63, wave = tid >> 6, nwaves = (int)blockDim.x >> 6;
+        for (int c = wave; c < 16; c += nwaves) {   // c = (wheel, shift, degree); uniform per wave
+            const int w = c >> 3, sh = (c >> 2) & 1, d = c & 3;
+            const double* ur = un + w * T + sh;
+            const double* pr = Pb + (size_t)d * nb;
             double acc = 0.0;
-            for (int t = part; t < T; t += parts) acc = fma(ur[t], Sm[(size_t)t * T + j], acc);
-            if (parts == 1) uf[o] = clampd(acc, P.u_max);
-            else psum[part * n_out + o] = acc;
+            for (int i = lane; i < nb; i += 64) acc = fma(pr[i], ur[i], acc);
+            acc = wave_sum(acc);
+            if (lane == 0) coef[w][sh][d] = acc;
         }
-        if (parts > 1) {
-            __syncthreads();
-            if (tid < n_out) {
-                double acc = 0.0;
-                for (int q = 0; q < parts; ++q) acc += psum[q * n_out + tid];
-                uf[tid] = clampd(acc, P.u_max);
-            }
-        }
-        if (n_out > (int)blockDim.x) {  // T > blockDim.x / 2: the plain loop for the outputs not covered above
-            for (int idx = tid + (int)blockDim.x; idx < n_out; idx += blockDim.x) {
-                const int c = idx >= T, j = idx - c * T;
-                const double* ur = un + c * T;
-                double acc = 0.0;
-                for (int t = 0; t < T; ++t) acc = fma(ur[t], Sm[(size_t)t * T + j], acc);
-                uf[idx] = clampd(acc, P.u_max);
-            }
+        __syncthreads();
+        const int half = (nb - 1) / 2;
+        for (int idx = tid; idx < 2 * T; idx += blockDim.x) {
+            const int w = idx >= T, j = idx - w * T;
+            const int sh = j <= half ? 0 : 1, e = j - sh;   // position inside its window (left window starts at 0, right at 1)
+            double acc = 0.0;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) acc = fma(Pb[(size_t)d * nb + e], coef[w][sh][d], acc);
+            uf[idx] = clampd(acc, P.u_max);
         }
     }
     __syncthreads();

@@ -13,12 +13,18 @@
 
 namespace mppi {
 
-// returns false if the window T-1 is even or <= polyorder (scipy of the reference's era raises)
-inline bool savgol_operator(int T, std::vector<double>& S) {
+constexpr int kSavgolOrder = 3;
+
+// The orthonormal basis itself, basis[d * (T-1) + i] = p_d(i), d = 0..3, i = 0..T-2: the operator is
+//   S[i + shift_j][j] = sum_d p_d(e_j) p_d(i),   e_j = j (j <= half) | j - 1,  shift_j = 0 | 1,  half = (T - 2) / 2
+// so  (u @ S)[j] = sum_d p_d(e_j) c_d[shift_j]  with the 8 coefficients  c_d[s] = sum_i p_d(i) u[i + s]  --
+// the finalize kernel filters through those (8 (T-1) + 4 T multiply-adds per wheel instead of T^2, 32 (T-1) bytes of
+// operator instead of 8 T^2).  returns false if the window T-1 is even or <= polyorder (scipy of the reference's era raises)
+inline bool savgol_basis(int T, std::vector<double>& basis) {
     const int n = T - 1;
-    const int order = 3;
+    const int order = kSavgolOrder;
     if (n <= order || (n % 2) == 0) return false;
-    // orthonormal basis p_d(i), d = 0..3, i = 0..n-1 by modified Gram-Schmidt on z^d
+    // by modified Gram-Schmidt on z^d
     std::vector<std::vector<double>> p(order + 1, std::vector<double>(n));
     const double c = 0.5 * (n - 1);
     for (int d = 0; d <= order; ++d) {
@@ -34,6 +40,17 @@ inline bool savgol_operator(int T, std::vector<double>& S) {
         nrm = std::sqrt(nrm);
         for (int i = 0; i < n; ++i) p[d][i] /= nrm;
     }
+    basis.assign((size_t)(order + 1) * n, 0.0);
+    for (int d = 0; d <= order; ++d)
+        for (int i = 0; i < n; ++i) basis[(size_t)d * n + i] = p[d][i];
+    return true;
+}
+
+inline bool savgol_operator(int T, std::vector<double>& S) {
+    std::vector<double> basis;
+    if (!savgol_basis(T, basis)) return false;
+    const int n = T - 1, order = kSavgolOrder;
+    auto pd = [&](int d, int i) { return basis[(size_t)d * n + i]; };
     // hat matrix H[e][j] = sum_d p_d(e) p_d(j): fitted value at window position e from sample j
     const int half = (n - 1) / 2;
     S.assign((size_t)T * T, 0.0);
@@ -42,7 +59,7 @@ inline bool savgol_operator(int T, std::vector<double>& S) {
         const int shift = (j <= half) ? 0 : 1;    // left window starts at 0, right window at 1
         for (int i = 0; i < n; ++i) {
             double h = 0.0;
-            for (int d = 0; d <= order; ++d) h += p[d][e] * p[d][i];
+            for (int d = 0; d <= order; ++d) h += pd(d, e) * pd(d, i);
             S[(size_t)(i + shift) * T + j] = h;
         }
     }
