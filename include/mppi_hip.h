@@ -283,6 +283,11 @@ int mppi_kernel_timing_period(mppi_engine *h, int period);
 int mppi_kernel_times(mppi_engine *h, double *ms /*[MPPI_KERNEL_COUNT]*/,
                       int64_t *launches /*[MPPI_KERNEL_COUNT]*/);
 
+/* Shader clock (MHz) the last lane-per-sample rollout launch ran at: one lane of that launch's middle workgroup reads
+ * the shader cycle counter (s_memtime) and the constant-rate counter (s_memrealtime) when its wave starts and ends.
+ * 0 before the first such launch.  Synchronises.  (Measurement aid: prices the VALU-issue roofline of bench.py.) */
+int mppi_shader_clock(mppi_engine *h, double *mhz);
+
 /* Bytes of HBM held by the engine, and the launch geometry (blocks) of a tick's kernels: rollout +
  * update on the lane-per-sample path; the scan kernel and update_blocks = 0 on the small-K path. */
 int mppi_engine_info(mppi_engine *h, size_t *hbm_bytes, int32_t *rollout_blocks,

@@ -83,6 +83,7 @@ SIGNATURES = {
     "mppi_kernel_timing": (C.c_int, [_H, C.c_uint32]),
     "mppi_kernel_timing_period": (C.c_int, [_H, C.c_int]),
     "mppi_kernel_times": (C.c_int, [_H, _dp, C.POINTER(C.c_int64)]),
+    "mppi_shader_clock": (C.c_int, [_H, _dp]),
     "mppi_engine_info": (C.c_int, [_H, C.POINTER(C.c_size_t), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }
 

@@ -22,6 +22,7 @@
 #include "../../include/mppi_hip.h"
 #include "mppi_kernels.hpp"
 #include "rollout_launch.hpp"
+#include "rollout_pk.hpp"
 #include "savgol.hpp"
 
 namespace {
@@ -105,6 +106,7 @@ struct mppi_engine {
     uint64_t lazy_seed = 0;
     uint32_t lazy_tick = 0;
     bool store_eps_always = false;  // MPPI_STORE_EPS=1: the tick path writes eps like mppi_rollout does
+    bool use_pk = true;             // MPPI_ROLLOUT_PK=0: keep the all-fp64 rollout kernel on the tick path (same-box A/B measurements)
     double* d_tc = nullptr;  // [A][T][8]
     double* d_base = nullptr;
     double* d_unom = nullptr;
@@ -116,6 +118,7 @@ struct mppi_engine {
     double* d_S = nullptr;
     double* d_out = nullptr;
     uint32_t* d_tick = nullptr;
+    unsigned long long* d_clk = nullptr;   // {shader cycles, wall-clock ticks} of the last rollout launch's probe wave
     signed char* d_grid = nullptr;
     size_t grid_bytes = 0;
     double* d_tmp = nullptr;
@@ -375,6 +378,18 @@ struct mppi_engine {
         a.unom = ro_unom ? ro_unom : d_unom; a.tc = d_tc; a.base = d_base;
         a.eps = d_eps; a.dP = d_dP; a.stot = d_stot; a.epart = d_epart;
         hipError_t e;
+        // the tick path of an fp32-storage engine with the node's own cost and model: the mixed-precision kernel, two
+        // samples per lane on the packed-fp32 pipe (rollout_pk.hpp); its heading series need the noise's reach bounded
+        if (use_pk && !f64() && ph && !store && a.inline_nominal && !a.general && k0 == 0 && k1 == cfg.samples &&
+            mppi::rollout_pk_applies(P.kth, P.dt, P.sigma, cfg.horizon)) {
+            mppi::RolloutPkArgs b{};
+            b.P = P; b.stream = st; b.inline_nominal = a.inline_nominal; b.seed = seed; b.tick = tick; b.tick_ptr = tick_ptr;
+            b.state = a.state; b.goal = a.goal; b.unom = a.unom; b.tc = d_tc; b.base = d_base;
+            b.dP = static_cast<float*>(d_dP); b.stot = static_cast<float*>(d_stot); b.epart = static_cast<float*>(d_epart);
+            b.al_guard = mppi::rollout_pk_guard(P.kth, P.dt, P.sigma);
+            b.ev_start = a.ev_start; b.ev_stop = a.ev_stop;
+            e = mppi::launch_rollout_pk(b);
+        } else
         if (f64()) e = nterm == 4 ? mppi::launch_rollout_typed<double, 4>(a) : nterm == 7 ? mppi::launch_rollout_typed<double, 7>(a) : mppi::launch_rollout_typed<double, 0>(a);
         else e = nterm == 4 ? mppi::launch_rollout_typed<float, 4>(a) : nterm == 7 ? mppi::launch_rollout_typed<float, 7>(a) : mppi::launch_rollout_typed<float, 0>(a);
         if (a.ev_start) {
@@ -597,6 +612,7 @@ struct mppi_engine {
     void init(const mppi_config& c) {
         cfg = c;
         if (const char* v = std::getenv("MPPI_STORE_EPS")) store_eps_always = std::atoi(v) != 0;
+        if (const char* v = std::getenv("MPPI_ROLLOUT_PK")) use_pk = std::atoi(v) != 0;
         if (const char* v = std::getenv("MPPI_SYNC_TIMEOUT_MS")) sync_timeout_ms = std::atoi(v);
         if (cfg.n_agents < 1 || cfg.samples < 1) fail(MPPI_E_INVALID, "n_agents and samples must be >= 1");
         if (cfg.n_agents > 65535) fail(MPPI_E_INVALID, "n_agents %d: agents are a grid dimension (<= 65535)", cfg.n_agents);
@@ -705,6 +721,9 @@ struct mppi_engine {
         d_S = dev_alloc<double>((size_t)4 * (T - 1), hbm_bytes);   // the Savitzky-Golay operator's orthonormal basis [4][T-1]
         d_out = dev_alloc<double>((size_t)A * 8, hbm_bytes);
         d_tick = dev_alloc<uint32_t>(1, hbm_bytes);
+        d_clk = dev_alloc<unsigned long long>(2, hbm_bytes);
+        HIPCHK(hipMemsetAsync(d_clk, 0, 2 * sizeof(unsigned long long), stream));
+        P.clk = d_clk;
         HIPCHK(hipMemsetAsync(d_unom, 0, (size_t)A * 2 * T * sizeof(double), stream));  // uvec_init, :65
         HIPCHK(hipMemsetAsync(d_ufilt, 0, (size_t)A * 2 * T * sizeof(double), stream));
         HIPCHK(hipMemsetAsync(d_out, 0, (size_t)A * 8 * sizeof(double), stream));
@@ -754,7 +773,7 @@ struct mppi_engine {
         if (h_stage) hipHostFree(h_stage);
         if (h_out) hipHostFree(h_out);
         if (h_seq) hipHostFree(h_seq);
-        void* bufs[] = {d_eps, d_dP, d_stot, d_epart, d_tc, d_base, d_unom, d_ufilt, d_state, d_goal, d_part, d_merged, d_S, d_out, d_tick, d_tmp, d_grid, d_prev};
+        void* bufs[] = {d_eps, d_dP, d_stot, d_epart, d_tc, d_base, d_unom, d_ufilt, d_state, d_goal, d_part, d_merged, d_S, d_out, d_tick, d_tmp, d_grid, d_prev, d_clk};
         for (void* b : bufs) if (b) hipFree(b);
         if (own_stream) hipStreamDestroy(own_stream);
     }
@@ -1326,6 +1345,17 @@ int mppi_kernel_times(mppi_engine* h, double* ms, int64_t* launches) {
         if (ms) ms[i] = h->t_ms[i];
         if (launches) launches[i] = h->t_n[i];
     }
+    API_END(h)
+}
+
+int mppi_shader_clock(mppi_engine* h, double* mhz) {
+    API_BEGIN(h)
+    if (!mhz) fail(MPPI_E_INVALID, "mhz is NULL");
+    unsigned long long v[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(v, h->d_clk, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+    h->wait_stream(__func__);
+    // v[1] counts the constant-rate wall clock (hipDeviceAttributeWallClockRate, kHz)
+    *mhz = v[1] ? (double)v[0] / (double)v[1] * (double)h->wall_clock_khz * 1e-3 : 0.0;
     API_END(h)
 }
 

@@ -59,6 +59,20 @@ struct DevParams {
     const signed char* grid;
     int grid_w, grid_h;
     double grid_res, grid_ox, grid_oy, grid_weight;
+    // shader-clock probe (mppi_shader_clock): one lane of the rollout launch's middle block notes how many shader cycles
+    // (s_memtime) and constant-rate ticks (s_memrealtime) its wave lived: {cycles, ticks}.  nullptr: off.
+    unsigned long long* clk;
+};
+struct ClockProbe {
+    unsigned long long c0 = 0, w0 = 0;
+    bool on;
+    __device__ __forceinline__ explicit ClockProbe(const DevParams& P)
+        : on(P.clk != nullptr && blockIdx.x == (gridDim.x >> 1) && blockIdx.y == 0 && threadIdx.x == 0) {
+        if (on) { c0 = clock64(); w0 = wall_clock64(); }
+    }
+    __device__ __forceinline__ void stop(const DevParams& P) {
+        if (on) { P.clk[0] = clock64() - c0; P.clk[1] = wall_clock64() - w0; }
+    }
 };
 
 // weight * cell / 100 of the cell holding (x, y); same arithmetic (divide + floor) as the oracle
@@ -483,11 +497,14 @@ __device__ __forceinline__ double lanes_scan_incl(double v, int t, double* sh, d
 // The nominal (eps = 0) rollout with lanes = timesteps: ONE wave for T <= 64 (every scan in registers),
 // the block's four waves for T <= 256.  Lane t < T gets its table row {un0, un1, lam*sig*un0,
 // lam*sig*un1, cb} and base[t].  All NWAVES * 64 lanes must call it (barriers when NWAVES > 1).
+// what the deviation-form rollout (rollout_pk_kernel) needs of the nominal trajectory beyond the table row: lane t's
+// clipped wheel speeds, its step's rotation h = 2 phi, the mid-step heading vector and the post-step position
+struct NomExtra { double u0c, u1c, h, th, c1, s1, X, Y; };
 template <int NWAVES>
 __device__ __forceinline__ void nominal_lanes(const DevParams& P, const double* __restrict__ state,
                                               const double* __restrict__ goal, const double* __restrict__ unom,
                                               int a, int t, double (&row)[5], double& base_t, double* sh,
-                                              double* head0 = nullptr) {
+                                              double* head0 = nullptr, NomExtra* ex = nullptr) {
     const int T = P.T;
     double tot_;
     const bool valid = t < T;
@@ -515,9 +532,11 @@ __device__ __forceinline__ void nominal_lanes(const DevParams& P, const double* 
         }
         const double aa = P.dt * P.rhalf * (u0 + u1) * (1.0 / 6.0);
         ix = aa * (c0 + 4.0 * c1 + c2); iy = aa * (s0 + 4.0 * s1 + s2);
+        if (ex) { ex->c1 = c1; ex->s1 = s1; }
     }
     const double X = state[a * 3 + 0] + lanes_scan_incl<NWAVES>(valid ? ix : 0.0, t, sh, tot_);
     const double Y = state[a * 3 + 1] + lanes_scan_incl<NWAVES>(valid ? iy : 0.0, t, sh, tot_);
+    if (ex) { ex->u0c = u0; ex->u1c = u1; ex->h = h; ex->th = th; ex->X = X; ex->Y = Y; }
     double cst = 0.0;
     row[0] = un0; row[1] = un1; row[2] = 0.0; row[3] = 0.0; row[4] = 0.0;
     if (valid) {
@@ -631,6 +650,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* lt = reinterpret_cast<double*>(smem_raw);  // [T][5] per-step table {un0, un1, w0, w1, cb}
     const int tid = threadIdx.x, a = blockIdx.y, T = P.T;
+    ClockProbe probe(P);
     // LEAN: the node's own cost and model (rk4 diff-drive, Q = diag(q, q, 0) with q > 0, no obstacle grid).
     // Its step is written in scaled variables so that constants fold away (5 fp64 instructions fewer per step):
     //   wheel speeds times half_kd (the table holds half_kd * un, the clip bound is half_kd * u_max):
@@ -943,6 +963,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     terminal();
     // value_fcn = reverse cumulative sum over t (control/src/mppi:175) = total - exclusive prefix
     if (active) Stot[(size_t)a * Ks + k] = (S)pre;
+    probe.stop(P);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,0 +1,335 @@
+// rollout_pk.hpp -- rollout_pk_kernel: the lane-per-sample rollout of the node's own configuration in MIXED precision,
+// TWO samples per lane on the packed-fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two fp32 operations in the
+// issue slot of one fp64 operation).  Runs the tick path of MPPI_STORE_F32 engines when
+//     device Philox noise, noise not stored, rk4 + dd_dynamics, Q = diag(q, q, 0) with q > 0, no obstacle grid, T <= 256
+// (everything else -- injected noise, stored noise, fp64 storage, the general cost, euler -- stays on rollout_kernel, which
+// is fp64 throughout).  Reference: control/src/mppi get_cost2go :127-178, get_cost :180-184, rk4 :39-54, dd_dynamics :23-30.
+//
+// DEVIATION FORM.  Every per-sample quantity is carried as its difference from the nominal (eps = 0) trajectory, which the
+// block's prologue computes in fp64 (nominal_lanes) and leaves in LDS as one 80-byte row per step:
+//     dp_i   = hk (clip(un_i + eps_i) - clip(un_i))             wheel-speed deviations (hk = kth dt / 2), exact clip
+//     dphi   = dp1 - dp0,  dPs = dp0 + dp1                       rotation / speed deviation of the step
+//     th    += 2 dphi                                            heading deviation                      [fp64 running sum]
+//     alpha  = th_start + dphi                                   mid-step heading deviation
+//     S = sin alpha, Cm = cos alpha - 1                          series, |alpha| <= 0.5 (guarded per chunk, see below)
+//     G  = rho (Pn + dPs) W(phin + dphi),  dG = G - Gn           Simpson-weighted speed and its deviation
+//     (a, b) = (G Cm + dG, G S)                                  increment deviation in the nominal mid-step heading frame
+//     dX += c1n a - s1n b,  dY += s1n a + c1n b                  position deviation (scaled by sqrt(q/2)) [fp64 running sums]
+//     pre += dX (2 Xn + dX) + dY (2 Yn + dY) + lam un.Sig.eps    stage cost minus nominal stage cost     [fp64 running sum]
+// fp32 (packed): the clip, the series, the speed / Simpson-weight deviations and the noise cost -- 28 packed operations
+// per step for two samples; fp64: the three running sums, the rotation into the world frame (it feeds the position sum
+// directly: as cheap as a packed rotation plus two conversions, and it keeps the increments' rounding out of the sum)
+// and the quadratic cost.  Every fp32 rounding error is proportional to a DEVIATION (none to the nominal's magnitude).
+// Measured against the fp64 oracle (tools/pk_error_model.py is this arithmetic in numpy; tests replay the kernel):
+// |V - V_oracle| <= ~1e-6 typical, <= 7e-6 worst at config 4 -- the class of the fp32 storage of V (5.4e-6 there).
+//
+// Guard: the series hold for |alpha| <= 0.5.  A chunk of <= 8 steps moves th by at most 8 * 2 hk sqrt2 * 5.53 sigma (the
+// Box-Muller radius is bounded), so a chunk whose lanes all start with |th| <= al_guard = 0.5 - that bound runs the
+// short series; otherwise (never at the node's sigma: 7 standard deviations) the same step runs series that hold for
+// |alpha| <= 2.  The engine selects this kernel only when T times that per-step bound is <= 2 (rollout_pk_applies).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <stdint.h>
+
+#include "mppi_kernels.hpp"
+
+namespace mppi {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+
+struct __attribute__((aligned(16))) PkRow {
+    float d0, d1, lo0, hi0;   // hk (un_i - clip(un_i)); clip bounds of the deviation: hk (-+u_max - clip(un_i))
+    float lo1, hi1, A1, Cn;   // dW = dphi (A1 + Cn dphi): A1 = -2 rho sin phin, Cn = -rho cos phin
+    float Wn, Pn, w0, w1;     // rho (4 + 2 cos phin); hk (u0c + u1c); lam (un . Sig) -- the noise-cost weights
+    float pad[4];
+    double c1n, s1n;          // nominal mid-step heading
+    double X2, Y2;            // 2 * scaled nominal position after the step (relative to the goal)
+};
+static_assert(sizeof(PkRow) == 96, "PkRow is read as six 16-byte LDS words");
+
+struct RolloutPkArgs {
+    DevParams P;
+    hipStream_t stream;
+    int inline_nominal;   // 1: one wave (T <= 64), 2: four waves (T <= 256)
+    uint64_t seed;
+    uint32_t tick;
+    const uint32_t* tick_ptr;
+    const double *state, *goal, *unom;
+    double *tc, *base;
+    float *dP, *stot, *epart;
+    float al_guard;
+    hipEvent_t ev_start, ev_stop;
+};
+hipError_t launch_rollout_pk(const RolloutPkArgs& a);
+// |2 dphi| of one step is at most 2 hk (|e0| + |e1|) <= 2 hk sqrt2 * 5.53 sigma (Box-Muller radius of a 22-bit uniform)
+inline double rollout_pk_step_bound(double kth, double dt, double sigma) { return 2.0 * (0.5 * kth * dt) * 1.41421356237 * 5.53 * sigma; }
+// largest |th| at the start of a chunk (<= 8 steps) for which the short series are valid
+inline float rollout_pk_guard(double kth, double dt, double sigma) { return (float)(0.5 - 8.0 * rollout_pk_step_bound(kth, dt, sigma)); }
+// the long series hold for |alpha| <= 2: the heading deviation can never leave that range over the whole horizon
+inline bool rollout_pk_applies(double kth, double dt, double sigma, int T) {
+    return T <= 256 && rollout_pk_guard(kth, dt, sigma) > 0.05f && (T + 1) * rollout_pk_step_bound(kth, dt, sigma) <= 2.0;
+}
+
+#ifdef MPPI_ROLLOUT_PK_TU
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 pk_med3(f2 v, float lo, float hi) {
+    return f2{__builtin_amdgcn_fmed3f(v.x, lo, hi), __builtin_amdgcn_fmed3f(v.y, lo, hi)};
+}
+
+template <int INLINE_NOM>
+__global__ __launch_bounds__(256) void rollout_pk_kernel(DevParams P, const double* __restrict__ state,
+                                                        const double* __restrict__ goal, double* __restrict__ tc,
+                                                        float* __restrict__ dP, float* __restrict__ Stot, uint64_t seed,
+                                                        uint32_t tick_arg, const uint32_t* __restrict__ tick_ptr,
+                                                        float* __restrict__ epart, const double* __restrict__ unom,
+                                                        double* __restrict__ base, float al_guard) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    PkRow* lt = reinterpret_cast<PkRow*>(smem_raw);  // [T]
+    __shared__ double fin_sh[1];                      // the nominal trajectory's final heading (unwrapped)
+    const int tid = threadIdx.x, a = blockIdx.y, T = P.T;
+    ClockProbe probe(P);
+    const double gx = goal[a * 3 + 0], gy = goal[a * 3 + 1], gth = goal[a * 3 + 2];
+    {
+        // the block runs the nominal rollout itself, lanes = timesteps (as rollout_kernel does), and derives the per-step
+        // constants of the deviation form from it
+        __shared__ double nom_sh[4];
+        if (INLINE_NOM == 2 || tid < 64) {
+            double row[5], base_t;
+            NomExtra ex;
+            nominal_lanes<(INLINE_NOM == 2 ? 4 : 1)>(P, state, goal, unom, a, tid, row, base_t, nom_sh, nullptr, &ex);
+            if (tid < T) {
+                const double hk = 0.5 * P.kth * P.dt, phin = 0.5 * ex.h;
+                double sp, cp;
+                if (fabs(phin) <= 0.25) small_sincos<7>(phin, sp, cp);
+                else sincos(phin, &sp, &cp);
+                PkRow r;
+                r.d0 = (float)(hk * (row[0] - ex.u0c)); r.d1 = (float)(hk * (row[1] - ex.u1c));
+                r.lo0 = (float)(hk * (-P.u_max - ex.u0c)); r.hi0 = (float)(hk * (P.u_max - ex.u0c));
+                r.lo1 = (float)(hk * (-P.u_max - ex.u1c)); r.hi1 = (float)(hk * (P.u_max - ex.u1c));
+                r.A1 = (float)(-2.0 * sp * P.lean_rho); r.Cn = (float)(-cp * P.lean_rho);
+                r.Wn = (float)((4.0 + 2.0 * cp) * P.lean_rho); r.Pn = (float)(hk * (ex.u0c + ex.u1c));
+                r.w0 = (float)row[2]; r.w1 = (float)row[3];
+                r.pad[0] = r.pad[1] = r.pad[2] = r.pad[3] = 0.f;
+                r.c1n = ex.c1; r.s1n = ex.s1;
+                r.X2 = 2.0 * P.lean_f * (ex.X - gx); r.Y2 = 2.0 * P.lean_f * (ex.Y - gy);
+                lt[tid] = r;
+                if (tid == T - 1) fin_sh[0] = ex.th + ex.h;
+                if (blockIdx.x == 0) {  // for mppi_download_value: V = base + Stot - dP
+                    base[(size_t)a * T + tid] = base_t;
+                    double* o = tc + ((size_t)a * T + tid) * kTcW;
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) o[i] = row[i];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int lane = tid & 63;
+    const int kwave = (int)blockIdx.x * 512 + (tid >> 6) * 128;  // this wave's 128 consecutive samples
+    const int kA = kwave + 2 * lane;                             // this lane's two: kA, kA + 1
+    const bool actA = kA < P.K, actB = kA + 1 < P.K;
+    const bool block_full = ((int)blockIdx.x + 1) * 512 <= P.K;  // (uniform)
+    const size_t Ks = (size_t)P.Ks, NW = Ks >> 6;
+    const uint64_t dP_a64 = reinterpret_cast<uint64_t>(dP + (size_t)a * T * Ks);
+    float* const dP_a = reinterpret_cast<float*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(dP_a64 >> 32)) << 32) |
+                                                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)dP_a64));
+    const __amdgpu_buffer_rsrc_t ep_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        epart, 0, (int)min((size_t)0x7FFFFFFF, (size_t)P.A * T * 2 * NW * sizeof(float)), 0x00020000);
+    const float hkf = (float)(0.5 * P.kth * P.dt);
+    const uint32_t key0 = (uint32_t)seed, key1 = (uint32_t)(seed >> 32);
+    const uint32_t ctrA = P.sample_offset + (uint32_t)kA;
+    const uint32_t tick = tick_ptr ? *tick_ptr : tick_arg;
+    const float sigf = (float)P.sigma;
+
+    constexpr int U = 6;  // steps per chunk = two Philox draws per sample (wave_sum16 carries the 12 eps sums)
+    float nz[U][4];       // the chunk's noise: [step]{wheel 0 of kA, wheel 0 of kA + 1, wheel 1 of kA, wheel 1 of kA + 1}
+    float tz[kStepsPerDraw][4];
+    double th[2] = {0.0, 0.0}, dX[2] = {0.0, 0.0}, dY[2] = {0.0, 0.0}, pre[2] = {0.0, 0.0};
+    f2 thf = {0.f, 0.f};  // (float)th at the start of the step
+
+    auto draw = [&](int t0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < U; j += kStepsPerDraw) {
+            float ea[6], eb[6];
+            philox_normals(ctrA, (uint32_t)((t0 + j) / kStepsPerDraw), tick, (uint32_t)a, key0, key1, sigf, ea);
+            philox_normals(ctrA + 1u, (uint32_t)((t0 + j) / kStepsPerDraw), tick, (uint32_t)a, key0, key1, sigf, eb);
+#pragma unroll
+            for (int i = 0; i < kStepsPerDraw; ++i) { nz[j + i][0] = ea[2 * i]; nz[j + i][1] = eb[2 * i]; nz[j + i][2] = ea[2 * i + 1]; nz[j + i][3] = eb[2 * i + 1]; }
+        }
+    };
+    // per-wave sums of eps (the E of the softmax floor term, control/src/mppi:193) for the chunk's steps x 2 wheels: the
+    // lane's two samples are added first, one 16-value reduce-scatter serves 128 samples.  epart keeps its
+    // [A][T][2][Ks/64] layout: the wave's total goes to the slot of its first 64 samples, 0 to the slot of the other 64
+    // (the update kernel only ever sums whole chunks of 8192 samples).
+    auto eps_sums = [&](int t0, auto full_tag, auto extra_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value, EXTRA = decltype(extra_tag)::value;
+        float ev[16];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            ev[2 * j] = FULL ? nz[j][0] + nz[j][1] : (actA ? nz[j][0] : 0.f) + (actB ? nz[j][1] : 0.f);
+            ev[2 * j + 1] = FULL ? nz[j][2] + nz[j][3] : (actA ? nz[j][2] : 0.f) + (actB ? nz[j][3] : 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            ev[12 + 2 * j] = !EXTRA ? 0.f : (FULL ? tz[j][0] + tz[j][1] : (actA ? tz[j][0] : 0.f) + (actB ? tz[j][1] : 0.f));
+            ev[13 + 2 * j] = !EXTRA ? 0.f : (FULL ? tz[j][2] + tz[j][3] : (actA ? tz[j][2] : 0.f) + (actB ? tz[j][3] : 0.f));
+        }
+        const float tot = wave_sum16<EXTRA>(ev, lane);
+        const int idx = sum16_index(lane), te = t0 + (idx >> 1), half = lane >> 4;
+        const size_t slot = (size_t)(kwave >> 6) + half;
+        const bool mine = lane < 32 && idx < (EXTRA ? 16 : 2 * U) && te < T && slot < NW;
+        const size_t at = (((size_t)a * T + te) * 2 + (idx & 1)) * NW + slot;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(half ? 0.f : tot), ep_rsrc, mine ? (unsigned)(at * 4) : 0xFFFFFFFFu, 0, 0);
+    };
+    auto step = [&](int t, f2 n0, f2 n1, auto full_tag, bool robust) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const PkRow& r = lt[t];
+        {   // dP[t] = the exclusive cost prefix (control/src/mppi:175 as total minus prefix)
+            const __amdgpu_buffer_rsrc_t row = __builtin_amdgcn_make_buffer_rsrc(dP_a + (size_t)t * Ks, 0, (int)(Ks * sizeof(float)), 0x00020000);
+            const float pa = (float)pre[0], pb = (float)pre[1];
+            if (FULL) {
+                __builtin_amdgcn_raw_buffer_store_b64(u2{__float_as_uint(pa), __float_as_uint(pb)}, row, (unsigned)kA * 4u, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pa), row, actA ? (unsigned)kA * 4u : 0xFFFFFFFFu, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pb), row, actB ? (unsigned)kA * 4u + 4u : 0xFFFFFFFFu, 0, 0);
+            }
+        }
+        // EXPLORE + CLIP (control/src/mppi:147-152) as deviations from the clipped nominal
+        const f2 dp0 = pk_med3(pk_fma(n0, f2{hkf, hkf}, f2{r.d0, r.d0}), r.lo0, r.hi0);
+        const f2 dp1 = pk_med3(pk_fma(n1, f2{hkf, hkf}, f2{r.d1, r.d1}), r.lo1, r.hi1);
+        const f2 dphi = dp1 - dp0, dPs = dp0 + dp1;
+        const f2 al = thf + dphi;
+        th[0] = fma(2.0, (double)dphi.x, th[0]);
+        th[1] = fma(2.0, (double)dphi.y, th[1]);
+        thf = f2{(float)th[0], (float)th[1]};
+        f2 S, Cm;
+        const f2 z = al * al;
+        if (robust) {  // (uniform, practically never) |alpha| <= 2: eight terms each, truncation < 4e-10
+            auto c2 = [](float v) { return f2{v, v}; };
+            f2 ps = pk_fma(z, c2(-1.f / 1307674368000.f), c2(1.f / 6227020800.f));
+            ps = pk_fma(z, ps, c2(-1.f / 39916800.f)); ps = pk_fma(z, ps, c2(1.f / 362880.f)); ps = pk_fma(z, ps, c2(-1.f / 5040.f));
+            ps = pk_fma(z, ps, c2(1.f / 120.f)); ps = pk_fma(z, ps, c2(-1.f / 6.f)); ps = pk_fma(z, ps, c2(1.f));
+            S = al * ps;
+            f2 pc = pk_fma(z, c2(1.f / 20922789888000.f), c2(-1.f / 87178291200.f));
+            pc = pk_fma(z, pc, c2(1.f / 479001600.f)); pc = pk_fma(z, pc, c2(-1.f / 3628800.f)); pc = pk_fma(z, pc, c2(1.f / 40320.f));
+            pc = pk_fma(z, pc, c2(-1.f / 720.f)); pc = pk_fma(z, pc, c2(1.f / 24.f)); pc = pk_fma(z, pc, c2(-0.5f));
+            Cm = z * pc;
+        } else {
+            S = al * pk_fma(z, pk_fma(z, pk_fma(z, f2{-1.f / 5040.f, -1.f / 5040.f}, f2{1.f / 120.f, 1.f / 120.f}), f2{-1.f / 6.f, -1.f / 6.f}), f2{1.f, 1.f});
+            Cm = z * pk_fma(z, pk_fma(z, pk_fma(z, f2{1.f / 40320.f, 1.f / 40320.f}, f2{-1.f / 720.f, -1.f / 720.f}), f2{1.f / 24.f, 1.f / 24.f}), f2{-0.5f, -0.5f});
+        }
+        // rk4 (control/src/mppi:39-54) for dd_dynamics (:23-30): Simpson bracket (4 + 2 cos phi) times the mid-step heading
+        const f2 dW = dphi * pk_fma(f2{r.Cn, r.Cn}, dphi, f2{r.A1, r.A1});
+        const f2 Pt = dPs + f2{r.Pn, r.Pn};
+        const f2 Aq = Pt * dW;
+        const f2 dG = pk_fma(dPs, f2{r.Wn, r.Wn}, Aq);
+        const f2 G = pk_fma(Pt, f2{r.Wn, r.Wn}, Aq);
+        const f2 av = pk_fma(G, Cm, dG), bv = G * S;
+        const double c1n = r.c1n, s1n = r.s1n, X2 = r.X2, Y2 = r.Y2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const double ad = (double)(i ? av.y : av.x), bd = (double)(i ? bv.y : bv.x);
+            dX[i] = fma(c1n, ad, fma(-s1n, bd, dX[i]));
+            dY[i] = fma(s1n, ad, fma(c1n, bd, dY[i]));
+        }
+        // get_cost (control/src/mppi:180-184) minus the nominal stage cost: u = NOMINAL, eps = UNCLIPPED
+        const f2 dcn = pk_fma(n0, f2{r.w0, r.w0}, n1 * f2{r.w1, r.w1});
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            pre[i] = fma(dX[i], X2 + dX[i], pre[i]);
+            pre[i] = fma(dY[i], Y2 + dY[i], pre[i]);
+            pre[i] += (double)(i ? dcn.y : dcn.x);
+        }
+    };
+    auto chunk = [&](int t0, int nsteps, auto full_tag) __attribute__((always_inline)) {
+        const bool safe = fabsf(thf.x) <= al_guard && fabsf(thf.y) <= al_guard;
+        const bool robust = !__all(safe);
+#pragma unroll
+        for (int j = 0; j < U; ++j)
+            if (j < nsteps) step(t0 + j, f2{nz[j][0], nz[j][1]}, f2{nz[j][2], nz[j][3]}, full_tag, robust);
+    };
+    const int T4 = T - T % U;
+    // T = 6 n + 1 or 6 n + 2 (the node's 50): the steps behind the last full chunk ride along with it (their draw is made
+    // with the chunk's two, their eps sums fill the reduce-scatter's four spare slots)
+    const bool ride = T4 >= U && (T - T4 == 1 || T - T4 == 2);  // (uniform)
+    auto run = [&](auto full_tag) __attribute__((always_inline)) {
+        const int t_loop = ride ? T4 - U : T4;
+        for (int t0 = 0; t0 < t_loop; t0 += U) {
+            draw(t0);
+            eps_sums(t0, full_tag, std::false_type{});
+            chunk(t0, U, full_tag);
+        }
+        if (ride) {
+            const int t0 = T4 - U;
+            draw(t0);
+            {
+                float ea[6], eb[6];
+                philox_normals(ctrA, (uint32_t)(T4 / kStepsPerDraw), tick, (uint32_t)a, key0, key1, sigf, ea);
+                philox_normals(ctrA + 1u, (uint32_t)(T4 / kStepsPerDraw), tick, (uint32_t)a, key0, key1, sigf, eb);
+#pragma unroll
+                for (int i = 0; i < kStepsPerDraw; ++i) {  // steps at or beyond T carry no noise (they are never integrated)
+                    const bool in = T4 + i < T;
+                    tz[i][0] = in ? ea[2 * i] : 0.f; tz[i][1] = in ? eb[2 * i] : 0.f;
+                    tz[i][2] = in ? ea[2 * i + 1] : 0.f; tz[i][3] = in ? eb[2 * i + 1] : 0.f;
+                }
+            }
+            eps_sums(t0, full_tag, std::true_type{});
+            chunk(t0, U, full_tag);
+#pragma unroll
+            for (int j = 0; j < kStepsPerDraw; ++j)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) nz[j][c] = tz[j][c];
+            chunk(T4, T - T4, full_tag);
+        } else if (T4 < T) {  // ragged tail: sums of steps at or beyond T are never stored, their noise is never integrated
+            draw(T4);
+            eps_sums(T4, full_tag, std::false_type{});
+            chunk(T4, T - T4, full_tag);
+        }
+    };
+    if (block_full) run(std::true_type{});
+    else run(std::false_type{});
+    // terminal cost (control/src/mppi:165-173) minus the nominal's; the theta error is not wrapped beyond rk4's own wrap
+    const PkRow& rT = lt[T - 1];
+    const double thn = fin_sh[0], inv_f2 = P.lean_inv_f * P.lean_inv_f;
+    const double thnw = (thn > M_PI || thn <= -M_PI) ? wrap_theta(thn) : thn;
+    const double dthn = thnw - gth;
+    float tot[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const double ths = thn + th[i];
+        const double thw = (ths > M_PI || ths <= -M_PI) ? wrap_theta(ths) : ths;
+        const double dths = thw - gth;
+        const double term = inv_f2 * (P.p0 * dX[i] * (rT.X2 + dX[i]) + P.p1 * dY[i] * (rT.Y2 + dY[i])) + P.p2 * (dths * dths - dthn * dthn);
+        tot[i] = (float)(pre[i] + term);
+    }
+    // value_fcn = reverse cumulative sum over t (control/src/mppi:175) = total - exclusive prefix
+    if (block_full) {
+        *reinterpret_cast<f2*>(Stot + (size_t)a * Ks + kA) = f2{tot[0], tot[1]};
+    } else {
+        if (actA) Stot[(size_t)a * Ks + kA] = tot[0];
+        if (actB) Stot[(size_t)a * Ks + kA + 1] = tot[1];
+    }
+    probe.stop(P);
+}
+
+hipError_t launch_rollout_pk(const RolloutPkArgs& a) {
+    dim3 grid((a.P.K + 511) / 512, a.P.A);
+    const unsigned lds = (unsigned)((size_t)a.P.T * sizeof(PkRow));
+#define MPPI_PK_GO(IN)                                                                                                        \
+    do {                                                                                                                      \
+        if (a.ev_start)                                                                                                       \
+            hipExtLaunchKernelGGL(rollout_pk_kernel<IN>, grid, dim3(256), lds, a.stream, a.ev_start, a.ev_stop, 0, a.P, a.state, \
+                                  a.goal, a.tc, a.dP, a.stot, a.seed, a.tick, a.tick_ptr, a.epart, a.unom, a.base, a.al_guard); \
+        else                                                                                                                  \
+            hipLaunchKernelGGL(rollout_pk_kernel<IN>, grid, dim3(256), lds, a.stream, a.P, a.state, a.goal, a.tc, a.dP, a.stot, \
+                               a.seed, a.tick, a.tick_ptr, a.epart, a.unom, a.base, a.al_guard);                              \
+    } while (0)
+    if (a.inline_nominal == 2) MPPI_PK_GO(2); else MPPI_PK_GO(1);
+#undef MPPI_PK_GO
+    return hipGetLastError();
+}
+#endif  // MPPI_ROLLOUT_PK_TU
+
+}  // namespace mppi

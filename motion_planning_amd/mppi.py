@@ -332,6 +332,12 @@ class Engine(object):
         self._ck(self._lib.mppi_kernel_times(self._h, ms, n))
         return {k: (ms[i], n[i]) for i, k in enumerate(_capi.KERNELS)}
 
+    def shader_clock_mhz(self):
+        """Shader clock the last lane-per-sample rollout launch ran at (a probe wave inside that launch), MHz."""
+        mhz = C.c_double()
+        self._ck(self._lib.mppi_shader_clock(self._h, C.byref(mhz)))
+        return mhz.value
+
     def info(self):
         b, r, u = C.c_size_t(), C.c_int32(), C.c_int32()
         self._ck(self._lib.mppi_engine_info(self._h, C.byref(b), C.byref(r), C.byref(u)))
