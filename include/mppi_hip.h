@@ -143,6 +143,11 @@ int mppi_set_sigma_lambda(mppi_engine *h, double sigma, double lambda);
  * matrix, lam * u . sig . eps (:184). */
 int mppi_set_sig_matrix(mppi_engine *h, const double *sig /*[4]*/, double lambda);
 
+/* Q, R, P1 of the stage / terminal cost (control/src/mppi:69-73; instance attributes the reference reads on every
+ * call, :168, :183) as their diagonals q[3], r[2], p1[3]; NULL keeps the current values.  Takes effect with the next
+ * rollout. */
+int mppi_set_weights(mppi_engine *h, const double *q, const double *r, const double *p1);
+
 /* Deadline of the blocking waits, in milliseconds (0 = wait forever).  See MPPI_E_TIMEOUT. */
 int mppi_set_sync_timeout(mppi_engine *h, int milliseconds);
 
@@ -160,6 +165,10 @@ int mppi_set_obstacle_grid(mppi_engine *h, const int8_t *cells, int32_t width, i
 
 /* MPPI.initialize, control/src/mppi:79-83: zero the nominal controls of one agent (-1: all). */
 int mppi_reset(mppi_engine *h, int agent);
+
+/* What the receding-horizon shift writes into the freed last column of one agent's nominal controls: the
+ * reference's uvec_init[:, 0] (control/src/mppi:101), fill [2].  Zeros (the reference's default uvec_init) until called. */
+int mppi_set_shift_fill(mppi_engine *h, int agent, const double *fill);
 
 /* latest_uvec [2][T] of one agent (control/src/mppi:81, :100-101). */
 int mppi_set_nominal(mppi_engine *h, int agent, const double *uvec);

@@ -7,8 +7,8 @@ control update run as hand-written gfx950 HIP kernels behind the C ABI of
 works anywhere, creating an engine needs the built library and a GPU.
 """
 from . import _capi  # noqa: F401
-from .mppi import MPPI, WHEEL_BASE, WHEEL_RADIUS, WHEEL_VEL_MAX, euler, rk4  # noqa: F401
+from .mppi import MPPI, WHEEL_BASE, WHEEL_RADIUS, WHEEL_VEL_MAX, dd_dynamics, euler, rk4, unicycle_dynamics  # noqa: F401
 from .controller import Controller, wheels_to_twist  # noqa: F401
 
-__all__ = ["MPPI", "Controller", "rk4", "euler", "wheels_to_twist",
+__all__ = ["MPPI", "Controller", "rk4", "euler", "dd_dynamics", "unicycle_dynamics", "wheels_to_twist",
            "WHEEL_VEL_MAX", "WHEEL_RADIUS", "WHEEL_BASE"]

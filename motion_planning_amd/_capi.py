@@ -47,6 +47,7 @@ SIGNATURES = {
     "mppi_get_stream": (C.c_int, [_H, C.POINTER(C.c_void_p)]),
     "mppi_set_sigma_lambda": (C.c_int, [_H, C.c_double, C.c_double]),
     "mppi_set_sig_matrix": (C.c_int, [_H, _dp, C.c_double]),
+    "mppi_set_weights": (C.c_int, [_H, _dp, _dp, _dp]),
     "mppi_set_sync_timeout": (C.c_int, [_H, C.c_int]),
     "mppi_set_tick_counter": (C.c_int, [_H, C.c_uint32]),
     "mppi_stream_wait_partials": (C.c_int, [_H, C.c_void_p]),
@@ -54,6 +55,7 @@ SIGNATURES = {
     "mppi_reset": (C.c_int, [_H, C.c_int]),
     "mppi_set_obstacle_grid": (C.c_int, [_H, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double,
                                          C.c_double]),
+    "mppi_set_shift_fill": (C.c_int, [_H, C.c_int, _dp]),
     "mppi_set_nominal": (C.c_int, [_H, C.c_int, _dp]),
     "mppi_get_nominal": (C.c_int, [_H, C.c_int, _dp]),
     "mppi_upload_noise": (C.c_int, [_H, _dp]),

@@ -106,6 +106,7 @@ struct mppi_engine {
     uint64_t lazy_seed = 0;
     uint32_t lazy_tick = 0;
     bool store_eps_always = false;  // MPPI_STORE_EPS=1: the tick path writes eps like mppi_rollout does
+    int pk_waves = 4;
     bool use_pk = true;             // MPPI_ROLLOUT_PK=0: keep the all-fp64 rollout kernel on the tick path (same-box A/B measurements)
     double* d_tc = nullptr;  // [A][T][8]
     double* d_base = nullptr;
@@ -118,6 +119,7 @@ struct mppi_engine {
     double* d_S = nullptr;
     double* d_out = nullptr;
     uint32_t* d_tick = nullptr;
+    double* d_fill = nullptr;               // [A][2] what the shift puts into the freed column (uvec_init[:, 0], control/src/mppi:101)
     unsigned long long* d_clk = nullptr;   // {shader cycles, wall-clock ticks} of the last rollout launch's probe wave
     signed char* d_grid = nullptr;
     size_t grid_bytes = 0;
@@ -387,6 +389,7 @@ struct mppi_engine {
             b.state = a.state; b.goal = a.goal; b.unom = a.unom; b.tc = d_tc; b.base = d_base;
             b.dP = static_cast<float*>(d_dP); b.stot = static_cast<float*>(d_stot); b.epart = static_cast<float*>(d_epart);
             b.al_guard = mppi::rollout_pk_guard(P.kth, P.dt, P.sigma);
+            b.waves = pk_waves;
             b.ev_start = a.ev_start; b.ev_stop = a.ev_stop;
             e = mppi::launch_rollout_pk(b);
         } else
@@ -596,6 +599,14 @@ struct mppi_engine {
         partials_ready = false;
     }
 
+    void refresh_weights() {   // the cost weights and what the lean rollout step derives from them
+        P.q0 = cfg.q[0]; P.q1 = cfg.q[1]; P.q2 = cfg.q[2];
+        P.r0 = cfg.r[0]; P.r1 = cfg.r[1];
+        P.p0 = cfg.p1[0]; P.p1 = cfg.p1[1]; P.p2 = cfg.p1[2];
+        P.lean_f = std::sqrt(0.5 * P.q0);
+        P.lean_rho = P.lean_f * (P.dt * P.rhalf * (1.0 / 6.0)) / (0.5 * P.kth * P.dt);
+        P.lean_inv_f = 1.0 / P.lean_f;
+    }
     void refresh_params() {
         P.sigma = cfg.sigma; P.lambda = cfg.lambda; P.inv_lambda = 1.0 / cfg.lambda;
         if (!sig_is_matrix) { sig_cost[0] = sig_cost[3] = cfg.sigma; sig_cost[1] = sig_cost[2] = 0.0; }
@@ -613,6 +624,7 @@ struct mppi_engine {
         cfg = c;
         if (const char* v = std::getenv("MPPI_STORE_EPS")) store_eps_always = std::atoi(v) != 0;
         if (const char* v = std::getenv("MPPI_ROLLOUT_PK")) use_pk = std::atoi(v) != 0;
+        if (const char* v = std::getenv("MPPI_PK_WAVES")) pk_waves = std::atoi(v);
         if (const char* v = std::getenv("MPPI_SYNC_TIMEOUT_MS")) sync_timeout_ms = std::atoi(v);
         if (cfg.n_agents < 1 || cfg.samples < 1) fail(MPPI_E_INVALID, "n_agents and samples must be >= 1");
         if (cfg.n_agents > 65535) fail(MPPI_E_INVALID, "n_agents %d: agents are a grid dimension (<= 65535)", cfg.n_agents);
@@ -653,16 +665,11 @@ struct mppi_engine {
         P.A = A; P.K = K; P.T = T; P.Ks = (K + 63) / 64 * 64;
         P.sample_offset = cfg.sample_offset;
         P.dt = cfg.dt;
-        P.q0 = cfg.q[0]; P.q1 = cfg.q[1]; P.q2 = cfg.q[2];
-        P.r0 = cfg.r[0]; P.r1 = cfg.r[1];
-        P.p0 = cfg.p1[0]; P.p1 = cfg.p1[1]; P.p2 = cfg.p1[2];
         P.u_max = cfg.u_max;
         P.kth = cfg.wheel_radius / cfg.wheel_base;
         P.rhalf = cfg.wheel_radius / 2.0;
         P.floor_w = cfg.floor_w;
-        P.lean_f = std::sqrt(0.5 * P.q0);
-        P.lean_rho = P.lean_f * (P.dt * P.rhalf * (1.0 / 6.0)) / (0.5 * P.kth * P.dt);
-        P.lean_inv_f = 1.0 / P.lean_f;
+        refresh_weights();
         refresh_params();
 
         roll_bs = 256;
@@ -724,6 +731,9 @@ struct mppi_engine {
         d_clk = dev_alloc<unsigned long long>(2, hbm_bytes);
         HIPCHK(hipMemsetAsync(d_clk, 0, 2 * sizeof(unsigned long long), stream));
         P.clk = d_clk;
+        d_fill = dev_alloc<double>((size_t)A * 2, hbm_bytes);
+        HIPCHK(hipMemsetAsync(d_fill, 0, (size_t)A * 2 * sizeof(double), stream));
+        P.shift_fill = d_fill;
         HIPCHK(hipMemsetAsync(d_unom, 0, (size_t)A * 2 * T * sizeof(double), stream));  // uvec_init, :65
         HIPCHK(hipMemsetAsync(d_ufilt, 0, (size_t)A * 2 * T * sizeof(double), stream));
         HIPCHK(hipMemsetAsync(d_out, 0, (size_t)A * 8 * sizeof(double), stream));
@@ -773,7 +783,7 @@ struct mppi_engine {
         if (h_stage) hipHostFree(h_stage);
         if (h_out) hipHostFree(h_out);
         if (h_seq) hipHostFree(h_seq);
-        void* bufs[] = {d_eps, d_dP, d_stot, d_epart, d_tc, d_base, d_unom, d_ufilt, d_state, d_goal, d_part, d_merged, d_S, d_out, d_tick, d_tmp, d_grid, d_prev, d_clk};
+        void* bufs[] = {d_eps, d_dP, d_stot, d_epart, d_tc, d_base, d_unom, d_ufilt, d_state, d_goal, d_part, d_merged, d_S, d_out, d_tick, d_tmp, d_grid, d_prev, d_clk, d_fill};
         for (void* b : bufs) if (b) hipFree(b);
         if (own_stream) hipStreamDestroy(own_stream);
     }
@@ -887,6 +897,19 @@ int mppi_set_sig_matrix(mppi_engine* h, const double* sig, double lambda) {
     API_END(h)
 }
 
+int mppi_set_weights(mppi_engine* h, const double* q, const double* r, const double* p1) {
+    API_BEGIN(h)
+    for (int i = 0; i < 3; ++i) if ((q && !std::isfinite(q[i])) || (p1 && !std::isfinite(p1[i]))) fail(MPPI_E_INVALID, "cost weights must be finite");
+    for (int i = 0; i < 2; ++i) if (r && !std::isfinite(r[i])) fail(MPPI_E_INVALID, "cost weights must be finite");
+    h->settle_lazy_state();   // the last tick's V may exist only as "re-run with these weights"
+    if (q) for (int i = 0; i < 3; ++i) h->cfg.q[i] = q[i];
+    if (r) for (int i = 0; i < 2; ++i) h->cfg.r[i] = r[i];
+    if (p1) for (int i = 0; i < 3; ++i) h->cfg.p1[i] = p1[i];
+    h->refresh_weights();
+    h->destroy_graph();
+    API_END(h)
+}
+
 int mppi_set_sync_timeout(mppi_engine* h, int milliseconds) {
     API_BEGIN(h)
     if (milliseconds < 0) fail(MPPI_E_INVALID, "timeout must be >= 0 (0 = wait forever)");
@@ -896,6 +919,7 @@ int mppi_set_sync_timeout(mppi_engine* h, int milliseconds) {
 
 int mppi_set_tick_counter(mppi_engine* h, uint32_t next_tick_id) {
     API_BEGIN(h)
+    h->settle_lazy_state();   // a graph replay's lazily re-drawn noise / V are addressed through this counter: materialise them first
     HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->d_tick), (int)next_tick_id, 1, h->stream));
     h->last_tick_eager = false;  // the counter now holds what the caller put there
     API_END(h)
@@ -944,6 +968,14 @@ int mppi_reset(mppi_engine* h, int agent) {
     if (agent < 0) HIPCHK(hipMemsetAsync(h->d_unom, 0, row * h->cfg.n_agents, h->stream));
     else if (agent < h->cfg.n_agents) HIPCHK(hipMemsetAsync(h->d_unom + (size_t)agent * 2 * h->cfg.horizon, 0, row, h->stream));
     else fail(MPPI_E_INVALID, "agent %d out of range", agent);
+    API_END(h)
+}
+
+int mppi_set_shift_fill(mppi_engine* h, int agent, const double* fill) {
+    API_BEGIN(h)
+    if (!fill || agent < 0 || agent >= h->cfg.n_agents) fail(MPPI_E_INVALID, "bad agent/fill");
+    HIPCHK(hipMemcpyAsync(h->d_fill + (size_t)agent * 2, fill, 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    h->wait_stream(__func__);
     API_END(h)
 }
 
@@ -1003,6 +1035,7 @@ int mppi_download_noise(mppi_engine* h, double* eps) {
 
 int mppi_rollout(mppi_engine* h, const double* state, const double* goal, int noise_mode, uint64_t seed, uint32_t tick_id) {
     API_BEGIN(h)
+    h->check_noise_mode(noise_mode);   // refuse before the inputs are staged: nothing half-set on failure
     h->set_inputs(state, goal);
     h->run_nominal();
     h->run_rollout(noise_mode, seed, tick_id, nullptr);
@@ -1084,6 +1117,7 @@ int mppi_shift(mppi_engine* h) {
 
 int mppi_tick_begin(mppi_engine* h, const double* state, const double* goal, int noise_mode, uint64_t seed, uint32_t tick_id) {
     API_BEGIN(h)
+    h->check_noise_mode(noise_mode);   // refuse before the inputs are staged: nothing half-set on failure
     h->set_inputs(state, goal, /*zero_copy=*/h->small_nb > 0);
     h->run_nominal();
     h->run_pipeline(noise_mode, seed, tick_id, nullptr);
@@ -1254,6 +1288,7 @@ int mppi_get_outputs(mppi_engine* h, double* next_state, double* u_applied) {
 // mppi_tick_begin with the knowledge that no exchange follows (the fused call)
 static int tick_begin_fused(mppi_engine* h, const double* state, const double* goal, int noise_mode, uint64_t seed, uint32_t tick_id) {
     API_BEGIN(h)
+    h->check_noise_mode(noise_mode);   // refuse before the inputs are staged: nothing half-set on failure
     h->set_inputs(state, goal, /*zero_copy=*/h->small_nb > 0);
     h->run_nominal();
     h->run_pipeline(noise_mode, seed, tick_id, nullptr, /*skip_small_merge=*/true);

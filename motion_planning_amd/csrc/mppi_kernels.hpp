@@ -62,6 +62,9 @@ struct DevParams {
     // shader-clock probe (mppi_shader_clock): one lane of the rollout launch's middle block notes how many shader cycles
     // (s_memtime) and constant-rate ticks (s_memrealtime) its wave lived: {cycles, ticks}.  nullptr: off.
     unsigned long long* clk;
+    // what the receding-horizon shift puts into the freed last column, [A][2] (control/src/mppi:101: uvec_init[:, 0]; zeros
+    // unless mppi_set_shift_fill was called)
+    const double* shift_fill;
 };
 struct ClockProbe {
     unsigned long long c0 = 0, w0 = 0;
@@ -1591,9 +1594,9 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
     for (int j = tid; j < T; j += blockDim.x) {
         ufilt[((size_t)a * 2 + 0) * T + j] = uf[j];
         ufilt[((size_t)a * 2 + 1) * T + j] = uf[T + j];
-        if (flags & 2) {  // shift left, zero the tail (:100-101)
-            unom[((size_t)a * 2 + 0) * T + j] = (j + 1 < T) ? uf[j + 1] : 0.0;
-            unom[((size_t)a * 2 + 1) * T + j] = (j + 1 < T) ? uf[T + j + 1] : 0.0;
+        if (flags & 2) {  // shift left, the freed column takes uvec_init[:, 0] (:100-101)
+            unom[((size_t)a * 2 + 0) * T + j] = (j + 1 < T) ? uf[j + 1] : P.shift_fill[a * 2 + 0];
+            unom[((size_t)a * 2 + 1) * T + j] = (j + 1 < T) ? uf[T + j + 1] : P.shift_fill[a * 2 + 1];
         } else {
             unom[((size_t)a * 2 + 0) * T + j] = uf[j];
             unom[((size_t)a * 2 + 1) * T + j] = uf[T + j];
@@ -1689,7 +1692,7 @@ __global__ void shift_kernel(DevParams P, double* __restrict__ unom) {
     double* u = unom + (size_t)blockIdx.x * P.T;
     for (int j = threadIdx.x; j < P.T; j += blockDim.x) row[j] = u[j];
     __syncthreads();
-    for (int j = threadIdx.x; j < P.T; j += blockDim.x) u[j] = (j + 1 < P.T) ? row[j + 1] : 0.0;
+    for (int j = threadIdx.x; j < P.T; j += blockDim.x) u[j] = (j + 1 < P.T) ? row[j + 1] : P.shift_fill[blockIdx.x];
 }
 #endif
 

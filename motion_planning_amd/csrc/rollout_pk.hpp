@@ -60,6 +60,7 @@ struct RolloutPkArgs {
     double *tc, *base;
     float *dP, *stot, *epart;
     float al_guard;
+    int waves;            // 4: the compiler's own allocation (no spills); 5: one more wave per SIMD at the price of a few spills
     hipEvent_t ev_start, ev_stop;
 };
 hipError_t launch_rollout_pk(const RolloutPkArgs& a);
@@ -78,8 +79,8 @@ __device__ __forceinline__ f2 pk_med3(f2 v, float lo, float hi) {
     return f2{__builtin_amdgcn_fmed3f(v.x, lo, hi), __builtin_amdgcn_fmed3f(v.y, lo, hi)};
 }
 
-template <int INLINE_NOM>
-__global__ __launch_bounds__(256) void rollout_pk_kernel(DevParams P, const double* __restrict__ state,
+template <int INLINE_NOM, int WAVES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void rollout_pk_kernel(DevParams P, const double* __restrict__ state,
                                                         const double* __restrict__ goal, double* __restrict__ tc,
                                                         float* __restrict__ dP, float* __restrict__ Stot, uint64_t seed,
                                                         uint32_t tick_arg, const uint32_t* __restrict__ tick_ptr,
@@ -149,14 +150,35 @@ __global__ __launch_bounds__(256) void rollout_pk_kernel(DevParams P, const doub
     double th[2] = {0.0, 0.0}, dX[2] = {0.0, 0.0}, dY[2] = {0.0, 0.0}, pre[2] = {0.0, 0.0};
     f2 thf = {0.f, 0.f};  // (float)th at the start of the step
 
+    // Box-Muller for the lane's two samples at once (same arithmetic as box_muller(), operation by operation, so the noise
+    // is bit-identical to what the update kernel's re-draw and mppi_download_noise produce): the exactly rounded steps run
+    // packed and the results land as (kA, kA + 1) pairs -- no register shuffling between the draw and the packed dynamics
+    const float nscale = -1.3862943611198906f * (sigf * sigf);
+    auto bm2 = [&](uint32_t a21a, uint32_t manta, uint32_t a21b, uint32_t mantb, f2& w0, f2& w1) __attribute__((always_inline)) {
+        const f2 u1 = pk_fma(f2{(float)a21a, (float)a21b}, f2{1.0f / 2097152.0f, 1.0f / 2097152.0f}, f2{1.0f / 4194304.0f, 1.0f / 4194304.0f});
+        const f2 lg = f2{__builtin_amdgcn_logf(u1.x), __builtin_amdgcn_logf(u1.y)} * f2{nscale, nscale};
+        const f2 r = f2{__builtin_amdgcn_sqrtf(lg.x), __builtin_amdgcn_sqrtf(lg.y)};
+        const float ra = __uint_as_float(0x3F800000u | manta), rb = __uint_as_float(0x3F800000u | mantb);
+        w0 = f2{__builtin_amdgcn_cosf(ra), __builtin_amdgcn_cosf(rb)} * r;
+        w1 = f2{__builtin_amdgcn_sinf(ra), __builtin_amdgcn_sinf(rb)} * r;
+    };
+    // the noise of steps 3 * triple .. 3 * triple + 2 of both samples (philox_normals for two counters)
+    auto draw3 = [&](uint32_t triple, f2 (&w0)[kStepsPerDraw], f2 (&w1)[kStepsPerDraw]) __attribute__((always_inline)) {
+        uint32_t oa[4], ob[4];
+        philox4x32_10(ctrA, triple, tick, (uint32_t)a, key0, key1, oa);
+        philox4x32_10(ctrA + 1u, triple, tick, (uint32_t)a, key0, key1, ob);
+        bm2(oa[0] >> 11, (oa[1] >> 9) & 0x7FFFFCu, ob[0] >> 11, (ob[1] >> 9) & 0x7FFFFCu, w0[0], w1[0]);
+        bm2(oa[2] >> 11, (oa[3] >> 9) & 0x7FFFFCu, ob[2] >> 11, (ob[3] >> 9) & 0x7FFFFCu, w0[1], w1[1]);
+        bm2(((oa[0] & 0x7FFu) << 10) | ((oa[1] & 0x7FFu) >> 1), ((oa[2] & 0x7FFu) << 12) | ((oa[3] & 0x7FEu) << 1),
+            ((ob[0] & 0x7FFu) << 10) | ((ob[1] & 0x7FFu) >> 1), ((ob[2] & 0x7FFu) << 12) | ((ob[3] & 0x7FEu) << 1), w0[2], w1[2]);
+    };
     auto draw = [&](int t0) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < U; j += kStepsPerDraw) {
-            float ea[6], eb[6];
-            philox_normals(ctrA, (uint32_t)((t0 + j) / kStepsPerDraw), tick, (uint32_t)a, key0, key1, sigf, ea);
-            philox_normals(ctrA + 1u, (uint32_t)((t0 + j) / kStepsPerDraw), tick, (uint32_t)a, key0, key1, sigf, eb);
+            f2 w0[kStepsPerDraw], w1[kStepsPerDraw];
+            draw3((uint32_t)((t0 + j) / kStepsPerDraw), w0, w1);
 #pragma unroll
-            for (int i = 0; i < kStepsPerDraw; ++i) { nz[j + i][0] = ea[2 * i]; nz[j + i][1] = eb[2 * i]; nz[j + i][2] = ea[2 * i + 1]; nz[j + i][3] = eb[2 * i + 1]; }
+            for (int i = 0; i < kStepsPerDraw; ++i) { nz[j + i][0] = w0[i].x; nz[j + i][1] = w0[i].y; nz[j + i][2] = w1[i].x; nz[j + i][3] = w1[i].y; }
         }
     };
     // per-wave sums of eps (the E of the softmax floor term, control/src/mppi:193) for the chunk's steps x 2 wheels: the
@@ -265,14 +287,13 @@ __global__ __launch_bounds__(256) void rollout_pk_kernel(DevParams P, const doub
             const int t0 = T4 - U;
             draw(t0);
             {
-                float ea[6], eb[6];
-                philox_normals(ctrA, (uint32_t)(T4 / kStepsPerDraw), tick, (uint32_t)a, key0, key1, sigf, ea);
-                philox_normals(ctrA + 1u, (uint32_t)(T4 / kStepsPerDraw), tick, (uint32_t)a, key0, key1, sigf, eb);
+                f2 w0[kStepsPerDraw], w1[kStepsPerDraw];
+                draw3((uint32_t)(T4 / kStepsPerDraw), w0, w1);
 #pragma unroll
                 for (int i = 0; i < kStepsPerDraw; ++i) {  // steps at or beyond T carry no noise (they are never integrated)
                     const bool in = T4 + i < T;
-                    tz[i][0] = in ? ea[2 * i] : 0.f; tz[i][1] = in ? eb[2 * i] : 0.f;
-                    tz[i][2] = in ? ea[2 * i + 1] : 0.f; tz[i][3] = in ? eb[2 * i + 1] : 0.f;
+                    tz[i][0] = in ? w0[i].x : 0.f; tz[i][1] = in ? w0[i].y : 0.f;
+                    tz[i][2] = in ? w1[i].x : 0.f; tz[i][3] = in ? w1[i].y : 0.f;
                 }
             }
             eps_sums(t0, full_tag, std::true_type{});
@@ -317,16 +338,17 @@ __global__ __launch_bounds__(256) void rollout_pk_kernel(DevParams P, const doub
 hipError_t launch_rollout_pk(const RolloutPkArgs& a) {
     dim3 grid((a.P.K + 511) / 512, a.P.A);
     const unsigned lds = (unsigned)((size_t)a.P.T * sizeof(PkRow));
-#define MPPI_PK_GO(IN)                                                                                                        \
+#define MPPI_PK_GO(IN, W)                                                                                                      \
     do {                                                                                                                      \
         if (a.ev_start)                                                                                                       \
-            hipExtLaunchKernelGGL(rollout_pk_kernel<IN>, grid, dim3(256), lds, a.stream, a.ev_start, a.ev_stop, 0, a.P, a.state, \
+            hipExtLaunchKernelGGL((rollout_pk_kernel<IN, W>), grid, dim3(256), lds, a.stream, a.ev_start, a.ev_stop, 0, a.P, a.state, \
                                   a.goal, a.tc, a.dP, a.stot, a.seed, a.tick, a.tick_ptr, a.epart, a.unom, a.base, a.al_guard); \
         else                                                                                                                  \
-            hipLaunchKernelGGL(rollout_pk_kernel<IN>, grid, dim3(256), lds, a.stream, a.P, a.state, a.goal, a.tc, a.dP, a.stot, \
+            hipLaunchKernelGGL((rollout_pk_kernel<IN, W>), grid, dim3(256), lds, a.stream, a.P, a.state, a.goal, a.tc, a.dP, a.stot, \
                                a.seed, a.tick, a.tick_ptr, a.epart, a.unom, a.base, a.al_guard);                              \
     } while (0)
-    if (a.inline_nominal == 2) MPPI_PK_GO(2); else MPPI_PK_GO(1);
+    if (a.waves == 5) { if (a.inline_nominal == 2) MPPI_PK_GO(2, 5); else MPPI_PK_GO(1, 5); }
+    else { if (a.inline_nominal == 2) MPPI_PK_GO(2, 4); else MPPI_PK_GO(1, 4); }
 #undef MPPI_PK_GO
     return hipGetLastError();
 }

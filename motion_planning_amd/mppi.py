@@ -19,12 +19,28 @@ WHEEL_RADIUS = 0.033
 WHEEL_BASE = 0.16
 
 
+def dd_dynamics(x, u):
+    """Differential-drive kinematics, control/src/mppi:23-30: x = [x, y, theta] ([3] or [3, N]), u = wheel speeds
+    [left, right] ([2] or [2, N]) -> xdot of the same shape as x.  Host-side helper kept for API parity (the reference
+    exports it at module level); the rollouts never call it -- the kernels fuse it."""
+    x, u = np.asarray(x, dtype=np.float64), np.asarray(u, dtype=np.float64)
+    v = 0.5 * WHEEL_RADIUS * (u[0] + u[1])
+    return np.array([v * np.cos(x[2]), v * np.sin(x[2]), (WHEEL_RADIUS / WHEEL_BASE) * (u[1] - u[0])])
+
+
+def unicycle_dynamics(x, u):
+    """Unicycle kinematics, control/src/mppi:33-36: u = [forward speed, turn rate].  Host-side helper, as dd_dynamics."""
+    x, u = np.asarray(x, dtype=np.float64), np.asarray(u, dtype=np.float64)
+    return np.array([np.cos(x[2]) * u[0], np.sin(x[2]) * u[0], u[1] + 0.0 * u[0]])
+
+
 class _Model(object):
     """One of the two integrator / dynamics pairs ``control/src/mppi`` defines, usable exactly like the
     reference's module-level functions: as the ``model=`` constructor argument (:62) and as a callable
     ``model(x0 [3,N], u [2,N], dt) -> [3,N]`` (how perform_action uses it, :210-213).  A call runs the
-    engine's own plant kernel (the reference's operation order, theta wrap included) -- there is no
-    host-side copy of the dynamics in this package."""
+    engine's own plant kernel (the reference's operation order, theta wrap included)."""
+
+    _CACHE = 4   # engines kept per model token, least recently used first out
 
     def __init__(self, name, doc):
         self.name = name
@@ -41,12 +57,23 @@ class _Model(object):
         xs = x0.reshape(3, -1)
         us = u.reshape(2, -1)
         n = xs.shape[1]
-        key = (n, float(dt))
-        eng = self._engines.get(key)
+        dt = float(dt)
+        if not dt > 0.0:
+            # the engine reads dt <= 0 as "1 / horizon" (control/src/mppi:67); a zero-length step is the wrapped identity
+            if dt == 0.0:
+                out = xs.copy()
+                if self.name == "rk4":
+                    out[2] = out[2] - (np.ceil((out[2] + np.pi) / (2.0 * np.pi)) - 1.0) * 2.0 * np.pi
+                return out[:, 0] if single else out
+            raise ValueError("dt must be >= 0 (the plant kernel integrates forward)")
+        key = (n, dt)
+        eng = self._engines.pop(key, None)
         if eng is None:
-            eng = self._engines[key] = Engine(1, 6, n_agents=n, dt=float(dt), model=self.name, storage="f64")
-        for a in range(n):
-            eng.set_nominal(np.repeat(us[:, a:a + 1], 6, axis=1), agent=a)
+            while len(self._engines) >= self._CACHE:
+                self._engines.pop(next(iter(self._engines))).close()
+            eng = Engine(1, 6, n_agents=n, dt=dt, model=self.name, storage="f64")
+        self._engines[key] = eng   # most recently used last
+        eng.set_nominal_all(np.repeat(us.T[:, :, None], 6, axis=2))
         out = eng.plant_step(np.ascontiguousarray(xs.T)).T
         return out[:, 0] if single else out
 
@@ -145,6 +172,7 @@ class Engine(object):
         if sigma != self.sigma or lam != self.lam:
             self._ck(self._lib.mppi_set_sigma_lambda(self._h, float(sigma), float(lam)))
             self.sigma, self.lam = float(sigma), float(lam)
+            self._sig_matrix = None
 
     def set_sig(self, sig, lam):
         """sig as get_path accepts it (control/src/mppi:88): a scalar sigma (= sigma * I) or any 2 x 2
@@ -157,8 +185,17 @@ class Engine(object):
         if sig[0, 1] == 0.0 and sig[1, 0] == 0.0 and sig[0, 0] == sig[1, 1]:
             return self.set_sigma_lambda(float(sig[0, 0]), lam)
         m = _f64(sig, (2, 2))
+        key = (m.tobytes(), float(lam))
+        if getattr(self, "_sig_matrix", None) == key:
+            return   # unchanged: the C call would settle the lazy state (a full re-rollout on the scan path) for nothing
         self._ck(self._lib.mppi_set_sig_matrix(self._h, _capi.dptr(m), float(lam)))
+        self._sig_matrix = key
         self.sigma, self.lam = None, float(lam)   # not a scalar any more: the next set_sigma_lambda always applies
+
+    def set_weights(self, q=None, r=None, p1=None):
+        """Diagonals of Q [3], R [2], P1 [3] (control/src/mppi:69-73); None keeps the current one."""
+        arrs = [None if v is None else _f64(v, (n,)) for v, n in ((q, 3), (r, 2), (p1, 3))]
+        self._ck(self._lib.mppi_set_weights(self._h, *[_capi.dptr(a) for a in arrs]))
 
     def set_sync_timeout(self, milliseconds):
         self._ck(self._lib.mppi_set_sync_timeout(self._h, int(milliseconds)))
@@ -191,6 +228,17 @@ class Engine(object):
     def set_nominal(self, uvec, agent=0):
         u = _f64(uvec, (2, self.T))
         self._ck(self._lib.mppi_set_nominal(self._h, int(agent), _capi.dptr(u)))
+
+    def set_shift_fill(self, fill, agent=0):
+        """What the receding-horizon shift puts into the freed last column: uvec_init[:, 0] (control/src/mppi:101)."""
+        f = _f64(fill, (2,))
+        self._ck(self._lib.mppi_set_shift_fill(self._h, int(agent), _capi.dptr(f)))
+
+    def set_nominal_all(self, uvecs):
+        """uvecs [A][2][T]: the nominal controls of every agent."""
+        u = _f64(uvecs, (self.A, 2, self.T))
+        for a in range(self.A):
+            self._ck(self._lib.mppi_set_nominal(self._h, a, _capi.dptr(u[a])))
 
     def get_nominal(self, agent=0):
         u = np.empty((2, self.T))
@@ -403,6 +451,9 @@ class MPPI(object):
         self.uvec_init = np.zeros((2, self.horizon))
         self.model = model
         self.dt = 1.0 / float(horizon)
+        self._eng = None
+        self._weights_sent = None
+        self._fill_sent = np.zeros(2)   # the engine starts with a zero fill
         self.Q = np.array([[1e3, 0.0, 0.0], [0.0, 1e3, 0.0], [0.0, 0.0, 0.0]])
         self.R = np.array([[1.0, 0.0], [0.0, 1.0]])
         self.P1 = np.array([[1e3, 0.0, 0.0], [0.0, 1e3, 0.0], [0.0, 0.0, 1e3]])
@@ -416,11 +467,43 @@ class MPPI(object):
                            tick_path=tick_path)
         self.initialize()
 
+    # Q, R, P1 (control/src/mppi:69-73) are plain instance attributes in the reference, read on every call (:168, :183):
+    # ``m.Q = ...`` or ``m.Q[0, 0] = ...`` must change the cost of the next rollout here too.  The attributes stay plain
+    # arrays; every call that rolls out hands their current diagonals to the engine first (mppi_set_weights) when they
+    # differ from what it has.  The kernels implement diagonal weights: anything else is refused by name.
+    def _sync_weights(self):
+        mats = []
+        for name, n in (("Q", 3), ("R", 2), ("P1", 3)):
+            m = np.asarray(getattr(self, name), dtype=np.float64)
+            if m.shape != (n, n):
+                raise ValueError("%s must be %d x %d (control/src/mppi:69-73)" % (name, n, n))
+            if np.count_nonzero(m - np.diag(np.diag(m))):
+                raise ValueError("%s has off-diagonal terms: libmppi_hip implements diagonal Q, R, P1 (the reference's own "
+                                 "are diagonal, control/src/mppi:69-73)" % name)
+            mats.append(np.diag(m).copy())
+        key = tuple(map(bytes, (v.tobytes() for v in mats)))
+        if key != self._weights_sent:
+            self._eng.set_weights(*mats)
+            self._weights_sent = key
+
+    def _load_uvec_init(self, init):
+        if np.any(init):
+            self._eng.set_nominal(init)
+        else:
+            self._eng.reset()                 # the reference's default: zeros (one asynchronous memset)
+        fill = init[:, 0].copy()
+        if self._fill_sent is None or np.any(fill != self._fill_sent):
+            self._eng.set_shift_fill(fill)
+            self._fill_sent = fill
+
     # control/src/mppi:79-83
     def initialize(self):
         self.fin_time = [0]
-        self._eng.reset()
-        self.uvec = np.array([self.uvec_init[:, 0]])
+        init = np.asarray(self.uvec_init, dtype=np.float64)
+        if init.shape != (2, self.horizon):
+            raise ValueError("uvec_init must be [2, horizon] (control/src/mppi:65)")
+        self._load_uvec_init(init)           # latest_uvec = uvec_init (:81); every later shift appends uvec_init[:, 0] (:101)
+        self.uvec = np.array([init[:, 0]])
         self.path = np.array([self.start])
 
     @property
@@ -448,6 +531,7 @@ class MPPI(object):
 
     # control/src/mppi:85-102
     def get_path(self, state, goal, sig=np.array([[.9, 0.0], [0.0, .9]]), lam=.001):
+        self._sync_weights()
         sigma = self._set_sig(sig, lam)
         if self.rng == "numpy":
             self._eng.upload_noise(self._draw(sigma))
@@ -467,7 +551,8 @@ class MPPI(object):
         self.goal = np.asarray(goal, dtype=np.float64)
         state = self.start
         self.path = np.array([state])
-        self._eng.reset()
+        init = np.asarray(self.uvec_init, dtype=np.float64)
+        self._load_uvec_init(init)            # latest_uvec = uvec_init (:114)
         i = 0
         while np.linalg.norm(state[:2] - self.goal[:2]) > self.thresh and i < max_iters:
             i += 1
@@ -476,6 +561,7 @@ class MPPI(object):
 
     # control/src/mppi:127-178
     def get_cost2go(self, state, uvec, goal, lam, sig):
+        self._sync_weights()
         sigma = self._set_sig(sig, lam)
         self._eng.set_nominal(uvec)
         if self.rng == "numpy":

@@ -76,13 +76,27 @@ def test_savgol_rejects_even_window():
         savgol_matrix(4)
 
 
-def test_host_helpers(kat):
-    """The only arithmetic the host side keeps: wheelsToTwist.  The models (`rk4`, `euler`) are tokens for
-    the `model=` argument whose calls run the engine's plant kernel (GPU test: test_model_tokens_run_the_plant_kernel)."""
+def test_host_helpers(kat, orc):
+    """The arithmetic the host side keeps: wheelsToTwist, and the two kinematics functions the reference exports at
+    module level (control/src/mppi:23-36) -- API parity only, no rollout calls them.  The integrators (`rk4`, `euler`)
+    are tokens for the `model=` argument whose calls run the engine's plant kernel (GPU test:
+    test_model_tokens_run_the_plant_kernel)."""
     import motion_planning_amd as pkg
     assert np.allclose(pkg.wheels_to_twist([1.0, 2.0]), kat["wheelsToTwist_1_2"], rtol=0, atol=1e-17)
     assert pkg.rk4.name == "rk4" and pkg.euler.name == "euler" and callable(pkg.rk4)
-    assert not hasattr(pkg, "dd_dynamics") and not hasattr(pkg.mppi, "dd_dynamics")   # no host copy of the dynamics
+    rs = np.random.RandomState(3)
+    for _ in range(20):
+        x, u = rs.uniform(-3, 3, 3), rs.uniform(-6, 6, 2)
+        assert np.abs(pkg.dd_dynamics(x, u) - orc.dd_dynamics(x, u)).max() < 1e-15
+        v, w = u
+        assert np.allclose(pkg.unicycle_dynamics(x, u), [np.cos(x[2]) * v, np.sin(x[2]) * v, w], rtol=0, atol=1e-15)
+    xs, us = rs.uniform(-3, 3, (3, 5)), rs.uniform(-6, 6, (2, 5))          # the reference calls them on [3, N] / [2, N] too
+    assert pkg.dd_dynamics(xs, us).shape == (3, 5)
+    assert np.abs(pkg.dd_dynamics(xs, us)[:, 2] - pkg.dd_dynamics(xs[:, 2], us[:, 2])).max() == 0.0
+    # a zero-length step is the (wrapped) identity and needs no GPU
+    assert np.abs(pkg.rk4(np.array([0.1, 0.2, 0.3]), np.array([1.0, 2.0]), 0.0) - [0.1, 0.2, 0.3]).max() == 0.0
+    with pytest.raises(ValueError):
+        pkg.rk4(np.zeros(3), np.zeros(2), -0.1)
 
 
 def test_product_reads_no_test_hooks_from_the_environment():
