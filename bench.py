@@ -32,7 +32,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.
 CLOCK_PEAK_HZ = 2.4e9  # max shader clock, same guide
 N_SIMD = 1024          # 256 CUs x 4 SIMDs
 BYTES_PER_STEP_PER_KERNEL = 12  # eps 2 x fp32 + V 1 x fp32, written once (rollout) / read once (update): SURVEY 8(d)
-PROFILE_ROUND = "r2"
+PROFILE_ROUND = "r3"
 
 WORKLOADS = {
     # name: (description, agents, K_total, T, goal)
@@ -213,7 +213,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f64-line", action="store_true", help="skip the extra all-fp64 measurement (N = 1, c4)")
     ap.add_argument("--graph", action="store_true", help="replay the tick as one hipGraph (N=1 only)")
-    ap.add_argument("--no-co-line", action="store_true", help="skip the co-scheduled (two engines on the one GPU) leg of config 4")
+    ap.add_argument("--no-co-line", action="store_true", help="(kept for old command lines; the co-scheduled tick is the headline handle's own now)")
+    ap.add_argument("--co-shards", type=int, default=None, help="mppi_config.co_shards of the measured engine (default: the engine's own rule)")
     ap.add_argument("--all-ranks-on-gpu0", action="store_true",
                     help="TEST ONLY: every rank drives cuda:0 and the process group is gloo (RCCL refuses two ranks on one "
                          "device) -- runs the N > 1 code path of this script on a one-GPU box; use with --exchange p2p")
@@ -274,18 +275,19 @@ def main():
         ktimes = dtimes
         eng.kernel_timing(())
         final_nxt, final_ua = eng.get_outputs()
+        timed_nxt, timed_ua, clock_mhz = final_nxt, final_ua, eng.shader_clock_mhz()
     else:
         if args.workload == "c5":  # independent agents: replicas, no collective
             lo, hi = sharded.shard_range(A_total, world, rank)
             A = hi - lo
             ticker, eng = sharded.make_replica_ticker(K_total, T, n_agents=A, storage=args.storage, local_rank=local_rank,
-                                                      tick_path=args.tick_path)
+                                                      tick_path=args.tick_path, co_shards=args.co_shards)
             states = np.array([[0.05 * a, 0.0, 0.0] for a in range(lo, hi)])
             goals = np.array([[0.05 * a, -1.0, 0.0] for a in range(lo, hi)])
             K_local, units_total = K_total, A_total * K_total
         else:
             ticker, eng = sharded.make_hip_ticker(K_total, T, n_agents=1, storage=args.storage, local_rank=local_rank,
-                                                  exchange=args.exchange, tick_path=args.tick_path)
+                                                  exchange=args.exchange, tick_path=args.tick_path, co_shards=args.co_shards)
             A = 1
             states, goals = np.zeros((1, 3)), np.array([goal])
             K_local, units_total = eng.K, K_total
@@ -352,6 +354,8 @@ def main():
         sync()
         elapsed = time.perf_counter() - t0
         ktimes = eng.kernel_times()
+        timed_nxt, timed_ua = eng.get_outputs()          # where the timed region ended (self-check against the one-engine run)
+        clock_mhz = eng.shader_clock_mhz()               # a probe wave inside the last rollout launch
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -470,80 +474,135 @@ def main():
                     "note": "eps / V stored as fp64, softmax in fp64 (exp2 in fp64): the reference's own precision end to end"}
         e64.close()
 
-    # Co-scheduled shards next to the one-engine line: N = 1, config 4 only.  Two engines on this one GPU, K / 2 samples each,
-    # own streams, coupled only by the p2p mailbox flags: one engine's HBM-bound update kernel runs under the other's
-    # VALU-bound rollout.  Same protocol as the headline (time-based warm-up, controller put back at the start, the same tick
-    # ids timed); reported beside `value`, never as `value`: per-kernel durations of overlapping kernels say nothing about a
-    # roofline, and the headline keeps the one-engine tick that `roofline` describes.
-    co_line = None
-    if (rank == 0 and world == 1 and args.workload == "c4" and args.storage == "f32" and not args.no_co_line
-            and not args.samples and not args.graph):
+    # One engine next to the headline: N = 1, config 4 only.  The headline handle splits its fused tick over co-scheduled
+    # engines (mppi_config.co_shards AUTO: one shard's HBM-bound update kernel runs under the other's VALU-bound rollout); with
+    # kernels of several engines overlapping, a launch's own duration is no longer a kernel's undisturbed time, so the
+    # per-kernel rooflines (SURVEY 8d accounting, VALU issue) are measured on the SAME workload with co_shards = 1 -- same
+    # protocol (time-based warm-up, controller put back at the start, the same tick ids timed).  It is also the self-check of
+    # the timed region: the two runs must end in the same state and controls (a timed region that skipped work would not).
+    one_line = None
+    if rank == 0 and world == 1 and args.workload == "c4" and not args.samples and not args.graph and info.get("co_shards", 1) > 1:
         if f64_line is None:
             eng.close()
-        try:   # an auxiliary leg: its failure is reported in the line, it does not take the headline down
-            ct = sharded.make_co_scheduled_ticker(K_total, T, n_shards=2, storage="f32", device=local_rank)
-            ct.set_nominal(nominal_warm(T))
-            ct.tick_async(np.zeros((1, 3)), np.array([goal]), "philox", 0, 0)
+        from motion_planning_amd.mppi import Engine
+        with Engine(K_total, T, storage=args.storage, device=local_rank, tick_path=args.tick_path, co_shards=1) as e1:
+            e1.set_nominal(nominal_warm(T))
+            e1.tick_async(np.zeros((1, 3)), np.array([goal]), "philox", 0, 0)
             t_w, i = time.perf_counter(), 1
             while time.perf_counter() - t_w < args.min_warmup_s or i < args.warmup:
-                ct.tick_async(None, None, "philox", 0, i)
+                e1.tick_async(None, None, "philox", 0, i)
                 i += 1
                 if i % 16 == 0:
-                    ct.synchronize()
-            ct.set_nominal(nominal_warm(T))
-            ct.tick_async(np.zeros((1, 3)), np.array([goal]), "philox", 0, 1_000_000)
-            ct.synchronize()
-            n_co = max(args.steps, 200)
+                    e1.synchronize()
+            e1.set_nominal(nominal_warm(T))
+            e1.tick_async(np.zeros((1, 3)), np.array([goal]), "philox", 0, 1_000_000)
+            e1.kernel_timing(("rollout",), period=4)
+            e1.synchronize()
             t0 = time.perf_counter()
-            for j in range(n_co):
-                ct.tick_async(None, None, "philox", 0, 1_000_001 + j)
-            ct.synchronize()
-            el_co = time.perf_counter() - t0
-            nxt_co, ua_co = ct.get_outputs()
-            assert np.isfinite(nxt_co).all() and np.isfinite(ua_co).all()
-            co_line = {"engines_per_gpu": 2, "samples_per_engine": [int(e.K) for e in ct.engines], "exchange": "p2p mailboxes (in-process pointers)",
-                       "ms_per_step": 1e3 * el_co / n_co, "value": K_total / (el_co / n_co), "steps": n_co,
-                       "note": "two engines on the one GPU, K/2 samples each, own streams, coupled by the finalize kernels' mailbox flags; "
-                               "one engine's update (HBM-bound) overlaps the other's rollout (VALU-bound)"}
-            ct.close()
-        except Exception as exc:
-            co_line = {"engines_per_gpu": 2, "error": "%s: %s" % (type(exc).__name__, exc)}
+            for j in range(args.steps):
+                e1.tick_async(None, None, "philox", 0, 1_000_001 + j)
+            e1.synchronize()
+            el1 = time.perf_counter() - t0
+            k1 = e1.kernel_times()
+            mhz1 = e1.shader_clock_mhz()
+            nxt1, ua1 = e1.get_outputs()
+            # every kernel bracketed
+            e1.kernel_timing(("rollout", "update", "merge", "finalize"), period=1)
+            for j in range(20):
+                e1.tick_async(None, None, "philox", 0, 3_000_000 + j)
+            e1.synchronize()
+            d1 = e1.kernel_times()
+            # the other regime: parked at the goal (1-7 % of a row carry weight, the update kernel re-draws their noise)
+            e1.set_nominal(np.zeros((2, T)))
+            e1.tick_async(np.array([goal]), np.array([goal]), "philox", 0, 5_000_000)
+            for j in range(30):
+                e1.tick_async(None, None, "philox", 0, 5_000_001 + j)
+            e1.kernel_timing(("rollout", "update", "merge", "finalize"), period=1)
+            e1.synchronize()
+            t0 = time.perf_counter()
+            for j in range(20):
+                e1.tick_async(None, None, "philox", 0, 5_000_100 + j)
+            e1.synchronize()
+            elp = time.perf_counter() - t0
+            p1 = e1.kernel_times()
+            e1.kernel_timing(())
+        one_line = {"co_shards": 1, "ms_per_step": 1e3 * el1 / args.steps, "value": K_total / (el1 / args.steps), "steps": args.steps,
+                    "rollout_us": k1["rollout"][0] * 1e3 / max(k1["rollout"][1], 1), "launches_timed": k1["rollout"][1],
+                    "shader_clock_mhz": mhz1,
+                    "kernels_us_bracketed": {k: (v[0] * 1e3 / v[1] if v[1] else None) for k, v in d1.items()},
+                    "final_state": [float(x) for x in nxt1[0]], "final_u": [float(x) for x in ua1[0]],
+                    "parked_at_goal": {"ms_per_step": 1e3 * elp / 20, "value": K_total / (elp / 20),
+                                       "kernels_us": {k: (v[0] * 1e3 / v[1] if v[1] else None) for k, v in p1.items()}}}
+        dev_s = float(np.abs(np.array(one_line["final_state"]) - timed_nxt[0]).max())
+        dev_u = float(np.abs(np.array(one_line["final_u"]) - timed_ua[0]).max())
+        one_line["self_check"] = {"max_abs_diff_state": dev_s, "max_abs_diff_u": dev_u, "tolerance": 1e-10,
+                                  "what": "final state / applied controls of the timed region: co-scheduled headline vs one engine, same seed, same ticks"}
+        if not (dev_s <= 1e-10 and dev_u <= 1e-10):
+            raise SystemExit("bench self-check FAILED: the timed region of the headline run and of the one-engine run ended in "
+                             "different states / controls: %r" % one_line["self_check"])
 
     if rank == 0:
-        steps_per_launch = A * K_local * T
+        lanes = info.get("tick_kernels", "lanes") == "lanes"
+        mixes = load_profile(PROFILE_ROUND + "_valu_mix.json") or {}
+        PK_MIN_SAMPLES = int(os.environ.get("MPPI_PK_MIN_SAMPLES", "400000"))   # the engine's own rule (mppi_engine.hip launch_rollout)
+
+        def kernel_roofline(k_launch, avg_s, mhz, n_timed):
+            """The dominant kernel of a launch over k_launch samples per agent: SURVEY 8(d) HBM accounting, and the VALU-issue
+            roofline it is really on -- wave-instructions of the steady-state loop from the compiler's own assembly
+            (tools/valu_mix.py), each class at its measured issue cost (tools/ubench.hip, shader clock read in-kernel),
+            over 1024 SIMDs at the clock a probe wave inside the launch measured (and at the 2.4 GHz peak)."""
+            steps = A * k_launch * T
+            pk = (lanes and args.storage == "f32" and A * k_launch >= PK_MIN_SAMPLES and T <= 256
+                  and os.environ.get("MPPI_ROLLOUT_PK", "1") != "0")
+            name = "rollout_pk_kernel" if pk else "rollout_kernel"
+            gbs = BYTES_PER_STEP_PER_KERNEL * steps / avg_s / 1e9
+            r = {"kernel": name, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                 "traffic": None, "algorithmic_bytes_per_launch": BYTES_PER_STEP_PER_KERNEL * steps, "samples_per_launch": A * k_launch,
+                 "avg_launch_us": avg_s * 1e6, "launches_timed": n_timed, "actual_bound": "valu-issue"}
+            mix = mixes.get(name)
+            if mix and lanes and args.storage == "f32":
+                wave_steps = steps / 64.0          # sample-steps per 64 lanes (the pk kernel's waves carry 128 samples)
+                cyc = mix["issue_cycles_per_step"] * wave_steps / N_SIMD
+                clk = mhz * 1e6 if mhz and mhz > 0 else CLOCK_PEAK_HZ
+                r["valu"] = {"bound": "valu-issue", "unit": "G wave-inst/s",
+                             "insts_per_launch": mix["valu_per_step"] * wave_steps,
+                             "achieved": mix["valu_per_step"] * wave_steps / avg_s / 1e9,
+                             "peak": N_SIMD * clk / mix["avg_cycles_per_valu"] / 1e9,
+                             "clock_mhz_under_load": mhz, "frac": cyc / clk / avg_s, "min_launch_us": cyc / clk * 1e6,
+                             "frac_at_peak_clock": cyc / CLOCK_PEAK_HZ / avg_s, "min_launch_us_at_peak_clock": cyc / CLOCK_PEAK_HZ * 1e6,
+                             "valu_per_step": mix["valu_per_step"], "issue_cycles_per_step": mix["issue_cycles_per_step"],
+                             "by_class_per_step": {k: v / mix["steps_per_iteration"] for k, v in mix["by_class_per_iteration"].items()},
+                             "source": "profiles/%s_valu_mix.json, profiles/%s_ubench.txt" % (PROFILE_ROUND, PROFILE_ROUND)}
+            return r
+
+        co_n = info.get("co_shards", 1)
+        k_launch = info["co_samples"][0] if co_n > 1 else K_local    # the launches this handle's events time: its own shard
+        steps_per_launch = A * k_launch * T
         ms, n = ktimes["rollout"]
         if n == 0:  # hipGraph replay: launches are not individually bracketed
             ms, n = dtimes["rollout"] if dtimes["rollout"][1] else (float("nan"), 1)
         avg_s = ms * 1e-3 / max(n, 1)
-        gbs = BYTES_PER_STEP_PER_KERNEL * steps_per_launch / avg_s / 1e9
         tick_s = elapsed / args.steps
-        roofline = {"kernel": "rollout_kernel", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-                    "algorithmic_bytes_per_launch": BYTES_PER_STEP_PER_KERNEL * steps_per_launch,
-                    "avg_launch_us": avg_s * 1e6, "launches_timed": n,
-                    "actual_bound": "valu-issue",
-                    "note": "SURVEY 8(d) accounting: algorithmic = 12 B/state-step per kernel (eps 2 x fp32 + V fp32; 24 B/step per "
+        roofline = kernel_roofline(k_launch, avg_s, clock_mhz, n)
+        tick_bytes = 2 * BYTES_PER_STEP_PER_KERNEL * A * K_local * T
+        roofline["note"] = ("SURVEY 8(d) accounting: algorithmic = 12 B/state-step per kernel (eps 2 x fp32 + V fp32; 24 B/step per "
                             "tick, written once by the rollout, read once by the update).  The kernel is NOT on the HBM roof: it "
                             "regenerates eps instead of storing it (writes 4.4 of the 12 B/step, see `traffic`) and is bound by "
-                            "VALU issue -- see `valu` for that roofline.",
-                    "tick_level": {"algorithmic_bytes": 2 * BYTES_PER_STEP_PER_KERNEL * steps_per_launch,
-                                   "achieved": 2 * BYTES_PER_STEP_PER_KERNEL * steps_per_launch / tick_s / 1e9,
-                                   "frac": 2 * BYTES_PER_STEP_PER_KERNEL * steps_per_launch / tick_s / 1e9 / HBM_PEAK_GBS}}
-        # VALU-issue roofline of the same kernel: wave-instructions per launch from the compiler's assembly of the
-        # steady-state loop (tools/valu_mix.py; agrees with the SQ_INSTS_VALU PMC count), each priced with its class's
-        # measured issue cost (tools/ubench.hip), against 1024 SIMDs at the 2.4 GHz peak clock.
-        mix = load_profile(PROFILE_ROUND + "_valu_mix.json") or load_profile("r1_valu_mix.json")
-        if mix and info.get("tick_kernels", "lanes") == "lanes" and args.storage == "f32":
-            wave_steps = steps_per_launch / 64.0
-            insts = mix["valu_per_step"] * wave_steps
-            t_min = mix["issue_cycles_per_step"] * wave_steps / N_SIMD / CLOCK_PEAK_HZ
-            roofline["valu"] = {"bound": "valu-issue", "unit": "G wave-inst/s",
-                                "insts_per_launch": insts, "achieved": insts / avg_s / 1e9,
-                                "peak": N_SIMD * CLOCK_PEAK_HZ / mix["avg_cycles_per_valu"] / 1e9,
-                                "frac": t_min / avg_s, "min_launch_us_at_peak_clock": t_min * 1e6,
-                                "valu_per_step": mix["valu_per_step"], "issue_cycles_per_step": mix["issue_cycles_per_step"],
-                                "by_class_per_step": {k: v / mix["steps_per_iteration"] for k, v in mix["by_class_per_iteration"].items()},
-                                "source": "profiles/%s_valu_mix.json" % PROFILE_ROUND}
+                            "VALU issue -- see `valu`." +
+                            ("  This handle runs its fused tick as %d co-scheduled engines: the launches timed here are shard 0's "
+                             "(%d samples), overlapping the other shard's kernels; `one_engine` holds the same kernel undisturbed."
+                             % (co_n, k_launch) if co_n > 1 else ""))
+        roofline["tick_level"] = {"algorithmic_bytes": tick_bytes, "achieved": tick_bytes / tick_s / 1e9,
+                                  "frac": tick_bytes / tick_s / 1e9 / HBM_PEAK_GBS,
+                                  "note": "24 B/state-step x all samples of the tick / tick time: both kernels (and, co-scheduled, both engines) together"}
+        if "valu" in roofline:   # VALU issue over the whole tick: every shard's rollout instructions against the tick time
+            v = roofline["valu"]
+            clk = (clock_mhz * 1e6) if clock_mhz and clock_mhz > 0 else CLOCK_PEAK_HZ
+            cyc_tick = v["issue_cycles_per_step"] * (A * K_local * T / 64.0) / N_SIMD
+            roofline["tick_level"]["valu_frac"] = cyc_tick / clk / tick_s
+            roofline["tick_level"]["valu_note"] = "rollout issue cycles of all shards / (tick time x measured clock): the update, merge and finalize kernels' instructions not counted"
+        if one_line:
+            one_line["roofline"] = kernel_roofline(K_local, one_line["rollout_us"] * 1e-6, one_line["shader_clock_mhz"], one_line["launches_timed"])
         # HBM bytes actually moved per launch of that kernel: rocprofv3 --pmc passes of this same command
         # (tools/pmc.sh), summary committed under profiles/ -- bench.py itself cannot host the profiler
         pmc_name = PROFILE_ROUND + "_pmc_summary_bench_c4.json"
@@ -553,7 +612,7 @@ def main():
             pm = load_profile(pmc_name)
         if args.workload == "c4" and args.storage == "f32" and world == 1 and not args.samples and pm:
             for kname, c in pm.items():
-                if "rollout_kernel" in kname or "rollout_pk_kernel" in kname:
+                if roofline["kernel"] + "<" in kname or kname.split("::")[-1].startswith(roofline["kernel"] + "<"):
                     rd = [v for k, v in c.items() if k.startswith("hbm_read_bytes")]
                     wr = [v for k, v in c.items() if k.startswith("hbm_write_bytes")]
                     if rd and wr:
@@ -575,9 +634,15 @@ def main():
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             cpu = cpu_baseline(T, goal if goal is not None else [0.0, -1.0, 0.0])
         value = units_total / (elapsed / args.steps)
-        lanes = info.get("tick_kernels", "lanes") == "lanes"
         if args.storage == "f64":
             dtype, detail = "f64", "fp64 state, cost, storage and softmax (the reference's precision end to end)"
+        elif roofline["kernel"] == "rollout_pk_kernel":
+            dtype = "f32"
+            detail = ("mixed: rollout deviations from the fp64 nominal trajectory in packed fp32 (clip, heading series, speed / Simpson-weight "
+                      "deviations, noise cost) with the three running sums (heading, position, cost prefix), the rotation into the world frame "
+                      "and the quadratic cost in fp64; noise drawn in fp32 (Philox + Box-Muller); HBM-resident cost prefix fp32 offsets from the "
+                      "nominal trajectory; softmax weights (exp, sums) fp32; merge / control update / filter / plant step fp64.  "
+                      "|V - V_oracle| <= 3e-7 max(1, |V - V_nominal|) + lambda / 100 (tests); the all-fp64 line is `f64_storage`")
         else:
             dtype = "f64"
             detail = ("rollout state + cost arithmetic fp64; noise drawn in fp32 (Philox + Box-Muller); HBM-resident cost prefix "
@@ -596,13 +661,14 @@ def main():
                        "noise": "device Philox4x32-10", "sigma": 0.9, "lambda": 0.001,
                        "parallelism": ("K-sharded x%d, exchange: %s" % (world, exch_kind)) if args.workload != "c5" else "agent replicas",
                        "graph": bool(args.graph), "tick_kernels": info.get("tick_kernels", "lanes"),
+                       "co_shards": info.get("co_shards", 1), "co_samples": info.get("co_samples"),
                        "min_warmup_s": args.min_warmup_s},
             "state_steps_per_s": value * T,
             "tick_us": tick_us,
             "final_state": [float(x) for x in final_nxt[0]], "final_u": [float(x) for x in final_ua[0]],
             "sync_tick_us": sync_tick_us,
             "kernels_us": kernels_us, "exchange_us": exchange_us, "per_rank": per_rank,
-            "roofline": roofline, "cpu_baseline": cpu, "f64_storage": f64_line, "co_scheduled": co_line,
+            "roofline": roofline, "cpu_baseline": cpu, "f64_storage": f64_line, "one_engine": one_line,
         }
         line.update(extra)
         print(json.dumps(line))

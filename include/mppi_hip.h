@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 2
+#define MPPI_ABI_VERSION 3
 
 /* error codes */
 #define MPPI_OK 0
@@ -86,6 +86,15 @@ extern "C" {
 #define MPPI_TICK_LANES 1
 #define MPPI_TICK_SCAN 2
 
+/* Co-scheduled shards (mppi_config.co_shards).  A fused mppi_tick with device noise may split its samples over G
+ * engines inside this one handle -- same GPU, one stream each, coupled only by device-side mailbox flags -- so that one
+ * shard's HBM-bound update kernel runs under another's VALU-bound rollout (config 4: +7-9 % rollouts/s).  Results equal
+ * the unsplit tick to rounding (sample ids are global, the tuple merge is exact); every other call of this ABI keeps
+ * working: after such a tick mppi_download_value / _noise / mppi_update re-run the rollout over all samples from a
+ * snapshot of the tick's inputs, bit for bit what the shards computed.  AUTO = 2 shards for n_agents * samples >= 500000
+ * on the lane-per-sample path, else none.  mppi_tick_begin / _finish (the caller's own exchange), mppi_tick_graph and
+ * injected-noise ticks always run unsplit; mppi_p2p_create on such a handle dissolves the group. */
+
 /* kernels, for mppi_kernel_timing (the scan kernel is timed as MPPI_KERNEL_ROLLOUT) */
 #define MPPI_KERNEL_NOMINAL 0
 #define MPPI_KERNEL_ROLLOUT 1
@@ -106,6 +115,8 @@ typedef struct mppi_config {
     uint32_t sample_offset;/* global index of local sample 0                                  */
     int32_t model;         /* MPPI_MODEL_*: the `model=` ctor argument (control/src/mppi:62)   */
     int32_t tick_path;     /* MPPI_TICK_*: which kernels a tick runs; default MPPI_TICK_AUTO          */
+    int32_t co_shards;     /* co-scheduled shards of the fused mppi_tick: 0 auto | 1 off | 2..8 (below)  */
+    int32_t reserved0;     /* 0                                                                       */
     double dt;             /* <= 0: 1/T  (control/src/mppi:67)                                */
     double sigma;          /* noise std-dev = sig[0,0] (control/src/mppi:145); default 0.9    */
     double lambda;         /* temperature; default 0.001 (control/src/mppi:89)                */
@@ -296,6 +307,10 @@ int mppi_kernel_times(mppi_engine *h, double *ms /*[MPPI_KERNEL_COUNT]*/,
  * the shader cycle counter (s_memtime) and the constant-rate counter (s_memrealtime) when its wave starts and ends.
  * 0 before the first such launch.  Synchronises.  (Measurement aid: prices the VALU-issue roofline of bench.py.) */
 int mppi_shader_clock(mppi_engine *h, double *mhz);
+
+/* How the fused device-noise mppi_tick of this handle runs: n_shards co-scheduled engines (1: unsplit) and the samples
+ * each owns (samples [8], zero-filled behind n_shards). */
+int mppi_co_info(mppi_engine *h, int32_t *n_shards, int32_t *samples);
 
 /* Bytes of HBM held by the engine, and the launch geometry (blocks) of a tick's kernels: rollout +
  * update on the lane-per-sample path; the scan kernel and update_blocks = 0 on the small-K path. */

@@ -14,13 +14,13 @@ MPPI_TICK_AUTO, MPPI_TICK_LANES, MPPI_TICK_SCAN = 0, 1, 2
 MPPI_E_TIMEOUT = -5
 IPC_HANDLE_BYTES = 64
 KERNELS = ("nominal", "rollout", "update", "merge", "finalize", "exchange")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class MppiConfig(C.Structure):
     _fields_ = [("n_agents", C.c_int32), ("samples", C.c_int32), ("horizon", C.c_int32),
                 ("storage", C.c_int32), ("device", C.c_int32), ("sample_offset", C.c_uint32),
-                ("model", C.c_int32), ("tick_path", C.c_int32),
+                ("model", C.c_int32), ("tick_path", C.c_int32), ("co_shards", C.c_int32), ("reserved0", C.c_int32),
                 ("dt", C.c_double), ("sigma", C.c_double), ("lambda_", C.c_double),
                 ("q", C.c_double * 3), ("r", C.c_double * 2), ("p1", C.c_double * 3),
                 ("u_max", C.c_double), ("wheel_radius", C.c_double), ("wheel_base", C.c_double),
@@ -86,6 +86,7 @@ SIGNATURES = {
     "mppi_kernel_timing_period": (C.c_int, [_H, C.c_int]),
     "mppi_kernel_times": (C.c_int, [_H, _dp, C.POINTER(C.c_int64)]),
     "mppi_shader_clock": (C.c_int, [_H, _dp]),
+    "mppi_co_info": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "mppi_engine_info": (C.c_int, [_H, C.POINTER(C.c_size_t), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }
 

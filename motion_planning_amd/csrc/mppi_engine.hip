@@ -107,6 +107,7 @@ struct mppi_engine {
     uint32_t lazy_tick = 0;
     bool store_eps_always = false;  // MPPI_STORE_EPS=1: the tick path writes eps like mppi_rollout does
     int pk_waves = 4;
+    long pk_min_samples = 400000;
     bool use_pk = true;             // MPPI_ROLLOUT_PK=0: keep the all-fp64 rollout kernel on the tick path (same-box A/B measurements)
     double* d_tc = nullptr;  // [A][T][8]
     double* d_base = nullptr;
@@ -237,6 +238,48 @@ struct mppi_engine {
         w.timeout_ticks = sync_timeout_ms > 0 ? (unsigned long long)sync_timeout_ms * (unsigned long long)wall_clock_khz : 0ull;
         return w;
     }
+
+    // Co-scheduled shards (mppi_config.co_shards): the samples of a big engine split over G engines on this one GPU, every
+    // engine on its own stream, coupled only through the p2p mailboxes their finalize kernels poll (no event, no host wait
+    // between them): one shard's HBM-bound update kernel runs under another's VALU-bound rollout.  THIS engine runs shard
+    // 0 of such a tick (so its nominal controls, state and outputs stay the handle's), `subs` the other shards; every
+    // other call of the ABI keeps working on this engine's own full-size buffers.
+    std::vector<mppi_engine*> subs;
+    int co_k0 = 0;             // samples of shard 0
+    bool co_synced = false;    // the subs hold this engine's nominal controls / state / goal
+    bool co_last = false;      // the last tick ran co-scheduled: its V / noise exist only as "re-run from the snapshot"
+    hipEvent_t ev_co = nullptr;
+    bool co_active() const { return !subs.empty(); }
+    void co_release() {
+        for (auto* e : subs) delete e;
+        subs.clear();
+        if (p2p_internal) { p2p_release(); p2p_internal = false; }
+    }
+    bool p2p_internal = false;  // the mailboxes belong to the co-scheduled group, not to a caller's cross-GPU exchange
+    // this engine's view of its own shard while a co-scheduled tick is enqueued: K, chunk count and launch geometry of shard 0
+    struct ShardView {
+        mppi_engine* e; int K, samples, NCH, roll_blocks; double* snap;
+        explicit ShardView(mppi_engine* e_) : e(e_), K(e_->P.K), samples(e_->cfg.samples), NCH(e_->NCH), roll_blocks(e_->roll_blocks), snap(e_->P.snap) {
+            e->P.K = e->co_k0; e->cfg.samples = e->co_k0; e->NCH = (e->co_k0 + e->CH - 1) / e->CH;
+            e->roll_blocks = (e->co_k0 + e->roll_bs - 1) / e->roll_bs; e->P.snap = e->d_prev;
+        }
+        ~ShardView() { e->P.K = K; e->cfg.samples = samples; e->NCH = NCH; e->roll_blocks = roll_blocks; e->P.snap = snap; }
+    };
+    void co_sync_subs() {   // (rare) something other than a co-scheduled tick changed this engine's nominal controls / state / goal
+        if (co_synced) return;
+        const size_t A_ = cfg.n_agents, T_ = cfg.horizon;
+        HIPCHK(hipEventRecord(ev_co, stream));
+        for (auto* e : subs) {
+            HIPCHK(hipStreamWaitEvent(e->stream, ev_co, 0));
+            HIPCHK(hipMemcpyAsync(e->d_unom, d_unom, A_ * 2 * T_ * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+            HIPCHK(hipMemcpyAsync(e->d_state, d_state, A_ * 3 * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+            HIPCHK(hipMemcpyAsync(e->d_goal, d_goal, A_ * 3 * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+            e->have_state = have_state; e->have_goal = have_goal;
+        }
+        co_synced = true;
+    }
+    void co_build();   // creates the subs (after init)
+    void co_tick(const double* state, const double* goal, uint64_t seed, uint32_t tick);
 
     // hipGraph of a whole tick
     hipGraph_t graph = nullptr;
@@ -382,8 +425,11 @@ struct mppi_engine {
         hipError_t e;
         // the tick path of an fp32-storage engine with the node's own cost and model: the mixed-precision kernel, two
         // samples per lane on the packed-fp32 pipe (rollout_pk.hpp); its heading series need the noise's reach bounded
+        // ... and enough waves: it halves their number and doubles their length, which only pays when every SIMD still gets
+        // several (same-box A/B at T = 50, rollout_kernel vs this one: 10^6 samples 106.8 vs 101.8 us, 750 000 83.0 vs 79.4,
+        // 500 000 58.2 vs 56.9, 375 000 47.1 vs 46.3, 250 000 34.5 vs 36.1, 125 000 24.6 vs 28.3)
         if (use_pk && !f64() && ph && !store && a.inline_nominal && !a.general && k0 == 0 && k1 == cfg.samples &&
-            mppi::rollout_pk_applies(P.kth, P.dt, P.sigma, cfg.horizon)) {
+            (long)cfg.n_agents * cfg.samples >= pk_min_samples && mppi::rollout_pk_applies(P.kth, P.dt, P.sigma, cfg.horizon)) {
             mppi::RolloutPkArgs b{};
             b.P = P; b.stream = st; b.inline_nominal = a.inline_nominal; b.seed = seed; b.tick = tick; b.tick_ptr = tick_ptr;
             b.state = a.state; b.goal = a.goal; b.unom = a.unom; b.tc = d_tc; b.base = d_base;
@@ -432,12 +478,16 @@ struct mppi_engine {
         ro_state = d_prev + (size_t)cfg.n_agents * 2 * cfg.horizon;
         ro_goal = ro_state + (size_t)cfg.n_agents * 3;
         try {
-            launch_rollout(stream, 0, cfg.samples, ph, true, lazy_seed, tick, nullptr);
+            // a co-scheduled tick's shards ran the tick-path kernel (noise not stored): the re-run takes the same kernel over
+            // all samples -- per sample bit-identical to what the shards computed -- and the noise is re-drawn next to it
+            launch_rollout(stream, 0, cfg.samples, ph, !(co_last && ph), lazy_seed, tick, nullptr);
+            if (co_last && ph) launch_regen(stream, lazy_seed, tick, nullptr);
         } catch (...) {
             ro_unom = ro_state = ro_goal = nullptr;
             throw;
         }
         ro_unom = ro_state = ro_goal = nullptr;
+        co_last = false;
         if (ph) { eps_lazy = false; injected_ready = true; }
         value_lazy = false; value_ready = true; epart_ready = true;
     }
@@ -518,13 +568,13 @@ struct mppi_engine {
             eps_lazy = ph;
             if (ph) injected_ready = false;  // the scan kernel never writes d_eps
             launch_scan_tick(ph, seed, tick, tick_ptr);
-            merge_skipped = (skip_small_merge || p2p_connected) && small_nb <= kDirectTuples;
+            merge_skipped = (skip_small_merge || (p2p_connected && !p2p_internal)) && small_nb <= kDirectTuples;
             direct_n = small_nb;
             if (!merge_skipped) launch_merge(small_nb);
             noise_ready = true; value_ready = false; value_lazy = true; partials_ready = true; epart_ready = false;
             return;
         }
-        merge_skipped = (skip_small_merge || p2p_connected) && NCH <= kDirectTuples;
+        merge_skipped = (skip_small_merge || (p2p_connected && !p2p_internal)) && NCH <= kDirectTuples;
         direct_n = NCH;
         launch_rollout(stream, 0, cfg.samples, ph, store, seed, tick, tick_ptr);
         launch_update(stream, 0, NCH, tick_ptr);
@@ -625,6 +675,7 @@ struct mppi_engine {
         if (const char* v = std::getenv("MPPI_STORE_EPS")) store_eps_always = std::atoi(v) != 0;
         if (const char* v = std::getenv("MPPI_ROLLOUT_PK")) use_pk = std::atoi(v) != 0;
         if (const char* v = std::getenv("MPPI_PK_WAVES")) pk_waves = std::atoi(v);
+        if (const char* v = std::getenv("MPPI_PK_MIN_SAMPLES")) pk_min_samples = std::atol(v);
         if (const char* v = std::getenv("MPPI_SYNC_TIMEOUT_MS")) sync_timeout_ms = std::atoi(v);
         if (cfg.n_agents < 1 || cfg.samples < 1) fail(MPPI_E_INVALID, "n_agents and samples must be >= 1");
         if (cfg.n_agents > 65535) fail(MPPI_E_INVALID, "n_agents %d: agents are a grid dimension (<= 65535)", cfg.n_agents);
@@ -644,6 +695,7 @@ struct mppi_engine {
                  cfg.horizon, cfg.samples);
         if (cfg.model != MPPI_MODEL_DIFFDRIVE_RK4 && cfg.model != MPPI_MODEL_UNICYCLE_EULER)
             fail(MPPI_E_INVALID, "unknown model %d (rk4 + dd_dynamics = 0, euler + unicycle_dynamics = 1)", cfg.model);
+        if (cfg.co_shards < 0 || cfg.co_shards > 8) fail(MPPI_E_INVALID, "co_shards must be 0 (auto), 1 (off) or 2..8");
         if (cfg.tick_path != MPPI_TICK_AUTO && cfg.tick_path != MPPI_TICK_LANES && cfg.tick_path != MPPI_TICK_SCAN)
             fail(MPPI_E_INVALID, "bad tick_path %d", cfg.tick_path);
         if (!(cfg.lambda > 0.0) || !(cfg.sigma >= 0.0)) fail(MPPI_E_INVALID, "lambda must be > 0 and sigma >= 0");
@@ -773,6 +825,9 @@ struct mppi_engine {
         hipSetDevice(device);
         struct Restore { bool on; int dev; ~Restore() { if (on) (void)hipSetDevice(dev); } } restore{back, prev};
         try { wait_stream("engine teardown"); } catch (...) {}  // a dead device must not hang the destructor either
+        for (auto* e : subs) delete e;
+        subs.clear();
+        if (ev_co) hipEventDestroy(ev_co);
         p2p_release();
         if (ev_partials) hipEventDestroy(ev_partials);
         if (ev_foreign) hipEventDestroy(ev_foreign);
@@ -803,6 +858,76 @@ struct mppi_engine {
     catch (const std::exception& e) { (h)->err = e.what(); return MPPI_E_INTERNAL; } \
     catch (...) { (h)->err = "unknown error"; return MPPI_E_INTERNAL; }
 
+void mppi_engine::co_build() {
+    int G = cfg.co_shards;
+    if (G < 0 || G > 8) fail(MPPI_E_INVALID, "co_shards must be 0 (auto), 1 (off) or 2..8");
+    const bool lanes = small_nb == 0;
+    const bool wanted = G > 1;
+    // AUTO: two shards where the pair measured faster than the one engine (config 4: +7-9 % rollouts/s; nothing below
+    // ~5e5 samples), on the lane-per-sample path only
+    if (G == 0) G = (lanes && (long)cfg.n_agents * cfg.samples >= 500000 && cfg.samples >= 4 * CH) ? 2 : 1;
+    if (G <= 1) return;
+    if (!lanes || cfg.samples < G * CH) {
+        if (wanted) fail(MPPI_E_INVALID, "co_shards = %d needs the lane-per-sample tick path and at least %d samples per shard", G, CH);
+        return;
+    }
+    try {
+        // boundaries on multiples of the update kernel's chunk (no shard ends in a ragged chunk), as equal as those allow
+        std::vector<int> cuts(G + 1, 0);
+        for (int g = 1; g < G; ++g) cuts[g] = (int)(((long)g * cfg.samples / G + CH / 2) / CH) * CH;
+        cuts[G] = cfg.samples;
+        for (int g = 0; g < G; ++g) if (cuts[g + 1] <= cuts[g]) fail(MPPI_E_INVALID, "co_shards = %d: %d samples do not split", G, cfg.samples);
+        co_k0 = cuts[1];
+        for (int g = 1; g < G; ++g) {
+            mppi_config c = cfg;
+            c.samples = cuts[g + 1] - cuts[g];
+            c.sample_offset = cfg.sample_offset + (uint32_t)cuts[g];
+            c.co_shards = 1;
+            c.tick_path = MPPI_TICK_LANES;
+            mppi_engine* e = new mppi_engine();
+            subs.push_back(e);
+            e->init(c);
+        }
+        std::vector<void*> ptrs(G, nullptr);
+        std::vector<mppi_engine*> all{this};
+        all.insert(all.end(), subs.begin(), subs.end());
+        for (int g = 0; g < G; ++g) {
+            if (mppi_p2p_create(all[g], G, g, nullptr)) fail(MPPI_E_HIP, "co-scheduled shard %d: %s", g, all[g]->err.c_str());
+            ptrs[g] = all[g]->p2p_mbox;
+        }
+        for (int g = 0; g < G; ++g)
+            if (mppi_p2p_connect(all[g], nullptr, ptrs.data())) fail(MPPI_E_HIP, "co-scheduled shard %d: %s", g, all[g]->err.c_str());
+        p2p_internal = true;
+        HIPCHK(hipEventCreateWithFlags(&ev_co, hipEventDisableTiming));
+        co_synced = false;
+    } catch (...) {
+        co_release();
+        if (wanted) throw;   // asked for by name: report; AUTO: the one engine serves every call anyway
+    }
+}
+
+void mppi_engine::co_tick(const double* state, const double* goal, uint64_t seed, uint32_t tick) {
+    co_sync_subs();
+    set_inputs(state, goal);
+    for (auto* e : subs) e->set_inputs(state, goal);
+    {
+        ShardView view(this);
+        run_nominal();
+        run_pipeline(MPPI_NOISE_PHILOX, seed, tick, nullptr, /*skip_small_merge=*/true);   // the publish kernel merges a handful of tuples itself
+    }
+    for (auto* e : subs) { e->run_nominal(); e->run_pipeline(MPPI_NOISE_PHILOX, seed, tick, nullptr, /*skip_small_merge=*/true); }
+    // one thread drives all engines: every publish is enqueued before any finalize that waits for it
+    p2p_wait = p2p_publish(merge_skipped ? nullptr : d_merged);
+    for (auto* e : subs) e->p2p_wait = e->p2p_publish(e->merge_skipped ? nullptr : e->d_merged);
+    const int par = (int)(p2p_epoch & 1u);
+    run_finalize(p2p_data(p2p_mbox, par, 0), p2p_n, 1 | 2, p2p_wait, p2p_slot / sizeof(double));
+    for (auto* e : subs) e->run_finalize(e->p2p_data(e->p2p_mbox, par, 0), e->p2p_n, 1 | 2, e->p2p_wait, e->p2p_slot / sizeof(double));
+    // the tick's V and noise exist shard by shard only: this handle re-runs them from the snapshot when asked (materialise_value)
+    noise_ready = true; value_ready = false; value_lazy = true; eps_lazy = true; injected_ready = false; epart_ready = false;
+    lazy_seed = seed; lazy_tick = tick; lazy_from_counter = false; lazy_counter_bumped = false;
+    co_last = true;
+}
+
 extern "C" {
 
 int mppi_abi_version(void) { return MPPI_ABI_VERSION; }
@@ -818,6 +943,7 @@ int mppi_default_config(mppi_config* cfg) {
     cfg->sample_offset = 0;
     cfg->model = MPPI_MODEL_DIFFDRIVE_RK4;  // MPPI(model=rk4), control/src/mppi:62
     cfg->tick_path = MPPI_TICK_AUTO;
+    cfg->co_shards = 0;   // auto
     cfg->dt = 0.0;
     cfg->sigma = 0.9;     // control/src/mppi:88
     cfg->lambda = 0.001;  // control/src/mppi:89
@@ -843,6 +969,7 @@ int mppi_create(const mppi_config* cfg, mppi_engine** out) {
     try {
         e = new mppi_engine();
         e->init(*cfg);
+        e->co_build();
         *out = e;
         return MPPI_OK;
     } catch (const EngineError& er) { g_create_error = er.msg; delete e; return er.code; }
@@ -874,6 +1001,7 @@ int mppi_get_stream(mppi_engine* h, void** hip_stream) {
 
 int mppi_set_sigma_lambda(mppi_engine* h, double sigma, double lambda) {
     API_BEGIN(h)
+    for (auto* sub__ : h->subs) if (int rc__ = mppi_set_sigma_lambda(sub__, sigma, lambda)) fail(rc__, "co-scheduled shard: %s", sub__->err.c_str());
     if (!(lambda > 0.0) || !(sigma >= 0.0)) fail(MPPI_E_INVALID, "lambda must be > 0 and sigma >= 0");
     h->settle_lazy_state();
     h->cfg.sigma = sigma; h->cfg.lambda = lambda;
@@ -886,6 +1014,7 @@ int mppi_set_sigma_lambda(mppi_engine* h, double sigma, double lambda) {
 int mppi_set_sig_matrix(mppi_engine* h, const double* sig, double lambda) {
     API_BEGIN(h)
     if (!sig) fail(MPPI_E_INVALID, "sig is NULL");
+    for (auto* sub__ : h->subs) if (int rc__ = mppi_set_sig_matrix(sub__, sig, lambda)) fail(rc__, "co-scheduled shard: %s", sub__->err.c_str());
     if (!(lambda > 0.0) || !(sig[0] >= 0.0)) fail(MPPI_E_INVALID, "lambda must be > 0 and sig[0][0] >= 0");
     for (int i = 0; i < 4; ++i) if (!std::isfinite(sig[i])) fail(MPPI_E_INVALID, "sig[%d] is not finite", i);
     h->settle_lazy_state();
@@ -899,6 +1028,7 @@ int mppi_set_sig_matrix(mppi_engine* h, const double* sig, double lambda) {
 
 int mppi_set_weights(mppi_engine* h, const double* q, const double* r, const double* p1) {
     API_BEGIN(h)
+    for (auto* sub__ : h->subs) if (int rc__ = mppi_set_weights(sub__, q, r, p1)) fail(rc__, "co-scheduled shard: %s", sub__->err.c_str());
     for (int i = 0; i < 3; ++i) if ((q && !std::isfinite(q[i])) || (p1 && !std::isfinite(p1[i]))) fail(MPPI_E_INVALID, "cost weights must be finite");
     for (int i = 0; i < 2; ++i) if (r && !std::isfinite(r[i])) fail(MPPI_E_INVALID, "cost weights must be finite");
     h->settle_lazy_state();   // the last tick's V may exist only as "re-run with these weights"
@@ -912,6 +1042,7 @@ int mppi_set_weights(mppi_engine* h, const double* q, const double* r, const dou
 
 int mppi_set_sync_timeout(mppi_engine* h, int milliseconds) {
     API_BEGIN(h)
+    for (auto* sub__ : h->subs) if (int rc__ = mppi_set_sync_timeout(sub__, milliseconds)) fail(rc__, "co-scheduled shard: %s", sub__->err.c_str());
     if (milliseconds < 0) fail(MPPI_E_INVALID, "timeout must be >= 0 (0 = wait forever)");
     h->sync_timeout_ms = milliseconds;
     API_END(h)
@@ -942,6 +1073,7 @@ int mppi_wait_for_stream(mppi_engine* h, void* other_stream) {
 int mppi_set_obstacle_grid(mppi_engine* h, const int8_t* cells, int32_t width, int32_t height, double resolution,
                            double origin_x, double origin_y, double weight) {
     API_BEGIN(h)
+    for (auto* sub__ : h->subs) if (int rc__ = mppi_set_obstacle_grid(sub__, cells, width, height, resolution, origin_x, origin_y, weight)) fail(rc__, "co-scheduled shard: %s", sub__->err.c_str());
     h->settle_lazy_state();
     h->wait_stream(__func__);
     h->destroy_graph();
@@ -964,6 +1096,7 @@ int mppi_set_obstacle_grid(mppi_engine* h, const int8_t* cells, int32_t width, i
 
 int mppi_reset(mppi_engine* h, int agent) {
     API_BEGIN(h)
+    for (auto* sub__ : h->subs) if (int rc__ = mppi_reset(sub__, agent)) fail(rc__, "co-scheduled shard: %s", sub__->err.c_str());
     const size_t row = (size_t)2 * h->cfg.horizon * sizeof(double);
     if (agent < 0) HIPCHK(hipMemsetAsync(h->d_unom, 0, row * h->cfg.n_agents, h->stream));
     else if (agent < h->cfg.n_agents) HIPCHK(hipMemsetAsync(h->d_unom + (size_t)agent * 2 * h->cfg.horizon, 0, row, h->stream));
@@ -973,6 +1106,7 @@ int mppi_reset(mppi_engine* h, int agent) {
 
 int mppi_set_shift_fill(mppi_engine* h, int agent, const double* fill) {
     API_BEGIN(h)
+    for (auto* sub__ : h->subs) if (int rc__ = mppi_set_shift_fill(sub__, agent, fill)) fail(rc__, "co-scheduled shard: %s", sub__->err.c_str());
     if (!fill || agent < 0 || agent >= h->cfg.n_agents) fail(MPPI_E_INVALID, "bad agent/fill");
     HIPCHK(hipMemcpyAsync(h->d_fill + (size_t)agent * 2, fill, 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
     h->wait_stream(__func__);
@@ -981,6 +1115,7 @@ int mppi_set_shift_fill(mppi_engine* h, int agent, const double* fill) {
 
 int mppi_set_nominal(mppi_engine* h, int agent, const double* uvec) {
     API_BEGIN(h)
+    for (auto* sub__ : h->subs) if (int rc__ = mppi_set_nominal(sub__, agent, uvec)) fail(rc__, "co-scheduled shard: %s", sub__->err.c_str());
     if (!uvec || agent < 0 || agent >= h->cfg.n_agents) fail(MPPI_E_INVALID, "bad agent/uvec");
     const size_t n = (size_t)2 * h->cfg.horizon;
     HIPCHK(hipMemcpyAsync(h->d_unom + agent * n, uvec, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -1035,6 +1170,7 @@ int mppi_download_noise(mppi_engine* h, double* eps) {
 
 int mppi_rollout(mppi_engine* h, const double* state, const double* goal, int noise_mode, uint64_t seed, uint32_t tick_id) {
     API_BEGIN(h)
+    h->co_synced = false;   // (the co-scheduled shards no longer hold this engine's nominal controls / state)
     h->check_noise_mode(noise_mode);   // refuse before the inputs are staged: nothing half-set on failure
     h->set_inputs(state, goal);
     h->run_nominal();
@@ -1080,6 +1216,7 @@ int mppi_upload_value(mppi_engine* h, const double* V) {
 
 int mppi_update(mppi_engine* h, double* uvec_out) {
     API_BEGIN(h)
+    h->co_synced = false;   // (the co-scheduled shards no longer hold this engine's nominal controls / state)
     h->run_update();
     h->run_finalize(nullptr, 1, 0);
     if (uvec_out) {
@@ -1092,6 +1229,7 @@ int mppi_update(mppi_engine* h, double* uvec_out) {
 
 int mppi_plant_step(mppi_engine* h, const double* state, double* next_state) {
     API_BEGIN(h)
+    h->co_synced = false;   // (the co-scheduled shards no longer hold this engine's nominal controls / state)
     const int A = h->cfg.n_agents;
     if (state) { h->stage_upload(state, h->d_state, (size_t)A * 3); h->have_state = true; }
     if (!h->have_state) fail(MPPI_E_STATE, "no state resident");
@@ -1110,6 +1248,7 @@ int mppi_plant_step(mppi_engine* h, const double* state, double* next_state) {
 
 int mppi_shift(mppi_engine* h) {
     API_BEGIN(h)
+    h->co_synced = false;   // (the co-scheduled shards no longer hold this engine's nominal controls / state)
     hipLaunchKernelGGL(mppi::shift_kernel, dim3(h->cfg.n_agents * 2), dim3(256), (size_t)h->cfg.horizon * sizeof(double), h->stream, h->P, h->d_unom);
     HIPCHK(hipGetLastError());
     API_END(h)
@@ -1117,6 +1256,7 @@ int mppi_shift(mppi_engine* h) {
 
 int mppi_tick_begin(mppi_engine* h, const double* state, const double* goal, int noise_mode, uint64_t seed, uint32_t tick_id) {
     API_BEGIN(h)
+    h->co_synced = false;   // (the co-scheduled shards no longer hold this engine's nominal controls / state)
     h->check_noise_mode(noise_mode);   // refuse before the inputs are staged: nothing half-set on failure
     h->set_inputs(state, goal, /*zero_copy=*/h->small_nb > 0);
     h->run_nominal();
@@ -1139,6 +1279,7 @@ int mppi_tick_finish(mppi_engine* h, const void* gathered_dev, int n_shards) {
 
 int mppi_p2p_create(mppi_engine* h, int n_ranks, int rank, void* ipc_handle_out) {
     API_BEGIN(h)
+    if (h->p2p_internal && h->co_active()) { h->wait_stream(__func__); for (auto* e__ : h->subs) e__->wait_stream(__func__); h->co_release(); }
     if (n_ranks < 1 || n_ranks > 8 || rank < 0 || rank >= n_ranks) fail(MPPI_E_INVALID, "p2p: 1 <= n_ranks <= 8, 0 <= rank < n_ranks");
     static_assert(sizeof(hipIpcMemHandle_t) <= MPPI_IPC_HANDLE_BYTES, "IPC handle does not fit the ABI's buffer");
     h->wait_stream(__func__);
@@ -1288,6 +1429,7 @@ int mppi_get_outputs(mppi_engine* h, double* next_state, double* u_applied) {
 // mppi_tick_begin with the knowledge that no exchange follows (the fused call)
 static int tick_begin_fused(mppi_engine* h, const double* state, const double* goal, int noise_mode, uint64_t seed, uint32_t tick_id) {
     API_BEGIN(h)
+    h->co_synced = false;   // (the co-scheduled shards no longer hold this engine's nominal controls / state)
     h->check_noise_mode(noise_mode);   // refuse before the inputs are staged: nothing half-set on failure
     h->set_inputs(state, goal, /*zero_copy=*/h->small_nb > 0);
     h->run_nominal();
@@ -1295,11 +1437,23 @@ static int tick_begin_fused(mppi_engine* h, const double* state, const double* g
     API_END(h)
 }
 
+// the fused tick of a handle that carries co-scheduled shards (device noise; injected noise lives in this engine's own buffer)
+static int tick_co(mppi_engine* h, const double* state, const double* goal, uint64_t seed, uint32_t tick_id) {
+    API_BEGIN(h)
+    h->co_tick(state, goal, seed, tick_id);
+    API_END(h)
+}
+
 int mppi_tick(mppi_engine* h, const double* state, const double* goal, int noise_mode, uint64_t seed, uint32_t tick_id,
               double* next_state, double* u_applied) {
-    int rc = tick_begin_fused(h, state, goal, noise_mode, seed, tick_id);
-    if (rc) return rc;
-    rc = mppi_tick_finish(h, nullptr, 1);
+    int rc;
+    if (h && h->co_active() && noise_mode == MPPI_NOISE_PHILOX) {
+        rc = tick_co(h, state, goal, seed, tick_id);
+    } else {
+        rc = tick_begin_fused(h, state, goal, noise_mode, seed, tick_id);
+        if (rc) return rc;
+        rc = mppi_tick_finish(h, nullptr, 1);
+    }
     if (rc) return rc;
     if (next_state || u_applied) rc = mppi_get_outputs(h, next_state, u_applied);
     return rc;
@@ -1307,6 +1461,7 @@ int mppi_tick(mppi_engine* h, const double* state, const double* goal, int noise
 
 int mppi_tick_graph(mppi_engine* h, uint64_t seed) {
     API_BEGIN(h)
+    h->co_synced = false;   // (the co-scheduled shards no longer hold this engine's nominal controls / state)
     if (!h->have_state || !h->have_goal) fail(MPPI_E_STATE, "tick_graph needs a resident state and goal (run one mppi_tick first)");
     if (h->stream == nullptr) fail(MPPI_E_STATE, "graph capture is not possible on the null stream");
     if (h->graph_exec && h->graph_seed != seed) h->destroy_graph();
@@ -1345,6 +1500,7 @@ int mppi_tick_graph(mppi_engine* h, uint64_t seed) {
 int mppi_synchronize(mppi_engine* h) {
     API_BEGIN(h)
     h->wait_stream(__func__);
+    for (auto* e : h->subs) e->wait_stream(__func__);
     API_END(h)
 }
 
@@ -1394,9 +1550,21 @@ int mppi_shader_clock(mppi_engine* h, double* mhz) {
     API_END(h)
 }
 
+int mppi_co_info(mppi_engine* h, int32_t* n_shards, int32_t* samples) {
+    API_BEGIN(h)
+    const int G = 1 + (int)h->subs.size();
+    if (n_shards) *n_shards = G;
+    if (samples) {
+        for (int g = 0; g < 8; ++g) samples[g] = 0;
+        samples[0] = h->co_active() ? h->co_k0 : h->cfg.samples;
+        for (int g = 1; g < G; ++g) samples[g] = h->subs[g - 1]->cfg.samples;
+    }
+    API_END(h)
+}
+
 int mppi_engine_info(mppi_engine* h, size_t* hbm_bytes, int32_t* rollout_blocks, int32_t* update_blocks) {
     API_BEGIN(h)
-    if (hbm_bytes) *hbm_bytes = h->hbm_bytes;
+    if (hbm_bytes) { *hbm_bytes = h->hbm_bytes; for (auto* e : h->subs) *hbm_bytes += e->hbm_bytes; }
     // what a tick launches: the scan kernel alone (no update kernel), or rollout + update
     const bool scan = h->small_nb > 0;
     if (rollout_blocks) *rollout_blocks = (scan ? h->small_nb : h->roll_blocks) * h->cfg.n_agents;

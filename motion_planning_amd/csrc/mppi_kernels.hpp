@@ -65,7 +65,21 @@ struct DevParams {
     // what the receding-horizon shift puts into the freed last column, [A][2] (control/src/mppi:101: uvec_init[:, 0]; zeros
     // unless mppi_set_shift_fill was called)
     const double* shift_fill;
+    // non-null: block 0 of a rollout launch leaves the pre-tick {unom [A][2][T], state [A][3], goal [A][3]} here (what the
+    // scan kernel's `prev` is): a co-scheduled tick's V exists only shard by shard, and mppi_download_value re-runs it
+    double* snap;
 };
+// pre-tick snapshot by block 0 of a rollout launch (all threads of the block call it)
+__device__ __forceinline__ void snapshot_inputs(const DevParams& P, const double* __restrict__ state, const double* __restrict__ goal,
+                                                const double* __restrict__ unom, int a) {
+    if (P.snap == nullptr || blockIdx.x != 0) return;
+    const int T = P.T;
+    for (int i = threadIdx.x; i < 2 * T; i += blockDim.x) P.snap[(size_t)a * 2 * T + i] = unom[(size_t)a * 2 * T + i];
+    if (threadIdx.x < 3) {
+        P.snap[(size_t)P.A * 2 * T + a * 3 + threadIdx.x] = state[a * 3 + threadIdx.x];
+        P.snap[(size_t)P.A * 2 * T + (size_t)P.A * 3 + a * 3 + threadIdx.x] = goal[a * 3 + threadIdx.x];
+    }
+}
 struct ClockProbe {
     unsigned long long c0 = 0, w0 = 0;
     bool on;
@@ -654,6 +668,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     double* lt = reinterpret_cast<double*>(smem_raw);  // [T][5] per-step table {un0, un1, w0, w1, cb}
     const int tid = threadIdx.x, a = blockIdx.y, T = P.T;
     ClockProbe probe(P);
+    snapshot_inputs(P, state, goal, unom, a);
     // LEAN: the node's own cost and model (rk4 diff-drive, Q = diag(q, q, 0) with q > 0, no obstacle grid).
     // Its step is written in scaled variables so that constants fold away (5 fp64 instructions fewer per step):
     //   wheel speeds times half_kd (the table holds half_kd * un, the clip bound is half_kd * u_max):

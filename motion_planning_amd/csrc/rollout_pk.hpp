@@ -91,6 +91,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
     __shared__ double fin_sh[1];                      // the nominal trajectory's final heading (unwrapped)
     const int tid = threadIdx.x, a = blockIdx.y, T = P.T;
     ClockProbe probe(P);
+    snapshot_inputs(P, state, goal, unom, a);
     const double gx = goal[a * 3 + 0], gy = goal[a * 3 + 1], gth = goal[a * 3 + 2];
     {
         // the block runs the nominal rollout itself, lanes = timesteps (as rollout_kernel does), and derives the per-step
@@ -267,7 +268,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
     };
     auto chunk = [&](int t0, int nsteps, auto full_tag) __attribute__((always_inline)) {
         const bool safe = fabsf(thf.x) <= al_guard && fabsf(thf.y) <= al_guard;
+#ifdef MPPI_PK_COUNT_ONLY   // `make asm`: the listing tools/valu_mix.py counts holds only what a chunk executes (the long series never run)
+        const bool robust = false;
+        (void)safe;
+#else
         const bool robust = !__all(safe);
+#endif
 #pragma unroll
         for (int j = 0; j < U; ++j)
             if (j < nsteps) step(t0 + j, f2{nz[j][0], nz[j][1]}, f2{nz[j][2], nz[j][3]}, full_tag, robust);

@@ -107,7 +107,7 @@ class Engine(object):
     default_tick_path = "auto"
 
     def __init__(self, samples, horizon, n_agents=1, storage="f32", device=0, sample_offset=0,
-                 dt=None, sigma=0.9, lam=0.001, model="rk4", tick_path=None, **overrides):
+                 dt=None, sigma=0.9, lam=0.001, model="rk4", tick_path=None, co_shards=None, **overrides):
         self._lib = _capi.load()
         cfg = _capi.default_config()
         cfg.n_agents, cfg.samples, cfg.horizon = int(n_agents), int(samples), int(horizon)
@@ -116,6 +116,8 @@ class Engine(object):
         cfg.sample_offset = int(sample_offset)
         cfg.model = _MODELS[model]
         cfg.tick_path = _TICK_PATHS[tick_path if tick_path is not None else self.default_tick_path]
+        # co-scheduled shards of the fused tick (include/mppi_hip.h): None = the engine's own rule, 1 = off, 2..8
+        cfg.co_shards = 0 if co_shards is None else int(co_shards)
         cfg.dt = 0.0 if dt is None else float(dt)
         cfg.sigma, cfg.lambda_ = float(sigma), float(lam)
         for key, val in overrides.items():
@@ -389,8 +391,11 @@ class Engine(object):
     def info(self):
         b, r, u = C.c_size_t(), C.c_int32(), C.c_int32()
         self._ck(self._lib.mppi_engine_info(self._h, C.byref(b), C.byref(r), C.byref(u)))
+        n, per = C.c_int32(), (C.c_int32 * 8)()
+        self._ck(self._lib.mppi_co_info(self._h, C.byref(n), per))
         return {"hbm_bytes": b.value, "rollout_blocks": r.value, "update_blocks": u.value,
-                "tick_kernels": "scan" if u.value == 0 else "lanes"}
+                "tick_kernels": "scan" if u.value == 0 else "lanes",
+                "co_shards": n.value, "co_samples": [per[g] for g in range(n.value)]}
 
 
 class _NominalView(np.ndarray):

@@ -25,7 +25,7 @@ def test_header_symbols_all_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), "libmppi_hip.so does not export %s" % n
     assert sorted(_capi.SIGNATURES) == names  # the ctypes binding covers exactly the header
-    assert lib.mppi_abi_version() == 2
+    assert lib.mppi_abi_version() == _capi.ABI_VERSION == 3
 
 
 def test_default_config_is_the_reference_node(kat):

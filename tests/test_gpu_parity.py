@@ -721,7 +721,11 @@ def _u_bound(mad, eV_rows, S, lam=LAM):
 # through the cost gradient 2 |X_nominal| ~ 44 summed over the remaining steps -- ~1e-6 typical, <= 7e-6 measured
 # (tools/pk_error_model.py), independent of how far the sample's cost is from the nominal's.  lambda / 100 = a softmax
 # weight off by at most 1 %.  (Injected-noise rollouts run the all-fp64 kernel: the relative term alone, _vtol.)
-V_ABS_PK = LAM / 100.0
+V_ABS_PK = LAM / 100.0     # at T = 50; the accumulation over the remaining steps grows like T^1.5
+
+
+def _v_abs_pk(T):
+    return V_ABS_PK * max(1.0, (T / 50.0) ** 1.5)
 
 
 def _replay_full(orc, V, eps, nxt, ua, lat, state, goal, u0, T, storage, params=None):
@@ -733,7 +737,7 @@ def _replay_full(orc, V, eps, nxt, ua, lat, state, goal, u0, T, storage, params=
     if storage == "f64":
         assert errV.max() <= 1e-9 * np.abs(Vo).max()
     else:  # per SAMPLE: 3e-7 of its own largest |V - V_nominal| + lambda / 100 (V_ABS_PK above)
-        assert (errV <= 3e-7 * np.maximum(1.0, np.abs(Vo - Vn).max(axis=0))[None, :] + V_ABS_PK).all()
+        assert (errV <= 3e-7 * np.maximum(1.0, np.abs(Vo - Vn).max(axis=0))[None, :] + _v_abs_pk(T)).all()
     eV_rows = errV.max(axis=1)
     mean, mad = _softmax_rows(Vo, eps)
     S = orc.savgol_matrix(T)

@@ -184,3 +184,68 @@ def test_large_k_single_engine_equals_four_small_ones(log2_k):
             nxt, ua = ct.tick([[0, 0, 0]] if i == 0 else None, [[0, -1, 0]] if i == 0 else None, "philox", SEED, i)
             assert np.abs(np.concatenate([nxt[0], ua[0]]) - ref[i]).max() < 1e-10, i
         assert np.abs(ct.get_nominal() - ref_lat).max() < 1e-10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,shards", [(40000, 2), (40000, 3), (450000, 2)])
+def test_co_scheduled_shards_behind_one_handle(K, shards):
+    """mppi_config.co_shards: the SAME calls on ONE handle (mppi_tick, then the two-stage calls) with the fused tick split
+    over co-scheduled engines inside it.  Closed loop of six device-noise ticks equals the unsplit engine to 1e-10 (sample
+    ids are global, the tuple merge is exact); V and the noise downloaded after such a tick -- re-run from the tick's
+    snapshot over all samples -- are bit for bit the unsplit engine's; calls that bypass the group (mppi_update on the
+    resident V, a split tick_begin / tick_finish) leave the shards behind and the next fused tick brings them back."""
+    from motion_planning_amd.mppi import Engine
+    T = 50
+    u0 = np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
+    goal = [[0.0, -1.0, 0.0]]
+    outs = {}
+    for co in (1, shards):
+        with Engine(K, T, storage="f32", tick_path="lanes", co_shards=co) as e:
+            info = e.info()
+            assert info["co_shards"] == co and sum(info["co_samples"]) == K and min(info["co_samples"]) > 0
+            e.set_nominal(u0)
+            st = np.zeros((1, 3))
+            traj = []
+            for i in range(6):
+                st, ua = e.tick(st if i % 2 == 0 else None, goal if i == 0 else None, noise="philox", seed=5, tick_id=i)
+                traj.append(np.concatenate([st[0], ua[0]]))
+            V, eps = e.download_value()[0], e.download_noise()[0]   # after a co-scheduled tick: re-run from the snapshot
+            lat = e.get_nominal()
+            # a call that bypasses the group, then the group again
+            u_upd = e.update()[0]                                    # update_action on the resident V / noise of tick 5
+            e.shift()
+            st2, ua2 = e.tick(None, None, noise="philox", seed=5, tick_id=6)
+            e.tick_begin(None, None, noise="philox", seed=5, tick_id=7)      # the split path always runs unsplit
+            e.tick_finish()
+            st3, ua3 = e.get_outputs()
+            st4, ua4 = e.tick(None, None, noise="philox", seed=5, tick_id=8)
+            outs[co] = (np.array(traj), V, eps, lat, u_upd, np.concatenate([st2[0], ua2[0], st3[0], ua3[0], st4[0], ua4[0]]))
+    a, b = outs[1], outs[shards]
+    assert np.abs(a[0] - b[0]).max() < 1e-10
+    assert np.array_equal(a[2], b[2])                                # the same noise, bit for bit
+    assert np.abs(a[1] - b[1]).max() <= 1e-5                         # V of tick 5: its inputs agree to 1e-10 only
+    assert np.abs(a[3] - b[3]).max() < 1e-10 and np.abs(a[4] - b[4]).max() < 1e-9
+    assert np.abs(a[5] - b[5]).max() < 1e-9
+
+
+@pytest.mark.gpu
+def test_co_scheduled_value_is_bit_identical_to_the_unsplit_engine():
+    """First tick from identical inputs: the V a co-scheduled handle hands back (re-run over all samples from the tick's
+    snapshot) equals the unsplit engine's bit for bit, on both rollout kernels (450 000 samples run the mixed-precision
+    one), and the AUTO rule splits config 4 in two."""
+    from motion_planning_amd.mppi import Engine
+    T = 50
+    u0 = np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
+    for K in (40000, 450000):
+        got = []
+        for co in (1, 2):
+            with Engine(K, T, storage="f32", tick_path="lanes", co_shards=co) as e:
+                e.set_nominal(u0)
+                nxt, ua = e.tick([0, 0, 0], [0, -1, 0], noise="philox", seed=2, tick_id=3)
+                got.append((e.download_value()[0], e.download_noise()[0], nxt, ua))
+        assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+        assert np.abs(got[0][2] - got[1][2]).max() < 1e-12 and np.abs(got[0][3] - got[1][3]).max() < 1e-10
+    with Engine(1000000, T) as e:
+        assert e.info()["co_shards"] == 2
+    with Engine(100000, 100) as e:
+        assert e.info()["co_shards"] == 1

@@ -1,0 +1,14 @@
+#!/bin/bash
+# profiles/rN_valu_mix.json: the static VALU mix of both tick-path rollout kernels (CPU only: hipcc cross-compiles)
+set -e
+R=$(cd "$(dirname "$0")/.." && pwd); N=${1:-r3}
+make -C $R/motion_planning_amd/csrc asm > /dev/null
+python3 - <<PY
+import json, subprocess, sys
+R="$R"
+def mix(*a): return json.loads(subprocess.check_output([sys.executable, R+"/tools/valu_mix.py", *a]))
+out={"rollout_kernel": mix(),
+     "rollout_pk_kernel": mix("--asm", R+"/build/asm/rollout_pk-hip-amdgcn-amd-amdhsa-gfx950.s", "--symbol", "rollout_pk_kernelILi1ELi4E", "--steps-per-iter", "12")}
+json.dump(out, open(R+"/profiles/$N"+"_valu_mix.json","w"), indent=1, sort_keys=True)
+for k,v in out.items(): print(k, "VALU/sample-step %.1f, issue cycles/sample-step %.1f" % (v["valu_per_step"], v["issue_cycles_per_step"]))
+PY

@@ -15,8 +15,10 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# cycles per wave64 instruction per SIMD (tools/ubench.hip on MI355X, profiles/README.md)
-COST = {"f64": 3.9, "trans_f32": 6.4, "mad_u64_u32": 3.7, "pk_f32": 3.6, "cvt_f64": 3.3, "vop3_f32": 3.0, "other_valu": 2.0}
+# cycles per wave64 instruction per SIMD at the MEASURED shader clock (tools/ubench.hip reads s_memtime against
+# s_memrealtime around every microbenchmark; profiles/r3_ubench.txt, 4 waves per SIMD).  Round 2's table was the same
+# measurements scaled by an ASSUMED 1.9 GHz and read ~10 % low (fp64 3.9 instead of 4.35).
+COST = {"f64": 4.35, "trans_f32": 8.2, "mad_u64_u32": 4.33, "pk_f32": 4.25, "cvt_f64": 4.2, "half_rate_f32": 4.25, "other_valu": 2.45}
 
 
 def classify(op):
@@ -32,8 +34,9 @@ def classify(op):
         return "trans_f32"
     if op.startswith(("v_mad_u64_u32", "v_mad_i64_i32")):
         return "mad_u64_u32"
-    if re.match(r"v_(fma|mad|med3|min3|max3|fmac)_f32", op) or op.endswith("_e64") and "_f32" in op:
-        return "vop3_f32"
+    # measured at ~4.2 cycles although single-precision: v_med3 / v_max / v_min, everything with a DPP operand, permlane swaps
+    if re.match(r"v_(med3|min3|max3|max|min)_f32", op) or op.endswith("_dpp") or op.startswith("v_permlane"):
+        return "half_rate_f32"
     return "other_valu"
 
 
@@ -42,11 +45,11 @@ def main():
     ap.add_argument("--asm", default=os.path.join(ROOT, "build", "asm", "rollout_f32_n4-hip-amdgcn-amd-amdhsa-gfx950.s"))
     # float storage, NTERM 4, Philox, eps not stored, inline nominal (one wave, T <= 64), rk4 model, the node's cost
     ap.add_argument("--symbol", default="rollout_kernelIfLi4ELb1ELb0ELi1ELi0ELb0E")
+    # sample-steps per loop iteration: 6 for rollout_kernel, 12 for rollout_pk_kernel (six steps of two samples per lane)
     ap.add_argument("--steps-per-iter", type=int, default=6)
     args = ap.parse_args()
     lines = open(args.asm).read().splitlines()
-    start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and args.symbol in l and l.rstrip().split(":")[0].endswith(args.symbol[-6:] + "EvNS_9DevParamsEPKdS3_PdPT_S6_S6_mjPKjiiS6_S3_S4_") or
-                 (l.startswith("_Z") and args.symbol in l.split(":")[0]))
+    start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and args.symbol in l.split(":")[0])
     end = next(i for i in range(start + 1, len(lines)) if lines[i].startswith(".Lfunc_end"))
     # loops: a backward branch to a label defined earlier in the function; body = everything in between
     # (a chunk of the rollout loop spans several compiler basic blocks).  The largest one is the full-chunk loop.
