@@ -440,8 +440,9 @@ def main():
     per_rank = None
     if world > 1:
         objs = [None] * world
-        dist.all_gather_object(objs, {"rank": rank, "kernels_us": kernels_us, "exchange_us": exchange_us,
-                                      "samples": int(eng.K)})
+        dist.all_gather_object(objs, {"rank": rank, "device": local_rank, "kernels_us": kernels_us, "exchange_us": exchange_us,
+                                      "samples": int(eng.K), "exchange": getattr(ticker, "exchange_report", None),
+                                      "shader_clock_mhz": clock_mhz, "co_shards": info.get("co_shards", 1)})
         per_rank = objs
 
     # All-fp64 line next to the fp32-storage one (the reference is float64 end to end): N = 1, config 4 only.
@@ -592,6 +593,13 @@ def main():
                             ("  This handle runs its fused tick as %d co-scheduled engines: the launches timed here are shard 0's "
                              "(%d samples), overlapping the other shard's kernels; `one_engine` holds the same kernel undisturbed."
                              % (co_n, k_launch) if co_n > 1 else ""))
+        if co_n > 1:
+            roofline["concurrent_launches"] = co_n
+            roofline["frac_all_shards_upper"] = roofline["frac"] * A * K_local / (A * k_launch)
+            roofline["concurrency_note"] = ("each shard's rollout launch covers %d of the %d samples and runs NEXT TO the other shards' launches "
+                                            "(own streams): `frac` is one launch's algorithmic bytes over its own duration, as SURVEY 8(d) defines it; "
+                                            "`frac_all_shards_upper` = all shards' bytes over that duration (exact if they overlap fully); "
+                                            "`one_engine.roofline` is the same kernel with the GPU to itself" % (A * k_launch, A * K_local))
         roofline["tick_level"] = {"algorithmic_bytes": tick_bytes, "achieved": tick_bytes / tick_s / 1e9,
                                   "frac": tick_bytes / tick_s / 1e9 / HBM_PEAK_GBS,
                                   "note": "24 B/state-step x all samples of the tick / tick time: both kernels (and, co-scheduled, both engines) together"}

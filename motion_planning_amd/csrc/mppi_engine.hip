@@ -108,6 +108,9 @@ struct mppi_engine {
     bool store_eps_always = false;  // MPPI_STORE_EPS=1: the tick path writes eps like mppi_rollout does
     int pk_waves = 4;
     long pk_min_samples = 400000;
+    int force_pk = -1;             // >= 0: the size rule is overridden (the re-run of a co-scheduled tick takes the shards' kernel)
+    bool last_rollout_pk = false;  // which kernel the last rollout launch was
+    bool co_shards_pk = false;     // ... and the one the shards of the last co-scheduled tick ran
     bool use_pk = true;             // MPPI_ROLLOUT_PK=0: keep the all-fp64 rollout kernel on the tick path (same-box A/B measurements)
     double* d_tc = nullptr;  // [A][T][8]
     double* d_base = nullptr;
@@ -428,8 +431,11 @@ struct mppi_engine {
         // ... and enough waves: it halves their number and doubles their length, which only pays when every SIMD still gets
         // several (same-box A/B at T = 50, rollout_kernel vs this one: 10^6 samples 106.8 vs 101.8 us, 750 000 83.0 vs 79.4,
         // 500 000 58.2 vs 56.9, 375 000 47.1 vs 46.3, 250 000 34.5 vs 36.1, 125 000 24.6 vs 28.3)
-        if (use_pk && !f64() && ph && !store && a.inline_nominal && !a.general && k0 == 0 && k1 == cfg.samples &&
-            (long)cfg.n_agents * cfg.samples >= pk_min_samples && mppi::rollout_pk_applies(P.kth, P.dt, P.sigma, cfg.horizon)) {
+        const bool pk_size = force_pk >= 0 ? force_pk != 0 : (long)cfg.n_agents * cfg.samples >= pk_min_samples;
+        const bool pk = use_pk && !f64() && ph && !store && a.inline_nominal && !a.general && k0 == 0 && k1 == cfg.samples && pk_size &&
+                        mppi::rollout_pk_applies(P.kth, P.dt, P.sigma, cfg.horizon);
+        last_rollout_pk = pk;
+        if (pk) {
             mppi::RolloutPkArgs b{};
             b.P = P; b.stream = st; b.inline_nominal = a.inline_nominal; b.seed = seed; b.tick = tick; b.tick_ptr = tick_ptr;
             b.state = a.state; b.goal = a.goal; b.unom = a.unom; b.tc = d_tc; b.base = d_base;
@@ -480,13 +486,14 @@ struct mppi_engine {
         try {
             // a co-scheduled tick's shards ran the tick-path kernel (noise not stored): the re-run takes the same kernel over
             // all samples -- per sample bit-identical to what the shards computed -- and the noise is re-drawn next to it
+            if (co_last) force_pk = co_shards_pk ? 1 : 0;
             launch_rollout(stream, 0, cfg.samples, ph, !(co_last && ph), lazy_seed, tick, nullptr);
             if (co_last && ph) launch_regen(stream, lazy_seed, tick, nullptr);
         } catch (...) {
-            ro_unom = ro_state = ro_goal = nullptr;
+            ro_unom = ro_state = ro_goal = nullptr; force_pk = -1;
             throw;
         }
-        ro_unom = ro_state = ro_goal = nullptr;
+        ro_unom = ro_state = ro_goal = nullptr; force_pk = -1;
         co_last = false;
         if (ph) { eps_lazy = false; injected_ready = true; }
         value_lazy = false; value_ready = true; epart_ready = true;
@@ -865,7 +872,8 @@ void mppi_engine::co_build() {
     const bool wanted = G > 1;
     // AUTO: two shards where the pair measured faster than the one engine (config 4: +7-9 % rollouts/s; nothing below
     // ~5e5 samples), on the lane-per-sample path only
-    if (G == 0) G = (lanes && (long)cfg.n_agents * cfg.samples >= 500000 && cfg.samples >= 4 * CH) ? 2 : 1;
+    // (and while a second set of buffers is small change against the 288 GB: the subs hold another half of this engine's)
+    if (G == 0) G = (lanes && (long)cfg.n_agents * cfg.samples >= 500000 && cfg.samples >= 4 * CH && hbm_bytes < ((size_t)48 << 30)) ? 2 : 1;
     if (G <= 1) return;
     if (!lanes || cfg.samples < G * CH) {
         if (wanted) fail(MPPI_E_INVALID, "co_shards = %d needs the lane-per-sample tick path and at least %d samples per shard", G, CH);
@@ -914,8 +922,13 @@ void mppi_engine::co_tick(const double* state, const double* goal, uint64_t seed
         ShardView view(this);
         run_nominal();
         run_pipeline(MPPI_NOISE_PHILOX, seed, tick, nullptr, /*skip_small_merge=*/true);   // the publish kernel merges a handful of tuples itself
+        co_shards_pk = last_rollout_pk;
     }
-    for (auto* e : subs) { e->run_nominal(); e->run_pipeline(MPPI_NOISE_PHILOX, seed, tick, nullptr, /*skip_small_merge=*/true); }
+    for (auto* e : subs) {   // every shard takes shard 0's kernel (sizes differ by a chunk at most; the re-run must match them all)
+        e->force_pk = co_shards_pk ? 1 : 0;
+        e->run_nominal();
+        e->run_pipeline(MPPI_NOISE_PHILOX, seed, tick, nullptr, /*skip_small_merge=*/true);
+    }
     // one thread drives all engines: every publish is enqueued before any finalize that waits for it
     p2p_wait = p2p_publish(merge_skipped ? nullptr : d_merged);
     for (auto* e : subs) e->p2p_wait = e->p2p_publish(e->merge_skipped ? nullptr : e->d_merged);

@@ -1070,19 +1070,23 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
 
     // pass 2: weights relative to the block minimum; eps only where the weight is representable
     const R scale = (R)(P.inv_lambda * 1.4426950408889634);  // log2(e) / lambda
-    const R cand = (R)(sizeof(S) == 4 ? -80.0 : -100.0);     // log2 of the smallest weight that is kept
+    // log2 of the smallest weight whose noise is fetched.  D sums EVERY weight; a weight below the cut only misses its
+    // e * eps in N.  fp32 mode: 2^-32 -- the sums are fp32 (the block minimum carries e = 1, so a dropped term is below
+    // 4e-9 of the sum's own rounding unit even before the weights' exponential thinning; at K = 10^6 parked at the goal the
+    // dropped mass is ~3e-13 of D); fp64 mode keeps everything down to 2^-100.
+    const R cand = (R)(sizeof(S) == 4 ? -32.0 : -100.0);
     R D = 0, N0 = 0, N1 = 0;
-    // REGEN (eps was never stored): a sample that carries weight needs its noise re-drawn -- one Philox call.
-    // Far from the goal a row has a handful of such samples; parked AT the goal 1-5 % of a row carry weight, and a
-    // re-draw inside this loop would run (wave-uniformly) for almost every one of the 32 values a lane walks through.
-    // So the loop only NOTES its weighted samples -- (index, weight) in the thread's own LDS slots, no atomics, no
-    // cross-lane traffic -- and the re-draws happen afterwards, once per slot: max-per-lane (~6) Philox rounds per
-    // wave instead of 32.  A lane that runs out of slots (sigma = 0, or every sample on the same cost) walks its
-    // values again from L2 in a rolled loop and re-draws the ones beyond its slots (rare, kept out of the hot loop).
-    constexpr int kSlots = 8;
-    __shared__ uint32_t q_k[REGEN ? kSlots : 1][256];
-    __shared__ R q_e[REGEN ? kSlots : 1][256];
-    int qn = 0;
+    // REGEN (eps was never stored): a sample that carries weight needs its noise re-drawn -- one Philox call.  Far from the
+    // goal a row has a handful of such samples; parked AT the goal a few per cent of a row carry weight.  The loop only
+    // NOTES them -- (index, weight) appended to ONE queue per block (a wave-aggregated LDS counter: one atomic per wave and
+    // value position that has any) -- and the re-draws happen afterwards, spread evenly over the block's 256 lanes:
+    // ceil(candidates / 256) Philox rounds per wave.  (Round 2 kept eight slots per lane: the rounds were the busiest
+    // lane's count, ~6 where the average lane had 2.)  A block whose queue overflows (sigma = 0, a flat cost: every sample
+    // carries weight) walks its values again from L2 and re-draws each candidate in place.
+    constexpr int kQueue = 2048;
+    __shared__ uint32_t q_k[REGEN ? kQueue : 1];
+    __shared__ R q_e[REGEN ? kQueue : 1];
+    __shared__ int q_n;
     const uint32_t tick_now = REGEN ? (tick_ptr ? *tick_ptr : tick_arg) : 0u;
     auto redraw = [&](uint32_t kk, R e) {
         float f0, f1;  // the same Philox counter the rollout used for this (sample, step)
@@ -1091,6 +1095,10 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
         N0 = fma(e, (R)(S)f0, N0);
         N1 = fma(e, (R)(S)f1, N1);
     };
+    if (REGEN) {
+        if (tid == 0) q_n = 0;
+        __syncthreads();
+    }
 #pragma unroll
     for (int j = 0; j < kUpdNV; ++j) {
         const int k = k_begin + (j * 256 + tid) * VEC;
@@ -1099,31 +1107,33 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
             const R x = (M - v[j][i]) * scale;  // <= 0; -inf for the padding
             const R e = Exp2<R>::f(x);
             D += e;
-            if (x > cand) {  // wave-uniformly skipped for almost every vector while the robot is far from its goal
-                if (REGEN) {
-                    if (qn < kSlots) { q_k[qn][tid] = (uint32_t)(k + i); q_e[qn][tid] = e; }
-                    ++qn;
-                } else {
-                    N0 = fma(e, (R)e0_row[k + i], N0);
-                    N1 = fma(e, (R)e1_row[k + i], N1);
+            if (REGEN) {
+                const unsigned long long bal = __ballot(x > cand);
+                if (bal) {  // (uniform) skipped for almost every value while the robot is far from its goal
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&q_n, __popcll(bal));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                    if (x > cand && pos < kQueue) { q_k[pos] = (uint32_t)(k + i); q_e[pos] = e; }
                 }
+            } else if (x > cand) {
+                N0 = fma(e, (R)e0_row[k + i], N0);
+                N1 = fma(e, (R)e1_row[k + i], N1);
             }
         }
     }
     if (REGEN) {
-#pragma unroll 1
-        for (int j = 0; j < kSlots; ++j) {
-            if (!__any(j < qn)) break;  // (uniform)
-            if (j < qn) redraw(q_k[j][tid], q_e[j][tid]);
-        }
-        if (__any(qn > kSlots)) {  // (uniform, rare) same walk, same order: skip what the slots already covered
-            int seen = 0;
+        __syncthreads();
+        const int total = q_n;  // (uniform)
+        if (total <= kQueue) {
+            for (int q = tid; q < total; q += 256) redraw(q_k[q], q_e[q]);
+        } else {  // (rare) every candidate of the lane's own values, in place
 #pragma unroll 1
             for (int idx = 0; idx < kUpdNV * VEC; ++idx) {
                 const int k = k_begin + ((idx / VEC) * 256 + tid) * VEC + idx % VEC;
-                if (k < k_end && qn > kSlots) {
+                if (k < k_end) {
                     const R x = (M - (s_row[k] - v_row[k])) * scale;
-                    if (x > cand && ++seen > kSlots) redraw((uint32_t)k, Exp2<R>::f(x));
+                    if (x > cand) redraw((uint32_t)k, Exp2<R>::f(x));
                 }
             }
         }

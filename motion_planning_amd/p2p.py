@@ -56,46 +56,74 @@ def _probe(dist, group, rank, world, local_rank, timeout_s=60.0):
     return all(_all_gather(dist, group, world, bool(ok)))
 
 
-def setup(engine, group, rank, world, local_rank, required=False, probe=None, selftest_rounds=8):
+def setup(engine, group, rank, world, local_rank, required=False, probe=None, selftest_rounds=8, report=None):
+    """Returns True when every rank has switched to the p2p exchange.  `report` (a dict, optional) is filled with what
+    happened on THIS rank, step by step -- bench.py prints it per rank, so that a reader of one JSON line can tell why a
+    rank fell back to RCCL: {"probe", "create", "connect", "selftest"} -> "ok" | "skipped" | "failed: <reason>" | "not reached",
+    "selftest_round_trip_us", "all_ranks_ok", "peer_reasons"."""
+    import time
     import torch.distributed as dist
+    rep = report if report is not None else {}
+    rep.update({"probe": "not reached", "create": "not reached", "connect": "not reached", "selftest": "not reached",
+                "selftest_round_trip_us": None, "all_ranks_ok": False, "peer_reasons": None})
     if world < 2 or world > 8:
+        rep["probe"] = "failed: the p2p exchange serves 2..8 ranks on one node (world = %d)" % world
         if required:
             raise RuntimeError("the p2p exchange serves 2..8 ranks on one node")
         return False
     if probe is None:
         probe = dist.get_backend(group) == "nccl"     # real multi-GPU run: guard the first contact
-    if probe and not _probe(dist, group, rank, world, local_rank):
-        if required:
-            raise RuntimeError("p2p probe failed on at least one rank")
-        return False
+    if probe:
+        ok_probe = _probe(dist, group, rank, world, local_rank)
+        rep["probe"] = "ok" if ok_probe else "failed: a rank's child process did not complete the handle exchange + self-test"
+        if not ok_probe:
+            if required:
+                raise RuntimeError("p2p probe failed on at least one rank")
+            return False
+    else:
+        rep["probe"] = "skipped"
     ok, handle, why = True, None, []
     try:
         handle = engine.p2p_create(world, rank)
+        rep["create"] = "ok"
     except Exception as e:
         ok = False
         why.append("create: %s" % e)
+        rep["create"] = "failed: %s" % e
     handles = _all_gather(dist, group, world, handle)
     ok = ok and all(h is not None for h in handles)
     if ok:
         try:
             engine.p2p_connect(handles=handles)
+            rep["connect"] = "ok"
         except Exception as e:
             ok = False
             why.append("connect: %s" % e)
+            rep["connect"] = "failed: %s" % e
+    elif rep["create"] == "ok":
+        rep["connect"] = "not reached: a peer has no mailbox"
     ok = all(_all_gather(dist, group, world, ok))
     if ok:
         try:
+            t0 = time.perf_counter()
             engine.p2p_selftest(selftest_rounds)      # collective: every rank publishes to every rank
+            rep["selftest"] = "ok"
+            rep["selftest_round_trip_us"] = 1e6 * (time.perf_counter() - t0) / max(selftest_rounds, 1)
         except Exception as e:
             ok = False
             why.append("selftest: %s" % e)
+            rep["selftest"] = "failed: %s" % e
         ok = all(_all_gather(dist, group, world, ok))
+    elif rep["connect"] == "ok":
+        rep["selftest"] = "not reached: a peer failed to connect"
+    rep["all_ranks_ok"] = bool(ok)
     if not ok:
         try:
             engine.p2p_destroy()
         except Exception:
             pass
         reasons = _all_gather(dist, group, world, "; ".join(why))
+        rep["peer_reasons"] = reasons
         if required:
             raise RuntimeError("p2p exchange could not be established on every rank: %s" % reasons)
         if rank == 0 and os.environ.get("MPPI_P2P_VERBOSE"):

@@ -167,14 +167,18 @@ def make_hip_ticker(samples_total, horizon, n_agents=1, storage="f32", local_ran
     eng = Engine(hi - lo, horizon, n_agents=n_agents, storage=storage, device=local_rank,
                  sample_offset=lo, **engine_kw)
     kind = "none" if not in_group else "rccl"
+    report = {"requested": exchange}
     if in_group and world > 1 and exchange in ("auto", "p2p"):
         from . import p2p
-        if p2p.setup(eng, group, rank, world, local_rank, required=(exchange == "p2p")):
+        if p2p.setup(eng, group, rank, world, local_rank, required=(exchange == "p2p"), report=report):
             kind = "p2p"
     # only the RCCL collective has to order with torch's stream; a single process and the p2p exchange keep the
     # engine's own stream (which is also what hipGraph capture needs -- the null stream cannot be captured)
     shard = HipShard(eng, torch.device("cuda", local_rank), use_torch_stream=(kind == "rccl"))
-    return ShardedTicker(shard, group, exchange=kind), eng
+    ticker = ShardedTicker(shard, group, exchange=kind)
+    report["ran"] = ticker.exchange
+    ticker.exchange_report = report     # what the set-up of the exchange did on this rank (bench.py prints it per rank)
+    return ticker, eng
 
 
 def make_replica_ticker(samples, horizon, n_agents, storage="f32", local_rank=0, **engine_kw):
@@ -269,7 +273,7 @@ def make_co_scheduled_ticker(samples_total, horizon, n_shards=2, n_agents=1, sto
     try:
         for g in range(n_shards):
             engines.append(Engine(cuts[g + 1] - cuts[g], horizon, n_agents=n_agents, storage=storage, device=device,
-                                  sample_offset=cuts[g], **engine_kw))
+                                  sample_offset=cuts[g], co_shards=1, **engine_kw))
         return CoScheduledTicker(engines)
     except Exception:
         for e in engines:

@@ -187,7 +187,7 @@ def test_large_k_single_engine_equals_four_small_ones(log2_k):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("K,shards", [(40000, 2), (40000, 3), (450000, 2)])
+@pytest.mark.parametrize("K,shards", [(40000, 2), (40000, 3), (820000, 2)])
 def test_co_scheduled_shards_behind_one_handle(K, shards):
     """mppi_config.co_shards: the SAME calls on ONE handle (mppi_tick, then the two-stage calls) with the fused tick split
     over co-scheduled engines inside it.  Closed loop of six device-noise ticks equals the unsplit engine to 1e-10 (sample
@@ -231,12 +231,12 @@ def test_co_scheduled_shards_behind_one_handle(K, shards):
 @pytest.mark.gpu
 def test_co_scheduled_value_is_bit_identical_to_the_unsplit_engine():
     """First tick from identical inputs: the V a co-scheduled handle hands back (re-run over all samples from the tick's
-    snapshot) equals the unsplit engine's bit for bit, on both rollout kernels (450 000 samples run the mixed-precision
-    one), and the AUTO rule splits config 4 in two."""
+    snapshot, with the kernel the shards ran) equals the unsplit engine's bit for bit, on both rollout kernels (820 000
+    samples: shards of >= 400 000, the mixed-precision one), and the AUTO rule splits config 4 in two."""
     from motion_planning_amd.mppi import Engine
     T = 50
     u0 = np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
-    for K in (40000, 450000):
+    for K in (40000, 820000):
         got = []
         for co in (1, 2):
             with Engine(K, T, storage="f32", tick_path="lanes", co_shards=co) as e:

@@ -174,8 +174,9 @@ def _p2p_setup_worker(rank, world, port, fail_rank, fail_at, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         eng = _FakeP2PEngine(rank, fail_at if rank == fail_rank else None)
-        ok = p2p.setup(eng, None, rank, world, 0, required=False, probe=False)
-        q.put((rank, ok, eng.calls))
+        rep = {}
+        ok = p2p.setup(eng, None, rank, world, 0, required=False, probe=False, report=rep)
+        q.put((rank, ok, eng.calls, rep))
     finally:
         dist.destroy_process_group()
 
@@ -192,16 +193,23 @@ def test_p2p_setup_is_all_or_nothing(fail_at):
     procs = [ctx.Process(target=_p2p_setup_worker, args=(r, 2, port, 1, fail_at, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in procs)
+    res = sorted((q.get(timeout=120) for _ in procs), key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, ok, calls in res:
+    for rank, ok, calls, rep in res:
         assert ok == (fail_at is None), (rank, ok, calls)
+        assert rep["all_ranks_ok"] == ok and rep["probe"] == "skipped"
         if fail_at is None:
             assert calls == ["create", "connect", "selftest"]
+            assert (rep["create"], rep["connect"], rep["selftest"]) == ("ok", "ok", "ok") and rep["selftest_round_trip_us"] >= 0
         else:
-            assert calls[-1] == "destroy" and "selftest" not in calls[:-1] or fail_at == "selftest"
+            assert calls[-1] == "destroy"                       # the mailbox is torn down on EVERY rank, also after a failed self-test
+            assert fail_at == "selftest" or "selftest" not in calls[:-1]
+            # the report says, on the failing rank, which step failed and why; on every rank, what its peers reported
+            if rank == 1:
+                assert rep[fail_at].startswith("failed: "), rep
+            assert any(fail_at in (r or "") for r in rep["peer_reasons"]), rep
 
 
 def test_co_scheduled_cuts_partition_the_samples():
