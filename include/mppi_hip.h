@@ -109,7 +109,7 @@ typedef struct mppi_engine mppi_engine;
 typedef struct mppi_config {
     int32_t n_agents;      /* A >= 1 independent controllers batched in one engine           */
     int32_t samples;       /* K >= 1 rollouts per agent owned by this engine (MPPI samples=)  */
-    int32_t horizon;       /* T >= 5, T-1 odd (Savitzky-Golay window, control/src/mppi:202)   */
+    int32_t horizon;       /* T >= 5 (Savitzky-Golay window T-1 > 3, control/src/mppi:202; odd T as scipy >= 1.x) */
     int32_t storage;       /* MPPI_STORE_F32 | MPPI_STORE_F64                                 */
     int32_t device;        /* HIP device ordinal                                              */
     uint32_t sample_offset;/* global index of local sample 0                                  */

@@ -632,8 +632,8 @@ struct mppi_engine {
         Scope sc(this, MPPI_KERNEL_FINALIZE);
         const int T = cfg.horizon;
         size_t lds = (size_t)4 * T * sizeof(double);
-        if (lds + (size_t)4 * (T - 1) * sizeof(double) + 1024 <= 64 * 1024) {  // the filter's basis fits next to the control rows: stage it
-            lds += (size_t)4 * (T - 1) * sizeof(double);
+        if (lds + (size_t)(4 * (T - 1) + 4) * sizeof(double) + 1024 <= 64 * 1024) {  // the filter's basis fits next to the control rows: stage it
+            lds += (size_t)(4 * (T - 1) + 4) * sizeof(double);
             flags |= 8;
         }
         // 16 lanes per row for the tuple merge, one wave per filter coefficient (16 of them): T = 50 -> 1024 threads; at least 256
@@ -686,9 +686,9 @@ struct mppi_engine {
         if (const char* v = std::getenv("MPPI_SYNC_TIMEOUT_MS")) sync_timeout_ms = std::atoi(v);
         if (cfg.n_agents < 1 || cfg.samples < 1) fail(MPPI_E_INVALID, "n_agents and samples must be >= 1");
         if (cfg.n_agents > 65535) fail(MPPI_E_INVALID, "n_agents %d: agents are a grid dimension (<= 65535)", cfg.n_agents);
-        if (cfg.horizon < 5 || ((cfg.horizon - 1) % 2) == 0)
-            fail(MPPI_E_INVALID, "horizon=%d: the Savitzky-Golay window horizon-1 must be odd and > 3 "
-                 "(scipy.signal.savgol_filter at control/src/mppi:202)", cfg.horizon);
+        if (cfg.horizon < 5)
+            fail(MPPI_E_INVALID, "horizon=%d: the Savitzky-Golay window horizon-1 must be > 3 "
+                 "(scipy.signal.savgol_filter(u, horizon - 1, 3) at control/src/mppi:202)", cfg.horizon);
         if ((size_t)cfg.horizon * 40 + 128 > 64 * 1024)   // + the rollout kernel's few static LDS words
             fail(MPPI_E_INVALID, "horizon %d: the per-step table (40 B/step) must fit 64 KB of LDS (horizon <= 1634)", cfg.horizon);
         if (cfg.storage != MPPI_STORE_F32 && cfg.storage != MPPI_STORE_F64) fail(MPPI_E_INVALID, "bad storage %d", cfg.storage);
@@ -784,7 +784,7 @@ struct mppi_engine {
         d_part = dev_alloc<double>((size_t)A * T * std::max(NCH, small_nb) * mppi::kTupleW, hbm_bytes);
         d_prev = dev_alloc<double>((size_t)A * (2 * T + 6), hbm_bytes);
         d_merged = dev_alloc<double>((size_t)A * T * mppi::kTupleW, hbm_bytes);
-        d_S = dev_alloc<double>((size_t)4 * (T - 1), hbm_bytes);   // the Savitzky-Golay operator's orthonormal basis [4][T-1]
+        d_S = dev_alloc<double>((size_t)4 * (T - 1) + 4, hbm_bytes);   // the Savitzky-Golay operator's orthonormal basis [4][T-1] (+ its four values at the even window's half-integer position)
         d_out = dev_alloc<double>((size_t)A * 8, hbm_bytes);
         d_tick = dev_alloc<uint32_t>(1, hbm_bytes);
         d_clk = dev_alloc<unsigned long long>(2, hbm_bytes);

@@ -1071,10 +1071,11 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
     // pass 2: weights relative to the block minimum; eps only where the weight is representable
     const R scale = (R)(P.inv_lambda * 1.4426950408889634);  // log2(e) / lambda
     // log2 of the smallest weight whose noise is fetched.  D sums EVERY weight; a weight below the cut only misses its
-    // e * eps in N.  fp32 mode: 2^-32 -- the sums are fp32 (the block minimum carries e = 1, so a dropped term is below
-    // 4e-9 of the sum's own rounding unit even before the weights' exponential thinning; at K = 10^6 parked at the goal the
-    // dropped mass is ~3e-13 of D); fp64 mode keeps everything down to 2^-100.
-    const R cand = (R)(sizeof(S) == 4 ? -32.0 : -100.0);
+    // e * eps in N.  fp32 mode: 2^-40 -- the sums are fp32 and the block minimum carries e = 1, so a dropped term is below
+    // 1e-12 of D, five orders under the sum's own rounding unit (at 2^-32 two shardings of the same samples still differed by
+    // a few 1e-10 in u -- the cut is relative to the CHUNK's minimum -- which the split-invariance tests see; round 2 cut at
+    // 2^-80 and fetched twice as many); fp64 mode keeps everything down to 2^-100.
+    const R cand = (R)(sizeof(S) == 4 ? -40.0 : -100.0);
     R D = 0, N0 = 0, N1 = 0;
     // REGEN (eps was never stored): a sample that carries weight needs its noise re-drawn -- one Philox call.  Far from the
     // goal a row has a handful of such samples; parked AT the goal a few per cent of a row carry weight.  The loop only
@@ -1533,7 +1534,7 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
     }
     double* un = reinterpret_cast<double*>(smem_raw);  // [2][T] updated + clipped
     double* uf = un + 2 * P.T;                          // [2][T] filtered + clipped
-    double* Sl = uf + 2 * P.T;                          // [4][T-1] staged copy of the filter's basis (flags bit3)
+    double* Sl = uf + 2 * P.T;                          // [4][T-1] + [4]: staged copy of the filter's basis (flags bit3)
     __shared__ double trig[3][2];
     const int tid = threadIdx.x, T = P.T;
     // the filter operator does not depend on anything this kernel waits for: fetch it now, all loads in
@@ -1541,7 +1542,7 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
     const bool staged = (flags & 8) != 0;
     const int nb = T - 1;  // basis length = the filter window
     if (staged)
-        for (int i = tid; i < 4 * nb; i += blockDim.x) Sl[i] = Smat[i];
+        for (int i = tid; i < 4 * nb + 4; i += blockDim.x) Sl[i] = Smat[i];
     // omg = exp(-V/lam) + 1e-8, normalised; uvec += eps . omg   (control/src/mppi:193-196), then clip (:198-199)
     auto apply = [&](int t, double d, double n0, double n1, double e0, double e1, double cnt) {
         const double den = d + P.floor_w * cnt;
@@ -1596,13 +1597,18 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
             if (lane == 0) coef[w][sh][d] = acc;
         }
         __syncthreads();
-        const int half = (nb - 1) / 2;
+        // position inside its window (left window starts at 0, right at 1).  Odd window: the left one up to its centre.  Even
+        // window (odd horizon, scipy >= 1.x semantics, savgol.hpp): the left one for j < nb/2, and the one interior sample
+        // j = nb/2 is the RIGHT window's cubic at the half-integer position nb/2 - 1/2 -- the basis' four extra values
+        const bool even = (nb & 1) == 0;
+        const int last_left = even ? nb / 2 - 1 : (nb - 1) / 2;
         for (int idx = tid; idx < 2 * T; idx += blockDim.x) {
             const int w = idx >= T, j = idx - w * T;
-            const int sh = j <= half ? 0 : 1, e = j - sh;   // position inside its window (left window starts at 0, right at 1)
+            const int sh = j <= last_left ? 0 : 1, e = j - sh;
+            const bool mid = even && j == nb / 2;
             double acc = 0.0;
 #pragma unroll
-            for (int d = 0; d < 4; ++d) acc = fma(Pb[(size_t)d * nb + e], coef[w][sh][d], acc);
+            for (int d = 0; d < 4; ++d) acc = fma(mid ? Pb[(size_t)4 * nb + d] : Pb[(size_t)d * nb + e], coef[w][sh][d], acc);
             uf[idx] = clampd(acc, P.u_max);
         }
     }

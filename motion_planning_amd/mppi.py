@@ -423,7 +423,7 @@ def savgol_matrix(horizon):
     S = np.empty((horizon, horizon))
     rc = _capi.load().mppi_savgol_matrix(int(horizon), _capi.dptr(S))
     if rc:
-        raise ValueError("horizon %d: Savitzky-Golay window horizon-1 must be odd and > 3" % horizon)
+        raise ValueError("horizon %d: the Savitzky-Golay window horizon - 1 must be > 3" % horizon)
     return S
 
 

@@ -22,7 +22,8 @@ class OrcParams(C.Structure):
                 ("wheel_base", C.c_double), ("floor_w", C.c_double), ("model", C.c_int),
                 ("grid", C.c_void_p), ("grid_w", C.c_int), ("grid_h", C.c_int),
                 ("grid_res", C.c_double), ("grid_ox", C.c_double), ("grid_oy", C.c_double),
-                ("grid_weight", C.c_double), ("use_sig", C.c_int), ("sig", C.c_double * 4)]
+                ("grid_weight", C.c_double), ("use_sig", C.c_int), ("sig", C.c_double * 4),
+                ("shift_fill", C.c_double * 2)]
 
 
 def build(force=False):

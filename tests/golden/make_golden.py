@@ -373,6 +373,41 @@ def main():
     out["sigmat_state"], out["sigmat_goal"], out["sigmat_u0"] = state, goal, nominal_warm(T)
     out["sigmat_lam"] = np.array(0.02)
 
+    # ---------------- K (round 3): an ODD horizon.  scipy >= 1.x accepts the even window T - 1 (the scipy of the reference's ROS
+    # era raised), so the reference as it runs today takes MPPI(horizon=51): the operator for T = 7, 51, 101 and a closed loop
+    for T in (7, 51, 101):
+        out["savgol_S_%d" % T] = savgol_filter(np.eye(T), T - 1, 3, axis=1)
+    K, T, seed, nt = 24, 51, 8, 6
+    mp = ref.MPPI(horizon=T, samples=K)
+    np.random.seed(seed)
+    st, goal = np.array([0.0, 0.0, 0.0]), np.array([0.3, -0.6, 0.5])
+    states, us = [], []
+    for _ in range(nt):
+        st = mp.get_path(st, goal)
+        states.append(st.copy())
+        us.append(mp.uvec[-1].copy())
+    out["odd_seq_states"], out["odd_seq_u"], out["odd_seq_latest_uvec"] = np.array(states), np.array(us), mp.latest_uvec.copy()
+    out["odd_seq_meta"] = np.array([K, T, seed, nt], dtype=np.int64)
+    out["odd_seq_goal"] = goal
+
+    # ---------------- L (round 3): uvec_init is an instance attribute too (:65): initialize() loads it into latest_uvec (:81) and
+    # every receding-horizon shift appends uvec_init[:, 0] (:101) -- a non-zero one
+    K, T, seed, nt = 20, 50, 17, 6
+    mp = ref.MPPI(horizon=T, samples=K)
+    mp.uvec_init = np.array([np.linspace(0.8, -0.4, T), np.linspace(-0.3, 0.9, T)])
+    mp.initialize()
+    np.random.seed(seed)
+    st, goal = np.array([0.05, 0.0, 0.2]), np.array([0.0, -1.0, 0.0])
+    states, us, lat = [], [], []
+    for _ in range(nt):
+        st = mp.get_path(st, goal)
+        states.append(st.copy())
+        us.append(mp.uvec[-1].copy())
+        lat.append(mp.latest_uvec.copy())
+    out["init_seq_states"], out["init_seq_u"], out["init_seq_latest_uvec"] = np.array(states), np.array(us), np.array(lat)
+    out["init_seq_meta"] = np.array([K, T, seed, nt], dtype=np.int64)
+    out["init_seq_state0"], out["init_seq_goal"], out["init_seq_uvec_init"] = np.array([0.05, 0.0, 0.2]), goal, mp.uvec_init.copy()
+
     np.savez_compressed(os.path.join(HERE, "mppi_golden.npz"), **out)
     with open(os.path.join(HERE, "mppi_kat.json"), "w") as f:
         json.dump(kat, f, indent=1, sort_keys=True)

@@ -19,7 +19,7 @@ def test_kat_kinematics(orc, kat):
     assert p.wheel_base == kat["constants"]["WHEEL_BASE"]
 
 
-@pytest.mark.parametrize("T", [6, 10, 20, 50, 100, 200])
+@pytest.mark.parametrize("T", [6, 7, 10, 20, 50, 51, 100, 101, 200])
 def test_savgol_operator_matches_scipy(orc, golden, T):
     S = orc.savgol_matrix(T)
     ref = golden["savgol_S_%d" % T]
@@ -34,9 +34,40 @@ def test_savgol_apply(orc, golden):
     assert np.abs(golden["savgol_in_50"] @ S - golden["savgol_out_50"]).max() < 1e-12
 
 
-def test_savgol_even_window_rejected(orc):
+def test_savgol_window_too_short_rejected(orc):
+    """Odd horizons (even windows) are accepted the way scipy >= 1.x accepts them (fixtures savgol_S_7 / _51 / _101);
+    a window that cannot hold a cubic is still refused."""
     with pytest.raises(ValueError):
-        orc.savgol_matrix(51)
+        orc.savgol_matrix(4)
+    assert orc.savgol_matrix(51).shape == (51, 51)
+
+
+def test_odd_horizon_closed_loop(orc, golden):
+    """MPPI(horizon=51) of the reference as it runs on today's scipy: six closed-loop ticks."""
+    K, T, seed, nt = [int(x) for x in golden["odd_seq_meta"]]
+    noise = orc.reference_noise(seed, SIG, T, K, n_ticks=nt)
+    st, lat = np.zeros(3), np.zeros((2, T))
+    for i in range(nt):
+        st, ua, lat = orc.get_path(st, golden["odd_seq_goal"], lat, noise[i], LAM, SIG)
+        assert np.abs(st - golden["odd_seq_states"][i]).max() < 1e-10, i
+        assert np.abs(ua - golden["odd_seq_u"][i]).max() < 1e-9, i
+    assert np.abs(lat - golden["odd_seq_latest_uvec"]).max() < 1e-9
+
+
+def test_nonzero_uvec_init_closed_loop(orc, golden):
+    """uvec_init != 0 (control/src/mppi:65): initialize() loads it (:81), every shift appends uvec_init[:, 0] (:101)."""
+    K, T, seed, nt = [int(x) for x in golden["init_seq_meta"]]
+    noise = orc.reference_noise(seed, SIG, T, K, n_ticks=nt)
+    init = golden["init_seq_uvec_init"]
+    p = orc.default_params()
+    p.shift_fill[0], p.shift_fill[1] = init[0, 0], init[1, 0]
+    st, lat = golden["init_seq_state0"].copy(), init.copy()
+    for i in range(nt):
+        st, ua, lat = orc.get_path(st, golden["init_seq_goal"], lat, noise[i], LAM, SIG, params=p)
+        assert np.abs(st - golden["init_seq_states"][i]).max() < 1e-10, i
+        assert np.abs(ua - golden["init_seq_u"][i]).max() < 1e-9, i
+        assert np.abs(lat - golden["init_seq_latest_uvec"][i]).max() < 1e-9, i
+        assert lat[0, -1] == init[0, 0] and lat[1, -1] == init[1, 0]
 
 
 @pytest.mark.parametrize("name", C2G)

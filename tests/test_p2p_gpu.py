@@ -60,7 +60,7 @@ def test_p2p_two_engines_one_process():
             e.close()
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, devices=None):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -69,8 +69,11 @@ def _worker(rank, world, port, q):
     from motion_planning_amd import sharded
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        ticker, eng = sharded.make_hip_ticker(K, T, storage="f32", local_rank=0, exchange="p2p", tick_path="lanes")
+        dev = 0 if devices is None else devices[rank]
+        ticker, eng = sharded.make_hip_ticker(K, T, storage="f32", local_rank=dev, exchange="p2p", tick_path="lanes")
         assert ticker.exchange == "p2p" and ticker.world == world and eng.K == K // world
+        rep = ticker.exchange_report
+        assert rep["ran"] == "p2p" and rep["all_ranks_ok"] and rep["selftest"] == "ok" and rep["selftest_round_trip_us"] > 0
         eng.set_nominal(_u0())
         outs = []
         for i in range(NT):
@@ -91,6 +94,31 @@ def test_p2p_two_processes_over_ipc():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, outs, lat in res:
+        assert np.abs(outs - ref).max() < 1e-10, rank
+        assert np.abs(lat - ref_lat).max() < 1e-10, rank
+
+
+def test_p2p_two_processes_across_two_devices():
+    """The same two-process exchange with the ranks on TWO GPUs -- mailbox stores and flags over xGMI instead of through
+    one device's memory.  Runs wherever two devices are visible (the one-GPU test boxes skip it); the first multi-GPU
+    box that runs the suite thereby exercises hipIpcOpenMemHandle + peer access + system-scope stores between devices."""
+    import multiprocessing as mp
+    import subprocess
+    n = int(subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True).stdout.strip() or 0)
+    if n < 2:
+        pytest.skip("one GPU visible")
+    ref, ref_lat = _reference()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, [0, 1])) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]
@@ -126,6 +154,11 @@ def test_bench_with_two_ranks_on_the_one_gpu(exchange):
     assert line["config"]["parallelism"] == "K-sharded x2, exchange: %s" % exchange and line["scaling"] == "strong"
     assert [r["rank"] for r in line["per_rank"]] == [0, 1] and all(r["samples"] == 25000 for r in line["per_rank"])
     assert all(r["kernels_us"]["rollout"] > 0 and r["exchange_us"] > 0 for r in line["per_rank"])
+    for r in line["per_rank"]:   # the line alone says which exchange every rank ran, and how its set-up went
+        rep = r["exchange"]
+        assert rep["requested"] == exchange and rep["ran"] == exchange
+        if exchange == "p2p":
+            assert rep["all_ranks_ok"] and (rep["create"], rep["connect"], rep["selftest"]) == ("ok", "ok", "ok") and rep["selftest_round_trip_us"] > 0
     assert line["value"] == pytest.approx(50000 / (line["ms_per_step"] * 1e-3))   # whole-job samples / max-over-ranks time
     plain = run([sys.executable] + common + ["--gpus", "1"])
     assert plain.returncode == 0, plain.stderr[-3000:]
