@@ -1077,6 +1077,7 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
     // 2^-80 and fetched twice as many); fp64 mode keeps everything down to 2^-100.
     const R cand = (R)(sizeof(S) == 4 ? -40.0 : -100.0);
     R D = 0, N0 = 0, N1 = 0;
+    double Na0 = 0.0, Na1 = 0.0;
     // REGEN (eps was never stored): a sample that carries weight needs its noise re-drawn -- one Philox call.  Far from the
     // goal a row has a handful of such samples; parked AT the goal a few per cent of a row carry weight.  The loop only
     // NOTES them -- (index, weight) appended to ONE queue per block (a wave-aggregated LDS counter: one atomic per wave and
@@ -1093,8 +1094,8 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
         float f0, f1;  // the same Philox counter the rollout used for this (sample, step)
         philox_normal_pair(P.sample_offset + kk, (uint32_t)t, tick_now, (uint32_t)a, (uint32_t)seed, (uint32_t)(seed >> 32),
                            (float)P.sigma, f0, f1);
-        N0 = fma(e, (R)(S)f0, N0);
-        N1 = fma(e, (R)(S)f1, N1);
+        Na0 = fma((double)e, (double)(S)f0, Na0);   // exact products, fp64 sums: independent of how the queue orders them
+        Na1 = fma((double)e, (double)(S)f1, Na1);
     };
     if (REGEN) {
         if (tid == 0) q_n = 0;
@@ -1103,24 +1104,38 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
 #pragma unroll
     for (int j = 0; j < kUpdNV; ++j) {
         const int k = k_begin + (j * 256 + tid) * VEC;
+        R xs[VEC], es[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-            const R x = (M - v[j][i]) * scale;  // <= 0; -inf for the padding
-            const R e = Exp2<R>::f(x);
-            D += e;
-            if (REGEN) {
-                const unsigned long long bal = __ballot(x > cand);
-                if (bal) {  // (uniform) skipped for almost every value while the robot is far from its goal
-                    int base = 0;
-                    if (lane == 0) base = atomicAdd(&q_n, __popcll(bal));
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-                    if (x > cand && pos < kQueue) { q_k[pos] = (uint32_t)(k + i); q_e[pos] = e; }
+            xs[i] = (M - v[j][i]) * scale;  // <= 0; -inf for the padding
+            es[i] = Exp2<R>::f(xs[i]);
+            D += es[i];
+        }
+        if (REGEN) {
+            // one queue reservation per wave and VECTOR (an LDS atomic with return is a round trip the wave waits for:
+            // one per value made 32 of them per row)
+            unsigned long long bal[VEC];
+            int n_here = 0;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) { bal[i] = __ballot(xs[i] > cand); n_here += (int)__popcll(bal[i]); }
+            if (n_here) {  // (uniform) skipped for almost every vector while the robot is far from its goal
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&q_n, n_here);
+                base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal[i] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal[i], 0u));
+                    if (xs[i] > cand && pos < kQueue) { q_k[pos] = (uint32_t)(k + i); q_e[pos] = es[i]; }
+                    base += (int)__popcll(bal[i]);
                 }
-            } else if (x > cand) {
-                N0 = fma(e, (R)e0_row[k + i], N0);
-                N1 = fma(e, (R)e1_row[k + i], N1);
             }
+        } else {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i)
+                if (xs[i] > cand) {
+                    N0 = fma(es[i], (R)e0_row[k + i], N0);
+                    N1 = fma(es[i], (R)e1_row[k + i], N1);
+                }
         }
     }
     if (REGEN) {
@@ -1139,12 +1154,18 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
             }
         }
     }
-    D = wave_sum(D); N0 = wave_sum(N0); N1 = wave_sum(N1); E0 = wave_sum(E0); E1 = wave_sum(E1);
-    if (lane == 0) { red[wid][1] = D; red[wid][2] = N0; red[wid][3] = N1; red[wid][4] = E0; red[wid][5] = E1; }
+    // sum_k e * eps across the block in fp64: a thread holds a few products at most (the queue spreads the candidates over
+    // the block -- a handful of them all sit in wave 0), and an fp32 tree would let the row's dominant term absorb the small
+    // ones differently for every way of splitting the samples over chunks / shards
+    __shared__ double redN[4][2];
+    const double N0d = wave_sum((double)N0 + Na0), N1d = wave_sum((double)N1 + Na1);
+    D = wave_sum(D); E0 = wave_sum(E0); E1 = wave_sum(E1);
+    if (lane == 0) { red[wid][1] = D; redN[wid][0] = N0d; redN[wid][1] = N1d; red[wid][4] = E0; red[wid][5] = E1; }
     __syncthreads();
     if (tid < 5) {
         const int c = tid + 1;
-        o[c] = (double)red[0][c] + (double)red[1][c] + (double)red[2][c] + (double)red[3][c];
+        o[c] = (c == 2 || c == 3) ? redN[0][c - 2] + redN[1][c - 2] + redN[2][c - 2] + redN[3][c - 2]
+                                  : (double)red[0][c] + (double)red[1][c] + (double)red[2][c] + (double)red[3][c];
     } else if (tid == 5) {
         o[0] = (double)M; o[6] = (double)(k_end - k_begin); o[7] = 0.0;
     }
