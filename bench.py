@@ -404,16 +404,19 @@ def main():
             ticker.tick_async(goals, goals, "philox", seed, 5_000_000)
             for i in range(30):
                 ticker.tick_async(None, None, "philox", seed, 5_000_001 + i)
-            eng.kernel_timing(("rollout", "update", "merge", "finalize"), period=1)
             sync()
             t0 = time.perf_counter()
-            for i in range(20):
+            for i in range(50):
                 ticker.tick_async(None, None, "philox", seed, 5_000_100 + i)
             sync()
             el = time.perf_counter() - t0
+            eng.kernel_timing(("rollout", "update", "merge", "finalize"), period=1)   # a second pass for the kernel times: brackets cost stream time
+            for i in range(20):
+                ticker.tick_async(None, None, "philox", seed, 5_000_200 + i)
+            sync()
             pt = eng.kernel_times()
             eng.kernel_timing(())
-            extra["parked_at_goal"] = {"ms_per_step": 1e3 * el / 20,
+            extra["parked_at_goal"] = {"ms_per_step": 1e3 * el / 50, "value": units_total / (el / 50),
                                        "kernels_us": {k: (v[0] * 1e3 / v[1] if v[1] else None) for k, v in pt.items()}}
             for a in range(A):
                 eng.set_nominal(nominal_warm(T), agent=a)
@@ -433,6 +436,9 @@ def main():
             btimes = eng.kernel_times()
             eng.kernel_timing(())
             sync_tick_us = dist_stats(lat)
+            sync_tick_us["max"] = float(max(lat))
+            sync_tick_us["max_at_call"] = int(np.argmax(lat))
+            sync_tick_us["first_calls"] = [float(x) for x in lat[:4]]
 
     info = eng.info()
     # per-rank kernel times (N > 1): gathered on rank 0
@@ -518,13 +524,16 @@ def main():
             e1.tick_async(np.array([goal]), np.array([goal]), "philox", 0, 5_000_000)
             for j in range(30):
                 e1.tick_async(None, None, "philox", 0, 5_000_001 + j)
-            e1.kernel_timing(("rollout", "update", "merge", "finalize"), period=1)
             e1.synchronize()
             t0 = time.perf_counter()
-            for j in range(20):
+            for j in range(50):
                 e1.tick_async(None, None, "philox", 0, 5_000_100 + j)
             e1.synchronize()
             elp = time.perf_counter() - t0
+            e1.kernel_timing(("rollout", "update", "merge", "finalize"), period=1)
+            for j in range(20):
+                e1.tick_async(None, None, "philox", 0, 5_000_200 + j)
+            e1.synchronize()
             p1 = e1.kernel_times()
             e1.kernel_timing(())
         one_line = {"co_shards": 1, "ms_per_step": 1e3 * el1 / args.steps, "value": K_total / (el1 / args.steps), "steps": args.steps,
@@ -532,7 +541,7 @@ def main():
                     "shader_clock_mhz": mhz1,
                     "kernels_us_bracketed": {k: (v[0] * 1e3 / v[1] if v[1] else None) for k, v in d1.items()},
                     "final_state": [float(x) for x in nxt1[0]], "final_u": [float(x) for x in ua1[0]],
-                    "parked_at_goal": {"ms_per_step": 1e3 * elp / 20, "value": K_total / (elp / 20),
+                    "parked_at_goal": {"ms_per_step": 1e3 * elp / 50, "value": K_total / (elp / 50),
                                        "kernels_us": {k: (v[0] * 1e3 / v[1] if v[1] else None) for k, v in p1.items()}}}
         dev_s = float(np.abs(np.array(one_line["final_state"]) - timed_nxt[0]).max())
         dev_u = float(np.abs(np.array(one_line["final_u"]) - timed_ua[0]).max())
@@ -620,14 +629,20 @@ def main():
             pm = load_profile(pmc_name)
         if args.workload == "c4" and args.storage == "f32" and world == 1 and not args.samples and pm:
             for kname, c in pm.items():
-                if roofline["kernel"] + "<" in kname or kname.split("::")[-1].startswith(roofline["kernel"] + "<"):
+                if kname.split("::")[-1].split("<")[0] == roofline["kernel"]:
                     rd = [v for k, v in c.items() if k.startswith("hbm_read_bytes")]
                     wr = [v for k, v in c.items() if k.startswith("hbm_write_bytes")]
                     if rd and wr:
-                        roofline["traffic"] = rd[0] + wr[0]
-                        roofline["traffic_source"] = "profiles/%s (FETCH_SIZE x2 + WRITE_SIZE, bytes/launch; separate --pmc passes of this command)" % pmc_name
+                        # the PMC passes run this command with --co-shards 1: bytes per launch over ALL samples; a shard's launch
+                        # moves its share (the rollout's traffic is its dP / Stot / epart stores: proportional to its samples)
+                        full = rd[0] + wr[0]
+                        roofline["traffic"] = full * (A * k_launch) / float(A * K_local)
+                        roofline["traffic_source"] = ("profiles/%s (FETCH_SIZE x2 + WRITE_SIZE, bytes per launch over all samples; separate --pmc "
+                                                      "passes of this command with --co-shards 1), scaled to this launch's samples" % pmc_name)
+                        if one_line and "roofline" in one_line:
+                            one_line["roofline"]["traffic"] = full
                         if "SQ_INSTS_VALU" in c and "valu" in roofline:
-                            roofline["valu"]["insts_per_launch_pmc"] = c["SQ_INSTS_VALU"]
+                            roofline["valu"]["insts_per_launch_pmc_all_samples"] = c["SQ_INSTS_VALU"]
         # the rollout launch in each phase of this command (what a rocprofv3 --kernel-trace --stats of the whole
         # command averages over): back-to-back ticks run a few % longer than launches behind an idle gap
         phases = {"timed": ktimes["rollout"], "diagnostic": dtimes["rollout"]}
@@ -679,6 +694,9 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "f64_storage": f64_line, "one_engine": one_line,
         }
         line.update(extra)
+        # the other regime of the closed loop at the top level too: the robot parked at its goal
+        if "parked_at_goal" in extra:
+            line["value_parked_at_goal"] = extra["parked_at_goal"]["value"]
         print(json.dumps(line))
     if in_group:
         dist.destroy_process_group()

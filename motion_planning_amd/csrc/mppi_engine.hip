@@ -259,6 +259,7 @@ struct mppi_engine {
         if (p2p_internal) { p2p_release(); p2p_internal = false; }
     }
     bool p2p_internal = false;  // the mailboxes belong to the co-scheduled group, not to a caller's cross-GPU exchange
+    bool is_co_sub = false;     // this engine is a co-scheduled shard inside another handle
     // this engine's view of its own shard while a co-scheduled tick is enqueued: K, chunk count and launch geometry of shard 0
     struct ShardView {
         mppi_engine* e; int K, samples, NCH, roll_blocks; double* snap;
@@ -713,7 +714,16 @@ struct mppi_engine {
         if (cfg.device < 0 || cfg.device >= ndev) fail(MPPI_E_INVALID, "device %d out of range (%d visible)", cfg.device, ndev);
         device = cfg.device;
         HIPCHK(hipSetDevice(device));
-        HIPCHK(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
+        {
+            // experiment switch (MPPI_CO_PRIO=1): the handle's own stream at the highest priority, the co-scheduled shards' streams at
+            // the lowest, so that shard 0's rollout runs ahead of shard 1's instead of sharing the SIMDs with it
+            int lo = 0, hi = 0;
+            const char* v = std::getenv("MPPI_CO_PRIO");
+            if (v && std::atoi(v) != 0 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+                HIPCHK(hipStreamCreateWithPriority(&own_stream, hipStreamNonBlocking, is_co_sub ? lo : hi));
+            else
+                HIPCHK(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
+        }
         {
             int khz = 0;
             if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) wall_clock_khz = khz;
@@ -894,6 +904,7 @@ void mppi_engine::co_build() {
             c.tick_path = MPPI_TICK_LANES;
             mppi_engine* e = new mppi_engine();
             subs.push_back(e);
+            e->is_co_sub = true;
             e->init(c);
         }
         std::vector<void*> ptrs(G, nullptr);

@@ -11,9 +11,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from motion_planning_amd.mppi import Engine
 
 
-def run(pk, K, T, ticks, parked=False):
+def run(pk, K, T, ticks, parked=False, co=1):
     os.environ["MPPI_ROLLOUT_PK"] = "1" if pk else "0"
-    with Engine(K, T, storage="f32", tick_path="lanes") as e:
+    with Engine(K, T, storage="f32", tick_path="lanes", co_shards=co) as e:
         u0 = np.zeros((2, T)) if parked else np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
         goal = np.array([[0.0, -1.0, 0.0]])
         start = goal if parked else np.zeros((1, 3))
@@ -54,7 +54,8 @@ if __name__ == "__main__":
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--ticks", type=int, default=300)
     ap.add_argument("--parked", action="store_true")
+    ap.add_argument("--co-shards", type=int, default=1, help="1: one engine (the kernels undisturbed); 0: the engine's own rule")
     a = ap.parse_args()
     for r in range(a.rounds):
         for pk in (0, 1):
-            print(json.dumps(dict(run(pk, a.samples, a.horizon, a.ticks, a.parked), round=r)), flush=True)
+            print(json.dumps(dict(run(pk, a.samples, a.horizon, a.ticks, a.parked, a.co_shards), round=r, co_shards=a.co_shards)), flush=True)

@@ -6,11 +6,11 @@ R=$GRAFT_REPO_ROOT; TAG=$1; shift
 mkdir -p $R/gpurun_out/$TAG
 cd /tmp && export TMPDIR=/tmp
 i=0
-for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
+for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU" \
            "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_LDS" \
            "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $R/gpurun_out/$TAG/pmc$i -- python $R/bench.py --steps 8 --warmup 2 --min-warmup-s 0 --no-cpu-baseline --no-f64-line --no-co-line "$@" > $R/gpurun_out/$TAG/pmc$i.log 2>&1
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $R/gpurun_out/$TAG/pmc$i -- python $R/bench.py --steps 8 --warmup 2 --min-warmup-s 0 --no-cpu-baseline --no-f64-line "$@" > $R/gpurun_out/$TAG/pmc$i.log 2>&1
 done
 python3 - <<PY
 import csv,glob,collections,os,json

@@ -5,20 +5,23 @@
 set -x
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final; mkdir -p $O
 cd $R
-( time timeout 900 python -m pytest tests -m gpu -q --timeout 300 2>&1 ) > $O/gpu_tests.log 2>&1; tail -4 $O/gpu_tests.log
+( time timeout 1500 python -m pytest tests -m gpu -q 2>&1 ) > $O/gpu_tests.log 2>&1; tail -4 $O/gpu_tests.log
 timeout 400 python bench.py 2>$O/bench_c4.err | tail -1 > $O/bench_c4.json
 timeout 300 python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_c4_driver_flags.json
 cd /tmp && export TMPDIR=/tmp
 for i in 1 2 3; do
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats$i -- python $R/bench.py --no-cpu-baseline --no-f64-line --no-co-line > $O/stats$i.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats$i -- python $R/bench.py --no-cpu-baseline --no-f64-line > $O/stats$i.log 2>&1
+  cp $O/stats$i/*/*kernel_stats.csv $O/kernel_stats_run$i.csv 2>/dev/null
 done
 cd $R
-timeout 900 bash tools/pmc.sh final/pmc > $O/pmc.log 2>&1; tail -4 $O/pmc.log
+timeout 900 bash tools/pmc.sh final/pmc --co-shards 1 > $O/pmc.log 2>&1; tail -4 $O/pmc.log
 for w in c2 c3 c5; do timeout 300 python bench.py --workload $w --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_$w.json; done
-for k in 500000 250000 125000; do timeout 200 python bench.py --samples $k --no-cpu-baseline --no-f64-line --steps 100 2>/dev/null | tail -1 > $O/bench_shard_$k.json; done
+for k in 500000 250000 125000; do timeout 200 python bench.py --samples $k --co-shards 1 --no-cpu-baseline --no-f64-line --steps 100 2>/dev/null | tail -1 > $O/bench_shard_$k.json; done
+python tools/ab_rollout.py --rounds 2 > $O/ab_rollout_c4.jsonl 2>/dev/null
+g++ -O2 -std=c++17 -Iinclude tools/node_tail.cpp -o tools/node_tail -Lmotion_planning_amd/lib -lmppi_hip -Wl,-rpath,$R/motion_planning_amd/lib && ( ./tools/node_tail 10 100 5000 0; ./tools/node_tail 10 100 3000 500; ./tools/node_tail 1000 50 3000 0; ./tools/node_tail 10000 50 3000 0 ) > $O/node_tail.txt 2>&1
 timeout 120 python tools/node_latency.py > $O/node_latency.txt 2>&1
 timeout 60 ./tools/ubench > $O/ubench.txt 2>&1
-[ -n "$SKIP_HANG_HUNT" ] || timeout 300 bash tools/hang_hunt.sh 1000 4 gpurun_out/final/hang 2>&1 | tail -5
+[ -n "$SKIP_HANG_HUNT" ] || timeout 300 bash tools/hang_hunt.sh 600 4 gpurun_out/final/hang 2>&1 | tail -5
 python3 - <<PY
 import csv, glob, json, collections
 rows = collections.defaultdict(list)
