@@ -890,9 +890,22 @@ void mppi_engine::co_build() {
         return;
     }
     try {
-        // boundaries on multiples of the update kernel's chunk (no shard ends in a ragged chunk), as equal as those allow
+        // boundaries on multiples of the update kernel's chunk (no shard ends in a ragged chunk)
         std::vector<int> cuts(G + 1, 0);
         for (int g = 1; g < G; ++g) cuts[g] = (int)(((long)g * cfg.samples / G + CH / 2) / CH) * CH;
+        // Two shards: 58 / 42.  Shard 0's launches go first, so the tick ends with shard 1's update + merge + finalize with nothing
+        // left to hide them under; a smaller shard 1 shortens that tail as long as its rollout still covers shard 0's update
+        // (same box, K = 10^6, tick us: 50/50 139.0, 55/45 136.4, 58/42 134.2, 60/40 135.4, 62/38 136, 65/35 137.1; 45/55 141.6)
+        if (G == 2) cuts[1] = std::max(CH, (int)(((long)cfg.samples * 58 / 100 + CH / 2) / CH) * CH);
+        if (const char* v = std::getenv("MPPI_CO_CUT_PCT")) {   // experiment switch: cumulative shares in per cent, "60" or "50,80"
+            const char* q = v;
+            for (int g = 1; g < G && *q; ++g) {
+                const int pct = std::atoi(q);
+                if (pct > 0 && pct < 100) cuts[g] = std::max(CH, (int)(((long)cfg.samples * pct / 100 + CH / 2) / CH) * CH);
+                while (*q && *q != ',') ++q;
+                if (*q == ',') ++q;
+            }
+        }
         cuts[G] = cfg.samples;
         for (int g = 0; g < G; ++g) if (cuts[g + 1] <= cuts[g]) fail(MPPI_E_INVALID, "co_shards = %d: %d samples do not split", G, cfg.samples);
         co_k0 = cuts[1];

@@ -312,17 +312,16 @@ template <> __device__ __forceinline__ double wave_min<double>(double v) {
 // exp() of the 16 tuples run side by side and the sums are four row-level DPP butterflies each: what a thread
 // looping over the tuples does in 16 dependent exp() calls (~10 us for a horizon's rows) takes ~1 us.  Every lane of
 // the wave must call it (DPP sources must be active lanes).
-__device__ __forceinline__ void merge_row16(const double* q, double inv_lambda, double (&t)[7]) {
-    const bool has = q != nullptr && q[6] > 0.0;
-    const double m = has ? q[0] : INFINITY;
+__device__ __forceinline__ void merge_row16_vals(bool has, double m, double (&v)[6], double inv_lambda, double (&t)[7]) {
+    if (!has) m = INFINITY;
     double M = m;
     M = fmin(M, dpp_mov_f64_keep<0xB1, 0xF>(M));   // quad_perm [1,0,3,2]
     M = fmin(M, dpp_mov_f64_keep<0x4E, 0xF>(M));   // quad_perm [2,3,0,1]
     M = fmin(M, dpp_mov_f64_keep<0x141, 0xF>(M));  // row_half_mirror
     M = fmin(M, dpp_mov_f64_keep<0x140, 0xF>(M));  // row_mirror
     const double sc = !has ? 0.0 : (m == M ? 1.0 : exp((M - m) * inv_lambda));
-    double v[6] = {0, 0, 0, 0, 0, 0};
-    if (has) { v[0] = sc * q[1]; v[1] = sc * q[2]; v[2] = sc * q[3]; v[3] = q[4]; v[4] = q[5]; v[5] = q[6]; }
+    if (has) { v[0] *= sc; v[1] *= sc; v[2] *= sc; }
+    else { v[0] = v[1] = v[2] = v[3] = v[4] = v[5] = 0.0; }
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         v[i] += dpp_mov_f64<0xB1, 0xF>(v[i]);
@@ -334,7 +333,12 @@ __device__ __forceinline__ void merge_row16(const double* q, double inv_lambda, 
 #pragma unroll
     for (int i = 0; i < 6; ++i) t[i + 1] = v[i];
 }
-
+__device__ __forceinline__ void merge_row16(const double* q, double inv_lambda, double (&t)[7]) {
+    const bool has = q != nullptr && q[6] > 0.0;
+    double v[6] = {0, 0, 0, 0, 0, 0};
+    if (has) { v[0] = q[1]; v[1] = q[2]; v[2] = q[3]; v[3] = q[4]; v[4] = q[5]; v[5] = q[6]; }
+    merge_row16_vals(has, has ? q[0] : INFINITY, v, inv_lambda, t);
+}
 // 64-lane sum with DPP adds only (no LDS traffic): after the four row steps every lane of a
 // 16-lane row holds its row sum, row_bcast15 / row_bcast31 chain the rows; LANE 63 holds the total.
 template <int CTRL, int ROW_MASK>
@@ -1478,7 +1482,9 @@ __global__ __launch_bounds__(256) void p2p_publish_kernel(const double* __restri
 }
 // The same with the shard's merge folded in: with a handful of chunk (or scan-block) tuples per row the merge kernel is
 // skipped and every publishing block merges the n_rows = A * T rows itself (redundantly per destination, 16 lanes per
-// row: merge_row16) straight into its peer's mailbox -- one launch and one boundary less per tick.
+// row: merge_row16) straight into its peer's mailbox -- one launch and one boundary less per tick.  (Not beyond 16 per row:
+// round 3 let every lane fold up to four tuples first -- 64 per row -- and the two publishing blocks of a 51-chunk shard took
+// 7 us longer than the 50-block merge launch they replaced: 141.4 against 134.2 us per co-scheduled tick.)
 __global__ __launch_bounds__(256) void p2p_publish_merge_kernel(DevParams P, const double* __restrict__ part, int NCH, int n_rows,
                                                                P2PPeers peers, uint32_t epoch) {
     double* dst = peers.data[blockIdx.x];
