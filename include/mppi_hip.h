@@ -39,6 +39,12 @@
  *   - K is the number of samples owned by THIS handle (one GPU's shard); sample_offset is
  *     the global index of its first sample (device-RNG streams are keyed by global index,
  *     so results do not depend on the shard count).
+ *
+ * Environment (measurement aids, read once by mppi_create; none changes results beyond rounding):
+ *   MPPI_SYNC_TIMEOUT_MS   default deadline of the blocking waits;   MPPI_STORE_EPS=1  the tick path stores its noise;
+ *   MPPI_ROLLOUT_PK=0      keep fp32-storage ticks on the all-fp64 rollout kernel (same-box A/B against the mixed-precision one),
+ *   MPPI_PK_MIN_SAMPLES    where the mixed-precision kernel takes over (default 400000), MPPI_PK_WAVES=5 its 5-waves-per-SIMD build;
+ *   MPPI_CO_CUT_PCT        shares of the co-scheduled shards in per cent, cumulative ("58", "45,80"), MPPI_CO_PRIO=1 stream priorities.
  */
 #ifndef MPPI_HIP_H
 #define MPPI_HIP_H

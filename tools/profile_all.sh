@@ -9,10 +9,17 @@ cd $R
 timeout 400 python bench.py 2>$O/bench_c4.err | tail -1 > $O/bench_c4.json
 timeout 300 python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_c4_driver_flags.json
 cd /tmp && export TMPDIR=/tmp
+# kernel stats: three runs with ONE engine (every rollout launch covers all 10^6 samples: its average is the duration the SURVEY 8(d)
+# accounting divides 600 MB by), one run of the default command (the co-scheduled headline: launches of 581 632 and 418 368 samples
+# next to each other, plus the one-engine leg's full-size ones -- a mixed average)
 for i in 1 2 3; do
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats$i -- python $R/bench.py --no-cpu-baseline --no-f64-line > $O/stats$i.log 2>&1
-  cp $O/stats$i/*/*kernel_stats.csv $O/kernel_stats_run$i.csv 2>/dev/null
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats$i -- python $R/bench.py --co-shards 1 --no-cpu-baseline --no-f64-line > $O/stats$i.log 2>&1
+  cp $O/stats$i/*/*kernel_stats.csv $O/kernel_stats_one_engine_run$i.csv 2>/dev/null
+  tail -1 $O/stats$i.log > $O/bench_under_rocprof_one_engine_run$i.json
 done
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_co -- python $R/bench.py --no-cpu-baseline --no-f64-line > $O/stats_co.log 2>&1
+cp $O/stats_co/*/*kernel_stats.csv $O/kernel_stats_co_headline.csv 2>/dev/null
+timeout 300 python $R/bench.py --co-shards 1 --no-cpu-baseline --no-f64-line 2>/dev/null | tail -1 > $O/bench_c4_one_engine.json
 cd $R
 timeout 900 bash tools/pmc.sh final/pmc --co-shards 1 > $O/pmc.log 2>&1; tail -4 $O/pmc.log
 for w in c2 c3 c5; do timeout 300 python bench.py --workload $w --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_$w.json; done
