@@ -282,3 +282,49 @@ def test_co_scheduled_value_is_bit_identical_to_the_unsplit_engine():
         assert e.info()["co_shards"] == 2
     with Engine(100000, 100) as e:
         assert e.info()["co_shards"] == 1
+
+
+@pytest.mark.gpu
+def test_co_scheduled_handle_follows_parameter_changes():
+    """Setters reach every engine inside a co-scheduled handle: other cost weights (the general-cost rollout), another sig /
+    lambda, an obstacle grid, a non-zero shift fill and a reset -- after each change the handle's fused ticks still equal the
+    unsplit engine's (1e-10), and mppi_p2p_create on such a handle dissolves the group and leaves a working engine."""
+    from motion_planning_amd.mppi import Engine
+    K, T = 40000, 50
+    u0 = np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
+    cells = np.zeros((40, 40), dtype=np.int8)
+    cells[10:30, 5:20] = 100
+    outs = []
+    for co in (1, 2):
+        with Engine(K, T, storage="f32", tick_path="lanes", co_shards=co) as e:
+            e.set_nominal(u0)
+            traj = []
+
+            def ticks(first, n, base):
+                for i in range(n):
+                    nxt, ua = e.tick([0.1, 0, 0.2] if (first and i == 0) else None, [0.4, -1, 0] if (first and i == 0) else None,
+                                     noise="philox", seed=9, tick_id=base + i)
+                    traj.append(np.concatenate([nxt[0], ua[0]]))
+            ticks(True, 2, 0)
+            e.set_weights(q=[350.0, 900.0, 15.0], r=[0.5, 2.0], p1=[800.0, 1200.0, 300.0])
+            ticks(False, 2, 10)
+            e.set_sig(np.array([[0.7, 0.1], [0.0, 0.5]]), 0.004)
+            ticks(False, 2, 20)
+            e.set_obstacle_grid(cells, 0.05, (-1.0, -1.5), 25.0)
+            ticks(False, 2, 30)
+            e.set_obstacle_grid(None, 1.0, (0, 0), 0.0)
+            e.set_weights(q=[1e3, 1e3, 0.0], r=[1.0, 1.0], p1=[1e3, 1e3, 1e3])
+            e.set_sig(0.9, 0.001)
+            e.set_shift_fill([0.3, -0.2])
+            ticks(False, 2, 40)
+            assert np.all(e.get_nominal()[:, -1] == [0.3, -0.2])
+            e.reset()
+            ticks(False, 2, 50)
+            if co == 2:
+                assert e.info()["co_shards"] == 2
+                e.p2p_create(1, 0)                       # a caller's own exchange: the group dissolves
+                assert e.info()["co_shards"] == 1
+                e.p2p_destroy()
+            ticks(False, 2, 60)
+            outs.append(np.array(traj))
+    assert np.abs(outs[0] - outs[1]).max() < 1e-10
