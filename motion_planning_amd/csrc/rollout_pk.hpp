@@ -43,11 +43,10 @@ struct __attribute__((aligned(16))) PkRow {
     float d0, d1, lo0, hi0;   // hk (un_i - clip(un_i)); clip bounds of the deviation: hk (-+u_max - clip(un_i))
     float lo1, hi1, A1, Cn;   // dW = dphi (A1 + Cn dphi): A1 = -2 rho sin phin, Cn = -rho cos phin
     float Wn, Pn, w0, w1;     // rho (4 + 2 cos phin); hk (u0c + u1c); lam (un . Sig) -- the noise-cost weights
-    float pad[4];
     double c1n, s1n;          // nominal mid-step heading
     double X2, Y2;            // 2 * scaled nominal position after the step (relative to the goal)
 };
-static_assert(sizeof(PkRow) == 96, "PkRow is read as six 16-byte LDS words");
+static_assert(sizeof(PkRow) == 80, "PkRow is read as five 16-byte LDS words");
 
 struct RolloutPkArgs {
     DevParams P;
@@ -113,7 +112,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
                 r.A1 = (float)(-2.0 * sp * P.lean_rho); r.Cn = (float)(-cp * P.lean_rho);
                 r.Wn = (float)((4.0 + 2.0 * cp) * P.lean_rho); r.Pn = (float)(hk * (ex.u0c + ex.u1c));
                 r.w0 = (float)row[2]; r.w1 = (float)row[3];
-                r.pad[0] = r.pad[1] = r.pad[2] = r.pad[3] = 0.f;
                 r.c1n = ex.c1; r.s1n = ex.s1;
                 r.X2 = 2.0 * P.lean_f * (ex.X - gx); r.Y2 = 2.0 * P.lean_f * (ex.Y - gy);
                 lt[tid] = r;

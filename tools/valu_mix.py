@@ -78,7 +78,9 @@ def main():
     def key(l):
         ops = [i.split()[0] for i in insts[l[0]:l[1] + 1]]
         return (sum(o.startswith("buffer_store") for o in ops), l[1] - l[0])
-    best = max(inner, key=key)
+    # rollout_pk_kernel: the full-block loop stores one 8-byte pair per lane and step, its ragged-block twin two dwords
+    paired = [l for l in inner if any(i.split()[0] == "buffer_store_dwordx2" for i in insts[l[0]:l[1] + 1])]
+    best = max(paired or inner, key=key)
     n, body = best[2], insts[best[0]:best[1] + 1]
     counts = {}
     n_salu = n_vmem = n_lds = n_other = 0
