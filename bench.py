@@ -653,6 +653,24 @@ def main():
             phases["blocking"] = btimes["rollout"]
         roofline["rollout_us_by_phase"] = {k: {"avg_us": (v[0] * 1e3 / v[1] if v[1] else None), "launches_timed": v[1]}
                                            for k, v in phases.items()}
+        if one_line and "roofline" in one_line:
+            # The roofline of the DOMINANT KERNEL is a statement about the kernel: it is taken from the launches that cover the whole
+            # workload with the GPU to themselves -- the one-engine leg of this same command (same workload, co_shards = 1, its own
+            # timed region of --steps ticks, HIP events riding on the launches; tools/profile_all.sh runs rocprofv3 on exactly that:
+            # `bench.py --co-shards 1`).  The headline's own launches (one shard each, next to the other shard's) are listed under it.
+            full = dict(one_line["roofline"])
+            full["measured_in"] = ("one_engine leg of this command: co_shards = 1, %d timed ticks, %d launches sampled by events; "
+                                   "the headline tick (`value`) is the co-scheduled one" % (one_line["steps"], one_line["launches_timed"]))
+            full["co_scheduled_launch"] = {k: roofline.get(k) for k in ("kernel", "samples_per_launch", "algorithmic_bytes_per_launch", "avg_launch_us",
+                                                                         "launches_timed", "achieved", "frac", "frac_all_shards_upper",
+                                                                         "concurrent_launches", "concurrency_note", "traffic")}
+            if "valu" in roofline:
+                full["co_scheduled_launch"]["valu_frac"] = roofline["valu"]["frac"]
+                full["co_scheduled_launch"]["clock_mhz_under_load"] = roofline["valu"]["clock_mhz_under_load"]
+            for k in ("tick_level", "rollout_us_by_phase", "update_us_warmup_phase", "note", "traffic_source"):
+                if k in roofline:
+                    full[k] = roofline[k]
+            roofline = full
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             cpu = cpu_baseline(T, goal if goal is not None else [0.0, -1.0, 0.0])
