@@ -809,16 +809,17 @@ def _v_abs_pk(T):
     return V_ABS_PK * max(1.0, (T / 50.0) ** 1.5)
 
 
-def _replay_full(orc, V, eps, nxt, ua, lat, state, goal, u0, T, storage, params=None):
+def _replay_full(orc, V, eps, nxt, ua, lat, state, goal, u0, T, storage, params=None, v_abs=None):
     """Full-size oracle replay of one device-RNG tick: V on ALL samples against the stated V tolerance, the
-    controls against the stated u tolerance evaluated at the measured V error.  Returns the measured errors."""
+    controls against the stated u tolerance evaluated at the measured V error.  Returns the measured errors.
+    v_abs: the absolute term of the fp32 V tolerance (None: the mixed-precision kernel's, 0: the all-fp64 kernel's)."""
     Vo = orc.get_cost2go(state, u0, goal, LAM, SIG, eps, params=params)
     Vn = orc.get_cost2go(state, u0, goal, LAM, SIG, np.zeros((T, 2, 1)), params=params)
     errV = np.abs(V - Vo)
     if storage == "f64":
         assert errV.max() <= 1e-9 * np.abs(Vo).max()
     else:  # per SAMPLE: 3e-7 of its own largest |V - V_nominal| + lambda / 100 (V_ABS_PK above)
-        assert (errV <= 3e-7 * np.maximum(1.0, np.abs(Vo - Vn).max(axis=0))[None, :] + _v_abs_pk(T)).all()
+        assert (errV <= 3e-7 * np.maximum(1.0, np.abs(Vo - Vn).max(axis=0))[None, :] + (_v_abs_pk(T) if v_abs is None else v_abs)).all()
     eV_rows = errV.max(axis=1)
     mean, mad = _softmax_rows(Vo, eps)
     S = orc.savgol_matrix(T)
@@ -841,6 +842,25 @@ def _replay_full(orc, V, eps, nxt, ua, lat, state, goal, u0, T, storage, params=
 FULL = {"c3": (100000, 100, [1.0, 0.0, 0.0]), "c4": (1000000, 50, [0.0, -1.0, 0.0])}
 # (max |V - V_oracle| over all T * K values, max |u - u_oracle| over applied + nominal controls)
 FULL_CAPS = {("c4", "f32"): (2e-4, 1e-9), ("c4", "f64"): (2e-9, 1e-12), ("c3", "f32"): (1e-3, 3e-7), ("c3", "f64"): (5e-9, 1e-12)}
+
+
+def test_full_size_replay_of_the_all_fp64_rollout_keeps_the_relative_tolerance(orc, tick_path, monkeypatch):
+    """Config 4 with the mixed-precision kernel switched off (MPPI_ROLLOUT_PK=0, read by mppi_create): the all-fp64 rollout
+    under fp32 storage still meets round 2's tolerance WITHOUT the absolute term -- the term restated in round 3 pays for the
+    mixed kernel's fp32 increments and for nothing else."""
+    if tick_path == "scan":
+        pytest.skip("lane kernels only at this size")
+    monkeypatch.setenv("MPPI_ROLLOUT_PK", "0")
+    K, T, goal = FULL["c4"]
+    u0 = np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
+    state = [0.0, 0.0, 0.0]
+    with _engine(K, T, "f32") as e:
+        e.set_nominal(u0)
+        nxt, ua = e.tick(state, goal, noise="philox", seed=0, tick_id=0)
+        V, eps, lat = e.download_value()[0], e.download_noise()[0], e.get_nominal()
+    m = _replay_full(orc, V, eps, nxt[0], ua[0], lat, state, goal, u0, T, "f32", v_abs=0.0)
+    assert m["eV_max"] <= 2e-4 and m["du_max"] <= 1e-9, m
+    print("full-size replay c4 f32, all-fp64 rollout: %s" % m)
 
 
 @pytest.mark.parametrize("storage", ["f32", "f64"])
