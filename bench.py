@@ -17,6 +17,7 @@ control/config/waypoints.yaml with blocking ticks (goal switches need the pose o
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import gc
 import ctypes as C
 import json
 import os
@@ -429,10 +430,18 @@ def main():
             n_lat = min(args.steps, 200)
             eng.kernel_timing(("rollout",), period=1)
             st, lat = nxt, []
+            # the interpreter's cyclic garbage collector is held off for these calls: with torch and numpy imported a full
+            # collection takes 30-45 ms and lands on a fixed call of this loop (call 11 at --steps 200, call 24 at 100:
+            # allocation counts, not the engine -- rounds 2 and 3 reported it as `max`); a node written in Python does the same
+            gc_was_on = gc.isenabled()
+            gc.collect()
+            gc.disable()
             for i in range(n_lat):
                 t0 = time.perf_counter()
                 st, _ = eng.tick(st, goals, noise="philox", seed=seed, tick_id=10_000_000 + i)
                 lat.append(1e6 * (time.perf_counter() - t0))
+            if gc_was_on:
+                gc.enable()
             btimes = eng.kernel_times()
             eng.kernel_timing(())
             sync_tick_us = dist_stats(lat)
