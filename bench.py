@@ -521,6 +521,7 @@ def main():
             el1 = time.perf_counter() - t0
             k1 = e1.kernel_times()
             mhz1 = e1.shader_clock_mhz()
+            kind1 = e1.info().get("rollout_kernel")
             nxt1, ua1 = e1.get_outputs()
             # every kernel bracketed
             e1.kernel_timing(("rollout", "update", "merge", "finalize"), period=1)
@@ -547,7 +548,7 @@ def main():
             e1.kernel_timing(())
         one_line = {"co_shards": 1, "ms_per_step": 1e3 * el1 / args.steps, "value": K_total / (el1 / args.steps), "steps": args.steps,
                     "rollout_us": k1["rollout"][0] * 1e3 / max(k1["rollout"][1], 1), "launches_timed": k1["rollout"][1],
-                    "shader_clock_mhz": mhz1,
+                    "shader_clock_mhz": mhz1, "rollout_kernel": kind1,
                     "kernels_us_bracketed": {k: (v[0] * 1e3 / v[1] if v[1] else None) for k, v in d1.items()},
                     "final_state": [float(x) for x in nxt1[0]], "final_u": [float(x) for x in ua1[0]],
                     "parked_at_goal": {"ms_per_step": 1e3 * elp / 50, "value": K_total / (elp / 50),
@@ -563,17 +564,15 @@ def main():
     if rank == 0:
         lanes = info.get("tick_kernels", "lanes") == "lanes"
         mixes = load_profile(PROFILE_ROUND + "_valu_mix.json") or {}
-        PK_MIN_SAMPLES = int(os.environ.get("MPPI_PK_MIN_SAMPLES", "400000"))   # the engine's own rule (mppi_engine.hip launch_rollout)
 
-        def kernel_roofline(k_launch, avg_s, mhz, n_timed):
+        def kernel_roofline(k_launch, avg_s, mhz, n_timed, kind):
             """The dominant kernel of a launch over k_launch samples per agent: SURVEY 8(d) HBM accounting, and the VALU-issue
             roofline it is really on -- wave-instructions of the steady-state loop from the compiler's own assembly
             (tools/valu_mix.py), each class at its measured issue cost (tools/ubench.hip, shader clock read in-kernel),
             over 1024 SIMDs at the clock a probe wave inside the launch measured (and at the 2.4 GHz peak)."""
             steps = A * k_launch * T
-            pk = (lanes and args.storage == "f32" and A * k_launch >= PK_MIN_SAMPLES and T <= 256
-                  and os.environ.get("MPPI_ROLLOUT_PK", "1") != "0")
-            name = "rollout_pk_kernel" if pk else "rollout_kernel"
+            # `kind`: what the engine says its last tick launched (mppi_rollout_kernel), not a copy of its rule
+            name = {"mixed": "rollout_pk_kernel", "fp64": "rollout_kernel", "scan": "scan_tick_kernel"}[kind]
             gbs = BYTES_PER_STEP_PER_KERNEL * steps / avg_s / 1e9
             r = {"kernel": name, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                  "traffic": None, "algorithmic_bytes_per_launch": BYTES_PER_STEP_PER_KERNEL * steps, "samples_per_launch": A * k_launch,
@@ -602,7 +601,7 @@ def main():
             ms, n = dtimes["rollout"] if dtimes["rollout"][1] else (float("nan"), 1)
         avg_s = ms * 1e-3 / max(n, 1)
         tick_s = elapsed / args.steps
-        roofline = kernel_roofline(k_launch, avg_s, clock_mhz, n)
+        roofline = kernel_roofline(k_launch, avg_s, clock_mhz, n, info["rollout_kernel"])
         tick_bytes = 2 * BYTES_PER_STEP_PER_KERNEL * A * K_local * T
         roofline["note"] = ("SURVEY 8(d) accounting: algorithmic = 12 B/state-step per kernel (eps 2 x fp32 + V fp32; 24 B/step per "
                             "tick, written once by the rollout, read once by the update).  The kernel is NOT on the HBM roof: it "
@@ -628,7 +627,7 @@ def main():
             roofline["tick_level"]["valu_frac"] = cyc_tick / clk / tick_s
             roofline["tick_level"]["valu_note"] = "rollout issue cycles of all shards / (tick time x measured clock): the update, merge and finalize kernels' instructions not counted"
         if one_line:
-            one_line["roofline"] = kernel_roofline(K_local, one_line["rollout_us"] * 1e-6, one_line["shader_clock_mhz"], one_line["launches_timed"])
+            one_line["roofline"] = kernel_roofline(K_local, one_line["rollout_us"] * 1e-6, one_line["shader_clock_mhz"], one_line["launches_timed"], one_line["rollout_kernel"])
         # HBM bytes actually moved per launch of that kernel: rocprofv3 --pmc passes of this same command
         # (tools/pmc.sh), summary committed under profiles/ -- bench.py itself cannot host the profiler
         pmc_name = PROFILE_ROUND + "_pmc_summary_bench_c4.json"

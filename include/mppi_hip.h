@@ -318,6 +318,17 @@ int mppi_shader_clock(mppi_engine *h, double *mhz);
  * each owns (samples [8], zero-filled behind n_shards). */
 int mppi_co_info(mppi_engine *h, int32_t *n_shards, int32_t *samples);
 
+/* Which rollout kernel this handle's last tick / mppi_rollout launched (a co-scheduled handle: its shards all take the same
+ * one; the re-run behind a later mppi_download_value does not count):
+ * MPPI_ROLLOUT_NONE before the first; _FP64 the one-sample-per-lane kernel (all arithmetic fp64); _MIXED the
+ * mixed-precision two-samples-per-lane kernel (fp32 storage, device noise, the node's cost and model, T <= 256, at least
+ * MPPI_PK_MIN_SAMPLES samples); _SCAN the single-kernel small-K tick.  What tests and bench.py label their numbers with. */
+#define MPPI_ROLLOUT_NONE 0
+#define MPPI_ROLLOUT_FP64 1
+#define MPPI_ROLLOUT_MIXED 2
+#define MPPI_ROLLOUT_SCAN 3
+int mppi_rollout_kernel(mppi_engine *h, int32_t *kind);
+
 /* Bytes of HBM held by the engine, and the launch geometry (blocks) of a tick's kernels: rollout +
  * update on the lane-per-sample path; the scan kernel and update_blocks = 0 on the small-K path. */
 int mppi_engine_info(mppi_engine *h, size_t *hbm_bytes, int32_t *rollout_blocks,

@@ -110,6 +110,7 @@ struct mppi_engine {
     long pk_min_samples = 400000;
     int force_pk = -1;             // >= 0: the size rule is overridden (the re-run of a co-scheduled tick takes the shards' kernel)
     bool last_rollout_pk = false;  // which kernel the last rollout launch was
+    int last_rollout_kind = MPPI_ROLLOUT_NONE;   // ... as mppi_rollout_kernel reports it
     bool co_shards_pk = false;     // ... and the one the shards of the last co-scheduled tick ran
     bool use_pk = true;             // MPPI_ROLLOUT_PK=0: keep the all-fp64 rollout kernel on the tick path (same-box A/B measurements)
     double* d_tc = nullptr;  // [A][T][8]
@@ -436,6 +437,7 @@ struct mppi_engine {
         const bool pk = use_pk && !f64() && ph && !store && a.inline_nominal && !a.general && k0 == 0 && k1 == cfg.samples && pk_size &&
                         mppi::rollout_pk_applies(P.kth, P.dt, P.sigma, cfg.horizon);
         last_rollout_pk = pk;
+        last_rollout_kind = pk ? MPPI_ROLLOUT_MIXED : MPPI_ROLLOUT_FP64;
         if (pk) {
             mppi::RolloutPkArgs b{};
             b.P = P; b.stream = st; b.inline_nominal = a.inline_nominal; b.seed = seed; b.tick = tick; b.tick_ptr = tick_ptr;
@@ -484,6 +486,7 @@ struct mppi_engine {
         ro_unom = d_prev;
         ro_state = d_prev + (size_t)cfg.n_agents * 2 * cfg.horizon;
         ro_goal = ro_state + (size_t)cfg.n_agents * 3;
+        const int kind_of_the_tick = last_rollout_kind;   // (the re-run is not what mppi_rollout_kernel reports)
         try {
             // a co-scheduled tick's shards ran the tick-path kernel (noise not stored): the re-run takes the same kernel over
             // all samples -- per sample bit-identical to what the shards computed -- and the noise is re-drawn next to it
@@ -495,6 +498,7 @@ struct mppi_engine {
             throw;
         }
         ro_unom = ro_state = ro_goal = nullptr; force_pk = -1;
+        last_rollout_kind = kind_of_the_tick;
         co_last = false;
         if (ph) { eps_lazy = false; injected_ready = true; }
         value_lazy = false; value_ready = true; epart_ready = true;
@@ -515,6 +519,7 @@ struct mppi_engine {
 #undef LAUNCH_SCAN_T
 #undef LAUNCH_SCAN
         HIPCHK(hipGetLastError());
+        last_rollout_kind = MPPI_ROLLOUT_SCAN;
         inputs_consumed();
     }
     void launch_regen(hipStream_t st, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
@@ -1596,6 +1601,13 @@ int mppi_co_info(mppi_engine* h, int32_t* n_shards, int32_t* samples) {
         samples[0] = h->co_active() ? h->co_k0 : h->cfg.samples;
         for (int g = 1; g < G; ++g) samples[g] = h->subs[g - 1]->cfg.samples;
     }
+    API_END(h)
+}
+
+int mppi_rollout_kernel(mppi_engine* h, int32_t* kind) {
+    API_BEGIN(h)
+    if (!kind) fail(MPPI_E_INVALID, "NULL argument");
+    *kind = h->last_rollout_kind;
     API_END(h)
 }
 

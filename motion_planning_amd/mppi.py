@@ -393,9 +393,13 @@ class Engine(object):
         self._ck(self._lib.mppi_engine_info(self._h, C.byref(b), C.byref(r), C.byref(u)))
         n, per = C.c_int32(), (C.c_int32 * 8)()
         self._ck(self._lib.mppi_co_info(self._h, C.byref(n), per))
+        kind = C.c_int32()
+        self._ck(self._lib.mppi_rollout_kernel(self._h, C.byref(kind)))
         return {"hbm_bytes": b.value, "rollout_blocks": r.value, "update_blocks": u.value,
                 "tick_kernels": "scan" if u.value == 0 else "lanes",
-                "co_shards": n.value, "co_samples": [per[g] for g in range(n.value)]}
+                "co_shards": n.value, "co_samples": [per[g] for g in range(n.value)],
+                # which kernel the last rollout launch was (include/mppi_hip.h MPPI_ROLLOUT_*)
+                "rollout_kernel": ("none", "fp64", "mixed", "scan")[kind.value]}
 
 
 class _NominalView(np.ndarray):

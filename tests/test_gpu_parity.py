@@ -836,7 +836,7 @@ def _replay_full(orc, V, eps, nxt, ua, lat, state, goal, u0, T, storage, params=
     assert np.abs(nxt - model_step(state, ua, 1.0 / T)).max() < 1e-12
     gap = np.sort(Vo, axis=1)[:, :2]
     return {"eV_max": float(errV.max()), "du_max": float(max(du_app.max(), du_lat.max())), "tol_max": float(tol.max()),
-            "gap_min_over_lam": float((gap[:, 1] - gap[:, 0]).min() / LAM), "mad_max": float(mad.max())}
+            "gap_min_over_lam": float((gap[:, 1] - gap[:, 0]).min() / LAM) if Vo.shape[1] > 1 else float("inf"), "mad_max": float(mad.max())}
 
 
 FULL = {"c3": (100000, 100, [1.0, 0.0, 0.0]), "c4": (1000000, 50, [0.0, -1.0, 0.0])}
@@ -893,6 +893,60 @@ def test_full_size_oracle_replay(orc, tick_path, cfg, storage, record_property):
     eV_cap, du_cap = FULL_CAPS[(cfg, storage)]
     assert m["eV_max"] <= eV_cap, (cfg, storage, m)
     assert m["du_max"] <= du_cap, (cfg, storage, m)
+
+
+PK_SMALL = [(1, 26), (2, 27), (511, 28), (513, 29), (1025, 30), (2049, 31), (777, 32), (1300, 49), (900, 50), (1100, 51), (640, 100),
+            (515, 255), (300, 256)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene", ["under_way", "saturated", "parked"])
+@pytest.mark.parametrize("K,T", PK_SMALL)
+def test_mixed_precision_rollout_at_small_sizes(orc, monkeypatch, K, T, scene):
+    """The benchmarked rollout kernel (rollout_pk_kernel: two samples per lane, deviations in packed fp32) takes over at
+    400 000 samples; here it is made to run from one sample up (MPPI_PK_MIN_SAMPLES=1, read by mppi_create) so that its corner
+    cases meet the oracle on every sample: one sample and odd K (a lane with one live sample), K around the 512-sample block,
+    every horizon class mod 6 (full chunks only: 30; one or two steps riding along: 31, 49 / 26, 32, 50; a tail chunk of its
+    own: 27, 28, 29, 51, 100, 255, 256), the shortest horizon it serves at dt = 1 / T and sigma = 0.9 (26: below that a step's
+    heading deviation is outside its short series -- rollout_pk_applies) and the longest (256); under way, with the nominal
+    wheel speeds driven into the clip (the deviation form's clip bounds become one-sided), and parked at the goal with zero
+    nominal controls."""
+    monkeypatch.setenv("MPPI_PK_MIN_SAMPLES", "1")
+    if scene == "under_way":
+        u0 = np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
+        state, goal = [0.0, 0.0, 0.2], [0.4, -0.3, 0.0]
+    elif scene == "saturated":
+        u0 = np.array([np.linspace(6.2, 6.35492, T), np.linspace(-6.35492, -5.9, T)])
+        state, goal = [0.1, -0.2, 3.0], [-0.5, 0.3, -3.0]
+    else:
+        u0 = np.zeros((2, T))
+        state, goal = [0.3, 0.1, -0.4], [0.3, 0.1, -0.4]
+    with _engine(K, T, "f32", tick_path="lanes") as e:
+        e.set_nominal(u0)
+        nxt, ua = e.tick(state, goal, noise="philox", seed=5, tick_id=9)
+        assert e.info()["rollout_kernel"] == "mixed"
+        V = e.download_value()[0]
+        eps = e.download_noise()[0]
+        lat = e.get_nominal()
+        assert e.info()["rollout_kernel"] == "mixed"   # (the re-run behind the downloads does not count)
+    assert np.isfinite(V).all() and np.isfinite(eps).all()
+    m = _replay_full(orc, V, eps, nxt[0], ua[0], lat, state, goal, u0, T, "f32")
+    print("mixed kernel K=%d T=%d %s: %s" % (K, T, scene, m))
+
+
+def test_the_mixed_rollout_hands_over_where_it_does_not_apply(monkeypatch):
+    """Beyond T = 256 (no inline nominal rollout), below T = 26 (steps too long for its series), in fp64 storage, with the heading weight or the euler model the tick runs
+    the all-fp64 kernel even when the size rule says mixed; the small-K path reports the scan kernel."""
+    monkeypatch.setenv("MPPI_PK_MIN_SAMPLES", "1")
+    for kw, want in [(dict(K=600, T=257), "fp64"), (dict(K=600, T=25), "fp64"), (dict(K=600, T=26), "mixed"), (dict(K=600, T=50, storage="f64"), "fp64"), (dict(K=600, T=50, model="euler"), "fp64"),
+                     (dict(K=600, T=50, q=(1e3, 1e3, 5.0)), "fp64"), (dict(K=600, T=50), "mixed"), (dict(K=600, T=50, tick_path="scan"), "scan")]:
+        kw = dict(kw)
+        K, T, storage = kw.pop("K"), kw.pop("T"), kw.pop("storage", "f32")
+        kw.setdefault("tick_path", "lanes")
+        with _engine(K, T, storage, **kw) as e:
+            assert e.info()["rollout_kernel"] == "none"
+            e.tick([0.0, 0.0, 0.0], [0.3, 0.2, 0.0], noise="philox", seed=1, tick_id=0)
+            assert e.info()["rollout_kernel"] == want, (kw, e.info())
 
 
 def test_f32_storage_against_f64_storage_at_config4(orc, tick_path):
