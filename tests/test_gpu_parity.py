@@ -902,7 +902,7 @@ PK_SMALL = [(1, 26), (2, 27), (511, 28), (513, 29), (1025, 30), (2049, 31), (777
 @pytest.mark.gpu
 @pytest.mark.parametrize("scene", ["under_way", "saturated", "parked"])
 @pytest.mark.parametrize("K,T", PK_SMALL)
-def test_mixed_precision_rollout_at_small_sizes(orc, monkeypatch, K, T, scene):
+def test_mixed_precision_rollout_at_small_sizes(orc, monkeypatch, tick_path, K, T, scene):
     """The benchmarked rollout kernel (rollout_pk_kernel: two samples per lane, deviations in packed fp32) takes over at
     400 000 samples; here it is made to run from one sample up (MPPI_PK_MIN_SAMPLES=1, read by mppi_create) so that its corner
     cases meet the oracle on every sample: one sample and odd K (a lane with one live sample), K around the 512-sample block,
@@ -911,6 +911,8 @@ def test_mixed_precision_rollout_at_small_sizes(orc, monkeypatch, K, T, scene):
     heading deviation is outside its short series -- rollout_pk_applies) and the longest (256); under way, with the nominal
     wheel speeds driven into the clip (the deviation form's clip bounds become one-sided), and parked at the goal with zero
     nominal controls."""
+    if tick_path == "scan":
+        pytest.skip("a lane-kernel test (the engines below name their tick path)")
     monkeypatch.setenv("MPPI_PK_MIN_SAMPLES", "1")
     if scene == "under_way":
         u0 = np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
@@ -934,9 +936,11 @@ def test_mixed_precision_rollout_at_small_sizes(orc, monkeypatch, K, T, scene):
     print("mixed kernel K=%d T=%d %s: %s" % (K, T, scene, m))
 
 
-def test_the_mixed_rollout_hands_over_where_it_does_not_apply(monkeypatch):
+def test_the_mixed_rollout_hands_over_where_it_does_not_apply(monkeypatch, tick_path):
     """Beyond T = 256 (no inline nominal rollout), below T = 26 (steps too long for its series), in fp64 storage, with the heading weight or the euler model the tick runs
     the all-fp64 kernel even when the size rule says mixed; the small-K path reports the scan kernel."""
+    if tick_path == "scan":
+        pytest.skip("the engines below name their tick path")
     monkeypatch.setenv("MPPI_PK_MIN_SAMPLES", "1")
     for kw, want in [(dict(K=600, T=257), "fp64"), (dict(K=600, T=25), "fp64"), (dict(K=600, T=26), "mixed"), (dict(K=600, T=50, storage="f64"), "fp64"), (dict(K=600, T=50, model="euler"), "fp64"),
                      (dict(K=600, T=50, q=(1e3, 1e3, 5.0)), "fp64"), (dict(K=600, T=50), "mixed"), (dict(K=600, T=50, tick_path="scan"), "scan")]:
