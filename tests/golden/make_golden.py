@@ -408,6 +408,26 @@ def main():
     out["init_seq_meta"] = np.array([K, T, seed, nt], dtype=np.int64)
     out["init_seq_state0"], out["init_seq_goal"], out["init_seq_uvec_init"] = np.array([0.05, 0.0, 0.2]), goal, mp.uvec_init.copy()
 
+    # ---------------- M (round 3): the smallest sizes the reference itself accepts -- one sample (the softmax of one weight),
+    # the shortest horizon scipy's filter takes with polyorder 3 (T = 5: an even window of 4; T = 6: the odd window 5), two and
+    # three samples on odd / even horizons, and one sample on the benchmark horizon.  Closed loops of four ticks each.
+    edge = [(1, 5, 51), (1, 6, 52), (2, 5, 53), (3, 7, 54), (2, 8, 55), (1, 50, 56)]
+    for K, T, seed in edge:
+        mp = ref.MPPI(horizon=T, samples=K)
+        np.random.seed(seed)
+        st, goal = np.array([0.02, -0.01, 0.1]), np.array([0.25, -0.4, -0.3])
+        states, us, lat = [], [], []
+        for _ in range(4):
+            st = mp.get_path(st, goal)
+            states.append(st.copy())
+            us.append(mp.uvec[-1].copy())
+            lat.append(mp.latest_uvec.copy())
+        tag = "edge_k%d_t%d" % (K, T)
+        out[tag + "_states"], out[tag + "_u"], out[tag + "_latest_uvec"] = np.array(states), np.array(us), np.array(lat)
+        out[tag + "_S"] = savgol_filter(np.eye(T), T - 1, 3, axis=1)
+    out["edge_meta"] = np.array(edge, dtype=np.int64)
+    out["edge_state0"], out["edge_goal"] = np.array([0.02, -0.01, 0.1]), np.array([0.25, -0.4, -0.3])
+
     np.savez_compressed(os.path.join(HERE, "mppi_golden.npz"), **out)
     with open(os.path.join(HERE, "mppi_kat.json"), "w") as f:
         json.dump(kat, f, indent=1, sort_keys=True)

@@ -320,6 +320,23 @@ def test_odd_horizon_golden(golden, storage):
 
 
 @pytest.mark.parametrize("storage", ["f64", "f32"])
+def test_smallest_sizes_golden(golden, storage):
+    """Golden section M through the class: one, two, three samples; horizons 5 (the shortest the reference's filter takes: an even
+    window of 4), 6, 7, 8, 50 -- four closed-loop ticks each against the reference's own."""
+    from motion_planning_amd import MPPI
+    for K, T, seed in [[int(x) for x in row] for row in golden["edge_meta"]]:
+        tag = "edge_k%d_t%d" % (K, T)
+        m = MPPI(horizon=T, samples=K, storage=storage)
+        np.random.seed(seed)
+        st = golden["edge_state0"].copy()
+        for i in range(4):
+            st = m.get_path(st, golden["edge_goal"])
+            assert np.abs(st - golden[tag + "_states"][i]).max() < (1e-10 if storage == "f64" else 1e-7), (tag, i)
+            assert np.abs(m.uvec[-1] - golden[tag + "_u"][i]).max() < (1e-9 if storage == "f64" else 2e-5), (tag, i)
+            assert np.abs(m.latest_uvec - golden[tag + "_latest_uvec"][i]).max() < (1e-9 if storage == "f64" else 2e-5), (tag, i)
+
+
+@pytest.mark.parametrize("storage", ["f64", "f32"])
 def test_nonzero_uvec_init_golden(golden, storage):
     """uvec_init is an instance attribute (control/src/mppi:65): initialize() loads it into latest_uvec (:81) and every
     receding-horizon shift appends uvec_init[:, 0] (:101).  Golden section L, through the class; both tick mappings."""

@@ -54,6 +54,21 @@ def test_odd_horizon_closed_loop(orc, golden):
     assert np.abs(lat - golden["odd_seq_latest_uvec"]).max() < 1e-9
 
 
+def test_smallest_sizes_closed_loop(orc, golden):
+    """Golden section M: one, two, three samples; horizons 5 (even filter window 4), 6, 7, 8 and 50 -- four closed-loop ticks of
+    the reference each, and the filter operator scipy builds for those horizons."""
+    for K, T, seed in [[int(x) for x in row] for row in golden["edge_meta"]]:
+        tag = "edge_k%d_t%d" % (K, T)
+        assert np.abs(orc.savgol_matrix(T) - golden[tag + "_S"]).max() < 2e-12, tag
+        noise = orc.reference_noise(seed, SIG, T, K, n_ticks=4)
+        st, lat = golden["edge_state0"].copy(), np.zeros((2, T))
+        for i in range(4):
+            st, ua, lat = orc.get_path(st, golden["edge_goal"], lat, noise[i], LAM, SIG)
+            assert np.abs(st - golden[tag + "_states"][i]).max() < 1e-10, (tag, i)
+            assert np.abs(ua - golden[tag + "_u"][i]).max() < 1e-9, (tag, i)
+            assert np.abs(lat - golden[tag + "_latest_uvec"][i]).max() < 1e-9, (tag, i)
+
+
 def test_nonzero_uvec_init_closed_loop(orc, golden):
     """uvec_init != 0 (control/src/mppi:65): initialize() loads it (:81), every shift appends uvec_init[:, 0] (:101)."""
     K, T, seed, nt = [int(x) for x in golden["init_seq_meta"]]
