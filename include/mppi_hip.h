@@ -44,6 +44,7 @@
  *   MPPI_SYNC_TIMEOUT_MS   default deadline of the blocking waits;   MPPI_STORE_EPS=1  the tick path stores its noise;
  *   MPPI_ROLLOUT_PK=0      keep fp32-storage ticks on the all-fp64 rollout kernel (same-box A/B against the mixed-precision one),
  *   MPPI_PK_MIN_SAMPLES    where the mixed-precision kernel takes over (default 400000), MPPI_PK_WAVES=5 its 5-waves-per-SIMD build;
+ *   MPPI_UPD_SKIP=0        the update kernel forms exp() for every sample again (round 2; default: wave-vectors without a weight above the cut are skipped),
  *   MPPI_CO_CUT_PCT        shares of the co-scheduled shards in per cent, cumulative ("58", "45,80"), MPPI_CO_PRIO=1 stream priorities.
  */
 #ifndef MPPI_HIP_H

@@ -112,6 +112,7 @@ struct mppi_engine {
     bool last_rollout_pk = false;  // which kernel the last rollout launch was
     int last_rollout_kind = MPPI_ROLLOUT_NONE;   // ... as mppi_rollout_kernel reports it
     bool co_shards_pk = false;     // ... and the one the shards of the last co-scheduled tick ran
+    int upd_skip_light = 1;         // MPPI_UPD_SKIP=0: the update kernel forms exp() for every sample (same-box A/B)
     bool use_pk = true;             // MPPI_ROLLOUT_PK=0: keep the all-fp64 rollout kernel on the tick path (same-box A/B measurements)
     double* d_tc = nullptr;  // [A][T][8]
     double* d_base = nullptr;
@@ -543,7 +544,7 @@ struct mppi_engine {
 #define LAUNCH_UPD(TYPE, REGEN)                                                                                  \
     hipLaunchKernelGGL((mppi::update_kernel<TYPE, REGEN>), grid, dim3(256), 0, st, P, static_cast<const TYPE*>(d_eps), \
                        static_cast<const TYPE*>(d_dP), static_cast<const TYPE*>(d_stot), d_part, NCH, ch0, nch,    \
-                       static_cast<const TYPE*>(d_epart), lazy_seed, lazy_tick, tick_ptr)
+                       static_cast<const TYPE*>(d_epart), lazy_seed, lazy_tick, tick_ptr, upd_skip_light)
         if (f64()) { if (eps_lazy) LAUNCH_UPD(double, true); else LAUNCH_UPD(double, false); }
         else { if (eps_lazy) LAUNCH_UPD(float, true); else LAUNCH_UPD(float, false); }
 #undef LAUNCH_UPD
@@ -687,6 +688,7 @@ struct mppi_engine {
         cfg = c;
         if (const char* v = std::getenv("MPPI_STORE_EPS")) store_eps_always = std::atoi(v) != 0;
         if (const char* v = std::getenv("MPPI_ROLLOUT_PK")) use_pk = std::atoi(v) != 0;
+        if (const char* v = std::getenv("MPPI_UPD_SKIP")) upd_skip_light = std::atoi(v) != 0;
         if (const char* v = std::getenv("MPPI_PK_WAVES")) pk_waves = std::atoi(v);
         if (const char* v = std::getenv("MPPI_PK_MIN_SAMPLES")) pk_min_samples = std::atol(v);
         if (const char* v = std::getenv("MPPI_SYNC_TIMEOUT_MS")) sync_timeout_ms = std::atoi(v);

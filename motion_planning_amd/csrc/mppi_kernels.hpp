@@ -1008,7 +1008,7 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
                                                     const S* __restrict__ dP, const S* __restrict__ Stot,
                                                     double* __restrict__ part, int NCH, int ch_first, int n_local,
                                                     const S* __restrict__ epart, uint64_t seed, uint32_t tick_arg,
-                                                    const uint32_t* __restrict__ tick_ptr) {
+                                                    const uint32_t* __restrict__ tick_ptr, int skip_light) {
     using R = S;
     constexpr int VEC = UpdCfg<S>::VEC, CH = UpdCfg<S>::CH;
     typedef S vec_t __attribute__((ext_vector_type(VEC)));
@@ -1074,8 +1074,9 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
 
     // pass 2: weights relative to the block minimum; eps only where the weight is representable
     const R scale = (R)(P.inv_lambda * 1.4426950408889634);  // log2(e) / lambda
-    // log2 of the smallest weight whose noise is fetched.  D sums EVERY weight; a weight below the cut only misses its
-    // e * eps in N.  fp32 mode: 2^-40 -- the sums are fp32 and the block minimum carries e = 1, so a dropped term is below
+    // log2 of the smallest weight whose noise is fetched.  D sums every weight of every wave-vector (64 lanes x one 16-byte
+    // vector) that holds at least one weight above the cut (vectors without one are skipped whole, see the loop); a weight
+    // below the cut only misses its e * eps in N.  fp32 mode: 2^-40 -- the sums are fp32 and the block minimum carries e = 1, so a dropped term is below
     // 1e-12 of D, five orders under the sum's own rounding unit (at 2^-32 two shardings of the same samples still differed by
     // a few 1e-10 in u -- the cut is relative to the CHUNK's minimum -- which the split-invariance tests see; round 2 cut at
     // 2^-80 and fetched twice as many); fp64 mode keeps everything down to 2^-100.
@@ -1110,18 +1111,21 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
         const int k = k_begin + (j * 256 + tid) * VEC;
         R xs[VEC], es[VEC];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            xs[i] = (M - v[j][i]) * scale;  // <= 0; -inf for the padding
-            es[i] = Exp2<R>::f(xs[i]);
-            D += es[i];
-        }
+        for (int i = 0; i < VEC; ++i) xs[i] = (M - v[j][i]) * scale;  // <= 0; -inf for the padding
+        // A wave's 64 vectors (256 samples) none of which reaches the cut are skipped whole: no exp, nothing added to D -- at most
+        // 256 * 2^-40 of the chunk's best weight per skip, 2^-27 of D over a chunk in the worst case (an eighth of D's fp32
+        // rounding unit; 2^-92 in fp64 mode).  Far from the goal that is almost every vector: the kernel is HBM-bound either
+        // way, but the instructions it does not issue are free slots for a rollout co-scheduled next to it.
+        unsigned long long bal[VEC];
+        int n_here = 0;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { bal[i] = __ballot(xs[i] > cand); n_here += (int)__popcll(bal[i]); }
+        if (skip_light && n_here == 0) continue;   // (uniform)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { es[i] = Exp2<R>::f(xs[i]); D += es[i]; }
         if (REGEN) {
             // one queue reservation per wave and VECTOR (an LDS atomic with return is a round trip the wave waits for:
             // one per value made 32 of them per row)
-            unsigned long long bal[VEC];
-            int n_here = 0;
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) { bal[i] = __ballot(xs[i] > cand); n_here += (int)__popcll(bal[i]); }
             if (n_here) {  // (uniform) skipped for almost every vector while the robot is far from its goal
                 int base = 0;
                 if (lane == 0) base = atomicAdd(&q_n, n_here);
