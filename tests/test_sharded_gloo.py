@@ -101,7 +101,7 @@ def test_shard_range_is_a_partition():
             assert max(sizes) - min(sizes) <= 1
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])   # 2, 4, 8: the world sizes of the driver's scaling runs; 3: ragged thirds
 def test_sharded_ticks_equal_unsharded_gloo(orc, world):
     import torch.multiprocessing as mp
     K, T, n_ticks = 301, 20, 3   # K not divisible by the world size: ragged shards
