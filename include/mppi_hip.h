@@ -99,7 +99,8 @@ extern "C" {
  * the unsplit tick to rounding (sample ids are global, the tuple merge is exact); every other call of this ABI keeps
  * working: after such a tick mppi_download_value / _noise / mppi_update re-run the rollout over all samples from a
  * snapshot of the tick's inputs, bit for bit what the shards computed.  AUTO = 2 shards for n_agents * samples >= 500000
- * on the lane-per-sample path, else none.  mppi_tick_begin / _finish (the caller's own exchange), mppi_tick_graph and
+ * on the lane-per-sample path with at least 32768 samples per agent and n_agents * horizon <= 256 rows (beyond that the
+ * shards' publish kernels cost more than the overlap gains), else none.  mppi_tick_begin / _finish (the caller's own exchange), mppi_tick_graph and
  * injected-noise ticks always run unsplit; mppi_p2p_create on such a handle dissolves the group. */
 
 /* kernels, for mppi_kernel_timing (the scan kernel is timed as MPPI_KERNEL_ROLLOUT) */

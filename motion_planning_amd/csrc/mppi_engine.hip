@@ -890,7 +890,11 @@ void mppi_engine::co_build() {
     // AUTO: two shards where the pair measured faster than the one engine (config 4: +7-9 % rollouts/s; nothing below
     // ~5e5 samples), on the lane-per-sample path only
     // (and while a second set of buffers is small change against the 288 GB: the subs hold another half of this engine's)
-    if (G == 0) G = (lanes && (long)cfg.n_agents * cfg.samples >= 500000 && cfg.samples >= 4 * CH && hbm_bytes < ((size_t)48 << 30)) ? 2 : 1;
+    // and while the shards' publish kernels (one block per peer walking all A * T rows, 16 per pass) stay small change: measured
+    // on one box, tick us one engine / two shards: A = 1 T = 100 K = 1e6 300 / 287, T = 25 99.4 / 96.5; A = 2 x 500 000 148 / 137;
+    // A = 4 x 250 000 149 / 145; A = 8 x 131 072 (400 rows) 150 / 159 -- no longer a gain
+    if (G == 0) G = (lanes && (long)cfg.n_agents * cfg.samples >= 500000 && cfg.samples >= 4 * CH && cfg.n_agents * cfg.horizon <= 256 &&
+                     hbm_bytes < ((size_t)48 << 30)) ? 2 : 1;
     if (G <= 1) return;
     if (!lanes || cfg.samples < G * CH) {
         if (wanted) fail(MPPI_E_INVALID, "co_shards = %d needs the lane-per-sample tick path and at least %d samples per shard", G, CH);

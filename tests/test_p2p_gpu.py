@@ -304,6 +304,23 @@ def test_co_scheduled_value_is_bit_identical_to_the_unsplit_engine():
         assert e.info()["co_shards"] == 2
     with Engine(100000, 100) as e:
         assert e.info()["co_shards"] == 1
+    # the AUTO rule over agents: two agents x 500 000 split (100 rows for the publish kernels to walk), eight x 131 072 and config 5
+    # do not (400 / 3200 rows: measured slower than one engine); two shards of a multi-agent handle still equal the one engine
+    for A, K, want in [(2, 500000, 2), (8, 131072, 1), (64, 16384, 1)]:
+        with Engine(K, T, n_agents=A) as e:
+            assert e.info()["co_shards"] == want, (A, K, e.info())
+    got = []
+    for co in (1, 2):
+        with Engine(70000, T, n_agents=3, storage="f32", tick_path="lanes", co_shards=co) as e:
+            for a in range(3):
+                e.set_nominal(u0 * (1.0 - 0.2 * a), agent=a)
+            st = np.array([[0, 0, 0], [0.1, 0, 0.2], [-0.1, 0.05, -0.3]], dtype=float)
+            goal = np.array([[0, -1, 0], [0.5, -0.5, 0.1], [-0.4, 0.3, 0.0]], dtype=float)
+            for i in range(3):
+                nxt, ua = e.tick(st if i == 0 else None, goal if i == 0 else None, noise="philox", seed=4, tick_id=i)
+            got.append((nxt, ua, np.array([e.get_nominal(agent=a) for a in range(3)])))
+    for x, y in zip(got[0], got[1]):
+        assert np.abs(x - y).max() < 1e-10
 
 
 @pytest.mark.gpu
