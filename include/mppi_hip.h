@@ -43,7 +43,7 @@
  * Environment (measurement aids, read once by mppi_create; none changes results beyond rounding):
  *   MPPI_SYNC_TIMEOUT_MS   default deadline of the blocking waits;   MPPI_STORE_EPS=1  the tick path stores its noise;
  *   MPPI_ROLLOUT_PK=0      keep fp32-storage ticks on the all-fp64 rollout kernel (same-box A/B against the mixed-precision one),
- *   MPPI_PK_MIN_SAMPLES    where the mixed-precision kernel takes over (default 400000), MPPI_PK_WAVES=5 its 5-waves-per-SIMD build;
+ *   MPPI_PK_MIN_SAMPLES    a plain size rule for the mixed-precision kernel (unset: chosen per size by rounds of waves; co-scheduled shards: 400000), MPPI_PK_WAVES=5 its 5-waves-per-SIMD build;
  *   MPPI_UPD_SKIP=0        the update kernel forms exp() for every sample again (round 2; default: wave-vectors without a weight above the cut are skipped),
  *   MPPI_CO_CUT_PCT        shares of the co-scheduled shards in per cent, cumulative ("58", "45,80"), MPPI_CO_PRIO=1 stream priorities.
  */
@@ -323,8 +323,8 @@ int mppi_co_info(mppi_engine *h, int32_t *n_shards, int32_t *samples);
 /* Which rollout kernel this handle's last tick / mppi_rollout launched (a co-scheduled handle: its shards all take the same
  * one; the re-run behind a later mppi_download_value does not count):
  * MPPI_ROLLOUT_NONE before the first; _FP64 the one-sample-per-lane kernel (all arithmetic fp64); _MIXED the
- * mixed-precision two-samples-per-lane kernel (fp32 storage, device noise, the node's cost and model, T <= 256, at least
- * MPPI_PK_MIN_SAMPLES samples); _SCAN the single-kernel small-K tick.  What tests and bench.py label their numbers with. */
+ * mixed-precision two-samples-per-lane kernel (fp32 storage, device noise, the node's cost and model, T <= 256, at the sizes
+ * where it is the faster of the two -- from about 262 000 samples); _SCAN the single-kernel small-K tick.  What tests and bench.py label their numbers with. */
 #define MPPI_ROLLOUT_NONE 0
 #define MPPI_ROLLOUT_FP64 1
 #define MPPI_ROLLOUT_MIXED 2

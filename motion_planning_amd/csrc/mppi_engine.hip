@@ -107,7 +107,8 @@ struct mppi_engine {
     uint32_t lazy_tick = 0;
     bool store_eps_always = false;  // MPPI_STORE_EPS=1: the tick path writes eps like mppi_rollout does
     int pk_waves = 4;
-    long pk_min_samples = 400000;
+    long pk_min_samples = 400000;   // the size rule of co-scheduled shards (and of every engine when MPPI_PK_MIN_SAMPLES is set)
+    bool pk_min_from_env = false;
     int force_pk = -1;             // >= 0: the size rule is overridden (the re-run of a co-scheduled tick takes the shards' kernel)
     bool last_rollout_pk = false;  // which kernel the last rollout launch was
     int last_rollout_kind = MPPI_ROLLOUT_NONE;   // ... as mppi_rollout_kernel reports it
@@ -434,7 +435,24 @@ struct mppi_engine {
         // ... and enough waves: it halves their number and doubles their length, which only pays when every SIMD still gets
         // several (same-box A/B at T = 50, rollout_kernel vs this one: 10^6 samples 106.8 vs 101.8 us, 750 000 83.0 vs 79.4,
         // 500 000 58.2 vs 56.9, 375 000 47.1 vs 46.3, 250 000 34.5 vs 36.1, 125 000 24.6 vs 28.3)
-        const bool pk_size = force_pk >= 0 ? force_pk != 0 : (long)cfg.n_agents * cfg.samples >= pk_min_samples;
+        // Which of the two is faster at a given size is a matter of ROUNDS OF WAVES: a launch takes as long as its busiest SIMD,
+        // i.e. ceil(blocks / 256 CUs) waves of the kernel's length, and a wave of this kernel (128 samples) costs 1.9 waves of the
+        // other (64 samples).  One engine, T = 50, tick us all-fp64 / mixed, sizes chosen around whole rounds (r = blocks / 256):
+        //   393 216 (r 3.00) 75.2 / 73.8   400 000 (3.05) 78.5 / 83.0   430 000 (3.28) 80.2 / 83.8   460 000 (3.51) 85.7 / 83.6
+        //   560 000 (4.27) 98.1 / 100.3    600 000 (4.58) 103.8 / 100.5  700 000 (5.34) 114.5 / 116.0  750 000 (5.72) 122.3 / 117.7
+        //   850 000 (6.49) 128.8 / 130.8   900 000 (6.87) 136.6 / 134.1  10^6 (7.63) 154.8 / 150.1   1 048 576 (8.00) 157.3 / 150.7
+        // -- 1.9 ceil(r_mixed) < ceil(r_fp64) calls 21 of the 23 sizes measured (300 000 ... 1 200 000) and ties on the other two.
+        // Below three rounds the long waves lose to latency whatever the rounds say (250 000: 34.5 vs 36.1 us).  Shards of a
+        // co-scheduled handle fill each other's gaps and keep the plain size rule (measured: 138-139 us against 142-145 per tick);
+        // so does an engine whose MPPI_PK_MIN_SAMPLES is set (tests, A/B runs).
+        bool pk_size;
+        if (force_pk >= 0) pk_size = force_pk != 0;
+        else if (pk_min_from_env || co_active() || is_co_sub) pk_size = (long)cfg.n_agents * cfg.samples >= pk_min_samples;
+        else {
+            const long r_pk = ((long)cfg.n_agents * ((cfg.samples + 511) / 512) + 255) / 256;
+            const long r_64 = ((long)cfg.n_agents * ((cfg.samples + 255) / 256) + 255) / 256;
+            pk_size = r_pk >= 3 && 19 * r_pk < 10 * r_64;
+        }
         const bool pk = use_pk && !f64() && ph && !store && a.inline_nominal && !a.general && k0 == 0 && k1 == cfg.samples && pk_size &&
                         mppi::rollout_pk_applies(P.kth, P.dt, P.sigma, cfg.horizon);
         last_rollout_pk = pk;
@@ -690,7 +708,7 @@ struct mppi_engine {
         if (const char* v = std::getenv("MPPI_ROLLOUT_PK")) use_pk = std::atoi(v) != 0;
         if (const char* v = std::getenv("MPPI_UPD_SKIP")) upd_skip_light = std::atoi(v) != 0;
         if (const char* v = std::getenv("MPPI_PK_WAVES")) pk_waves = std::atoi(v);
-        if (const char* v = std::getenv("MPPI_PK_MIN_SAMPLES")) pk_min_samples = std::atol(v);
+        if (const char* v = std::getenv("MPPI_PK_MIN_SAMPLES")) { pk_min_samples = std::atol(v); pk_min_from_env = true; }
         if (const char* v = std::getenv("MPPI_SYNC_TIMEOUT_MS")) sync_timeout_ms = std::atoi(v);
         if (cfg.n_agents < 1 || cfg.samples < 1) fail(MPPI_E_INVALID, "n_agents and samples must be >= 1");
         if (cfg.n_agents > 65535) fail(MPPI_E_INVALID, "n_agents %d: agents are a grid dimension (<= 65535)", cfg.n_agents);

@@ -921,7 +921,7 @@ PK_SMALL = [(1, 26), (2, 27), (511, 28), (513, 29), (1025, 30), (2049, 31), (777
 @pytest.mark.parametrize("K,T", PK_SMALL)
 def test_mixed_precision_rollout_at_small_sizes(orc, monkeypatch, tick_path, K, T, scene):
     """The benchmarked rollout kernel (rollout_pk_kernel: two samples per lane, deviations in packed fp32) takes over at
-    400 000 samples; here it is made to run from one sample up (MPPI_PK_MIN_SAMPLES=1, read by mppi_create) so that its corner
+    a few hundred thousand samples; here it is made to run from one sample up (MPPI_PK_MIN_SAMPLES=1, read by mppi_create) so that its corner
     cases meet the oracle on every sample: one sample and odd K (a lane with one live sample), K around the 512-sample block,
     every horizon class mod 6 (full chunks only: 30; one or two steps riding along: 31, 49 / 26, 32, 50; a tail chunk of its
     own: 27, 28, 29, 51, 100, 255, 256), the shortest horizon it serves at dt = 1 / T and sigma = 0.9 (26: below that a step's
@@ -968,6 +968,14 @@ def test_the_mixed_rollout_hands_over_where_it_does_not_apply(monkeypatch, tick_
             assert e.info()["rollout_kernel"] == "none"
             e.tick([0.0, 0.0, 0.0], [0.3, 0.2, 0.0], noise="philox", seed=1, tick_id=0)
             assert e.info()["rollout_kernel"] == want, (kw, e.info())
+    # without the switch the two lane kernels are chosen by rounds of waves (launch_rollout in mppi_engine.hip): the mixed one where
+    # 1.9 x its rounds undercut the all-fp64 kernel's, from three rounds on; shards of a co-scheduled handle by size alone
+    monkeypatch.delenv("MPPI_PK_MIN_SAMPLES")
+    for K, A, co, want in [(393216, 1, 1, "mixed"), (400000, 1, 1, "fp64"), (460000, 1, 1, "mixed"), (560000, 1, 1, "fp64"), (250000, 1, 1, "fp64"),
+                           (1000000, 1, 1, "mixed"), (16384, 64, 1, "mixed"), (1000000, 1, 2, "mixed"), (500000, 1, 2, "fp64")]:
+        with _engine(K, 50, "f32", n_agents=A, tick_path="lanes", co_shards=co) as e:
+            e.tick(np.zeros((A, 3)), np.tile([0.3, 0.2, 0.0], (A, 1)), noise="philox", seed=1, tick_id=0)
+            assert e.info()["rollout_kernel"] == want, (K, A, co, e.info())
 
 
 def test_f32_storage_against_f64_storage_at_config4(orc, tick_path):
