@@ -441,7 +441,7 @@ struct mppi_engine {
         //   393 216 (r 3.00) 75.2 / 73.8   400 000 (3.05) 78.5 / 83.0   430 000 (3.28) 80.2 / 83.8   460 000 (3.51) 85.7 / 83.6
         //   560 000 (4.27) 98.1 / 100.3    600 000 (4.58) 103.8 / 100.5  700 000 (5.34) 114.5 / 116.0  750 000 (5.72) 122.3 / 117.7
         //   850 000 (6.49) 128.8 / 130.8   900 000 (6.87) 136.6 / 134.1  10^6 (7.63) 154.8 / 150.1   1 048 576 (8.00) 157.3 / 150.7
-        // -- 1.9 ceil(r_mixed) < ceil(r_fp64) calls 21 of the 23 sizes measured (300 000 ... 1 200 000) and ties on the other two.
+        // -- 1.9 ceil(r_mixed) < ceil(r_fp64) picks the faster kernel at 21 of the 23 sizes measured (300 000 ... 1 200 000; 0.7 % and 2.2 % slower at the other two).
         // Below three rounds the long waves lose to latency whatever the rounds say (250 000: 34.5 vs 36.1 us).  Shards of a
         // co-scheduled handle fill each other's gaps and keep the plain size rule (measured: 138-139 us against 142-145 per tick);
         // so does an engine whose MPPI_PK_MIN_SAMPLES is set (tests, A/B runs).
