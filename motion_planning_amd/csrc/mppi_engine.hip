@@ -24,6 +24,7 @@
 #include "rollout_launch.hpp"
 #include "rollout_pk.hpp"
 #include "savgol.hpp"
+#include "tick_fused.hpp"
 
 namespace {
 
@@ -105,16 +106,16 @@ struct mppi_engine {
     bool eps_lazy = false, lazy_from_counter = false, lazy_counter_bumped = false;
     uint64_t lazy_seed = 0;
     uint32_t lazy_tick = 0;
-    bool store_eps_always = false;  // MPPI_STORE_EPS=1: the tick path writes eps like mppi_rollout does
+    bool store_eps_always = false;  // option "store_eps": the tick path writes eps like mppi_rollout does
     int pk_waves = 4;
-    long pk_min_samples = 400000;   // the size rule of co-scheduled shards (and of every engine when MPPI_PK_MIN_SAMPLES is set)
-    bool pk_min_from_env = false;
+    long pk_min_samples = 400000;   // the size rule of co-scheduled shards (and of every engine whose option "pk_min_samples" is set)
+    bool pk_min_set = false;
     int force_pk = -1;             // >= 0: the size rule is overridden (the re-run of a co-scheduled tick takes the shards' kernel)
     bool last_rollout_pk = false;  // which kernel the last rollout launch was
     int last_rollout_kind = MPPI_ROLLOUT_NONE;   // ... as mppi_rollout_kernel reports it
     bool co_shards_pk = false;     // ... and the one the shards of the last co-scheduled tick ran
-    int upd_skip_light = 1;         // MPPI_UPD_SKIP=0: the update kernel forms exp() for every sample (same-box A/B)
-    bool use_pk = true;             // MPPI_ROLLOUT_PK=0: keep the all-fp64 rollout kernel on the tick path (same-box A/B measurements)
+    int upd_skip_light = 1;         // option "upd_skip" = 0: the update kernel forms exp() for every sample (same-box A/B)
+    bool use_pk = true;             // option "rollout_pk" = 0: keep the all-fp64 rollout kernel on the tick path (same-box A/B measurements)
     double* d_tc = nullptr;  // [A][T][8]
     double* d_base = nullptr;
     double* d_unom = nullptr;
@@ -252,6 +253,7 @@ struct mppi_engine {
     // other call of the ABI keeps working on this engine's own full-size buffers.
     std::vector<mppi_engine*> subs;
     int co_k0 = 0;             // samples of shard 0
+    int co_cut_pct = 58;       // two shards: shard 0's share in per cent (option "co_cut_pct" rebuilds the group)
     bool co_synced = false;    // the subs hold this engine's nominal controls / state / goal
     bool co_last = false;      // the last tick ran co-scheduled: its V / noise exist only as "re-run from the snapshot"
     hipEvent_t ev_co = nullptr;
@@ -422,9 +424,7 @@ struct mppi_engine {
         a.P = P; a.stream = st; a.k0 = k0; a.k1 = k1; a.philox = ph; a.store_eps = store;
         a.model = cfg.model;
         a.inline_nominal = !inline_nominal() ? 0 : (cfg.horizon <= 64 ? 1 : 2);
-        // the lean instantiation is written for the node's cost: Q = diag(q, q, 0), q > 0 (and sane: it scales
-        // positions by sqrt(q/2)), no obstacle grid
-        a.general = P.q2 != 0.0 || P.grid_weight != 0.0 || P.q0 != P.q1 || !(P.q0 > 1e-100 && P.q0 < 1e100);
+        a.general = general_cost();
         a.seed = seed; a.tick = tick; a.tick_ptr = tick_ptr;
         a.state = ro_state ? ro_state : d_state; a.goal = ro_goal ? ro_goal : d_goal;
         a.unom = ro_unom ? ro_unom : d_unom; a.tc = d_tc; a.base = d_base;
@@ -444,17 +444,8 @@ struct mppi_engine {
         // -- 1.9 ceil(r_mixed) < ceil(r_fp64) picks the faster kernel at 21 of the 23 sizes measured (300 000 ... 1 200 000; 0.7 % and 2.2 % slower at the other two).
         // Below three rounds the long waves lose to latency whatever the rounds say (250 000: 34.5 vs 36.1 us).  Shards of a
         // co-scheduled handle fill each other's gaps and keep the plain size rule (measured: 138-139 us against 142-145 per tick);
-        // so does an engine whose MPPI_PK_MIN_SAMPLES is set (tests, A/B runs).
-        bool pk_size;
-        if (force_pk >= 0) pk_size = force_pk != 0;
-        else if (pk_min_from_env || co_active() || is_co_sub) pk_size = (long)cfg.n_agents * cfg.samples >= pk_min_samples;
-        else {
-            const long r_pk = ((long)cfg.n_agents * ((cfg.samples + 511) / 512) + 255) / 256;
-            const long r_64 = ((long)cfg.n_agents * ((cfg.samples + 255) / 256) + 255) / 256;
-            pk_size = r_pk >= 3 && 19 * r_pk < 10 * r_64;
-        }
-        const bool pk = use_pk && !f64() && ph && !store && a.inline_nominal && !a.general && k0 == 0 && k1 == cfg.samples && pk_size &&
-                        mppi::rollout_pk_applies(P.kth, P.dt, P.sigma, cfg.horizon);
+        // so does an engine whose MPPI_PK_MIN_SAMPLES is set (tests, A/B runs).  (pick_pk)
+        const bool pk = pick_pk(ph, store, k0, k1);
         last_rollout_pk = pk;
         last_rollout_kind = pk ? MPPI_ROLLOUT_MIXED : MPPI_ROLLOUT_FP64;
         if (pk) {
@@ -584,6 +575,78 @@ struct mppi_engine {
     // one boundary less per tick: the finalize kernel (skip_small_merge: the fused mppi_tick, no exchange follows) or the
     // merging publish kernel of the p2p exchange.  "A handful" = at most kDirectTuples chunk / scan-block tuples per row
     // (K <= 131072 samples on the lane kernels).
+    // The fused tick (tick_fused.hpp): rollout + update work items of one launch.  fused_mode: -1 auto, 0 off, 1 wherever it applies
+    int fused_mode = -1, fused_lag = 0 /* 0: one round of resident rollout items per XCD */, fused_prio = 0;
+    uint32_t* d_fq = nullptr;        // [2 parities][8 * kFusedHeadStride ticket heads + A * NCH arrival counters]
+    uint32_t* d_fstatus = nullptr;   // != 0: a work item's wait ran into its deadline
+    size_t fq_words = 0;
+    uint32_t fused_epoch = 0;
+    bool last_tick_fused = false;
+    bool general_cost() const {
+        // the lean rollout instantiations are written for the node's cost: Q = diag(q, q, 0), q > 0 (and sane: they scale
+        // positions by sqrt(q/2)), no obstacle grid
+        return P.q2 != 0.0 || P.grid_weight != 0.0 || P.q0 != P.q1 || !(P.q0 > 1e-100 && P.q0 < 1e100);
+    }
+    // which of the two lane-per-sample rollouts a device-noise tick of this engine takes (see launch_rollout)
+    bool pick_pk(bool ph, bool store, int k0, int k1) const {
+        bool pk_size;
+        if (force_pk >= 0) pk_size = force_pk != 0;
+        else if (pk_min_set || co_active() || is_co_sub) pk_size = (long)cfg.n_agents * cfg.samples >= pk_min_samples;
+        else {
+            const long r_pk = ((long)cfg.n_agents * ((cfg.samples + 511) / 512) + 255) / 256;
+            const long r_64 = ((long)cfg.n_agents * ((cfg.samples + 255) / 256) + 255) / 256;
+            pk_size = r_pk >= 3 && 19 * r_pk < 10 * r_64;
+        }
+        return use_pk && !f64() && ph && !store && inline_nominal() && !general_cost() && k0 == 0 && k1 == cfg.samples && pk_size &&
+               mppi::rollout_pk_applies(P.kth, P.dt, P.sigma, cfg.horizon);
+    }
+    bool fused_applies(bool ph, bool store, const uint32_t* tick_ptr) const {
+        if (fused_mode == 0 || f64() || !ph || store || tick_ptr || capturing || small_nb > 0 || !inline_nominal() || general_cost()) return false;
+        return true;
+    }
+    void launch_fused(uint64_t seed, uint32_t tick) {
+        const bool pk = pick_pk(true, false, 0, cfg.samples);
+        mppi::FusedLaunch a{};
+        a.P = P; a.stream = stream; a.inline_nominal = cfg.horizon <= 64 ? 1 : 2;
+        if ((time_mask & (1u << MPPI_KERNEL_FUSED)) && (time_seen[MPPI_KERNEL_FUSED]++ % time_period) == 0) {
+            a.ev_start = get_event();
+            a.ev_stop = get_event();
+        }
+        mppi::FusedArgs& F = a.F;
+        const int bs = pk ? 512 : 256;
+        F.g.n_cols = cfg.n_agents * NCH; F.g.NCH = NCH; F.g.RB = CH / bs; F.g.T = cfg.horizon;
+        // lag: a queue's update items start behind one round of that XCD's resident rollout items (32 CUs x 4 or 5 workgroups)
+        F.g.L = fused_lag > 0 ? fused_lag : std::max(1, (32 * (pk ? 4 : 5) + F.g.RB - 1) / F.g.RB);
+        const size_t half = fq_words / 2;
+        const int par = (int)(fused_epoch & 1u);
+        fused_epoch += 1u;
+        F.heads = d_fq + (size_t)par * half;
+        F.done = F.heads + mppi::kFusedQueues * mppi::kFusedHeadStride;
+        F.zero_base = d_fq + (size_t)(par ^ 1) * half;
+        F.zero_n = (int)half;
+        F.status = d_fstatus;
+        F.timeout_ticks = sync_timeout_ms > 0 ? (unsigned long long)sync_timeout_ms * (unsigned long long)wall_clock_khz : 0ull;
+        F.prio_mode = fused_prio;
+        F.state = ro_state ? ro_state : d_state; F.goal = ro_goal ? ro_goal : d_goal; F.unom = ro_unom ? ro_unom : d_unom;
+        F.tc = d_tc; F.base = d_base;
+        F.dP = static_cast<float*>(d_dP); F.stot = static_cast<float*>(d_stot); F.epart = static_cast<float*>(d_epart);
+        F.seed = seed; F.tick = tick;
+        F.al_guard = mppi::rollout_pk_guard(P.kth, P.dt, P.sigma);
+        F.part = d_part; F.skip_light = upd_skip_light;
+        hipError_t e = pk ? mppi::launch_tick_fused_pk(a)
+                          : (nterm == 4 ? mppi::launch_tick_fused_f32<4>(a) : nterm == 7 ? mppi::launch_tick_fused_f32<7>(a) : mppi::launch_tick_fused_f32<0>(a));
+        last_rollout_pk = pk;
+        last_rollout_kind = pk ? MPPI_ROLLOUT_MIXED : MPPI_ROLLOUT_FP64;
+        if (a.ev_start) {
+            if (e == hipSuccess) {
+                pending.push_back({MPPI_KERNEL_FUSED, a.ev_start, a.ev_stop});
+                if (pending.size() >= 4096) drain_timing();
+            } else {
+                ev_pool.push_back(a.ev_start); ev_pool.push_back(a.ev_stop);
+            }
+        }
+        if (e != hipSuccess) fail(MPPI_E_HIP, "fused tick launch failed: %s", hipGetErrorString(e));
+    }
     bool merge_skipped = false;
     int direct_n = 0;   // tuples per row in d_part when the merge was skipped
     static constexpr int kDirectTuples = 16;
@@ -608,8 +671,13 @@ struct mppi_engine {
         }
         merge_skipped = (skip_small_merge || (p2p_connected && !p2p_internal)) && NCH <= kDirectTuples;
         direct_n = NCH;
-        launch_rollout(stream, 0, cfg.samples, ph, store, seed, tick, tick_ptr);
-        launch_update(stream, 0, NCH, tick_ptr);
+        last_tick_fused = fused_applies(ph, store, tick_ptr);
+        if (last_tick_fused) {
+            launch_fused(seed, tick);   // rollout + update work items of ONE launch (tick_fused.hpp)
+        } else {
+            launch_rollout(stream, 0, cfg.samples, ph, store, seed, tick, tick_ptr);
+            launch_update(stream, 0, NCH, tick_ptr);
+        }
         if (!merge_skipped) launch_merge(NCH);
         noise_ready = true; value_ready = true; value_lazy = false; partials_ready = true; epart_ready = true;
     }
@@ -704,11 +772,8 @@ struct mppi_engine {
 
     void init(const mppi_config& c) {
         cfg = c;
-        if (const char* v = std::getenv("MPPI_STORE_EPS")) store_eps_always = std::atoi(v) != 0;
-        if (const char* v = std::getenv("MPPI_ROLLOUT_PK")) use_pk = std::atoi(v) != 0;
-        if (const char* v = std::getenv("MPPI_UPD_SKIP")) upd_skip_light = std::atoi(v) != 0;
-        if (const char* v = std::getenv("MPPI_PK_WAVES")) pk_waves = std::atoi(v);
-        if (const char* v = std::getenv("MPPI_PK_MIN_SAMPLES")) { pk_min_samples = std::atol(v); pk_min_from_env = true; }
+        // the one environment variable the library reads (a deployment knob: the default deadline of the blocking waits);
+        // every measurement / test switch is an mppi_set_option key
         if (const char* v = std::getenv("MPPI_SYNC_TIMEOUT_MS")) sync_timeout_ms = std::atoi(v);
         if (cfg.n_agents < 1 || cfg.samples < 1) fail(MPPI_E_INVALID, "n_agents and samples must be >= 1");
         if (cfg.n_agents > 65535) fail(MPPI_E_INVALID, "n_agents %d: agents are a grid dimension (<= 65535)", cfg.n_agents);
@@ -739,16 +804,7 @@ struct mppi_engine {
         if (cfg.device < 0 || cfg.device >= ndev) fail(MPPI_E_INVALID, "device %d out of range (%d visible)", cfg.device, ndev);
         device = cfg.device;
         HIPCHK(hipSetDevice(device));
-        {
-            // experiment switch (MPPI_CO_PRIO=1): the handle's own stream at the highest priority, the co-scheduled shards' streams at
-            // the lowest, so that shard 0's rollout runs ahead of shard 1's instead of sharing the SIMDs with it
-            int lo = 0, hi = 0;
-            const char* v = std::getenv("MPPI_CO_PRIO");
-            if (v && std::atoi(v) != 0 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
-                HIPCHK(hipStreamCreateWithPriority(&own_stream, hipStreamNonBlocking, is_co_sub ? lo : hi));
-            else
-                HIPCHK(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
-        }
+        HIPCHK(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
         {
             int khz = 0;
             if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) wall_clock_khz = khz;
@@ -825,6 +881,11 @@ struct mppi_engine {
         d_clk = dev_alloc<unsigned long long>(2, hbm_bytes);
         HIPCHK(hipMemsetAsync(d_clk, 0, 2 * sizeof(unsigned long long), stream));
         P.clk = d_clk;
+        fq_words = 2 * ((size_t)mppi::kFusedQueues * mppi::kFusedHeadStride + (size_t)A * NCH);
+        d_fq = dev_alloc<uint32_t>(fq_words + 1, hbm_bytes);
+        d_fstatus = d_fq + fq_words;
+        HIPCHK(hipMemsetAsync(d_fq, 0, (fq_words + 1) * sizeof(uint32_t), stream));
+        P.fstatus = d_fstatus;
         d_fill = dev_alloc<double>((size_t)A * 2, hbm_bytes);
         HIPCHK(hipMemsetAsync(d_fill, 0, (size_t)A * 2 * sizeof(double), stream));
         P.shift_fill = d_fill;
@@ -880,7 +941,7 @@ struct mppi_engine {
         if (h_stage) hipHostFree(h_stage);
         if (h_out) hipHostFree(h_out);
         if (h_seq) hipHostFree(h_seq);
-        void* bufs[] = {d_eps, d_dP, d_stot, d_epart, d_tc, d_base, d_unom, d_ufilt, d_state, d_goal, d_part, d_merged, d_S, d_out, d_tick, d_tmp, d_grid, d_prev, d_clk, d_fill};
+        void* bufs[] = {d_eps, d_dP, d_stot, d_epart, d_tc, d_base, d_unom, d_ufilt, d_state, d_goal, d_part, d_merged, d_S, d_out, d_tick, d_tmp, d_grid, d_prev, d_clk, d_fill, d_fq};
         for (void* b : bufs) if (b) hipFree(b);
         if (own_stream) hipStreamDestroy(own_stream);
     }
@@ -925,16 +986,7 @@ void mppi_engine::co_build() {
         // Two shards: 58 / 42.  Shard 0's launches go first, so the tick ends with shard 1's update + merge + finalize with nothing
         // left to hide them under; a smaller shard 1 shortens that tail as long as its rollout still covers shard 0's update
         // (same box, K = 10^6, tick us: 50/50 139.0, 55/45 136.4, 58/42 134.2, 60/40 135.4, 62/38 136, 65/35 137.1; 45/55 141.6)
-        if (G == 2) cuts[1] = std::max(CH, (int)(((long)cfg.samples * 58 / 100 + CH / 2) / CH) * CH);
-        if (const char* v = std::getenv("MPPI_CO_CUT_PCT")) {   // experiment switch: cumulative shares in per cent, "60" or "50,80"
-            const char* q = v;
-            for (int g = 1; g < G && *q; ++g) {
-                const int pct = std::atoi(q);
-                if (pct > 0 && pct < 100) cuts[g] = std::max(CH, (int)(((long)cfg.samples * pct / 100 + CH / 2) / CH) * CH);
-                while (*q && *q != ',') ++q;
-                if (*q == ',') ++q;
-            }
-        }
+        if (G == 2) cuts[1] = std::max(CH, (int)(((long)cfg.samples * co_cut_pct / 100 + CH / 2) / CH) * CH);
         cuts[G] = cfg.samples;
         for (int g = 0; g < G; ++g) if (cuts[g + 1] <= cuts[g]) fail(MPPI_E_INVALID, "co_shards = %d: %d samples do not split", G, cfg.samples);
         co_k0 = cuts[1];
@@ -1561,6 +1613,72 @@ int mppi_tick_graph(mppi_engine* h, uint64_t seed) {
     h->eps_lazy = small || !h->store_eps_always; h->lazy_seed = seed; h->lazy_from_counter = true; h->lazy_counter_bumped = true;
     h->injected_ready = !h->eps_lazy; h->last_tick_eager = false;
     API_END(h)
+}
+
+// Measurement / test switches (include/mppi_hip.h lists the keys); none changes results beyond rounding.
+int mppi_set_option(mppi_engine* h, const char* key, int64_t value) {
+    API_BEGIN(h)
+    if (!key) fail(MPPI_E_INVALID, "option key is NULL");
+    const std::string k(key);
+    for (auto* sub__ : h->subs)
+        if (k != "co_cut_pct") if (int rc__ = mppi_set_option(sub__, key, value)) fail(rc__, "co-scheduled shard: %s", sub__->err.c_str());
+    if (k == "store_eps") { h->settle_lazy_state(); h->store_eps_always = value != 0; h->destroy_graph(); }
+    else if (k == "rollout_pk") { h->settle_lazy_state(); h->use_pk = value != 0; h->destroy_graph(); }
+    else if (k == "upd_skip") h->upd_skip_light = value != 0;
+    else if (k == "pk_waves") { if (value != 4 && value != 5) fail(MPPI_E_INVALID, "pk_waves: 4 or 5"); h->pk_waves = (int)value; }
+    else if (k == "pk_min_samples") { h->settle_lazy_state(); h->pk_min_set = value >= 0; h->pk_min_samples = value >= 0 ? (long)value : 400000; h->destroy_graph(); }
+    else if (k == "fused") { if (value < -1 || value > 1) fail(MPPI_E_INVALID, "fused: -1 auto, 0 off, 1 on"); h->fused_mode = (int)value; }
+    else if (k == "fused_lag") { if (value < 0 || value > 4096) fail(MPPI_E_INVALID, "fused_lag: 0 (auto) .. 4096 columns"); h->fused_lag = (int)value; }
+    else if (k == "fused_prio") { if (value < 0 || value > 3) fail(MPPI_E_INVALID, "fused_prio: bit 0 update items first, bit 1 rollout waves by progress"); h->fused_prio = (int)value; }
+    else if (k == "co_cut_pct") {
+        if (value < 1 || value > 99) fail(MPPI_E_INVALID, "co_cut_pct: 1..99");
+        if (h->is_co_sub) fail(MPPI_E_INVALID, "co_cut_pct is a property of the handle");
+        h->co_cut_pct = (int)value;
+        if (h->co_active() && h->p2p_internal) {   // re-cut the group
+            h->wait_stream(__func__);
+            for (auto* e : h->subs) e->wait_stream(__func__);
+            const int G = 1 + (int)h->subs.size();
+            h->co_release();
+            const int asked = h->cfg.co_shards;
+            h->cfg.co_shards = G;
+            try { h->co_build(); } catch (...) { h->cfg.co_shards = asked; throw; }
+            h->cfg.co_shards = asked;
+            for (auto* e : h->subs) {   // the new shards take over this handle's switches
+                e->store_eps_always = h->store_eps_always; e->use_pk = h->use_pk; e->upd_skip_light = h->upd_skip_light; e->pk_waves = h->pk_waves;
+                e->pk_min_set = h->pk_min_set; e->pk_min_samples = h->pk_min_samples; e->fused_mode = h->fused_mode; e->fused_lag = h->fused_lag;
+                e->fused_prio = h->fused_prio; e->sync_timeout_ms = h->sync_timeout_ms;
+            }
+        }
+    }
+    else fail(MPPI_E_INVALID, "unknown option '%s'", key);
+    API_END(h)
+}
+
+int mppi_get_option(mppi_engine* h, const char* key, int64_t* value) {
+    API_BEGIN(h)
+    if (!key || !value) fail(MPPI_E_INVALID, "NULL argument");
+    const std::string k(key);
+    if (k == "store_eps") *value = h->store_eps_always;
+    else if (k == "rollout_pk") *value = h->use_pk;
+    else if (k == "upd_skip") *value = h->upd_skip_light;
+    else if (k == "pk_waves") *value = h->pk_waves;
+    else if (k == "pk_min_samples") *value = h->pk_min_set ? h->pk_min_samples : -1;
+    else if (k == "fused") *value = h->fused_mode;
+    else if (k == "fused_lag") *value = h->fused_lag;
+    else if (k == "fused_prio") *value = h->fused_prio;
+    else if (k == "co_cut_pct") *value = h->co_cut_pct;
+    else if (k == "last_tick_fused") *value = h->last_tick_fused;   // read-only: the last tick ran rollout + update as ONE launch
+    else fail(MPPI_E_INVALID, "unknown option '%s'", key);
+    API_END(h)
+}
+
+// host-side mirror of the fused tick's ticket -> work item map (the same fused_decode the kernel calls): a test aid
+int mppi_fused_decode(int n_cols, int cols_per_agent, int rollout_items, int update_items, int lag, int queue, int ticket, int32_t* item) {
+    if (!item || n_cols < 1 || cols_per_agent < 1 || rollout_items < 1 || update_items < 1 || queue < 0 || queue >= mppi::kFusedQueues) return MPPI_E_INVALID;
+    const mppi::FusedGeom g{n_cols, cols_per_agent, rollout_items, update_items, lag};
+    const mppi::FusedItem it = mppi::fused_decode(g, queue, ticket);
+    item[0] = it.kind; item[1] = it.col; item[2] = it.idx; item[3] = mppi::fused_queue_len(g, queue);
+    return MPPI_OK;
 }
 
 int mppi_synchronize(mppi_engine* h) {

@@ -1,0 +1,9 @@
+// tick_fused_kernel with the one-sample-per-lane rollout (rollout_body<float, NTERM = 7, ...>) as its rollout work items: see tick_fused.hpp
+#define MPPI_ROLLOUT_TU 1
+#define MPPI_FUSED_TU 1
+#include "tick_fused.hpp"
+namespace mppi {
+template <> hipError_t launch_tick_fused_f32<7>(const FusedLaunch& a) {
+    return a.inline_nominal == 2 ? tick_fused_go<FusedRollF32<7, 2>>(a) : tick_fused_go<FusedRollF32<7, 1>>(a);
+}
+}  // namespace mppi

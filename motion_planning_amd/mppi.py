@@ -105,9 +105,11 @@ class Engine(object):
 
     # which kernels a tick runs when the constructor is not told (include/mppi_hip.h MPPI_TICK_*)
     default_tick_path = "auto"
+    # mppi_set_option switches every new engine gets (tests and A/B measurements set this; the product leaves it empty)
+    default_options = {}
 
     def __init__(self, samples, horizon, n_agents=1, storage="f32", device=0, sample_offset=0,
-                 dt=None, sigma=0.9, lam=0.001, model="rk4", tick_path=None, co_shards=None, **overrides):
+                 dt=None, sigma=0.9, lam=0.001, model="rk4", tick_path=None, co_shards=None, options=None, **overrides):
         self._lib = _capi.load()
         cfg = _capi.default_config()
         cfg.n_agents, cfg.samples, cfg.horizon = int(n_agents), int(samples), int(horizon)
@@ -138,6 +140,17 @@ class Engine(object):
         self.dt = 1.0 / self.T if dt is None else float(dt)
         self.storage = "f64" if cfg.storage == MPPI_STORE_F64 else "f32"
         self.sigma, self.lam = cfg.sigma, cfg.lambda_
+        for key, val in dict(self.default_options, **(options or {})).items():
+            self.set_option(key, val)
+
+    def set_option(self, key, value):
+        """A measurement / test switch of include/mppi_hip.h (mppi_set_option)."""
+        self._ck(self._lib.mppi_set_option(self._h, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = C.c_int64()
+        self._ck(self._lib.mppi_get_option(self._h, key.encode(), C.byref(v)))
+        return int(v.value)
 
     # -- lifetime ------------------------------------------------------------------------
     def close(self):
@@ -399,7 +412,9 @@ class Engine(object):
                 "tick_kernels": "scan" if u.value == 0 else "lanes",
                 "co_shards": n.value, "co_samples": [per[g] for g in range(n.value)],
                 # which kernel the last rollout launch was (include/mppi_hip.h MPPI_ROLLOUT_*)
-                "rollout_kernel": ("none", "fp64", "mixed", "scan")[kind.value]}
+                "rollout_kernel": ("none", "fp64", "mixed", "scan")[kind.value],
+                # the last tick ran rollout + update as work items of ONE launch (tick_fused_kernel)
+                "tick_fused": bool(self.get_option("last_tick_fused"))}
 
 
 class _NominalView(np.ndarray):

@@ -25,7 +25,7 @@ def test_header_symbols_all_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), "libmppi_hip.so does not export %s" % n
     assert sorted(_capi.SIGNATURES) == names  # the ctypes binding covers exactly the header
-    assert lib.mppi_abi_version() == _capi.ABI_VERSION == 3
+    assert lib.mppi_abi_version() == _capi.ABI_VERSION == 4
 
 
 def test_default_config_is_the_reference_node(kat):
@@ -100,10 +100,53 @@ def test_host_helpers(kat, orc):
 
 
 def test_product_reads_no_test_hooks_from_the_environment():
-    """Engine construction is configured by arguments only (the test-suite picks the tick path through
-    Engine.default_tick_path, not through an environment variable read in the product)."""
-    src = open(os.path.join(ROOT, "motion_planning_amd", "mppi.py")).read()
-    assert "os.environ" not in src and "MPPI_TICK_PATH" not in src
+    """Engine construction is configured by arguments and mppi_set_option only: the Python shell reads no environment
+    variable, and the library reads exactly one -- MPPI_SYNC_TIMEOUT_MS, the documented deployment knob (every measurement /
+    test switch is a per-handle option)."""
+    import glob
+    for path in glob.glob(os.path.join(ROOT, "motion_planning_amd", "*.py")):
+        src = open(path).read()
+        assert "MPPI_TICK_PATH" not in src
+        if os.path.basename(path) in ("mppi.py", "_capi.py", "controller.py"):
+            assert "os.environ" not in src, path
+    reads = []
+    for path in glob.glob(os.path.join(ROOT, "motion_planning_amd", "csrc", "*")):
+        for m in re.finditer(r'getenv\s*\(\s*"([A-Z_0-9]+)"', open(path).read()):
+            reads.append(m.group(1))
+    assert reads == ["MPPI_SYNC_TIMEOUT_MS"], reads
+
+
+def test_fused_tick_queue_map_is_a_valid_schedule():
+    """The ticket -> work item map of the fused tick (mppi_fused_decode = the function its workgroups call): over the 8
+    queues every rollout and update work item appears exactly once, a queue only holds its own columns, and an update item
+    comes after ALL rollout items of its column in the SAME queue -- the property that makes its wait deadlock-free
+    whatever the dispatch order.  Geometries: config 4 on both rollout kernels, the 125 000-sample share, config 5, one
+    column, a lag beyond the queue, no lag."""
+    from motion_planning_amd import _capi
+    lib = _capi.load()
+    it = (C.c_int32 * 4)()
+    for n_cols, nch, rb, t_items, lag in [(123, 123, 16, 50, 8), (123, 123, 32, 50, 5), (16, 16, 32, 50, 5), (128, 2, 16, 50, 8), (1, 1, 32, 50, 3),
+                                           (5, 5, 16, 100, 0), (9, 3, 16, 7, 100), (123, 123, 16, 50, 1)]:
+        seen = set()
+        for x in range(8):
+            assert lib.mppi_fused_decode(n_cols, nch, rb, t_items, lag, x, 0, it) == 0
+            qlen, rolled = it[3], {}
+            for n in range(qlen + 2):
+                lib.mppi_fused_decode(n_cols, nch, rb, t_items, lag, x, n, it)
+                kind, col, idx = it[0], it[1], it[2]
+                if n >= qlen:
+                    assert kind == 2
+                    continue
+                assert kind in (0, 1) and col % 8 == x and col < n_cols
+                if kind == 0:
+                    assert 0 <= idx < rb
+                    rolled[col] = rolled.get(col, 0) + 1
+                else:
+                    assert 0 <= idx < t_items and rolled.get(col, 0) == rb
+                assert (kind, col, idx) not in seen
+                seen.add((kind, col, idx))
+        assert len(seen) == n_cols * (rb + t_items)
+    assert lib.mppi_fused_decode(0, 1, 1, 1, 1, 0, 0, it) != 0 and lib.mppi_fused_decode(8, 1, 1, 1, 1, 8, 0, it) != 0
 
 
 def test_create_fails_loudly_without_gpu():

@@ -862,12 +862,13 @@ FULL_CAPS = {("c4", "f32"): (2e-4, 1e-9), ("c4", "f64"): (2e-9, 1e-12), ("c3", "
 
 
 def test_full_size_replay_of_the_all_fp64_rollout_keeps_the_relative_tolerance(orc, tick_path, monkeypatch):
-    """Config 4 with the mixed-precision kernel switched off (MPPI_ROLLOUT_PK=0, read by mppi_create): the all-fp64 rollout
+    """Config 4 with the mixed-precision kernel switched off (option "rollout_pk" = 0): the all-fp64 rollout
     under fp32 storage still meets round 2's tolerance WITHOUT the absolute term -- the term restated in round 3 pays for the
     mixed kernel's fp32 increments and for nothing else."""
     if tick_path == "scan":
         pytest.skip("lane kernels only at this size")
-    monkeypatch.setenv("MPPI_ROLLOUT_PK", "0")
+    from motion_planning_amd.mppi import Engine
+    monkeypatch.setattr(Engine, "default_options", {"rollout_pk": 0})
     K, T, goal = FULL["c4"]
     u0 = np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
     state = [0.0, 0.0, 0.0]
@@ -921,7 +922,7 @@ PK_SMALL = [(1, 26), (2, 27), (511, 28), (513, 29), (1025, 30), (2049, 31), (777
 @pytest.mark.parametrize("K,T", PK_SMALL)
 def test_mixed_precision_rollout_at_small_sizes(orc, monkeypatch, tick_path, K, T, scene):
     """The benchmarked rollout kernel (rollout_pk_kernel: two samples per lane, deviations in packed fp32) takes over at
-    a few hundred thousand samples; here it is made to run from one sample up (MPPI_PK_MIN_SAMPLES=1, read by mppi_create) so that its corner
+    a few hundred thousand samples; here it is made to run from one sample up (option "pk_min_samples" = 1) so that its corner
     cases meet the oracle on every sample: one sample and odd K (a lane with one live sample), K around the 512-sample block,
     every horizon class mod 6 (full chunks only: 30; one or two steps riding along: 31, 49 / 26, 32, 50; a tail chunk of its
     own: 27, 28, 29, 51, 100, 255, 256), the shortest horizon it serves at dt = 1 / T and sigma = 0.9 (26: below that a step's
@@ -930,7 +931,8 @@ def test_mixed_precision_rollout_at_small_sizes(orc, monkeypatch, tick_path, K, 
     nominal controls."""
     if tick_path == "scan":
         pytest.skip("a lane-kernel test (the engines below name their tick path)")
-    monkeypatch.setenv("MPPI_PK_MIN_SAMPLES", "1")
+    from motion_planning_amd.mppi import Engine
+    monkeypatch.setattr(Engine, "default_options", {"pk_min_samples": 1})
     if scene == "under_way":
         u0 = np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
         state, goal = [0.0, 0.0, 0.2], [0.4, -0.3, 0.0]
@@ -958,7 +960,8 @@ def test_the_mixed_rollout_hands_over_where_it_does_not_apply(monkeypatch, tick_
     the all-fp64 kernel even when the size rule says mixed; the small-K path reports the scan kernel."""
     if tick_path == "scan":
         pytest.skip("the engines below name their tick path")
-    monkeypatch.setenv("MPPI_PK_MIN_SAMPLES", "1")
+    from motion_planning_amd.mppi import Engine
+    monkeypatch.setattr(Engine, "default_options", {"pk_min_samples": 1})
     for kw, want in [(dict(K=600, T=257), "fp64"), (dict(K=600, T=25), "fp64"), (dict(K=600, T=26), "mixed"), (dict(K=600, T=50, storage="f64"), "fp64"), (dict(K=600, T=50, model="euler"), "fp64"),
                      (dict(K=600, T=50, q=(1e3, 1e3, 5.0)), "fp64"), (dict(K=600, T=50), "mixed"), (dict(K=600, T=50, tick_path="scan"), "scan")]:
         kw = dict(kw)
@@ -970,7 +973,7 @@ def test_the_mixed_rollout_hands_over_where_it_does_not_apply(monkeypatch, tick_
             assert e.info()["rollout_kernel"] == want, (kw, e.info())
     # without the switch the two lane kernels are chosen by rounds of waves (launch_rollout in mppi_engine.hip): the mixed one where
     # 1.9 x its rounds undercut the all-fp64 kernel's, from three rounds on; shards of a co-scheduled handle by size alone
-    monkeypatch.delenv("MPPI_PK_MIN_SAMPLES")
+    monkeypatch.setattr(Engine, "default_options", {})
     for K, A, co, want in [(393216, 1, 1, "mixed"), (400000, 1, 1, "fp64"), (460000, 1, 1, "mixed"), (560000, 1, 1, "fp64"), (250000, 1, 1, "fp64"),
                            (1000000, 1, 1, "mixed"), (16384, 64, 1, "mixed"), (1000000, 1, 2, "mixed"), (500000, 1, 2, "fp64")]:
         with _engine(K, 50, "f32", n_agents=A, tick_path="lanes", co_shards=co) as e:

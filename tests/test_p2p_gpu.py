@@ -252,7 +252,7 @@ def test_co_scheduled_shards_behind_one_handle(K, shards, monkeypatch):
     from motion_planning_amd.mppi import Engine
     # one rollout kernel on both sides: left alone the unsplit engine picks it by rounds of waves (820 000 samples: the all-fp64
     # one), the shards by size (475 000: the mixed one) -- equal within the fp32 mode's tolerance, not to the 1e-10 asked here
-    monkeypatch.setenv("MPPI_PK_MIN_SAMPLES", "400000")
+    monkeypatch.setattr(Engine, "default_options", {"pk_min_samples": 400000})
     T = 50
     u0 = np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
     goal = [[0.0, -1.0, 0.0]]
@@ -294,7 +294,7 @@ def test_co_scheduled_value_is_bit_identical_to_the_unsplit_engine(monkeypatch):
     from motion_planning_amd.mppi import Engine
     T = 50
     u0 = np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
-    monkeypatch.setenv("MPPI_PK_MIN_SAMPLES", "400000")   # the same kernel rule for the unsplit engine and the shards (see above)
+    monkeypatch.setattr(Engine, "default_options", {"pk_min_samples": 400000})   # the same kernel rule for the unsplit engine and the shards (see above)
     for K in (40000, 820000):
         got = []
         for co in (1, 2):
@@ -304,7 +304,7 @@ def test_co_scheduled_value_is_bit_identical_to_the_unsplit_engine(monkeypatch):
                 got.append((e.download_value()[0], e.download_noise()[0], nxt, ua))
         assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
         assert np.abs(got[0][2] - got[1][2]).max() < 1e-12 and np.abs(got[0][3] - got[1][3]).max() < 1e-10
-    monkeypatch.delenv("MPPI_PK_MIN_SAMPLES")
+    monkeypatch.setattr(Engine, "default_options", {})
     with Engine(1000000, T) as e:
         assert e.info()["co_shards"] == 2
     with Engine(100000, 100) as e:
