@@ -349,6 +349,9 @@ int mppi_shader_clock(mppi_engine *h, double *mhz);
 /* How the fused device-noise mppi_tick of this handle runs: n_shards co-scheduled engines (1: unsplit) and the samples
  * each owns (samples [8], zero-filled behind n_shards). */
 int mppi_co_info(mppi_engine *h, int32_t *n_shards, int32_t *samples);
+/* Why this handle runs unsplit although co_shards AUTO would have split it (the second set of buffers could not be
+ * built), or why a group was dissolved (a co-scheduled tick failed half-way): "" when there is nothing to report.  Never NULL. */
+const char *mppi_co_note(const mppi_engine *h);
 
 /* Which rollout kernel this handle's last tick / mppi_rollout launched (a co-scheduled handle: its shards all take the same
  * one; the re-run behind a later mppi_download_value does not count):

@@ -90,6 +90,7 @@ SIGNATURES = {
     "mppi_kernel_times": (C.c_int, [_H, _dp, C.POINTER(C.c_int64)]),
     "mppi_shader_clock": (C.c_int, [_H, _dp]),
     "mppi_co_info": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "mppi_co_note": (C.c_char_p, [_H]),
     "mppi_rollout_kernel": (C.c_int, [_H, C.POINTER(C.c_int32)]),
     "mppi_engine_info": (C.c_int, [_H, C.POINTER(C.c_size_t), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }

@@ -1074,7 +1074,7 @@ __device__ __forceinline__ void update_body(const DevParams& P, const S* __restr
     const int k_end = min(P.K, k_begin + CH);
     double* o = part + (((size_t)a * P.T + t) * NCH + ch) * kTupleW;
     if (k_end <= k_begin) {  // empty chunk (uniform)
-        if (tid == 0) { o[0] = INFINITY; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = 0; o[7] = 0; }
+        if (tid == 0) { store_out<FUSED>(o + 0, (double)INFINITY); for (int i = 1; i < 8; ++i) store_out<FUSED>(o + i, 0.0); }
         return;
     }
     __shared__ R red[4][6];
@@ -1220,12 +1220,13 @@ __device__ __forceinline__ void update_body(const DevParams& P, const S* __restr
     D = wave_sum(D); E0 = wave_sum(E0); E1 = wave_sum(E1);
     if (lane == 0) { red[wid][1] = D; redN[wid][0] = N0d; redN[wid][1] = N1d; red[wid][4] = E0; red[wid][5] = E1; }
     __syncthreads();
+    // (FUSED: the tuple may be read by a kernel that is already running -- the update stream's join -- so it goes out write-through)
     if (tid < 5) {
         const int c = tid + 1;
-        o[c] = (c == 2 || c == 3) ? redN[0][c - 2] + redN[1][c - 2] + redN[2][c - 2] + redN[3][c - 2]
-                                  : (double)red[0][c] + (double)red[1][c] + (double)red[2][c] + (double)red[3][c];
+        store_out<FUSED>(o + c, (c == 2 || c == 3) ? redN[0][c - 2] + redN[1][c - 2] + redN[2][c - 2] + redN[3][c - 2]
+                                                   : (double)red[0][c] + (double)red[1][c] + (double)red[2][c] + (double)red[3][c]);
     } else if (tid == 5) {
-        o[0] = (double)M; o[6] = (double)(k_end - k_begin); o[7] = 0.0;
+        store_out<FUSED>(o + 0, (double)M); store_out<FUSED>(o + 6, (double)(k_end - k_begin)); store_out<FUSED>(o + 7, 0.0);
     }
 }
 template <typename S, bool REGEN>

@@ -91,6 +91,18 @@ struct FusedArgs {
     // update
     double* part;
     int skip_light;
+    // --- the update STREAM (rollout_arrive_kernel + update_stream_kernel, below) ---
+    uint32_t epoch;          // this engine's tick number on the update stream: 1, 2, ...
+    uint32_t* epoch_flag;    // the rollout launch's first workgroup stores `epoch` here: the gate of the update stream's workgroups
+    uint32_t* col_done;      // [n_cols] rollout workgroups that have arrived, per column, MONOTONIC over the ticks (epoch * count)
+    uint32_t* items_done;    // update items finished, monotonic; this tick's are done at items_target
+    uint32_t items_target;
+    uint32_t* uheads;        // [8 * kFusedHeadStride] update-ticket counters, zeroed by the rollout launch's first workgroup
+    uint32_t* exits;         // update-stream workgroups that have left their ticket loop for good, monotonic over the ticks
+    uint32_t exit_target;    // ... of all EARLIER ticks: nobody touches the ticket heads any more once this is reached
+    int join;                // the tail launch: workgroup 0 leaves only when this tick's items are all done
+    int bs;                  // samples per rollout workgroup (256 | 512)
+    int ch;                  // samples per chunk column (8192)
 };
 
 struct FusedLaunch {
@@ -103,6 +115,45 @@ struct FusedLaunch {
 // the two families of instantiations (one translation unit each, see tick_fused_*.hip)
 hipError_t launch_tick_fused_pk(const FusedLaunch& a);                 // rollout items = rollout_pk_body (512 samples each)
 template <int NTERM> hipError_t launch_tick_fused_f32(const FusedLaunch& a);   // rollout items = rollout_body<float, ...> (256 samples each)
+
+// ---- The update stream: TWO concurrent launches instead of one fused one --------------------------------------------------
+// Measured (profiles/r4_fused_single_launch_ab.jsonl): the single fused launch is SLOWER than rollout + update one after the other.
+// A launch has ONE register allocation -- the rollout's 107 VGPRs -- so an update work item occupies a rollout-sized slot, the
+// rollout already fills every slot (4 waves per SIMD), and queueing update items between rollout items only delays the rollout.
+// What does fit next to four rollout waves of 112 VGPRs is ONE wave of <= 64: exactly an update workgroup per CU -- if it is a
+// launch of its own.  So:
+//   main stream   rollout_arrive_kernel   the stand-alone rollout grid; write-through stores; each workgroup adds 1 to its
+//                                         column's arrival counter when its stores have drained; workgroup 0 opens the gate
+//                 update_stream_kernel    (tail, big grid, join = 1) takes whatever update tickets are left -- by stream order
+//                                         its columns are all complete -- and its workgroup 0 waits until every item of the
+//                                         tick is done before the launch ends: the kernels behind it (merge, publish, finalize)
+//                                         are ordered by the stream as they always were
+//   second stream update_stream_kernel    (head start, one workgroup per CU) enqueued right behind the rollout launch: waits at
+//                                         the gate, then takes update tickets in column order, each waiting for its column
+// No host synchronisation and no event between the two streams; the coupling is a handful of device words, all monotonic over
+// the ticks except the ticket heads: the gate (= the tick number), the per-column arrival counters, the items-done counter and
+// an exit counter.  The ticket heads are re-armed by the rollout launch's first workgroup BEFORE it opens the gate, and only
+// after every update-stream workgroup of earlier ticks has counted itself out (the exit counter; the host knows how many it
+// launched) -- so a workgroup of an old tick that the hardware starts late can never take a ticket of a newer one: it finds the
+// gate past its own tick number and leaves.  Whatever the order in which the hardware starts the launches, nothing can
+// deadlock: rollout workgroups never wait (the first one only for workgroups that are on their way out), the head-start launch
+// has at most one workgroup per CU (it cannot crowd the rollout out), and the tail launch starts after the rollout launch has
+// ended.
+struct UpdateStreamLaunch {
+    DevParams P;
+    FusedArgs F;
+    hipStream_t stream;
+    int blocks;
+    hipEvent_t ev_start, ev_stop;
+};
+hipError_t launch_update_stream(const UpdateStreamLaunch& a);
+hipError_t launch_rollout_arrive_pk(const FusedLaunch& a);
+template <int NTERM> hipError_t launch_rollout_arrive_f32(const FusedLaunch& a);
+// rollout workgroups with samples in chunk column ch of an agent (the ragged last column has fewer)
+__host__ __device__ inline int fused_col_blocks(int K, int ch, int ch_samples, int bs) {
+    const long lo = (long)ch * ch_samples, hi = lo + ch_samples < (long)K ? lo + ch_samples : (long)K;
+    return hi > lo ? (int)((hi - lo + bs - 1) / bs) : 0;
+}
 
 #ifdef MPPI_FUSED_TU
 __device__ __forceinline__ int fused_xcc_id() {
@@ -180,6 +231,116 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RO::kWaves,
     update_body<float, true, true>(P, static_cast<const float*>(nullptr), F.dP, F.stot, F.part, F.g.NCH, a, idx, ch, F.epart, F.seed, F.tick,
                                    nullptr, F.skip_light);
 }
+
+// wrap-safe "counter has reached target" for monotonic 32-bit counters
+__device__ __forceinline__ bool reached(uint32_t v, uint32_t target) { return (int32_t)(v - target) >= 0; }
+// one lane polls a word until it reaches `target` (bounded by the deadline); returns false when it gave up
+__device__ __forceinline__ bool poll_reached(const uint32_t* w, uint32_t target, unsigned long long timeout_ticks, int sleep) {
+    const unsigned long long t0 = wall_clock64();
+    while (!reached(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), target)) {
+        if (timeout_ticks && wall_clock64() - t0 > timeout_ticks) return false;
+        if (sleep > 8) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(8);
+    }
+    return true;
+}
+
+template <class RO>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RO::kWaves, 8))) void rollout_arrive_kernel(DevParams P, FusedArgs F) {
+    const int bx = (int)blockIdx.x, a = (int)blockIdx.y;
+    if (bx == 0 && a == 0 && threadIdx.x == 0) {
+        // the gate.  Everything before this launch on its stream is done; the update-stream workgroups of earlier ticks are done with
+        // their items (the tail launch joined them) but may still be on their way out: wait until they have all counted themselves
+        // out, re-arm the ticket heads, and only then let this tick's update workgroups in
+        if (!poll_reached(F.exits, F.exit_target, F.timeout_ticks, 8)) __hip_atomic_store(F.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 0; i < kFusedQueues; ++i) __hip_atomic_store(F.uheads + i * kFusedHeadStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(F.epoch_flag, F.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    RO::run(P, F, bx, a, blockIdx.x == (gridDim.x >> 1) && a == 0, F.prio_mode);
+    // release: every wave's write-through stores have left, then ONE agent-scope add on the column's counter
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(F.col_done + a * F.g.NCH + (bx * RO::kBS) / F.ch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <class RO>
+static hipError_t rollout_arrive_go(const FusedLaunch& a) {
+    dim3 grid((a.P.K + RO::kBS - 1) / RO::kBS, a.P.A);
+    const unsigned lds = (unsigned)((size_t)a.P.T * RO::kLdsPerStep);
+    auto kern = rollout_arrive_kernel<RO>;
+    if (a.ev_start) hipExtLaunchKernelGGL(kern, grid, dim3(256), lds, a.stream, a.ev_start, a.ev_stop, 0, a.P, a.F);
+    else hipLaunchKernelGGL(kern, grid, dim3(256), lds, a.stream, a.P, a.F);
+    return hipGetLastError();
+}
+
+#ifdef MPPI_UPDATE_STREAM_TU
+// Persistent update workgroups: take update tickets (queue x = this XCD's columns first, then the others'), wait for the
+// ticket's column, run update_body on it, count the item.  <= 64 VGPRs, so that a workgroup fits next to four rollout waves.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void update_stream_kernel(DevParams P, FusedArgs F) {
+    __shared__ int item_sh[4];
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        // the gate: this tick's rollout launch has re-armed the ticket heads.  (The tail launch sits behind that launch on its
+        // stream and finds the gate open; a head-start workgroup that the hardware starts after its tick is over finds the gate
+        // PAST its tick number: its items were done by others, it only counts itself out.)
+        int ok = poll_reached(F.epoch_flag, F.epoch, F.timeout_ticks, 32);
+        if (!ok) __hip_atomic_store(F.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ok && __hip_atomic_load(F.epoch_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != F.epoch) ok = 0;
+        item_sh[3] = ok;
+        if (!ok) __hip_atomic_fetch_add(F.exits, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!item_sh[3]) return;
+    if (F.prio_mode & 1) __builtin_amdgcn_s_setprio(3);
+    const int x0 = fused_xcc_id();
+    const int T = F.g.T;
+    unsigned dead = 0u;   // (lane 0) queues this workgroup has found exhausted: not probed again
+    for (;;) {
+        __syncthreads();   // (item_sh: the previous round's readers are through)
+        if (tid == 0) {
+            int kind = kFusedNone, col = 0, t = 0;
+            for (int i = 0; i < kFusedQueues; ++i) {
+                const int x = (x0 + i) & (kFusedQueues - 1);
+                if (dead & (1u << x)) continue;
+                const int len = fused_queue_cols(F.g, x) * T;
+                uint32_t n = (uint32_t)len;
+                if (len) n = __hip_atomic_fetch_add(F.uheads + x * kFusedHeadStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (n < (uint32_t)len) { kind = kFusedUpdate; col = x + kFusedQueues * (int)(n / (uint32_t)T); t = (int)(n % (uint32_t)T); break; }
+                dead |= 1u << x;
+            }
+            if (kind == kFusedUpdate) {   // the column's rollout workgroups: epoch * (their number), monotonic
+                const int a = col / F.g.NCH, ch = col - a * F.g.NCH;
+                const uint32_t target = F.epoch * (uint32_t)fused_col_blocks(P.K, ch, F.ch, F.bs);
+                if (!poll_reached(F.col_done + col, target, F.timeout_ticks, 8)) {
+                    __hip_atomic_store(F.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    kind = kFusedNone;
+                }
+            }
+            item_sh[0] = kind; item_sh[1] = col; item_sh[2] = t;
+        }
+        __syncthreads();
+        const int kind = item_sh[0], col = item_sh[1], t = item_sh[2];
+        if (kind != kFusedUpdate) break;   // (uniform) no tickets left
+        asm volatile("" ::: "memory");
+        const int a = col / F.g.NCH, ch = col - a * F.g.NCH;
+        update_body<float, true, true>(P, static_cast<const float*>(nullptr), F.dP, F.stot, F.part, F.g.NCH, a, t, ch, F.epart, F.seed, F.tick,
+                                       nullptr, F.skip_light);
+        // the tuple went out write-through: drained, then counted
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(F.items_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0) {
+        __hip_atomic_fetch_add(F.exits, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // done with the ticket heads for good
+        if (F.join && blockIdx.x == 0)   // the tail launch ends only when the head-start launch's items are in as well
+            if (!poll_reached(F.items_done, F.items_target, F.timeout_ticks, 8)) __hip_atomic_store(F.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+hipError_t launch_update_stream(const UpdateStreamLaunch& a) {
+    if (a.ev_start) hipExtLaunchKernelGGL(update_stream_kernel, dim3(a.blocks), dim3(256), 0, a.stream, a.ev_start, a.ev_stop, 0, a.P, a.F);
+    else hipLaunchKernelGGL(update_stream_kernel, dim3(a.blocks), dim3(256), 0, a.stream, a.P, a.F);
+    return hipGetLastError();
+}
+#endif  // MPPI_UPDATE_STREAM_TU
 
 template <class RO>
 static hipError_t tick_fused_go(const FusedLaunch& a) {

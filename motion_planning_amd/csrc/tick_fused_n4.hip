@@ -6,4 +6,7 @@ namespace mppi {
 template <> hipError_t launch_tick_fused_f32<4>(const FusedLaunch& a) {
     return a.inline_nominal == 2 ? tick_fused_go<FusedRollF32<4, 2>>(a) : tick_fused_go<FusedRollF32<4, 1>>(a);
 }
+template <> hipError_t launch_rollout_arrive_f32<4>(const FusedLaunch& a) {
+    return a.inline_nominal == 2 ? rollout_arrive_go<FusedRollF32<4, 2>>(a) : rollout_arrive_go<FusedRollF32<4, 1>>(a);
+}
 }  // namespace mppi

@@ -8,4 +8,7 @@ namespace mppi {
 hipError_t launch_tick_fused_pk(const FusedLaunch& a) {
     return a.inline_nominal == 2 ? tick_fused_go<FusedRollPk<2>>(a) : tick_fused_go<FusedRollPk<1>>(a);
 }
+hipError_t launch_rollout_arrive_pk(const FusedLaunch& a) {
+    return a.inline_nominal == 2 ? rollout_arrive_go<FusedRollPk<2>>(a) : rollout_arrive_go<FusedRollPk<1>>(a);
+}
 }  // namespace mppi

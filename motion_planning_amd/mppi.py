@@ -411,10 +411,12 @@ class Engine(object):
         return {"hbm_bytes": b.value, "rollout_blocks": r.value, "update_blocks": u.value,
                 "tick_kernels": "scan" if u.value == 0 else "lanes",
                 "co_shards": n.value, "co_samples": [per[g] for g in range(n.value)],
+                "co_note": (self._lib.mppi_co_note(self._h) or b"").decode(),
                 # which kernel the last rollout launch was (include/mppi_hip.h MPPI_ROLLOUT_*)
                 "rollout_kernel": ("none", "fp64", "mixed", "scan")[kind.value],
-                # the last tick ran rollout + update as work items of ONE launch (tick_fused_kernel)
-                "tick_fused": bool(self.get_option("last_tick_fused"))}
+                # how the last tick ran its rollout + update: 0 two stand-alone launches one after the other, 1 work items of ONE
+                # launch (tick_fused_kernel), 2 the update stream (the update gets a head start under the rollout)
+                "tick_fused": self.get_option("last_tick_fused")}
 
 
 class _NominalView(np.ndarray):
@@ -510,6 +512,17 @@ class MPPI(object):
             self._eng.set_weights(*mats)
             self._weights_sent = key
 
+    # uvec_init[:, 0] is what every receding-horizon shift appends, read live on each get_path (control/src/mppi:101): an
+    # assignment to m.uvec_init (or into it) between calls must reach the engine without an initialize()
+    def _sync_fill(self):
+        init = np.asarray(self.uvec_init, dtype=np.float64)
+        if init.ndim != 2 or init.shape[0] != 2 or init.shape[1] < 1:
+            raise ValueError("uvec_init must be [2, horizon] (control/src/mppi:65)")
+        fill = init[:, 0].copy()
+        if self._fill_sent is None or np.any(fill != self._fill_sent):
+            self._eng.set_shift_fill(fill)
+            self._fill_sent = fill
+
     def _load_uvec_init(self, init):
         if np.any(init):
             self._eng.set_nominal(init)
@@ -556,6 +569,7 @@ class MPPI(object):
     # control/src/mppi:85-102
     def get_path(self, state, goal, sig=np.array([[.9, 0.0], [0.0, .9]]), lam=.001):
         self._sync_weights()
+        self._sync_fill()
         sigma = self._set_sig(sig, lam)
         if self.rng == "numpy":
             self._eng.upload_noise(self._draw(sigma))

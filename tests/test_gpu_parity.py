@@ -358,6 +358,24 @@ def test_nonzero_uvec_init_golden(golden, storage):
         assert lat[0, -1] == init[0, 0] and lat[1, -1] == init[1, 0]
 
 
+def test_uvec_init_is_read_live_by_every_shift():
+    """control/src/mppi:101 reads self.uvec_init[:, 0] on every get_path: writing into the attribute (or replacing it)
+    BETWEEN calls, without initialize(), changes what the next shift appends -- and nothing else."""
+    from motion_planning_amd import MPPI
+    m = MPPI(horizon=20, samples=64, rng="philox", seed=3)
+    st = m.get_path(np.zeros(3), np.array([0.4, 0.1, 0.0]))
+    assert np.all(m.latest_uvec[:, -1] == 0.0)
+    m.uvec_init[:, 0] = [0.3, -0.2]                      # in place
+    st = m.get_path(st, np.array([0.4, 0.1, 0.0]))
+    lat = m.latest_uvec
+    assert lat[0, -1] == 0.3 and lat[1, -1] == -0.2 and np.all(lat[:, -2] == 0.0)   # the column the previous shift appended moved up
+    init = np.zeros((2, 20)); init[:, 0] = [-1.5, 2.5]
+    m.uvec_init = init                                    # replaced
+    m.get_path(st, np.array([0.4, 0.1, 0.0]))
+    lat = m.latest_uvec
+    assert lat[0, -1] == -1.5 and lat[1, -1] == 2.5 and lat[0, -2] == 0.3 and lat[1, -2] == -0.2
+
+
 @pytest.mark.parametrize("storage", ["f64", "f32"])
 def test_other_sigma_and_lambda_golden(golden, storage):
     """MPPI.get_path with other sig / lam arguments (control/src/mppi:88-89) against the reference (golden

@@ -69,17 +69,26 @@ def main():
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--out", default=None)
     ap.add_argument("--configs", default="c4,share125k,share250k,share500k,c5,small")
+    ap.add_argument("--family", default="stream", choices=["one", "stream", "both"], help="one: the single fused launch; stream: the update stream")
     args = ap.parse_args()
     configs = {
         "c4": (1000000, 50, 1), "share500k": (500000, 50, 1), "share250k": (250000, 50, 1), "share125k": (125000, 50, 1),
         "c5": (16384, 50, 64), "small": (40000, 50, 1), "c3": (100000, 100, 1),
     }
-    variants = [("standalone", {"fused": 0}), ("fused", {"fused": 1}), ("fused_p1", {"fused": 1, "fused_prio": 1}),
-                ("fused_p2", {"fused": 1, "fused_prio": 2}), ("fused_p3", {"fused": 1, "fused_prio": 3})]
-    if not args.quick:
-        variants += [("fused_p3_lag2", {"fused": 1, "fused_prio": 3, "fused_lag": 2}), ("fused_p3_lag4", {"fused": 1, "fused_prio": 3, "fused_lag": 4}),
-                     ("fused_lag4", {"fused": 1, "fused_lag": 4}), ("fused_lag16", {"fused": 1, "fused_lag": 16}),
-                     ("fused_p1_lag4", {"fused": 1, "fused_prio": 1, "fused_lag": 4})]
+    variants = [("standalone", {"fused": 0})]
+    if args.family in ("one", "both"):
+        variants += [("fused", {"fused": 1}), ("fused_p1", {"fused": 1, "fused_prio": 1}), ("fused_p2", {"fused": 1, "fused_prio": 2}),
+                     ("fused_p3", {"fused": 1, "fused_prio": 3})]
+        if not args.quick:
+            variants += [("fused_p3_lag2", {"fused": 1, "fused_prio": 3, "fused_lag": 2}), ("fused_p3_lag4", {"fused": 1, "fused_prio": 3, "fused_lag": 4}),
+                         ("fused_lag4", {"fused": 1, "fused_lag": 4}), ("fused_lag16", {"fused": 1, "fused_lag": 16}),
+                         ("fused_p1_lag4", {"fused": 1, "fused_prio": 1, "fused_lag": 4})]
+    if args.family in ("stream", "both"):
+        variants += [("us", {"fused": 2}), ("us_p1", {"fused": 2, "fused_prio": 1}), ("us_p2", {"fused": 2, "fused_prio": 2}), ("us_p3", {"fused": 2, "fused_prio": 3})]
+        if not args.quick:
+            variants += [("us_p3_b512", {"fused": 2, "fused_prio": 3, "us_blocks": 512}), ("us_p3_b128", {"fused": 2, "fused_prio": 3, "us_blocks": 128}),
+                         ("us_p3_t512", {"fused": 2, "fused_prio": 3, "us_tail_blocks": 512}), ("us_p3_t4096", {"fused": 2, "fused_prio": 3, "us_tail_blocks": 4096}),
+                         ("us_p2_b512", {"fused": 2, "fused_prio": 2, "us_blocks": 512}), ("us_b512", {"fused": 2, "us_blocks": 512})]
     out = open(args.out, "w") if args.out else None
     bad = 0
     for name in args.configs.split(","):
@@ -88,7 +97,7 @@ def main():
         ref = None
         for co in ((1, 2) if name == "c4" else (1,)):
             for vname, opts in variants:
-                if co == 2 and vname not in ("standalone", "fused", "fused_p3"):
+                if co == 2 and vname not in ("standalone", "fused", "fused_p3", "us", "us_p3"):
                     continue
                 r = run(K, T, A, co, opts, args.steps, want_v=want_v)
                 if ref is None:
@@ -96,7 +105,7 @@ def main():
                 ds = float(np.abs(r["state"] - ref["state"]).max())
                 du = float(np.abs(r["u"] - ref["u"]).max())
                 v_same = None if r["V"] is None else bool(np.array_equal(r["V"], ref["V"]))
-                ok = ds <= 1e-10 and du <= 1e-10 and v_same is not False and r["fused"] == (opts.get("fused", 0) == 1)
+                ok = ds <= 1e-10 and du <= 1e-10 and v_same is not False and r["fused"] == opts.get("fused", 0)
                 bad += 0 if ok else 1
                 line = {"config": name, "K": K, "T": T, "A": A, "co_shards": r["co"], "variant": vname, "options": opts, "tick_us": r["tick_us"],
                         "fused_ran": r["fused"], "rollout_kernel": r["rollout_kernel"], "kernels_us": r["kernels_us"],
