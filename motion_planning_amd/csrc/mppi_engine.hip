@@ -614,7 +614,7 @@ struct mppi_engine {
     uint32_t us_epoch = 0;             // ticks run on the update stream so far
     uint32_t us_exit_target = 0;       // update-stream workgroups launched by all earlier ticks
     int us_blocks = 256, us_tail_blocks = 2048;
-    // layout of d_us: one 64-byte line each for {gate, items_done, exits}, then the 8 ticket heads (a line each), then [A * NCH] column counters
+    // layout of d_us (64-byte lines): gate | items_done [8] | exits [8] | ticket heads [8] | then [A * NCH] column counters
     uint32_t* us_word(int i) const { return d_us + (size_t)i * mppi::kFusedHeadStride; }
     void fill_fused_args(mppi::FusedArgs& F, bool pk, uint64_t seed, uint32_t tick) const {
         const int bs = pk ? 512 : 256;
@@ -653,11 +653,11 @@ struct mppi_engine {
         mppi::FusedArgs& F = r.F;
         us_epoch += 1u;
         const uint32_t n_items = (uint32_t)F.g.n_cols * (uint32_t)F.g.T;
-        F.epoch = us_epoch; F.epoch_flag = us_word(0); F.items_done = us_word(1); F.exits = us_word(2);
+        F.epoch = us_epoch; F.epoch_flag = us_word(0); F.items_done = us_word(1); F.exits = us_word(1 + mppi::kFusedQueues);
         F.items_target = us_epoch * n_items;
         F.exit_target = us_exit_target;
-        F.uheads = us_word(3);
-        F.col_done = us_word(3 + mppi::kFusedQueues);
+        F.uheads = us_word(1 + 2 * mppi::kFusedQueues);
+        F.col_done = us_word(1 + 3 * mppi::kFusedQueues);
         F.join = 0;
         const int head_blocks = (int)std::max<long>(1, std::min<long>(us_blocks, (long)n_items));
         const int tail_blocks = (int)std::max<long>(1, std::min<long>(us_tail_blocks, (long)n_items));
@@ -956,7 +956,7 @@ struct mppi_engine {
         HIPCHK(hipMemsetAsync(d_fq, 0, (fq_words + 1) * sizeof(uint32_t), stream));
         P.fstatus = d_fstatus;
         {
-            const size_t us_words = (size_t)(3 + mppi::kFusedQueues) * mppi::kFusedHeadStride + (size_t)A * NCH;
+            const size_t us_words = (size_t)(1 + 3 * mppi::kFusedQueues) * mppi::kFusedHeadStride + (size_t)A * NCH;
             d_us = dev_alloc<uint32_t>(us_words, hbm_bytes);
             HIPCHK(hipMemsetAsync(d_us, 0, us_words * sizeof(uint32_t), stream));
         }

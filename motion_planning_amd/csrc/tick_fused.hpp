@@ -95,10 +95,10 @@ struct FusedArgs {
     uint32_t epoch;          // this engine's tick number on the update stream: 1, 2, ...
     uint32_t* epoch_flag;    // the rollout launch's first workgroup stores `epoch` here: the gate of the update stream's workgroups
     uint32_t* col_done;      // [n_cols] rollout workgroups that have arrived, per column, MONOTONIC over the ticks (epoch * count)
-    uint32_t* items_done;    // update items finished, monotonic; this tick's are done at items_target
+    uint32_t* items_done;    // [8 lines] update items finished, by queue, monotonic; this tick's are done when the SUM reaches items_target
     uint32_t items_target;
     uint32_t* uheads;        // [8 * kFusedHeadStride] update-ticket counters, zeroed by the rollout launch's first workgroup
-    uint32_t* exits;         // update-stream workgroups that have left their ticket loop for good, monotonic over the ticks
+    uint32_t* exits;         // [8 lines] update-stream workgroups that have left their ticket loop for good (by XCD), monotonic over the ticks
     uint32_t exit_target;    // ... of all EARLIER ticks: nobody touches the ticket heads any more once this is reached
     int join;                // the tail launch: workgroup 0 leaves only when this tick's items are all done
     int bs;                  // samples per rollout workgroup (256 | 512)
@@ -234,6 +234,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RO::kWaves,
 
 // wrap-safe "counter has reached target" for monotonic 32-bit counters
 __device__ __forceinline__ bool reached(uint32_t v, uint32_t target) { return (int32_t)(v - target) >= 0; }
+// Counters that thousands of workgroups add to are kept as 8 words, a 64-byte line apart, one per XCD queue: atomics on ONE
+// address retire at ~12 ns each (6150 update items counting themselves on one word took 74 us of a 77-us tail launch,
+// profiles/r4_update_stream_ab_v1.jsonl); the reader sums the eight.
+__device__ __forceinline__ uint32_t load_sum8(const uint32_t* w) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int i = 0; i < kFusedQueues; ++i) v += __hip_atomic_load(w + i * kFusedHeadStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+}
+__device__ __forceinline__ bool poll_sum8_reached(const uint32_t* w, uint32_t target, unsigned long long timeout_ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (!((int32_t)(load_sum8(w) - target) >= 0)) {
+        if (timeout_ticks && wall_clock64() - t0 > timeout_ticks) return false;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    return true;
+}
 // one lane polls a word until it reaches `target` (bounded by the deadline); returns false when it gave up
 __device__ __forceinline__ bool poll_reached(const uint32_t* w, uint32_t target, unsigned long long timeout_ticks, int sleep) {
     const unsigned long long t0 = wall_clock64();
@@ -251,7 +268,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RO::kWaves,
         // the gate.  Everything before this launch on its stream is done; the update-stream workgroups of earlier ticks are done with
         // their items (the tail launch joined them) but may still be on their way out: wait until they have all counted themselves
         // out, re-arm the ticket heads, and only then let this tick's update workgroups in
-        if (!poll_reached(F.exits, F.exit_target, F.timeout_ticks, 8)) __hip_atomic_store(F.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!poll_sum8_reached(F.exits, F.exit_target, F.timeout_ticks)) __hip_atomic_store(F.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int i = 0; i < kFusedQueues; ++i) __hip_atomic_store(F.uheads + i * kFusedHeadStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(F.epoch_flag, F.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -286,7 +303,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         if (!ok) __hip_atomic_store(F.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (ok && __hip_atomic_load(F.epoch_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != F.epoch) ok = 0;
         item_sh[3] = ok;
-        if (!ok) __hip_atomic_fetch_add(F.exits, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!ok) __hip_atomic_fetch_add(F.exits + fused_xcc_id() * kFusedHeadStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (!item_sh[3]) return;
@@ -303,7 +320,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 if (dead & (1u << x)) continue;
                 const int len = fused_queue_cols(F.g, x) * T;
                 uint32_t n = (uint32_t)len;
-                if (len) n = __hip_atomic_fetch_add(F.uheads + x * kFusedHeadStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (a look before the read-modify-write: exhausted queues are found by a load, which the L2 serves in parallel, instead
+                // of one more serialised atomic on a word thousands of workgroups hit at the end of the launch)
+                if (len && __hip_atomic_load(F.uheads + x * kFusedHeadStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)len)
+                    n = __hip_atomic_fetch_add(F.uheads + x * kFusedHeadStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (n < (uint32_t)len) { kind = kFusedUpdate; col = x + kFusedQueues * (int)(n / (uint32_t)T); t = (int)(n % (uint32_t)T); break; }
                 dead |= 1u << x;
             }
@@ -327,12 +347,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         // the tuple went out write-through: drained, then counted
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(F.items_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_fetch_add(F.items_done + (col & (kFusedQueues - 1)) * kFusedHeadStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (tid == 0) {
-        __hip_atomic_fetch_add(F.exits, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // done with the ticket heads for good
+        __hip_atomic_fetch_add(F.exits + x0 * kFusedHeadStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // done with the ticket heads for good
         if (F.join && blockIdx.x == 0)   // the tail launch ends only when the head-start launch's items are in as well
-            if (!poll_reached(F.items_done, F.items_target, F.timeout_ticks, 8)) __hip_atomic_store(F.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!poll_sum8_reached(F.items_done, F.items_target, F.timeout_ticks)) __hip_atomic_store(F.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 hipError_t launch_update_stream(const UpdateStreamLaunch& a) {

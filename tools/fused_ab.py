@@ -86,9 +86,10 @@ def main():
     if args.family in ("stream", "both"):
         variants += [("us", {"fused": 2}), ("us_p1", {"fused": 2, "fused_prio": 1}), ("us_p2", {"fused": 2, "fused_prio": 2}), ("us_p3", {"fused": 2, "fused_prio": 3})]
         if not args.quick:
-            variants += [("us_p3_b512", {"fused": 2, "fused_prio": 3, "us_blocks": 512}), ("us_p3_b128", {"fused": 2, "fused_prio": 3, "us_blocks": 128}),
-                         ("us_p3_t512", {"fused": 2, "fused_prio": 3, "us_tail_blocks": 512}), ("us_p3_t4096", {"fused": 2, "fused_prio": 3, "us_tail_blocks": 4096}),
-                         ("us_p2_b512", {"fused": 2, "fused_prio": 2, "us_blocks": 512}), ("us_b512", {"fused": 2, "us_blocks": 512})]
+            variants += [("us_t512", {"fused": 2, "us_tail_blocks": 512}), ("us_t1024", {"fused": 2, "us_tail_blocks": 1024}),
+                         ("us_p2_t1024", {"fused": 2, "fused_prio": 2, "us_tail_blocks": 1024}), ("us_p3_t1024", {"fused": 2, "fused_prio": 3, "us_tail_blocks": 1024}),
+                         ("us_b512_t1024", {"fused": 2, "us_blocks": 512, "us_tail_blocks": 1024}), ("us_b128_t1024", {"fused": 2, "us_blocks": 128, "us_tail_blocks": 1024}),
+                         ("us_b64_t1024", {"fused": 2, "us_blocks": 64, "us_tail_blocks": 1024})]
     out = open(args.out, "w") if args.out else None
     bad = 0
     for name in args.configs.split(","):
