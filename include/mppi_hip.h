@@ -253,7 +253,9 @@ int mppi_wait_for_stream(mppi_engine *h, void *other_stream);
  *   mppi_p2p_create   allocates this rank's mailbox (fine-grained device memory, [2][n_ranks] slots + flags) and
  *                     returns its HIP IPC handle in ipc_handle_out (MPPI_IPC_HANDLE_BYTES bytes; NULL: not wanted);
  *   mppi_p2p_connect  maps the peers' mailboxes: ipc_handles = n_ranks handles, rank-major (other processes), and / or
- *                     local_ptrs[g] = mppi_p2p_mailbox_ptr of an engine in THIS process (non-NULL entries win);
+ *                     local_ptrs[g] = mppi_p2p_mailbox_ptr of an engine in THIS process (non-NULL entries win) -- on this GPU or on
+ *                     another one of the node: peer access from this engine's device is enabled on the way, MPPI_E_INVALID
+ *                     names the pair when the two devices have no peer path;
  *   mppi_tick_exchange_p2p   replaces mppi_tick_finish after mppi_tick_begin: a publish kernel stores this rank's
  *                     tuples into every peer's mailbox over xGMI and raises a flag; the finalize kernel waits for its
  *                     own mailbox's n_ranks flags and finishes the tick.  Asynchronous, no host involvement, no collective;
@@ -269,6 +271,12 @@ int mppi_wait_for_stream(mppi_engine *h, void *other_stream);
 #define MPPI_IPC_HANDLE_BYTES 64
 int mppi_p2p_create(mppi_engine *h, int n_ranks, int rank, void *ipc_handle_out);
 int mppi_p2p_connect(mppi_engine *h, const void *ipc_handles, void *const *local_ptrs);
+/* mppi_p2p_create + mppi_p2p_connect for ranks that are separate processes with nothing but a file system in common (no process
+ * group, no torch): rank r leaves its IPC handle in the file "<path_prefix>.<r>" and waits up to timeout_ms (0: forever) for
+ * the other ranks' files.  The prefix must be fresh for every group (e.g. inside a directory the launcher made for this run:
+ * a stale file of an earlier run would be taken for a peer's handle); the files are left behind for the launcher to remove
+ * once every rank has returned. */
+int mppi_p2p_rendezvous(mppi_engine *h, const char *path_prefix, int n_ranks, int rank, int timeout_ms);
 int mppi_p2p_mailbox_ptr(mppi_engine *h, void **dev_ptr);
 int mppi_p2p_selftest(mppi_engine *h, int rounds);
 int mppi_p2p_destroy(mppi_engine *h);

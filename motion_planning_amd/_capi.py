@@ -71,6 +71,7 @@ SIGNATURES = {
     "mppi_tick_finish": (C.c_int, [_H, C.c_void_p, C.c_int]),
     "mppi_p2p_create": (C.c_int, [_H, C.c_int, C.c_int, C.c_void_p]),
     "mppi_p2p_connect": (C.c_int, [_H, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mppi_p2p_rendezvous": (C.c_int, [_H, C.c_char_p, C.c_int, C.c_int, C.c_int]),
     "mppi_p2p_mailbox_ptr": (C.c_int, [_H, C.POINTER(C.c_void_p)]),
     "mppi_p2p_selftest": (C.c_int, [_H, C.c_int]),
     "mppi_p2p_destroy": (C.c_int, [_H]),

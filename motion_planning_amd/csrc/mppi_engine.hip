@@ -1516,7 +1516,20 @@ int mppi_p2p_connect(mppi_engine* h, const void* ipc_handles, void* const* local
     h->p2p_connected = false;
     for (int g = 0; g < h->p2p_n; ++g) {
         if (g == h->p2p_rank) { h->p2p_peer[g] = h->p2p_mbox; continue; }
-        if (local_ptrs && local_ptrs[g]) { h->p2p_peer[g] = static_cast<char*>(local_ptrs[g]); continue; }  // same process
+        if (local_ptrs && local_ptrs[g]) {   // an engine of THIS process -- possibly on another GPU of the node
+            hipPointerAttribute_t at{};
+            if (hipPointerGetAttributes(&at, local_ptrs[g]) != hipSuccess) { (void)hipGetLastError(); fail(MPPI_E_INVALID, "p2p connect: local_ptrs[%d] is not a device pointer", g); }
+            if (at.device != h->device) {
+                int can = 0;
+                HIPCHK(hipDeviceCanAccessPeer(&can, h->device, at.device));
+                if (!can) fail(MPPI_E_INVALID, "p2p connect: device %d cannot access device %d (rank %d's mailbox): no peer path between the two", h->device, at.device, g);
+                const hipError_t pe = hipDeviceEnablePeerAccess(at.device, 0);   // (the engine's device is current: DeviceGuard)
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) fail(MPPI_E_HIP, "hipDeviceEnablePeerAccess(%d) from device %d: %s", at.device, h->device, hipGetErrorString(pe));
+                (void)hipGetLastError();
+            }
+            h->p2p_peer[g] = static_cast<char*>(local_ptrs[g]);
+            continue;
+        }
         if (!ipc_handles) fail(MPPI_E_INVALID, "p2p connect: no handle for rank %d", g);
         hipIpcMemHandle_t hd;
         std::memcpy(&hd, static_cast<const char*>(ipc_handles) + (size_t)g * MPPI_IPC_HANDLE_BYTES, sizeof(hd));
@@ -1525,6 +1538,47 @@ int mppi_p2p_connect(mppi_engine* h, const void* ipc_handles, void* const* local
         h->p2p_peer[g] = static_cast<char*>(p); h->p2p_peer_ipc[g] = true;
     }
     h->p2p_connected = true;
+    API_END(h)
+}
+
+// mppi_p2p_create + exchange of the IPC handles through files + mppi_p2p_connect, for ranks that are separate PROCESSES of one
+// node and have no process group to carry the handles (a plain C++ / ROS node needs no torch for this): rank r writes its
+// handle to "<prefix>.<r>" (written under a temporary name and renamed, so a reader never sees half a file), waits until all
+// n_ranks files exist, connects.
+int mppi_p2p_rendezvous(mppi_engine* h, const char* prefix, int n_ranks, int rank, int timeout_ms) {
+    if (!h) return MPPI_E_INVALID;
+    if (!prefix || !*prefix) { h->err = "p2p rendezvous: empty path prefix"; return MPPI_E_INVALID; }
+    unsigned char mine[MPPI_IPC_HANDLE_BYTES];
+    if (int rc = mppi_p2p_create(h, n_ranks, rank, mine)) return rc;
+    API_BEGIN(h)
+    const std::string base(prefix);
+    auto name = [&](int r) { return base + "." + std::to_string(r); };
+    {
+        const std::string tmp = name(rank) + ".tmp";
+        FILE* f = std::fopen(tmp.c_str(), "wb");
+        if (!f) fail(MPPI_E_INVALID, "p2p rendezvous: cannot write %s", tmp.c_str());
+        const size_t w = std::fwrite(mine, 1, sizeof(mine), f);
+        if (std::fclose(f) != 0 || w != sizeof(mine) || std::rename(tmp.c_str(), name(rank).c_str()) != 0)
+            fail(MPPI_E_INVALID, "p2p rendezvous: cannot publish %s", name(rank).c_str());
+    }
+    std::vector<unsigned char> all((size_t)n_ranks * MPPI_IPC_HANDLE_BYTES, 0);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < n_ranks; ++r) {
+        if (r == rank) { std::memcpy(all.data() + (size_t)r * MPPI_IPC_HANDLE_BYTES, mine, sizeof(mine)); continue; }
+        for (;;) {
+            FILE* f = std::fopen(name(r).c_str(), "rb");
+            if (f) {
+                const size_t got = std::fread(all.data() + (size_t)r * MPPI_IPC_HANDLE_BYTES, 1, MPPI_IPC_HANDLE_BYTES, f);
+                std::fclose(f);
+                if (got == MPPI_IPC_HANDLE_BYTES) break;
+            }
+            const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+            if (timeout_ms > 0 && ms > timeout_ms) fail(MPPI_E_TIMEOUT, "p2p rendezvous: rank %d's handle (%s) did not appear within %d ms", r, name(r).c_str(), timeout_ms);
+            struct timespec ts = {0, 2000000};
+            nanosleep(&ts, nullptr);
+        }
+    }
+    if (int rc = mppi_p2p_connect(h, all.data(), nullptr)) fail(rc, "%s", h->err.c_str());
     API_END(h)
 }
 

@@ -457,15 +457,6 @@ __device__ __forceinline__ float wave_sum16(const float (&v)[16], int lane) {
     }
     return y;
 }
-template <bool FULL16 = false>
-__device__ __forceinline__ double wave_sum16(const double (&v)[16], int lane) {  // exact-parity mode: plain sums
-    double r = 0.0;
-    const int mine = sum16_index(lane);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { const double t = wave_sum(v[i]); if (i == mine) r = t; }
-    return r;
-}
-
 
 // 64-lane inclusive prefix sum on the DPP network (no LDS crossbar, no barriers): Kogge-Stone inside each
 // 16-lane row (row_shr 1, 2, 4, 8), then the row totals chained by row_bcast:15 (rows 1, 3) and
@@ -822,15 +813,19 @@ __device__ __forceinline__ void rollout_body(const DevParams& P, const double* _
         constexpr bool EXTRA = decltype(extra_tag)::value;  // slots 12..15 carry steps t0 + 6, t0 + 7 (from tl)
         {   // sum_k eps per wave for the chunk's 6 steps x 2 wheels (the E of the softmax floor term,
             // control/src/mppi:193): saves the update kernel from reading eps at all (8 of its 12 B/step)
-            S ev[16];
+            // The sums are formed in fp32 in BOTH storage modes: E only enters the control update through the weight floor, as
+            // 1e-8 * E / (D + 1e-8 K) (control/src/mppi:193-196), so fp32 rounding of a 64-term sum (~1e-6) moves u by ~1e-14 --
+            // and the fp64 form of this reduction (sixteen serial full-wave fp64 DPP sums per chunk) cost the all-fp64 mode 50 us
+            // of its 190-us rollout launch (round 3: 190.7 us against 107.8 for the same arithmetic under fp32 storage).
+            float ev[16];
 #pragma unroll
             for (int j = 0; j < U; ++j) {
-                ev[2 * j] = (FULL || active) ? cur[j][0] : (S)0;
-                ev[2 * j + 1] = (FULL || active) ? cur[j][1] : (S)0;
+                ev[2 * j] = (FULL || active) ? (float)cur[j][0] : 0.f;
+                ev[2 * j + 1] = (FULL || active) ? (float)cur[j][1] : 0.f;
             }
 #pragma unroll
-            for (int j = 2 * U; j < 16; ++j) ev[j] = !EXTRA ? (S)0 : ((FULL || active) ? tl[(j - 2 * U) >> 1][j & 1] : (S)0);
-            const S tot = wave_sum16<EXTRA>(ev, tid & 63);
+            for (int j = 2 * U; j < 16; ++j) ev[j] = !EXTRA ? 0.f : ((FULL || active) ? (float)tl[(j - 2 * U) >> 1][j & 1] : 0.f);
+            const float tot = wave_sum16<EXTRA>(ev, tid & 63);
             const int idx = sum16_index(tid & 63), te = t0 + (idx >> 1);
             const bool mine = (tid & 63) < 16 && idx < (EXTRA ? 16 : 2 * U) && te < T && (size_t)(k >> 6) < NW;
             const size_t at = (((size_t)a * T + te) * 2 + (idx & 1)) * NW + (k >> 6);
@@ -838,10 +833,10 @@ __device__ __forceinline__ void rollout_body(const DevParams& P, const double* _
                 // predication by address instead of by branch: a buffer store whose offset lies beyond
                 // num_records is dropped by the hardware, so the chunk stays one basic block and the
                 // scheduler may interleave the noise chains with the fp64 dynamics that follow
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)tot), ep_rsrc,
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(tot), ep_rsrc,
                                                       mine ? (unsigned)(at * 4) : 0xFFFFFFFFu, 0, kAux);
             } else if (mine) {
-                epart[at] = tot;
+                epart[at] = (S)tot;
             }
         }
     };

@@ -333,6 +333,10 @@ class Engine(object):
             arr = (C.c_void_p * len(local_ptrs))(*[C.c_void_p(p) if p else None for p in local_ptrs])
         self._ck(self._lib.mppi_p2p_connect(self._h, blob, arr))
 
+    def p2p_rendezvous(self, path_prefix, n_ranks, rank, timeout_ms=60000):
+        """p2p_create + connect for ranks in separate processes with only a file system in common (no process group)."""
+        self._ck(self._lib.mppi_p2p_rendezvous(self._h, str(path_prefix).encode(), int(n_ranks), int(rank), int(timeout_ms)))
+
     def p2p_mailbox_ptr(self):
         p = C.c_void_p()
         self._ck(self._lib.mppi_p2p_mailbox_ptr(self._h, C.byref(p)))

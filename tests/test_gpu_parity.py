@@ -1364,3 +1364,35 @@ def test_cpp_node_matches_the_python_shim(tmp_path, tick_path, task, waypoints, 
         plant = rk4(plant.reshape(3, 1), u.reshape(2, 1), c.mppi.dt)[:, 0]
     assert ticks > n_cb // 2  # the loop really drove the engine
 
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,G", [("--handles", 2), ("--handles", 8), ("--procs", 2), ("--procs", 8)])
+def test_cpp_node_sharded_without_python(tmp_path, tick_path, mode, G):
+    """N > 1 WITHOUT Python or torch (control/src/mppi:296-342 is one object and one call; the K-split lives behind it):
+    examples/mppi_node --handles G -- one process, G engines, mailboxes connected by pointer (device g where the box has that
+    many GPUs, all on device 0 otherwise) -- and --procs G -- G forked processes, IPC handles exchanged through files
+    (mppi_p2p_rendezvous) -- publish the SAME twists as the one-handle node on the same noise streams (global sample ids).
+    STATED tolerance: 1e-9 on the wheel speeds over the closed loop (fp32 storage: a chunk's sum of weights is an fp32 sum and
+    G shards group the samples differently, cf. test_p2p_gpu._run_ranks), 1e-12 on the pose fed back (the same plant)."""
+    import os
+    import subprocess
+    if tick_path == "scan":
+        pytest.skip("the node names its tick path")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "mppi_node")
+    subprocess.run(["make", "-B", "-C", os.path.join(root, "examples"), "OUT=" + exe], check=True, capture_output=True)
+    K, T, n_cb = 48000, 50, 12
+    common = [exe, "--task", "pentagon", "--samples", str(K), "--horizon", str(T), "--callbacks", str(n_cb), "--thresh", "0.97", "--seed", "9",
+              "--tick-path", "lanes"]
+    env = dict(os.environ, MPPI_SYNC_TIMEOUT_MS="8000", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = subprocess.run(common, capture_output=True, text=True, timeout=60, env=env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    many = subprocess.run(common + [mode, str(G)], capture_output=True, text=True, timeout=120, env=env)
+    assert many.returncode == 0, many.stderr[-2000:]
+    a = np.array([[float(x) for x in ln.split()] for ln in one.stdout.strip().splitlines()])
+    b = np.array([[float(x) for x in ln.split()] for ln in many.stdout.strip().splitlines()])
+    assert a.shape == b.shape == (n_cb, 14)
+    assert np.abs(a[:, 1:7] - b[:, 1:7]).max() < 1e-12                      # poses and goals
+    assert np.abs(a[:, 7:11] - b[:, 7:11]).max() < 1e-9, np.abs(a[:, 7:11] - b[:, 7:11]).max()   # wheel speeds and twists
+    assert np.array_equal(a[:, 11:], b[:, 11:]) and np.any(a[:, 7:9] != 0.0)
+

@@ -120,6 +120,148 @@ def test_p2p_processes_over_ipc(world):
     _run_ranks(world)
 
 
+def _c4_worker(rank, world, port, q, K_total, n_ticks, outdir):
+    """One rank of BASELINE config 4 as stated: K_total / world samples, the p2p exchange, `n_ticks` closed-loop ticks.  Leaves its
+    shard of the noise the device drew and of V (every tick) as .npy files for the parent's oracle replay."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    from motion_planning_amd import sharded
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ticker, eng = sharded.make_hip_ticker(K_total, T, storage="f32", local_rank=0, exchange="p2p", tick_path="lanes")
+        assert ticker.exchange == "p2p" and ticker.world == world
+        lo, hi = sharded.shard_range(K_total, world, rank)
+        assert eng.K == hi - lo
+        eng.set_nominal(_u0())
+        outs = []
+        for i in range(n_ticks):
+            nxt, ua = ticker.tick([[0, 0, 0]] if i == 0 else None, [[0, -1, 0]] if i == 0 else None, "philox", SEED, i)
+            kernel = eng.info()["rollout_kernel"]
+            eps = eng.download_noise()[0]                                                          # [T][2][K_rank]
+            assert np.array_equal(eps.astype(np.float32).astype(np.float64), eps)                 # fp32 storage: what the kernels used IS fp32
+            np.save(os.path.join(outdir, "eps_%d_%d.npy" % (i, rank)), eps.astype(np.float32))
+            np.save(os.path.join(outdir, "V_%d_%d.npy" % (i, rank)), eng.download_value()[0])     # [T][K_rank]
+            outs.append((nxt[0].copy(), ua[0].copy(), eng.get_nominal().copy(), kernel))
+        dist.barrier()                         # nobody unmaps a mailbox a peer may still be writing to
+        q.put((rank, lo, hi, outs))
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config4_as_stated_eight_ranks_against_the_oracle(orc, tmp_path):
+    """BASELINE config 4 AS STATED: K = 1 000 000, T = 50, split over EIGHT ranks of 125 000 samples -- eight processes on this
+    box's one GPU, the product's ShardedTicker on the p2p exchange (one [A][T][8] tuple block per rank and tick) -- two closed-loop
+    ticks.  The reference's only cross-sample coupling is the per-timestep softmax of update_action (control/src/mppi:187-196): the
+    sharded result is held to THAT line, not to another engine -- rank 0's applied controls, predicted state and nominal controls
+    against the oracle's replay of ALL 10^6 samples on the noise the eight devices-side shards drew (V of every sample against the stated
+    V tolerance, the controls against the stated u bound at the measured V error; asserted caps = config 4's on one engine,
+    FULL_CAPS in test_gpu_parity.py).  Then against the N = 1 handle (one process, co-scheduled, the mixed-precision rollout where
+    the eight shards run the all-fp64 one): STATED cross-kernel tolerance 1e-8 on the controls / 1e-10 on the state -- both sides
+    sit within 1e-9 of the oracle on this scene (its rows are decided, gap / lambda ~ 100); every rank ends with bit-identical
+    nominal controls."""
+    import multiprocessing as mp
+    from test_gpu_parity import _replay_full
+    from motion_planning_amd.mppi import Engine
+    world, K_total, n_ticks = 8, 1000000, 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_c4_worker, args=(r, world, port, q, K_total, n_ticks, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [r[0] for r in res] == list(range(world)) and res[0][1] == 0 and res[-1][2] == K_total
+    assert all(res[i][2] == res[i + 1][1] for i in range(world - 1))            # the shards tile [0, K)
+    for i in range(n_ticks):                                                      # every rank finishes every tick identically
+        for r in res[1:]:
+            assert np.array_equal(r[3][i][2], res[0][3][i][2]) and np.array_equal(r[3][i][0], res[0][3][i][0])
+    assert all(o[3] == "fp64" for r in res for o in r[3])                        # 125 000 samples: the all-fp64 rollout
+    state, u0 = np.zeros(3), _u0()
+    for i in range(n_ticks):
+        eps = np.concatenate([np.load(os.path.join(str(tmp_path), "eps_%d_%d.npy" % (i, r))) for r in range(world)], axis=2).astype(np.float64)
+        V = np.concatenate([np.load(os.path.join(str(tmp_path), "V_%d_%d.npy" % (i, r))) for r in range(world)], axis=1)
+        for r in range(world):
+            os.remove(os.path.join(str(tmp_path), "eps_%d_%d.npy" % (i, r)))
+            os.remove(os.path.join(str(tmp_path), "V_%d_%d.npy" % (i, r)))
+        nxt, ua, lat, _ = res[0][3][i]
+        m = _replay_full(orc, V, eps, nxt, ua, lat, state, [0.0, -1.0, 0.0], u0, T, "f32", v_abs=0.0)
+        print("config 4 as stated (8 x 125 000, p2p), tick %d: %s" % (i, m))
+        assert m["eV_max"] <= 2e-4 and m["du_max"] <= 1e-9, m
+        state, u0 = nxt, lat                                                      # closed loop: the next tick's inputs
+        del eps, V
+    # the N = 1 handle on the same noise streams (global sample ids), its own kernel choice
+    with Engine(K_total, T, storage="f32") as e:
+        e.set_nominal(_u0())
+        for i in range(n_ticks):
+            nxt1, ua1 = e.tick([0, 0, 0] if i == 0 else None, [0, -1, 0] if i == 0 else None, noise="philox", seed=SEED, tick_id=i)
+            assert np.abs(ua1[0] - res[0][3][i][1]).max() <= 1e-8 and np.abs(nxt1[0] - res[0][3][i][0]).max() <= 1e-10, i
+        assert e.info()["rollout_kernel"] == "mixed"
+        assert np.abs(e.get_nominal() - res[0][3][-1][2]).max() <= 1e-8
+
+
+def _c5_worker(rank, world, q):
+    """One replica rank of BASELINE config 5: its 64 / world agents in one engine, no exchange; every agent replayed on the oracle."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from motion_planning_amd import sharded
+    from oracle import oracle as orc
+    from test_gpu_parity import _replay_full
+    orc.build()
+    A_total, K5 = 64, 16384
+    lo, hi = sharded.shard_range(A_total, world, rank)
+    ticker, eng = sharded.make_replica_ticker(K5, T, n_agents=hi - lo, storage="f32", local_rank=0, tick_path="lanes")
+    assert ticker.exchange == "none"
+    for a in range(hi - lo):
+        eng.set_nominal(_u0(), agent=a)
+    states = np.array([[0.05 * a, 0.0, 0.0] for a in range(lo, hi)])
+    goals = np.array([[0.05 * a, -1.0, 0.0] for a in range(lo, hi)])
+    nxt, ua = ticker.tick(states, goals, "philox", SEED, 0)
+    V, eps = eng.download_value(), eng.download_noise()
+    worst = 0.0
+    for a in range(hi - lo):
+        m = _replay_full(orc, V[a], eps[a], nxt[a], ua[a], eng.get_nominal(a), states[a], goals[a], _u0(), T, "f32", v_abs=0.0)
+        worst = max(worst, m["du_max"])
+    q.put((rank, lo, hi, nxt.copy(), ua.copy(), eng.info()["rollout_kernel"], worst))
+    eng.close()
+
+
+def test_config5_as_eight_replica_ranks_against_the_oracle():
+    """BASELINE config 5 as SURVEY 8(e) runs it on eight GPUs: replicas only -- eight processes (here on the one GPU), eight of the
+    64 agents each, no exchange.  Every agent of every rank is replayed on the oracle (V on all its 16 384 samples, the controls
+    against the stated bound; cap 1e-3 rad/s as in the one-engine test: near-tie rows), and the eight ranks' controls equal
+    the one 64-agent engine's within the STATED cross-kernel tolerance 1e-4 (the ranks' 8 x 16 384 samples run the all-fp64
+    rollout, the 64-agent engine the mixed one; measured ~1e-5 on the worst near-tie agent)."""
+    import multiprocessing as mp
+    from motion_planning_amd.mppi import Engine
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_c5_worker, args=(r, world, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [(r[1], r[2]) for r in res] == [(8 * i, 8 * i + 8) for i in range(world)]
+    print("config 5 as 8 replica ranks: rollout kernels %s, worst |du| against the oracle %.2e" % (sorted(set(r[5] for r in res)), max(r[6] for r in res)))
+    assert max(r[6] for r in res) <= 1e-3
+    nxt8, ua8 = np.concatenate([r[3] for r in res]), np.concatenate([r[4] for r in res])
+    with Engine(16384, T, n_agents=64, storage="f32") as e:
+        for a in range(64):
+            e.set_nominal(_u0(), agent=a)
+        nxt, ua = e.tick(np.array([[0.05 * a, 0.0, 0.0] for a in range(64)]), np.array([[0.05 * a, -1.0, 0.0] for a in range(64)]),
+                         noise="philox", seed=SEED, tick_id=0)
+    assert np.abs(ua - ua8).max() <= 1e-4 and np.abs(nxt - nxt8).max() <= 1e-6, (np.abs(ua - ua8).max(), np.abs(nxt - nxt8).max())
+
+
 def _visible_devices():
     import subprocess
     out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True).stdout.strip()
