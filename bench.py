@@ -33,7 +33,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.
 CLOCK_PEAK_HZ = 2.4e9  # max shader clock, same guide
 N_SIMD = 1024          # 256 CUs x 4 SIMDs
 BYTES_PER_STEP_PER_KERNEL = 12  # eps 2 x fp32 + V 1 x fp32, written once (rollout) / read once (update): SURVEY 8(d)
-PROFILE_ROUND = "r3"
+PROFILE_ROUND = "r4"
+HBM_ACHIEVABLE_GBS = 6300.0  # what a streaming read reaches on this part (MI355X_MICROARCH.md, HBM section)
 
 WORKLOADS = {
     # name: (description, agents, K_total, T, goal)
@@ -282,7 +283,7 @@ def main():
             lo, hi = sharded.shard_range(A_total, world, rank)
             A = hi - lo
             ticker, eng = sharded.make_replica_ticker(K_total, T, n_agents=A, storage=args.storage, local_rank=local_rank,
-                                                      tick_path=args.tick_path, co_shards=args.co_shards)
+                                                      tick_path=args.tick_path, co_shards=args.co_shards, agent_offset=lo)
             states = np.array([[0.05 * a, 0.0, 0.0] for a in range(lo, hi)])
             goals = np.array([[0.05 * a, -1.0, 0.0] for a in range(lo, hi)])
             K_local, units_total = K_total, A_total * K_total
@@ -563,104 +564,131 @@ def main():
 
     if rank == 0:
         lanes = info.get("tick_kernels", "lanes") == "lanes"
-        mixes = load_profile(PROFILE_ROUND + "_valu_mix.json") or {}
+        mixes = load_profile(PROFILE_ROUND + "_valu_mix.json") or load_profile("r3_valu_mix.json") or {}
 
-        def kernel_roofline(k_launch, avg_s, mhz, n_timed, kind):
-            """The dominant kernel of a launch over k_launch samples per agent: SURVEY 8(d) HBM accounting, and the VALU-issue
-            roofline it is really on -- wave-instructions of the steady-state loop from the compiler's own assembly
-            (tools/valu_mix.py), each class at its measured issue cost (tools/ubench.hip, shader clock read in-kernel),
-            over 1024 SIMDs at the clock a probe wave inside the launch measured (and at the 2.4 GHz peak)."""
+        pmc_name = PROFILE_ROUND + "_pmc_summary_bench_c4.json"
+        pm = load_profile(pmc_name)
+        for older in ("r3", "r1"):
+            if pm is None:
+                pmc_name = older + "_pmc_summary_bench_c4.json"
+                pm = load_profile(pmc_name)
+        pmc_ok = bool(pm) and args.workload == "c4" and args.storage == "f32" and not args.samples and args.horizon in (0, 50)
+
+        def pmc_of(kernel_name):
+            """Per-launch PMC averages of one kernel over ALL of config 4's samples (tools/pmc.sh: separate rocprofv3 --pmc passes of
+            `bench.py --co-shards 1`; FETCH_SIZE doubled -- the guide's gfx950 correction --, WRITE_SIZE as reported), or None."""
+            if not pmc_ok:
+                return None
+            for kname, c in pm.items():
+                if kname.split("::")[-1].split("<")[0] == kernel_name:
+                    rd = [v for k, v in c.items() if k.startswith("hbm_read_bytes")]
+                    wr = [v for k, v in c.items() if k.startswith("hbm_write_bytes")]
+                    if rd and wr:
+                        return {"read": rd[0], "write": wr[0], "valu_insts": c.get("SQ_INSTS_VALU")}
+            return None
+
+        def kernel_roofline(k_launch, avg_s, mhz, n_timed, kind, upd_us=None, merge_us=None, fin_us=None, tick_s=None):
+            """The dominant kernel of a launch over k_launch samples per agent.
+            TOP LEVEL = the roof it is on: VALU issue -- wave-instructions of the steady-state loop from the compiler's own assembly
+            (tools/valu_mix.py), each class at its measured issue cost (tools/ubench.hip, shader clock read in-kernel), over 1024
+            SIMDs at the clock a probe wave inside the launch measured (`frac`; `frac_at_peak_clock` at 2.4 GHz).
+            `hbm`: what the kernels really move (PMC counters) against the 8 TB/s peak -- rollout and update.
+            `accounting_8d`: SURVEY 8(d)'s figure -- 12 algorithmic B / state-step / kernel over the launch duration -- kept as the
+            contract defines it; it is an accounting figure, not a distance to a roof.
+            `tick_floor_us`: max(rollout issue time, update bytes / achievable HBM rate) + measured merge + finalize."""
             steps = A * k_launch * T
+            share = (A * k_launch) / float(A * K_local)          # a co-scheduled shard's launch moves its share of the bytes
             # `kind`: what the engine says its last tick launched (mppi_rollout_kernel), not a copy of its rule
             name = {"mixed": "rollout_pk_kernel", "fp64": "rollout_kernel", "scan": "scan_tick_kernel"}[kind]
             gbs = BYTES_PER_STEP_PER_KERNEL * steps / avg_s / 1e9
-            r = {"kernel": name, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                 "traffic": None, "algorithmic_bytes_per_launch": BYTES_PER_STEP_PER_KERNEL * steps, "samples_per_launch": A * k_launch,
-                 "avg_launch_us": avg_s * 1e6, "launches_timed": n_timed, "actual_bound": "valu-issue"}
+            acc = {"bound": "hbm", "bytes_per_state_step_per_kernel": BYTES_PER_STEP_PER_KERNEL, "algorithmic_bytes_per_launch": BYTES_PER_STEP_PER_KERNEL * steps,
+                   "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                   "note": "SURVEY 8(d): eps 2 x fp32 + V fp32 per state-step, written once by the rollout and read once by the update = 12 B/step per "
+                           "kernel, 24 per tick.  NOT the distance to a roof: eps is never stored (it is re-drawn from its Philox counter), so the "
+                           "kernels move about a third of these bytes (`hbm`), and the tick-level figure can exceed 1"}
+            r = {"kernel": name, "bound": "valu-issue", "achieved": None, "peak": None, "unit": "G wave-inst/s", "frac": None, "traffic": None,
+                 "samples_per_launch": A * k_launch, "avg_launch_us": avg_s * 1e6, "launches_timed": n_timed, "accounting_8d": acc}
             mix = mixes.get(name)
             if mix and lanes and args.storage == "f32":
                 wave_steps = steps / 64.0          # sample-steps per 64 lanes (the pk kernel's waves carry 128 samples)
                 cyc = mix["issue_cycles_per_step"] * wave_steps / N_SIMD
                 clk = mhz * 1e6 if mhz and mhz > 0 else CLOCK_PEAK_HZ
-                r["valu"] = {"bound": "valu-issue", "unit": "G wave-inst/s",
-                             "insts_per_launch": mix["valu_per_step"] * wave_steps,
-                             "achieved": mix["valu_per_step"] * wave_steps / avg_s / 1e9,
-                             "peak": N_SIMD * clk / mix["avg_cycles_per_valu"] / 1e9,
-                             "clock_mhz_under_load": mhz, "frac": cyc / clk / avg_s, "min_launch_us": cyc / clk * 1e6,
-                             "frac_at_peak_clock": cyc / CLOCK_PEAK_HZ / avg_s, "min_launch_us_at_peak_clock": cyc / CLOCK_PEAK_HZ * 1e6,
-                             "valu_per_step": mix["valu_per_step"], "issue_cycles_per_step": mix["issue_cycles_per_step"],
+                r.update({"achieved": mix["valu_per_step"] * wave_steps / avg_s / 1e9, "peak": N_SIMD * clk / mix["avg_cycles_per_valu"] / 1e9,
+                          "frac": cyc / clk / avg_s, "frac_at_peak_clock": cyc / CLOCK_PEAK_HZ / avg_s, "clock_mhz_under_load": mhz,
+                          "min_launch_us": cyc / clk * 1e6, "min_launch_us_at_peak_clock": cyc / CLOCK_PEAK_HZ * 1e6})
+                r["valu"] = {"insts_per_launch": mix["valu_per_step"] * wave_steps, "valu_per_step": mix["valu_per_step"],
+                             "issue_cycles_per_step": mix["issue_cycles_per_step"], "avg_cycles_per_valu": mix["avg_cycles_per_valu"],
                              "by_class_per_step": {k: v / mix["steps_per_iteration"] for k, v in mix["by_class_per_iteration"].items()},
                              "source": "profiles/%s_valu_mix.json, profiles/%s_ubench.txt" % (PROFILE_ROUND, PROFILE_ROUND)}
+            else:   # no assembly count for this kernel / mode: the contract's HBM accounting is what there is
+                r.update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS})
+            hbm = {"peak": HBM_PEAK_GBS, "achievable": HBM_ACHIEVABLE_GBS, "unit": "GB/s",
+                   "source": "profiles/%s (FETCH_SIZE x 2 + WRITE_SIZE per launch over all samples of config 4, separate --pmc passes of "
+                             "`bench.py --co-shards 1`), scaled to this launch's samples; durations measured live in this run" % pmc_name}
+            pr, pu = pmc_of(name), pmc_of("update_kernel")
+            if pr:
+                b = (pr["read"] + pr["write"]) * share
+                r["traffic"] = b
+                hbm["rollout"] = {"counter_bytes": b, "read_bytes": pr["read"] * share, "write_bytes": pr["write"] * share, "avg_launch_us": avg_s * 1e6,
+                                  "achieved": b / avg_s / 1e9, "frac": b / avg_s / 1e9 / HBM_PEAK_GBS,
+                                  "vs_algorithmic": b / (BYTES_PER_STEP_PER_KERNEL * steps)}
+                if pr["valu_insts"] and "valu" in r:
+                    r["valu"]["insts_per_launch_pmc_all_samples"] = pr["valu_insts"]
+            if pu and upd_us:
+                b = (pu["read"] + pu["write"]) * share
+                hbm["update"] = {"kernel": "update_kernel", "counter_bytes": b, "avg_launch_us": upd_us, "achieved": b / (upd_us * 1e-6) / 1e9,
+                                 "frac": b / (upd_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "frac_of_achievable": b / (upd_us * 1e-6) / 1e9 / HBM_ACHIEVABLE_GBS,
+                                 "vs_algorithmic": b / (BYTES_PER_STEP_PER_KERNEL * steps)}
+            r["hbm"] = hbm
+            if "min_launch_us" in r and upd_us and fin_us is not None and tick_s:
+                upd_floor = (hbm["update"]["counter_bytes"] / (HBM_ACHIEVABLE_GBS * 1e9) * 1e6) if "update" in hbm else upd_us
+                floor = max(r["min_launch_us"], upd_floor) + (merge_us or 0.0) + fin_us
+                r["tick_floor_us"] = floor
+                r["tick_frac"] = floor / (tick_s * 1e6)
+                r["tick_floor_terms"] = {"rollout_issue_us": r["min_launch_us"], "update_bytes_over_achievable_hbm_us": upd_floor,
+                                         "merge_us_measured": merge_us or 0.0, "finalize_us_measured": fin_us, "tick_us": tick_s * 1e6,
+                                         "what": "max(rollout VALU-issue time at the measured clock, update counter bytes / 6.3 TB/s) + the measured merge "
+                                                 "and finalize launches: the two big kernels fully overlapped, the small ones as they are"}
             return r
 
         co_n = info.get("co_shards", 1)
         k_launch = info["co_samples"][0] if co_n > 1 else K_local    # the launches this handle's events time: its own shard
-        steps_per_launch = A * k_launch * T
         ms, n = ktimes["rollout"]
         if n == 0:  # hipGraph replay: launches are not individually bracketed
             ms, n = dtimes["rollout"] if dtimes["rollout"][1] else (float("nan"), 1)
         avg_s = ms * 1e-3 / max(n, 1)
         tick_s = elapsed / args.steps
-        roofline = kernel_roofline(k_launch, avg_s, clock_mhz, n, info["rollout_kernel"])
+        roofline = kernel_roofline(k_launch, avg_s, clock_mhz, n, info["rollout_kernel"], upd_us=kernels_us.get("update"),
+                                   merge_us=kernels_us.get("merge"), fin_us=kernels_us.get("finalize"), tick_s=tick_s)
         tick_bytes = 2 * BYTES_PER_STEP_PER_KERNEL * A * K_local * T
-        roofline["note"] = ("SURVEY 8(d) accounting: algorithmic = 12 B/state-step per kernel (eps 2 x fp32 + V fp32; 24 B/step per "
-                            "tick, written once by the rollout, read once by the update).  The kernel is NOT on the HBM roof: it "
-                            "regenerates eps instead of storing it (writes 4.4 of the 12 B/step, see `traffic`) and is bound by "
-                            "VALU issue -- see `valu`." +
-                            ("  This handle runs its fused tick as %d co-scheduled engines: the launches timed here are shard 0's "
-                             "(%d samples), overlapping the other shard's kernels; `one_engine` holds the same kernel undisturbed."
-                             % (co_n, k_launch) if co_n > 1 else ""))
         if co_n > 1:
             roofline["concurrent_launches"] = co_n
-            roofline["frac_all_shards_upper"] = roofline["frac"] * A * K_local / (A * k_launch)
-            roofline["concurrency_note"] = ("each shard's rollout launch covers %d of the %d samples and runs NEXT TO the other shards' launches "
-                                            "(own streams): `frac` is one launch's algorithmic bytes over its own duration, as SURVEY 8(d) defines it; "
-                                            "`frac_all_shards_upper` = all shards' bytes over that duration (exact if they overlap fully); "
-                                            "`one_engine.roofline` is the same kernel with the GPU to itself" % (A * k_launch, A * K_local))
-        roofline["tick_level"] = {"algorithmic_bytes": tick_bytes, "achieved": tick_bytes / tick_s / 1e9,
-                                  "frac": tick_bytes / tick_s / 1e9 / HBM_PEAK_GBS,
-                                  "note": "24 B/state-step x all samples of the tick / tick time: both kernels (and, co-scheduled, both engines) together"}
-        if "valu" in roofline:   # VALU issue over the whole tick: every shard's rollout instructions against the tick time
-            v = roofline["valu"]
+            roofline["concurrency_note"] = ("this handle runs its fused tick as %d co-scheduled engines: each shard's rollout launch covers %d of the %d samples and "
+                                            "runs NEXT TO the other shards' launches (own streams), so its own duration says little about the kernel; the "
+                                            "per-kernel figures of this line are those of the one-engine leg" % (co_n, A * k_launch, A * K_local))
+        tick_level = {"accounting_8d": {"algorithmic_bytes": tick_bytes, "achieved": tick_bytes / tick_s / 1e9, "frac": tick_bytes / tick_s / 1e9 / HBM_PEAK_GBS,
+                                        "note": "24 B/state-step x all samples of the tick / tick time: both kernels (and, co-scheduled, both engines) together; above 1 "
+                                                "means what the note of accounting_8d says -- most of these bytes never exist"}}
+        if roofline.get("issue_cycles_per_step") or "valu" in roofline:   # VALU issue over the whole tick: every shard's rollout instructions against the tick time
             clk = (clock_mhz * 1e6) if clock_mhz and clock_mhz > 0 else CLOCK_PEAK_HZ
-            cyc_tick = v["issue_cycles_per_step"] * (A * K_local * T / 64.0) / N_SIMD
-            roofline["tick_level"]["valu_frac"] = cyc_tick / clk / tick_s
-            roofline["tick_level"]["valu_note"] = "rollout issue cycles of all shards / (tick time x measured clock): the update, merge and finalize kernels' instructions not counted"
+            cyc_tick = roofline["valu"]["issue_cycles_per_step"] * (A * K_local * T / 64.0) / N_SIMD
+            tick_level["valu_frac"] = cyc_tick / clk / tick_s
+            tick_level["valu_note"] = "rollout issue cycles of all shards / (tick time x measured clock): the update, merge and finalize kernels' instructions not counted"
         if one_line:
-            one_line["roofline"] = kernel_roofline(K_local, one_line["rollout_us"] * 1e-6, one_line["shader_clock_mhz"], one_line["launches_timed"], one_line["rollout_kernel"])
-        # HBM bytes actually moved per launch of that kernel: rocprofv3 --pmc passes of this same command
-        # (tools/pmc.sh), summary committed under profiles/ -- bench.py itself cannot host the profiler
-        pmc_name = PROFILE_ROUND + "_pmc_summary_bench_c4.json"
-        pm = load_profile(pmc_name)
-        if pm is None:
-            pmc_name = "r1_pmc_summary_bench_c4.json"
-            pm = load_profile(pmc_name)
-        if args.workload == "c4" and args.storage == "f32" and world == 1 and not args.samples and pm:
-            for kname, c in pm.items():
-                if kname.split("::")[-1].split("<")[0] == roofline["kernel"]:
-                    rd = [v for k, v in c.items() if k.startswith("hbm_read_bytes")]
-                    wr = [v for k, v in c.items() if k.startswith("hbm_write_bytes")]
-                    if rd and wr:
-                        # the PMC passes run this command with --co-shards 1: bytes per launch over ALL samples; a shard's launch
-                        # moves its share (the rollout's traffic is its dP / Stot / epart stores: proportional to its samples)
-                        full = rd[0] + wr[0]
-                        roofline["traffic"] = full * (A * k_launch) / float(A * K_local)
-                        roofline["traffic_source"] = ("profiles/%s (FETCH_SIZE x2 + WRITE_SIZE, bytes per launch over all samples; separate --pmc "
-                                                      "passes of this command with --co-shards 1), scaled to this launch's samples" % pmc_name)
-                        if one_line and "roofline" in one_line:
-                            one_line["roofline"]["traffic"] = full
-                        if "SQ_INSTS_VALU" in c and "valu" in roofline:
-                            roofline["valu"]["insts_per_launch_pmc_all_samples"] = c["SQ_INSTS_VALU"]
+            kb = one_line["kernels_us_bracketed"]
+            one_line["roofline"] = kernel_roofline(K_local, one_line["rollout_us"] * 1e-6, one_line["shader_clock_mhz"], one_line["launches_timed"],
+                                                   one_line["rollout_kernel"], upd_us=kb.get("update"), merge_us=kb.get("merge"), fin_us=kb.get("finalize"),
+                                                   tick_s=one_line["ms_per_step"] * 1e-3)
         # the rollout launch in each phase of this command (what a rocprofv3 --kernel-trace --stats of the whole
         # command averages over): back-to-back ticks run a few % longer than launches behind an idle gap
         phases = {"timed": ktimes["rollout"], "diagnostic": dtimes["rollout"]}
+        extra_roof = {}
         if args.workload != "c3":
             phases["warmup (closed loop, parks at the goal after ~600 ticks; sampled 1 in 8)"] = wtimes["rollout"]
-            roofline["update_us_warmup_phase"] = wtimes["update"][0] * 1e3 / wtimes["update"][1] if wtimes["update"][1] else None
+            extra_roof["update_us_warmup_phase"] = wtimes["update"][0] * 1e3 / wtimes["update"][1] if wtimes["update"][1] else None
         if btimes:
             phases["blocking"] = btimes["rollout"]
-        roofline["rollout_us_by_phase"] = {k: {"avg_us": (v[0] * 1e3 / v[1] if v[1] else None), "launches_timed": v[1]}
-                                           for k, v in phases.items()}
+        extra_roof["rollout_us_by_phase"] = {k: {"avg_us": (v[0] * 1e3 / v[1] if v[1] else None), "launches_timed": v[1]} for k, v in phases.items()}
         if one_line and "roofline" in one_line:
             # The roofline of the DOMINANT KERNEL is a statement about the kernel: it is taken from the launches that cover the whole
             # workload with the GPU to themselves -- the one-engine leg of this same command (same workload, co_shards = 1, its own
@@ -669,16 +697,15 @@ def main():
             full = dict(one_line["roofline"])
             full["measured_in"] = ("one_engine leg of this command: co_shards = 1, %d timed ticks, %d launches sampled by events; "
                                    "the headline tick (`value`) is the co-scheduled one" % (one_line["steps"], one_line["launches_timed"]))
-            full["co_scheduled_launch"] = {k: roofline.get(k) for k in ("kernel", "samples_per_launch", "algorithmic_bytes_per_launch", "avg_launch_us",
-                                                                         "launches_timed", "achieved", "frac", "frac_all_shards_upper",
-                                                                         "concurrent_launches", "concurrency_note", "traffic")}
-            if "valu" in roofline:
-                full["co_scheduled_launch"]["valu_frac"] = roofline["valu"]["frac"]
-                full["co_scheduled_launch"]["clock_mhz_under_load"] = roofline["valu"]["clock_mhz_under_load"]
-            for k in ("tick_level", "rollout_us_by_phase", "update_us_warmup_phase", "note", "traffic_source"):
-                if k in roofline:
-                    full[k] = roofline[k]
+            full["co_scheduled_launch"] = {k: roofline.get(k) for k in ("kernel", "samples_per_launch", "avg_launch_us", "launches_timed", "achieved", "frac",
+                                                                         "clock_mhz_under_load", "concurrent_launches", "concurrency_note", "traffic")}
+            full["co_scheduled_launch"]["accounting_8d_frac"] = roofline["accounting_8d"]["frac"]
+            full["headline_tick"] = {"tick_us": tick_s * 1e6, "tick_floor_us": full.get("tick_floor_us"),
+                                     "tick_frac": (full["tick_floor_us"] / (tick_s * 1e6)) if full.get("tick_floor_us") else None,
+                                     "note": "the one-engine floor against the co-scheduled headline tick"}
             roofline = full
+        roofline["tick_level"] = tick_level
+        roofline.update(extra_roof)
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             cpu = cpu_baseline(T, goal if goal is not None else [0.0, -1.0, 0.0])

@@ -121,7 +121,8 @@ typedef struct mppi_config {
     int32_t model;         /* MPPI_MODEL_*: the `model=` ctor argument (control/src/mppi:62)   */
     int32_t tick_path;     /* MPPI_TICK_*: which kernels a tick runs; default MPPI_TICK_AUTO          */
     int32_t co_shards;     /* co-scheduled shards of the fused mppi_tick: 0 auto | 1 off | 2..8 (below)  */
-    int32_t reserved0;     /* 0                                                                       */
+    int32_t agent_offset;  /* global index of local agent 0 (independent agents split over engines / GPUs: the device-RNG streams
+                              are keyed by the GLOBAL agent index, so a replica rank draws what the one big engine would)   */
     double dt;             /* <= 0: 1/T  (control/src/mppi:67)                                */
     double sigma;          /* noise std-dev = sig[0,0] (control/src/mppi:145); default 0.9    */
     double lambda;         /* temperature; default 0.001 (control/src/mppi:89)                */

@@ -20,7 +20,7 @@ ABI_VERSION = 4
 class MppiConfig(C.Structure):
     _fields_ = [("n_agents", C.c_int32), ("samples", C.c_int32), ("horizon", C.c_int32),
                 ("storage", C.c_int32), ("device", C.c_int32), ("sample_offset", C.c_uint32),
-                ("model", C.c_int32), ("tick_path", C.c_int32), ("co_shards", C.c_int32), ("reserved0", C.c_int32),
+                ("model", C.c_int32), ("tick_path", C.c_int32), ("co_shards", C.c_int32), ("agent_offset", C.c_int32),
                 ("dt", C.c_double), ("sigma", C.c_double), ("lambda_", C.c_double),
                 ("q", C.c_double * 3), ("r", C.c_double * 2), ("p1", C.c_double * 3),
                 ("u_max", C.c_double), ("wheel_radius", C.c_double), ("wheel_base", C.c_double),

@@ -883,6 +883,8 @@ struct mppi_engine {
         const int A = cfg.n_agents, K = cfg.samples, T = cfg.horizon;
         P.A = A; P.K = K; P.T = T; P.Ks = (K + 63) / 64 * 64;
         P.sample_offset = cfg.sample_offset;
+        if (cfg.agent_offset < 0) fail(MPPI_E_INVALID, "agent_offset must be >= 0");
+        P.agent_offset = (uint32_t)cfg.agent_offset;
         P.dt = cfg.dt;
         P.u_max = cfg.u_max;
         P.kth = cfg.wheel_radius / cfg.wheel_base;

@@ -45,6 +45,7 @@ constexpr int kTcW = 8;     // {un0, un1, w0, w1, cb, 0, 0, 0}
 struct DevParams {
     int A, K, Ks, T;          // Ks: padded row pitch (elements) of eps / dP rows
     uint32_t sample_offset;
+    uint32_t agent_offset;    // global index of local agent 0: the device-noise streams are keyed by the GLOBAL agent index
     double dt, sigma, lambda, inv_lambda;
     double q0, q1, q2, r0, r1, p0, p1, p2;
     double u_max, kth, rhalf, floor_w;  // kth = wheel_radius / wheel_base, rhalf = wheel_radius / 2
@@ -795,7 +796,7 @@ __device__ __forceinline__ void rollout_body(const DevParams& P, const double* _
         for (int j = 0; j < U; j += kStepsPerDraw) {
             if (!TAIL || t0 + j < T) {  // (uniform)
                 float e[6];
-                philox_normals(ctr0, (uint32_t)((t0 + j) / kStepsPerDraw), tick, (uint32_t)a, key0, key1, sigf, e);
+                philox_normals(ctr0, (uint32_t)((t0 + j) / kStepsPerDraw), tick, P.agent_offset + (uint32_t)a, key0, key1, sigf, e);
 #pragma unroll
                 for (int i = 0; i < kStepsPerDraw; ++i) { buf[j + i][0] = (S)e[2 * i]; buf[j + i][1] = (S)e[2 * i + 1]; }
             } else {
@@ -984,7 +985,7 @@ __device__ __forceinline__ void rollout_body(const DevParams& P, const double* _
             draw_chunk(t0, cur, std::false_type{});
             {
                 float e[6];
-                philox_normals(ctr0, (uint32_t)(T4 / kStepsPerDraw), tick, (uint32_t)a, key0, key1, sigf, e);
+                philox_normals(ctr0, (uint32_t)(T4 / kStepsPerDraw), tick, P.agent_offset + (uint32_t)a, key0, key1, sigf, e);
 #pragma unroll
                 for (int i = 0; i < kStepsPerDraw; ++i) {  // steps at or beyond T: no noise (they are never integrated)
                     tl[i][0] = T4 + i < T ? (S)e[2 * i] : (S)0;
@@ -1142,7 +1143,7 @@ __device__ __forceinline__ void update_body(const DevParams& P, const S* __restr
     const uint32_t tick_now = REGEN ? (tick_ptr ? *tick_ptr : tick_arg) : 0u;
     auto redraw = [&](uint32_t kk, R e) {
         float f0, f1;  // the same Philox counter the rollout used for this (sample, step)
-        philox_normal_pair(P.sample_offset + kk, (uint32_t)t, tick_now, (uint32_t)a, (uint32_t)seed, (uint32_t)(seed >> 32),
+        philox_normal_pair(P.sample_offset + kk, (uint32_t)t, tick_now, P.agent_offset + (uint32_t)a, (uint32_t)seed, (uint32_t)(seed >> 32),
                            (float)P.sigma, f0, f1);
         Na0 = fma((double)e, (double)(S)f0, Na0);   // exact products, fp64 sums: independent of how the queue orders them
         Na1 = fma((double)e, (double)(S)f1, Na1);
@@ -1268,7 +1269,7 @@ __global__ __launch_bounds__(256) void eps_regen_kernel(DevParams P, S* __restri
     if (k >= P.K) return;
     const uint32_t tick = tick_ptr ? *tick_ptr : tick_arg;
     float e[6];
-    philox_normals(P.sample_offset + (uint32_t)k, (uint32_t)triple, tick, (uint32_t)a, (uint32_t)seed,
+    philox_normals(P.sample_offset + (uint32_t)k, (uint32_t)triple, tick, P.agent_offset + (uint32_t)a, (uint32_t)seed,
                    (uint32_t)(seed >> 32), (float)P.sigma, e);
     const size_t Ks = (size_t)P.Ks;
 #pragma unroll
@@ -1395,7 +1396,7 @@ __global__ __launch_bounds__(256) void scan_tick_kernel(DevParams P, const doubl
         if (valid) {
             if (PHILOX) {
                 float f0, f1;  // only this step's pair of the draw's three
-                philox_normal_pair(P.sample_offset + (uint32_t)k, (uint32_t)t, tick, (uint32_t)a, key0, key1, sigf, f0, f1);
+                philox_normal_pair(P.sample_offset + (uint32_t)k, (uint32_t)t, tick, P.agent_offset + (uint32_t)a, key0, key1, sigf, f0, f1);
                 e0 = (double)(S)f0;
                 e1 = (double)(S)f1;
             } else {

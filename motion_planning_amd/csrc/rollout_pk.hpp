@@ -169,8 +169,8 @@ __device__ __forceinline__ void rollout_pk_body(const DevParams& P, const double
     // the noise of steps 3 * triple .. 3 * triple + 2 of both samples (philox_normals for two counters)
     auto draw3 = [&](uint32_t triple, f2 (&w0)[kStepsPerDraw], f2 (&w1)[kStepsPerDraw]) __attribute__((always_inline)) {
         uint32_t oa[4], ob[4];
-        philox4x32_10(ctrA, triple, tick, (uint32_t)a, key0, key1, oa);
-        philox4x32_10(ctrA + 1u, triple, tick, (uint32_t)a, key0, key1, ob);
+        philox4x32_10(ctrA, triple, tick, P.agent_offset + (uint32_t)a, key0, key1, oa);
+        philox4x32_10(ctrA + 1u, triple, tick, P.agent_offset + (uint32_t)a, key0, key1, ob);
         bm2(oa[0] >> 11, (oa[1] >> 9) & 0x7FFFFCu, ob[0] >> 11, (ob[1] >> 9) & 0x7FFFFCu, w0[0], w1[0]);
         bm2(oa[2] >> 11, (oa[3] >> 9) & 0x7FFFFCu, ob[2] >> 11, (ob[3] >> 9) & 0x7FFFFCu, w0[1], w1[1]);
         bm2(((oa[0] & 0x7FFu) << 10) | ((oa[1] & 0x7FFu) >> 1), ((oa[2] & 0x7FFu) << 12) | ((oa[3] & 0x7FEu) << 1),

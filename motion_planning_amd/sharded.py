@@ -182,7 +182,9 @@ def make_hip_ticker(samples_total, horizon, n_agents=1, storage="f32", local_ran
 
 
 def make_replica_ticker(samples, horizon, n_agents, storage="f32", local_rank=0, **engine_kw):
-    """Independent agents (BASELINE config 5): this rank's agents in one engine, no exchange."""
+    """Independent agents (BASELINE config 5): this rank's agents in one engine, no exchange.  Pass ``agent_offset`` = the global
+    index of this rank's first agent: the device-noise streams are keyed by the global agent index, so the ranks together draw
+    exactly what one engine holding all agents would."""
     import torch
     from .mppi import Engine
     torch.cuda.set_device(local_rank)

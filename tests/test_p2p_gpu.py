@@ -216,7 +216,7 @@ def _c5_worker(rank, world, q):
     orc.build()
     A_total, K5 = 64, 16384
     lo, hi = sharded.shard_range(A_total, world, rank)
-    ticker, eng = sharded.make_replica_ticker(K5, T, n_agents=hi - lo, storage="f32", local_rank=0, tick_path="lanes")
+    ticker, eng = sharded.make_replica_ticker(K5, T, n_agents=hi - lo, storage="f32", local_rank=0, tick_path="lanes", agent_offset=lo)
     assert ticker.exchange == "none"
     for a in range(hi - lo):
         eng.set_nominal(_u0(), agent=a)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # profiles/rN_valu_mix.json: the static VALU mix of both tick-path rollout kernels (CPU only: hipcc cross-compiles)
 set -e
-R=$(cd "$(dirname "$0")/.." && pwd); N=${1:-r3}
+R=$(cd "$(dirname "$0")/.." && pwd); N=${1:-r4}
 make -C $R/motion_planning_amd/csrc asm > /dev/null
 python3 - <<PY
 import json, subprocess, sys
