@@ -1053,7 +1053,9 @@ void mppi_engine::co_build() {
     // and while the shards' publish kernels (one block per peer walking all A * T rows, 16 per pass) stay small change: measured
     // on one box, tick us one engine / two shards: A = 1 T = 100 K = 1e6 300 / 287, T = 25 99.4 / 96.5; A = 2 x 500 000 148 / 137;
     // A = 4 x 250 000 149 / 145; A = 8 x 131 072 (400 rows) 150 / 159 -- no longer a gain
-    if (G == 0) G = (lanes && (long)cfg.n_agents * cfg.samples >= 500000 && cfg.samples >= 4 * CH && cfg.n_agents * cfg.horizon <= 256 &&
+    // ... and in fp32 storage only: the all-fp64 mode's two big kernels are both bound by HBM traffic (400 MB written, 400 MB read),
+    // there is nothing complementary to overlap -- measured 0.277 ms split against 0.250 ms unsplit (profiles/r4_bench_c4_f64_*.json)
+    if (G == 0) G = (lanes && !f64() && (long)cfg.n_agents * cfg.samples >= 500000 && cfg.samples >= 4 * CH && cfg.n_agents * cfg.horizon <= 256 &&
                      hbm_bytes < ((size_t)48 << 30)) ? 2 : 1;
     if (G <= 1) return;
     if (!lanes || cfg.samples < G * CH) {

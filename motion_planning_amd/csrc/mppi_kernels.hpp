@@ -859,12 +859,18 @@ __device__ __forceinline__ void rollout_body(const DevParams& P, const double* _
                         eps_a[(size_t)(t * 2 + 0) * Ks] = cur[j][0];
                         eps_a[(size_t)(t * 2 + 1) * Ks] = cur[j][1];
                     }
-                    if (sizeof(S) == 4 && FULL) {
+                    if (FULL) {
                         // row t of dP as its own buffer: the descriptor is scalar arithmetic (base + t * pitch on
-                        // the SALU), the lane offset k * 4 is loop-invariant -- no per-store 64-bit VALU address
+                        // the SALU), the lane offset k * sizeof(S) is loop-invariant -- no per-store 64-bit VALU address
+                        // (a row stays below 2 GiB in either storage mode: mppi_create checks)
                         const __amdgpu_buffer_rsrc_t row = __builtin_amdgcn_make_buffer_rsrc(
                             dP_a + (size_t)t * Ks, 0, (int)(Ks * sizeof(S)), 0x00020000);
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)pre), row, (unsigned)k * 4u, 0, kAux);
+                        if (sizeof(S) == 4) {
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)pre), row, (unsigned)k * 4u, 0, kAux);
+                        } else {
+                            typedef unsigned u2v __attribute__((ext_vector_type(2)));
+                            __builtin_amdgcn_raw_buffer_store_b64(u2v{(unsigned)__double2loint(pre), (unsigned)__double2hiint(pre)}, row, (unsigned)k * 8u, 0, kAux);
+                        }
                     } else {
                         store_out<FUSED>(dp + (size_t)t * Ks, (S)pre);
                     }
@@ -1014,7 +1020,7 @@ __device__ __forceinline__ void rollout_body(const DevParams& P, const double* _
     probe.stop(P);
 }
 template <typename S, int NTERM, bool PHILOX, bool STORE_EPS, int INLINE_NOM, int MODEL, bool GENERAL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void rollout_kernel(DevParams P, const double* __restrict__ state,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(S) == 8 ? 4 : 5, 8))) void rollout_kernel(DevParams P, const double* __restrict__ state,
                                                      const double* __restrict__ goal,
                                                      double* __restrict__ tc, S* __restrict__ eps,
                                                      S* __restrict__ dP, S* __restrict__ Stot, uint64_t seed,
@@ -1136,7 +1142,10 @@ __device__ __forceinline__ void update_body(const DevParams& P, const S* __restr
     // ceil(candidates / 256) Philox rounds per wave.  (Round 2 kept eight slots per lane: the rounds were the busiest
     // lane's count, ~6 where the average lane had 2.)  A block whose queue overflows (sigma = 0, a flat cost: every sample
     // carries weight) walks its values again from L2 and re-draws each candidate in place.
-    constexpr int kQueue = 2048;
+    // (the fp64 mode keeps half the queue: its 8-byte weights made the block's LDS 24.8 KB = six blocks per CU, and the kernel is
+    // bound by the bytes it keeps in flight -- 107 us for 400 MB, 3.7 TB/s, against the fp32 mode's 5.2; with 12 KB the registers
+    // decide.  A chunk is 4096 samples there: 1024 candidates are a quarter of it, beyond that the block walks its values again)
+    constexpr int kQueue = sizeof(S) == 8 ? 1024 : 2048;
     __shared__ uint32_t q_k[REGEN ? kQueue : 1];
     __shared__ R q_e[REGEN ? kQueue : 1];
     __shared__ int q_n;
