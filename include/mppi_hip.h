@@ -106,8 +106,7 @@ extern "C" {
 #define MPPI_KERNEL_MERGE 3
 #define MPPI_KERNEL_FINALIZE 4
 #define MPPI_KERNEL_EXCHANGE 5 /* the p2p publish kernel (the wait for the peers is inside MPPI_KERNEL_FINALIZE) */
-#define MPPI_KERNEL_FUSED 6    /* tick_fused_kernel: rollout + update work items of one launch (then ROLLOUT / UPDATE stay empty) */
-#define MPPI_KERNEL_COUNT 7
+#define MPPI_KERNEL_COUNT 6
 
 typedef struct mppi_engine mppi_engine;
 
@@ -300,37 +299,18 @@ int mppi_set_tick_counter(mppi_engine *h, uint32_t next_tick_id);
 int mppi_synchronize(mppi_engine *h);
 
 /*
- * The fused tick.  A device-noise tick of an fp32-storage engine on the lane-per-sample path (the node's cost and model,
- * T <= 256) runs its rollout AND its per-timestep softmax partials as work items of ONE launch (tick_fused_kernel): a chunk
- * column of 8192 samples is produced by rollout work items and consumed, a few columns later in the same ticket queue, by
- * one update work item per timestep, so the HBM-bound reduction of the columns that are done runs under the VALU-bound
- * rollout of the columns that are not (control/src/mppi:127-178 followed by :187-196, same arithmetic per sample as the
- * two stand-alone kernels -- results agree to the split-invariance bound of the tuple merge).  Everything else (injected
- * noise, fp64 storage, the scan path, graph capture, other costs / models) takes the stand-alone kernels.
- *
- * Per-handle switches for measurements and tests (none changes results beyond rounding); a co-scheduled handle passes
- * them on to its shards.  Keys of mppi_set_option (value) / mppi_get_option:
- *   "fused"           -1 auto (default) | 0 never | 1 wherever it applies
- *   "fused_lag"       columns of a queue whose rollout items precede a column's update items (0 = one round of resident items)
- *   "fused_prio"      bit 0: update work items run at the highest wave priority; bit 1: rollout waves rise in priority
- *                     with their progress through the horizon (their chunks then complete one after the other)
+ * Per-handle switches for measurements and tests (none changes results beyond rounding); a co-scheduled handle passes them
+ * on to its shards.  Keys of mppi_set_option (value) / mppi_get_option:
  *   "rollout_pk"      0: fp32-storage ticks stay on the all-fp64 rollout (same-box A/B against the mixed-precision one)
  *   "pk_min_samples"  >= 0: a plain size rule for the mixed-precision rollout; -1 (default): chosen by rounds of waves
- *   "pk_waves"        4 | 5: the mixed-precision rollout's 5-waves-per-SIMD build (stand-alone kernel only)
+ *   "pk_waves"        4 | 5: the mixed-precision rollout's 5-waves-per-SIMD build
  *   "upd_skip"        0: the update forms exp() for every sample (default 1: wave-vectors without a weight above the cut are skipped)
  *   "store_eps"       1: the tick path stores its noise like mppi_rollout does
  *   "co_cut_pct"      share of shard 0 of a two-shard co-scheduled handle in per cent (default 58); re-cuts the group
- *   "last_tick_fused" (read only) 1 when the handle's last tick ran as the fused launch
  * Unknown keys and out-of-range values return MPPI_E_INVALID.
  */
 int mppi_set_option(mppi_engine *h, const char *key, int64_t value);
 int mppi_get_option(mppi_engine *h, const char *key, int64_t *value);
-/* Test aid (host only, no handle): the fused tick's ticket -> work item map, the function its workgroups call.  n_cols chunk
- * columns (cols_per_agent per agent) are dealt to 8 queues (queue x owns columns x, x + 8, ...); a column has rollout_items
- * rollout and update_items update work items.  item = {kind (0 rollout, 1 update, 2 none: ticket beyond the queue),
- * column, index within the column (rollout block | timestep), length of the queue}. */
-int mppi_fused_decode(int n_cols, int cols_per_agent, int rollout_items, int update_items, int lag, int queue, int ticket,
-                      int32_t *item /*[4]*/);
 
 /* Savitzky-Golay operator S [T][T] with u_f = u @ S, as savgol_filter(u, T-1, 3, axis=1)
  * (mode='interp') applies it at control/src/mppi:202.  Host only. */

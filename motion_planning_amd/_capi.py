@@ -13,7 +13,7 @@ MPPI_MODEL_DIFFDRIVE_RK4, MPPI_MODEL_UNICYCLE_EULER = 0, 1
 MPPI_TICK_AUTO, MPPI_TICK_LANES, MPPI_TICK_SCAN = 0, 1, 2
 MPPI_E_TIMEOUT = -5
 IPC_HANDLE_BYTES = 64
-KERNELS = ("nominal", "rollout", "update", "merge", "finalize", "exchange", "fused")
+KERNELS = ("nominal", "rollout", "update", "merge", "finalize", "exchange")
 ABI_VERSION = 4
 
 
@@ -84,7 +84,6 @@ SIGNATURES = {
     "mppi_synchronize": (C.c_int, [_H]),
     "mppi_set_option": (C.c_int, [_H, C.c_char_p, C.c_int64]),
     "mppi_get_option": (C.c_int, [_H, C.c_char_p, C.POINTER(C.c_int64)]),
-    "mppi_fused_decode": (C.c_int, [C.c_int] * 7 + [C.POINTER(C.c_int32)]),
     "mppi_savgol_matrix": (C.c_int, [C.c_int, _dp]),
     "mppi_kernel_timing": (C.c_int, [_H, C.c_uint32]),
     "mppi_kernel_timing_period": (C.c_int, [_H, C.c_int]),

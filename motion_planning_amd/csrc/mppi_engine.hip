@@ -24,7 +24,6 @@
 #include "rollout_launch.hpp"
 #include "rollout_pk.hpp"
 #include "savgol.hpp"
-#include "tick_fused.hpp"
 
 namespace {
 
@@ -309,7 +308,6 @@ struct mppi_engine {
     void drain_timing() {
         if (pending.empty()) return;
         wait_stream("kernel-timing drain");
-        if (stream2) { hipStream_t st2 = stream2; bounded_wait([st2] { return hipStreamQuery(st2); }, "kernel-timing drain (update stream)"); }
         for (auto& p : pending) {
             float ms = 0.f;
             HIPCHK(hipEventElapsedTime(&ms, p.a, p.b));
@@ -572,18 +570,6 @@ struct mppi_engine {
         if (noise_mode != MPPI_NOISE_INJECTED && noise_mode != MPPI_NOISE_PHILOX)
             fail(MPPI_E_INVALID, "unknown noise_mode %d", noise_mode);
     }
-    // rollout + update + merge of one tick
-    // The merge launch is skipped when whoever consumes the tuples can merge a handful per row itself -- one launch and
-    // one boundary less per tick: the finalize kernel (skip_small_merge: the fused mppi_tick, no exchange follows) or the
-    // merging publish kernel of the p2p exchange.  "A handful" = at most kDirectTuples chunk / scan-block tuples per row
-    // (K <= 131072 samples on the lane kernels).
-    // The fused tick (tick_fused.hpp): rollout + update work items of one launch.  fused_mode: -1 auto, 0 off, 1 wherever it applies
-    int fused_mode = -1, fused_lag = 0 /* 0: one round of resident rollout items per XCD */, fused_prio = 0;
-    uint32_t* d_fq = nullptr;        // [2 parities][8 * kFusedHeadStride ticket heads + A * NCH arrival counters]
-    uint32_t* d_fstatus = nullptr;   // != 0: a work item's wait ran into its deadline
-    size_t fq_words = 0;
-    uint32_t fused_epoch = 0;
-    int last_tick_fused = 0;           // which way the last tick ran (fused_kind)
     bool general_cost() const {
         // the lean rollout instantiations are written for the node's cost: Q = diag(q, q, 0), q > 0 (and sane: they scale
         // positions by sqrt(q/2)), no obstacle grid
@@ -602,117 +588,11 @@ struct mppi_engine {
         return use_pk && !f64() && ph && !store && inline_nominal() && !general_cost() && k0 == 0 && k1 == cfg.samples && pk_size &&
                mppi::rollout_pk_applies(P.kth, P.dt, P.sigma, cfg.horizon);
     }
-    // 0: the stand-alone kernels; 1: the single fused launch (option "fused" = 1); 2: the update stream (rollout_arrive + update_stream)
-    int fused_kind(bool ph, bool store, const uint32_t* tick_ptr) const {
-        if (fused_mode == 0 || f64() || !ph || store || tick_ptr || capturing || small_nb > 0 || !inline_nominal() || general_cost()) return 0;
-        if (fused_mode > 0) return fused_mode;
-        return 0;   // AUTO
-    }
-    // ---- the update stream ----
-    hipStream_t stream2 = nullptr;     // the head-start launch's stream (created with the first such tick)
-    uint32_t* d_us = nullptr;          // device words of the update stream, see us_word()
-    uint32_t us_epoch = 0;             // ticks run on the update stream so far
-    uint32_t us_exit_target = 0;       // update-stream workgroups launched by all earlier ticks
-    int us_blocks = 256, us_tail_blocks = 2048;
-    // layout of d_us (64-byte lines): gate | items_done [8] | exits [8] | ticket heads [8] | then [A * NCH] column counters
-    uint32_t* us_word(int i) const { return d_us + (size_t)i * mppi::kFusedHeadStride; }
-    void fill_fused_args(mppi::FusedArgs& F, bool pk, uint64_t seed, uint32_t tick) const {
-        const int bs = pk ? 512 : 256;
-        F.g.n_cols = cfg.n_agents * NCH; F.g.NCH = NCH; F.g.RB = CH / bs; F.g.T = cfg.horizon;
-        // lag: a queue's update items start behind one round of that XCD's resident rollout items (32 CUs x 4 or 5 workgroups)
-        F.g.L = fused_lag > 0 ? fused_lag : std::max(1, (32 * (pk ? 4 : 5) + F.g.RB - 1) / F.g.RB);
-        F.status = d_fstatus;
-        F.timeout_ticks = sync_timeout_ms > 0 ? (unsigned long long)sync_timeout_ms * (unsigned long long)wall_clock_khz : 0ull;
-        F.prio_mode = fused_prio;
-        F.state = ro_state ? ro_state : d_state; F.goal = ro_goal ? ro_goal : d_goal; F.unom = ro_unom ? ro_unom : d_unom;
-        F.tc = d_tc; F.base = d_base;
-        F.dP = static_cast<float*>(d_dP); F.stot = static_cast<float*>(d_stot); F.epart = static_cast<float*>(d_epart);
-        F.seed = seed; F.tick = tick;
-        F.al_guard = mppi::rollout_pk_guard(P.kth, P.dt, P.sigma);
-        F.part = d_part; F.skip_light = upd_skip_light;
-        F.bs = bs; F.ch = CH;
-    }
-    void timed_launch_done(int kid, hipEvent_t a, hipEvent_t b, hipError_t e, const char* what) {
-        if (a) {
-            if (e == hipSuccess) {
-                pending.push_back({kid, a, b});
-                if (pending.size() >= 4096) drain_timing();
-            } else {
-                ev_pool.push_back(a); ev_pool.push_back(b);
-            }
-        }
-        if (e != hipSuccess) fail(MPPI_E_HIP, "%s launch failed: %s", what, hipGetErrorString(e));
-    }
-    bool want_timing(int kid) { return (time_mask & (1u << kid)) && (time_seen[kid]++ % time_period) == 0; }
-    void launch_update_stream_tick(uint64_t seed, uint32_t tick) {
-        if (!stream2) HIPCHK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
-        const bool pk = pick_pk(true, false, 0, cfg.samples);
-        mppi::FusedLaunch r{};
-        r.P = P; r.stream = stream; r.inline_nominal = cfg.horizon <= 64 ? 1 : 2;
-        fill_fused_args(r.F, pk, seed, tick);
-        mppi::FusedArgs& F = r.F;
-        us_epoch += 1u;
-        const uint32_t n_items = (uint32_t)F.g.n_cols * (uint32_t)F.g.T;
-        F.epoch = us_epoch; F.epoch_flag = us_word(0); F.items_done = us_word(1); F.exits = us_word(1 + mppi::kFusedQueues);
-        F.items_target = us_epoch * n_items;
-        F.exit_target = us_exit_target;
-        F.uheads = us_word(1 + 2 * mppi::kFusedQueues);
-        F.col_done = us_word(1 + 3 * mppi::kFusedQueues);
-        F.join = 0;
-        const int head_blocks = (int)std::max<long>(1, std::min<long>(us_blocks, (long)n_items));
-        const int tail_blocks = (int)std::max<long>(1, std::min<long>(us_tail_blocks, (long)n_items));
-        us_exit_target += (uint32_t)(head_blocks + tail_blocks);
-        // 1. the rollout, on the engine's stream
-        if (want_timing(MPPI_KERNEL_ROLLOUT)) { r.ev_start = get_event(); r.ev_stop = get_event(); }
-        hipError_t e = pk ? mppi::launch_rollout_arrive_pk(r)
-                          : (nterm == 4 ? mppi::launch_rollout_arrive_f32<4>(r) : nterm == 7 ? mppi::launch_rollout_arrive_f32<7>(r) : mppi::launch_rollout_arrive_f32<0>(r));
-        last_rollout_pk = pk;
-        last_rollout_kind = pk ? MPPI_ROLLOUT_MIXED : MPPI_ROLLOUT_FP64;
-        timed_launch_done(MPPI_KERNEL_ROLLOUT, r.ev_start, r.ev_stop, e, "rollout (update stream)");
-        // 2. the head start, on the second stream: at most one workgroup per CU, gated by the rollout launch's first workgroup
-        mppi::UpdateStreamLaunch u{};
-        u.P = P; u.F = F; u.stream = stream2; u.blocks = head_blocks;
-        if (want_timing(MPPI_KERNEL_FUSED)) { u.ev_start = get_event(); u.ev_stop = get_event(); }
-        e = mppi::launch_update_stream(u);
-        timed_launch_done(MPPI_KERNEL_FUSED, u.ev_start, u.ev_stop, e, "update stream (head start)");
-        // 3. the tail + join, behind the rollout on the engine's stream
-        mppi::UpdateStreamLaunch t{};
-        t.P = P; t.F = F; t.F.join = 1; t.stream = stream; t.blocks = tail_blocks;
-        if (want_timing(MPPI_KERNEL_UPDATE)) { t.ev_start = get_event(); t.ev_stop = get_event(); }
-        e = mppi::launch_update_stream(t);
-        timed_launch_done(MPPI_KERNEL_UPDATE, t.ev_start, t.ev_stop, e, "update stream (tail)");
-    }
-    void launch_fused(uint64_t seed, uint32_t tick) {
-        const bool pk = pick_pk(true, false, 0, cfg.samples);
-        mppi::FusedLaunch a{};
-        a.P = P; a.stream = stream; a.inline_nominal = cfg.horizon <= 64 ? 1 : 2;
-        if ((time_mask & (1u << MPPI_KERNEL_FUSED)) && (time_seen[MPPI_KERNEL_FUSED]++ % time_period) == 0) {
-            a.ev_start = get_event();
-            a.ev_stop = get_event();
-        }
-        mppi::FusedArgs& F = a.F;
-        fill_fused_args(F, pk, seed, tick);
-        const size_t half = fq_words / 2;
-        const int par = (int)(fused_epoch & 1u);
-        fused_epoch += 1u;
-        F.heads = d_fq + (size_t)par * half;
-        F.done = F.heads + mppi::kFusedQueues * mppi::kFusedHeadStride;
-        F.zero_base = d_fq + (size_t)(par ^ 1) * half;
-        F.zero_n = (int)half;
-        hipError_t e = pk ? mppi::launch_tick_fused_pk(a)
-                          : (nterm == 4 ? mppi::launch_tick_fused_f32<4>(a) : nterm == 7 ? mppi::launch_tick_fused_f32<7>(a) : mppi::launch_tick_fused_f32<0>(a));
-        last_rollout_pk = pk;
-        last_rollout_kind = pk ? MPPI_ROLLOUT_MIXED : MPPI_ROLLOUT_FP64;
-        if (a.ev_start) {
-            if (e == hipSuccess) {
-                pending.push_back({MPPI_KERNEL_FUSED, a.ev_start, a.ev_stop});
-                if (pending.size() >= 4096) drain_timing();
-            } else {
-                ev_pool.push_back(a.ev_start); ev_pool.push_back(a.ev_stop);
-            }
-        }
-        if (e != hipSuccess) fail(MPPI_E_HIP, "fused tick launch failed: %s", hipGetErrorString(e));
-    }
+    // rollout + update + merge of one tick
+    // The merge launch is skipped when whoever consumes the tuples can merge a handful per row itself -- one launch and
+    // one boundary less per tick: the finalize kernel (skip_small_merge: the fused mppi_tick, no exchange follows) or the
+    // merging publish kernel of the p2p exchange.  "A handful" = at most kDirectTuples chunk / scan-block tuples per row
+    // (K <= 131072 samples on the lane kernels).
     bool merge_skipped = false;
     int direct_n = 0;   // tuples per row in d_part when the merge was skipped
     static constexpr int kDirectTuples = 16;
@@ -737,16 +617,8 @@ struct mppi_engine {
         }
         merge_skipped = (skip_small_merge || (p2p_connected && !p2p_internal)) && NCH <= kDirectTuples;
         direct_n = NCH;
-        const int fk = fused_kind(ph, store, tick_ptr);
-        last_tick_fused = fk;
-        if (fk == 1) {
-            launch_fused(seed, tick);   // rollout + update work items of ONE launch (tick_fused.hpp)
-        } else if (fk == 2) {
-            launch_update_stream_tick(seed, tick);   // the update gets a head start on a second stream, under the rollout
-        } else {
-            launch_rollout(stream, 0, cfg.samples, ph, store, seed, tick, tick_ptr);
-            launch_update(stream, 0, NCH, tick_ptr);
-        }
+        launch_rollout(stream, 0, cfg.samples, ph, store, seed, tick, tick_ptr);
+        launch_update(stream, 0, NCH, tick_ptr);
         if (!merge_skipped) launch_merge(NCH);
         noise_ready = true; value_ready = true; value_lazy = false; partials_ready = true; epart_ready = true;
     }
@@ -952,16 +824,6 @@ struct mppi_engine {
         d_clk = dev_alloc<unsigned long long>(2, hbm_bytes);
         HIPCHK(hipMemsetAsync(d_clk, 0, 2 * sizeof(unsigned long long), stream));
         P.clk = d_clk;
-        fq_words = 2 * ((size_t)mppi::kFusedQueues * mppi::kFusedHeadStride + (size_t)A * NCH);
-        d_fq = dev_alloc<uint32_t>(fq_words + 1, hbm_bytes);
-        d_fstatus = d_fq + fq_words;
-        HIPCHK(hipMemsetAsync(d_fq, 0, (fq_words + 1) * sizeof(uint32_t), stream));
-        P.fstatus = d_fstatus;
-        {
-            const size_t us_words = (size_t)(1 + 3 * mppi::kFusedQueues) * mppi::kFusedHeadStride + (size_t)A * NCH;
-            d_us = dev_alloc<uint32_t>(us_words, hbm_bytes);
-            HIPCHK(hipMemsetAsync(d_us, 0, us_words * sizeof(uint32_t), stream));
-        }
         d_fill = dev_alloc<double>((size_t)A * 2, hbm_bytes);
         HIPCHK(hipMemsetAsync(d_fill, 0, (size_t)A * 2 * sizeof(double), stream));
         P.shift_fill = d_fill;
@@ -1004,11 +866,6 @@ struct mppi_engine {
         hipSetDevice(device);
         struct Restore { bool on; int dev; ~Restore() { if (on) (void)hipSetDevice(dev); } } restore{back, prev};
         try { wait_stream("engine teardown"); } catch (...) {}  // a dead device must not hang the destructor either
-        if (stream2) {
-            hipStream_t st2 = stream2;
-            try { bounded_wait([st2] { return hipStreamQuery(st2); }, "engine teardown (update stream)"); } catch (...) {}
-            hipStreamDestroy(stream2);
-        }
         for (auto* e : subs) delete e;
         subs.clear();
         if (ev_co) hipEventDestroy(ev_co);
@@ -1022,7 +879,7 @@ struct mppi_engine {
         if (h_stage) hipHostFree(h_stage);
         if (h_out) hipHostFree(h_out);
         if (h_seq) hipHostFree(h_seq);
-        void* bufs[] = {d_eps, d_dP, d_stot, d_epart, d_tc, d_base, d_unom, d_ufilt, d_state, d_goal, d_part, d_merged, d_S, d_out, d_tick, d_tmp, d_grid, d_prev, d_clk, d_fill, d_fq, d_us};
+        void* bufs[] = {d_eps, d_dP, d_stot, d_epart, d_tc, d_base, d_unom, d_ufilt, d_state, d_goal, d_part, d_merged, d_S, d_out, d_tick, d_tmp, d_grid, d_prev, d_clk, d_fill};
         for (void* b : bufs) if (b) hipFree(b);
         if (own_stream) hipStreamDestroy(own_stream);
     }
@@ -1793,11 +1650,6 @@ int mppi_set_option(mppi_engine* h, const char* key, int64_t value) {
     else if (k == "upd_skip") h->upd_skip_light = value != 0;
     else if (k == "pk_waves") { if (value != 4 && value != 5) fail(MPPI_E_INVALID, "pk_waves: 4 or 5"); h->pk_waves = (int)value; }
     else if (k == "pk_min_samples") { h->settle_lazy_state(); h->pk_min_set = value >= 0; h->pk_min_samples = value >= 0 ? (long)value : 400000; h->destroy_graph(); }
-    else if (k == "fused") { if (value < -1 || value > 2) fail(MPPI_E_INVALID, "fused: -1 auto, 0 off, 1 one launch, 2 update stream"); h->fused_mode = (int)value; }
-    else if (k == "us_blocks") { if (value < 1 || value > 65536) fail(MPPI_E_INVALID, "us_blocks: 1..65536"); h->us_blocks = (int)value; }
-    else if (k == "us_tail_blocks") { if (value < 1 || value > 65536) fail(MPPI_E_INVALID, "us_tail_blocks: 1..65536"); h->us_tail_blocks = (int)value; }
-    else if (k == "fused_lag") { if (value < 0 || value > 4096) fail(MPPI_E_INVALID, "fused_lag: 0 (auto) .. 4096 columns"); h->fused_lag = (int)value; }
-    else if (k == "fused_prio") { if (value < 0 || value > 3) fail(MPPI_E_INVALID, "fused_prio: bit 0 update items first, bit 1 rollout waves by progress"); h->fused_prio = (int)value; }
     else if (k == "co_cut_pct") {
         if (value < 1 || value > 99) fail(MPPI_E_INVALID, "co_cut_pct: 1..99");
         if (h->is_co_sub) fail(MPPI_E_INVALID, "co_cut_pct is a property of the handle");
@@ -1813,8 +1665,7 @@ int mppi_set_option(mppi_engine* h, const char* key, int64_t value) {
             h->cfg.co_shards = asked;
             for (auto* e : h->subs) {   // the new shards take over this handle's switches
                 e->store_eps_always = h->store_eps_always; e->use_pk = h->use_pk; e->upd_skip_light = h->upd_skip_light; e->pk_waves = h->pk_waves;
-                e->pk_min_set = h->pk_min_set; e->pk_min_samples = h->pk_min_samples; e->fused_mode = h->fused_mode; e->fused_lag = h->fused_lag;
-                e->fused_prio = h->fused_prio; e->sync_timeout_ms = h->sync_timeout_ms; e->us_blocks = h->us_blocks; e->us_tail_blocks = h->us_tail_blocks;
+                e->pk_min_set = h->pk_min_set; e->pk_min_samples = h->pk_min_samples; e->sync_timeout_ms = h->sync_timeout_ms;
             }
         }
     }
@@ -1831,24 +1682,9 @@ int mppi_get_option(mppi_engine* h, const char* key, int64_t* value) {
     else if (k == "upd_skip") *value = h->upd_skip_light;
     else if (k == "pk_waves") *value = h->pk_waves;
     else if (k == "pk_min_samples") *value = h->pk_min_set ? h->pk_min_samples : -1;
-    else if (k == "fused") *value = h->fused_mode;
-    else if (k == "fused_lag") *value = h->fused_lag;
-    else if (k == "fused_prio") *value = h->fused_prio;
-    else if (k == "us_blocks") *value = h->us_blocks;
-    else if (k == "us_tail_blocks") *value = h->us_tail_blocks;
     else if (k == "co_cut_pct") *value = h->co_cut_pct;
-    else if (k == "last_tick_fused") *value = h->last_tick_fused;   // read-only: 0 stand-alone kernels, 1 one fused launch, 2 update stream
     else fail(MPPI_E_INVALID, "unknown option '%s'", key);
     API_END(h)
-}
-
-// host-side mirror of the fused tick's ticket -> work item map (the same fused_decode the kernel calls): a test aid
-int mppi_fused_decode(int n_cols, int cols_per_agent, int rollout_items, int update_items, int lag, int queue, int ticket, int32_t* item) {
-    if (!item || n_cols < 1 || cols_per_agent < 1 || rollout_items < 1 || update_items < 1 || queue < 0 || queue >= mppi::kFusedQueues) return MPPI_E_INVALID;
-    const mppi::FusedGeom g{n_cols, cols_per_agent, rollout_items, update_items, lag};
-    const mppi::FusedItem it = mppi::fused_decode(g, queue, ticket);
-    item[0] = it.kind; item[1] = it.col; item[2] = it.idx; item[3] = mppi::fused_queue_len(g, queue);
-    return MPPI_OK;
 }
 
 int mppi_synchronize(mppi_engine* h) {

@@ -69,13 +69,11 @@ struct DevParams {
     // non-null: block 0 of a rollout launch leaves the pre-tick {unom [A][2][T], state [A][3], goal [A][3]} here (what the
     // scan kernel's `prev` is): a co-scheduled tick's V exists only shard by shard, and mppi_download_value re-runs it
     double* snap;
-    // non-null: the fused tick's status word -- != 0 when one of its work items gave up waiting (finalize poisons the outputs)
-    const uint32_t* fstatus;
 };
 // pre-tick snapshot by block 0 of a rollout launch (all threads of the block call it)
 __device__ __forceinline__ void snapshot_inputs(const DevParams& P, const double* __restrict__ state, const double* __restrict__ goal,
-                                                const double* __restrict__ unom, int a, int bx) {
-    if (P.snap == nullptr || bx != 0) return;
+                                                const double* __restrict__ unom, int a) {
+    if (P.snap == nullptr || blockIdx.x != 0) return;
     const int T = P.T;
     for (int i = threadIdx.x; i < 2 * T; i += blockDim.x) P.snap[(size_t)a * 2 * T + i] = unom[(size_t)a * 2 * T + i];
     if (threadIdx.x < 3) {
@@ -86,9 +84,8 @@ __device__ __forceinline__ void snapshot_inputs(const DevParams& P, const double
 struct ClockProbe {
     unsigned long long c0 = 0, w0 = 0;
     bool on;
-    // probe_block: this is the launch's middle workgroup (a stand-alone launch: blockIdx.x == gridDim.x / 2 of agent 0)
-    __device__ __forceinline__ explicit ClockProbe(const DevParams& P, bool probe_block)
-        : on(P.clk != nullptr && probe_block && threadIdx.x == 0) {
+    __device__ __forceinline__ explicit ClockProbe(const DevParams& P)
+        : on(P.clk != nullptr && blockIdx.x == (gridDim.x >> 1) && blockIdx.y == 0 && threadIdx.x == 0) {
         if (on) { c0 = clock64(); w0 = wall_clock64(); }
     }
     __device__ __forceinline__ void stop(const DevParams& P) {
@@ -655,45 +652,20 @@ __device__ __forceinline__ void philox_normal_pair(uint32_t gk, uint32_t t, uint
 // grid = (ceil(K / 256), A), block = 256, LDS = the 40*T-byte per-step table.  Per lane and step: 2 eps + 1 dP element
 // through HBM, fully coalesced (consecutive lanes = consecutive k).
 // ---------------------------------------------------------------------------------------------
-// FUSED: the body runs as one work item of tick_fused_kernel (tick_fused.hpp), next to update work items of the SAME launch that
-// read what it writes: every store another workgroup reads goes out write-through (sc1: buffer stores with aux = 16, agent-scope
-// atomic stores), so that draining the wave's stores (s_waitcnt vmcnt(0)) is all the release the hand-off needs
-// (cdna_hip_programming.md Guideline 16, R1).  bx = the block's index along the samples of agent a.
-constexpr int kAuxSc1 = 16;   // cache-policy bits of a raw buffer access: sc1 = agent scope, write-through
-// issue priority of this wave among the waves of its SIMD (s_setprio takes an immediate)
-__device__ __forceinline__ void set_wave_prio(int level) {
-    if (level <= 0) __builtin_amdgcn_s_setprio(0);
-    else if (level == 1) __builtin_amdgcn_s_setprio(1);
-    else if (level == 2) __builtin_amdgcn_s_setprio(2);
-    else __builtin_amdgcn_s_setprio(3);
-}
-// fused tick, prio_mode bit 1: a rollout wave's priority grows with its progress through the horizon (shortest remaining time
-// first), so the waves sharing a SIMD finish one after the other instead of all at the end of a round -- their chunks become
-// ready for the update work items while other rollout waves still have VALU work to hide those under
-__device__ __forceinline__ void prio_by_progress(int prio_mode, int t0, int T) {
-    if (prio_mode & 2) set_wave_prio((int)(4 * t0 >= T) + (int)(2 * t0 >= T) + (int)(4 * t0 >= 3 * T));
-}
-template <bool FUSED, typename V>
-__device__ __forceinline__ void store_out(V* p, V v) {
-    if (FUSED) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
-template <typename S, int NTERM, bool PHILOX, bool STORE_EPS, int INLINE_NOM, int MODEL, bool GENERAL, bool FUSED>
-__device__ __forceinline__ void rollout_body(const DevParams& P, const double* __restrict__ state,
-                                             const double* __restrict__ goal,
-                                             double* __restrict__ tc, S* __restrict__ eps,
-                                             S* __restrict__ dP, S* __restrict__ Stot, uint64_t seed,
-                                             uint32_t tick_arg, const uint32_t* __restrict__ tick_ptr,
-                                             int k_first, int k_last, S* __restrict__ epart,
-                                             const double* __restrict__ unom, double* __restrict__ base,
-                                             const int bx, const int a, const bool probe_block, const int prio_mode) {
-    static_assert(!FUSED || (sizeof(S) == 4 && PHILOX && !STORE_EPS), "the fused tick runs the fp32-storage device-noise rollout");
+template <typename S, int NTERM, bool PHILOX, bool STORE_EPS, int INLINE_NOM, int MODEL, bool GENERAL>
+// (fp64 storage: 4 waves per SIMD -- at 5 the kernel spilled 22 registers around its 8-byte stores; 140.8 -> 136.1 us together with the row-buffer stores)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(S) == 8 ? 4 : 5, 8))) void rollout_kernel(DevParams P, const double* __restrict__ state,
+                                                     const double* __restrict__ goal,
+                                                     double* __restrict__ tc, S* __restrict__ eps,
+                                                     S* __restrict__ dP, S* __restrict__ Stot, uint64_t seed,
+                                                     uint32_t tick_arg, const uint32_t* __restrict__ tick_ptr,
+                                                     int k_first, int k_last, S* __restrict__ epart,
+                                                     const double* __restrict__ unom, double* __restrict__ base) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* lt = reinterpret_cast<double*>(smem_raw);  // [T][5] per-step table {un0, un1, w0, w1, cb}
-    const int tid = threadIdx.x, T = P.T;
-    constexpr int kAux = FUSED ? kAuxSc1 : 0;
-    ClockProbe probe(P, probe_block);
-    snapshot_inputs(P, state, goal, unom, a, bx);
+    const int tid = threadIdx.x, a = blockIdx.y, T = P.T;
+    ClockProbe probe(P);
+    snapshot_inputs(P, state, goal, unom, a);
     // LEAN: the node's own cost and model (rk4 diff-drive, Q = diag(q, q, 0) with q > 0, no obstacle grid).
     // Its step is written in scaled variables so that constants fold away (5 fp64 instructions fewer per step):
     //   wheel speeds times half_kd (the table holds half_kd * un, the clip bound is half_kd * u_max):
@@ -722,7 +694,7 @@ __device__ __forceinline__ void rollout_body(const DevParams& P, const double* _
             if (tid < T) {
 #pragma unroll
                 for (int i = 0; i < 5; ++i) lt[tid * 5 + i] = (LEAN && i < 2) ? row[i] * (0.5 * P.kth * P.dt) : row[i];
-                if (bx == 0 && k_first == 0) {
+                if (blockIdx.x == 0 && k_first == 0) {
                     base[(size_t)a * T + tid] = base_t;
                     double* o = tc + ((size_t)a * T + tid) * kTcW;
 #pragma unroll
@@ -737,7 +709,7 @@ __device__ __forceinline__ void rollout_body(const DevParams& P, const double* _
         }
     }
     __syncthreads();
-    const int k = k_first + bx * 256 + tid;  // this launch covers samples [k_first, k_last)
+    const int k = k_first + blockIdx.x * 256 + tid;  // this launch covers samples [k_first, k_last)
     const bool active = k < k_last;
     const size_t Ks = (size_t)P.Ks;
     double gx = goal[a * 3 + 0], gy = goal[a * 3 + 1];
@@ -768,7 +740,7 @@ __device__ __forceinline__ void rollout_body(const DevParams& P, const double* _
     // raw buffer view of epart (byte-addressed, bounds-checked by the hardware); < 4 GB by construction
     const __amdgpu_buffer_rsrc_t ep_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         epart, 0, (int)min((size_t)0x7FFFFFFF, (size_t)P.A * T * 2 * NW * sizeof(S)), 0x00020000);
-    const bool block_full = k_first + (bx + 1) * 256 <= k_last;  // uniform
+    const bool block_full = k_first + (int)(blockIdx.x + 1) * 256 <= k_last;  // uniform
 
     uint32_t key0 = 0, key1 = 0, ctr0 = 0, tick = 0;
     float sigf = 0.f;
@@ -815,9 +787,9 @@ __device__ __forceinline__ void rollout_body(const DevParams& P, const double* _
         {   // sum_k eps per wave for the chunk's 6 steps x 2 wheels (the E of the softmax floor term,
             // control/src/mppi:193): saves the update kernel from reading eps at all (8 of its 12 B/step)
             // The sums are formed in fp32 in BOTH storage modes: E only enters the control update through the weight floor, as
-            // 1e-8 * E / (D + 1e-8 K) (control/src/mppi:193-196), so fp32 rounding of a 64-term sum (~1e-6) moves u by ~1e-14 --
-            // and the fp64 form of this reduction (sixteen serial full-wave fp64 DPP sums per chunk) cost the all-fp64 mode 50 us
-            // of its 190-us rollout launch (round 3: 190.7 us against 107.8 for the same arithmetic under fp32 storage).
+            // 1e-8 * E / (D + 1e-8 K) (control/src/mppi:193-196), so fp32 rounding of a 64-term sum (~1e-7 relative) moves u by
+            // ~1e-15 -- and the fp64 form of this reduction (sixteen serial full-wave fp64 DPP sums per chunk) cost the all-fp64
+            // mode a quarter of its rollout launch (round 3: 190.7 us against 107.8 for the same arithmetic under fp32 storage).
             float ev[16];
 #pragma unroll
             for (int j = 0; j < U; ++j) {
@@ -835,7 +807,7 @@ __device__ __forceinline__ void rollout_body(const DevParams& P, const double* _
                 // num_records is dropped by the hardware, so the chunk stays one basic block and the
                 // scheduler may interleave the noise chains with the fp64 dynamics that follow
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(tot), ep_rsrc,
-                                                      mine ? (unsigned)(at * 4) : 0xFFFFFFFFu, 0, kAux);
+                                                      mine ? (unsigned)(at * 4) : 0xFFFFFFFFu, 0, 0);
             } else if (mine) {
                 epart[at] = (S)tot;
             }
@@ -866,13 +838,13 @@ __device__ __forceinline__ void rollout_body(const DevParams& P, const double* _
                         const __amdgpu_buffer_rsrc_t row = __builtin_amdgcn_make_buffer_rsrc(
                             dP_a + (size_t)t * Ks, 0, (int)(Ks * sizeof(S)), 0x00020000);
                         if (sizeof(S) == 4) {
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)pre), row, (unsigned)k * 4u, 0, kAux);
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)pre), row, (unsigned)k * 4u, 0, 0);
                         } else {
                             typedef unsigned u2v __attribute__((ext_vector_type(2)));
-                            __builtin_amdgcn_raw_buffer_store_b64(u2v{(unsigned)__double2loint(pre), (unsigned)__double2hiint(pre)}, row, (unsigned)k * 8u, 0, kAux);
+                            __builtin_amdgcn_raw_buffer_store_b64(u2v{(unsigned)__double2loint(pre), (unsigned)__double2hiint(pre)}, row, (unsigned)k * 8u, 0, 0);
                         }
                     } else {
-                        store_out<FUSED>(dp + (size_t)t * Ks, (S)pre);
+                        dp[(size_t)t * Ks] = (S)pre;
                     }
                 }
                 // EXPLORE + CLIP (control/src/mppi:147-152)
@@ -976,7 +948,6 @@ __device__ __forceinline__ void rollout_body(const DevParams& P, const double* _
     auto run = [&](auto full_tag) {
         const int t_loop = ride ? T4 - U : T4;
         for (int t0 = 0; t0 < t_loop; t0 += U) {  // full chunks: straight-line code
-            if (FUSED) prio_by_progress(prio_mode, t0, T);
             if (PHILOX) draw_chunk(t0, cur, std::false_type{});
             else load_chunk(t0 + U, nxt);  // prefetch: HBM latency hides under this chunk's math
             eps_sums(t0, full_tag, std::false_type{});
@@ -1016,20 +987,8 @@ __device__ __forceinline__ void rollout_body(const DevParams& P, const double* _
     else run(std::false_type{});
     terminal();
     // value_fcn = reverse cumulative sum over t (control/src/mppi:175) = total - exclusive prefix
-    if (active) store_out<FUSED>(Stot + (size_t)a * Ks + k, (S)pre);
+    if (active) Stot[(size_t)a * Ks + k] = (S)pre;
     probe.stop(P);
-}
-template <typename S, int NTERM, bool PHILOX, bool STORE_EPS, int INLINE_NOM, int MODEL, bool GENERAL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(S) == 8 ? 4 : 5, 8))) void rollout_kernel(DevParams P, const double* __restrict__ state,
-                                                     const double* __restrict__ goal,
-                                                     double* __restrict__ tc, S* __restrict__ eps,
-                                                     S* __restrict__ dP, S* __restrict__ Stot, uint64_t seed,
-                                                     uint32_t tick_arg, const uint32_t* __restrict__ tick_ptr,
-                                                     int k_first, int k_last, S* __restrict__ epart,
-                                                     const double* __restrict__ unom, double* __restrict__ base) {
-    rollout_body<S, NTERM, PHILOX, STORE_EPS, INLINE_NOM, MODEL, GENERAL, false>(
-        P, state, goal, tc, eps, dP, Stot, seed, tick_arg, tick_ptr, k_first, k_last, epart, unom, base, (int)blockIdx.x, (int)blockIdx.y,
-        blockIdx.x == (gridDim.x >> 1) && blockIdx.y == 0, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1047,25 +1006,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(S) =
 constexpr int kUpdNV = 8;  // 16-byte vectors per lane: chunk = 256 * kUpdNV * (16 / sizeof(S)) samples
 template <typename S> struct UpdCfg { static constexpr int VEC = 16 / (int)sizeof(S); static constexpr int CH = 256 * kUpdNV * VEC; };
 
-// value another workgroup of the SAME launch stored write-through (fused tick): an agent-scope load (sc1: served by the L2,
-// never by this CU's L1); stand-alone kernels read what an earlier launch wrote with plain loads
-template <bool FUSED, typename V>
-__device__ __forceinline__ V load_in(const V* p) {
-    if (FUSED) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return *p;
-}
-// update_body: the work of one (agent a, timestep t, chunk ch) block; update_kernel below is its stand-alone launch, the fused
-// tick (tick_fused.hpp) runs it as a work item behind the rollout work items that produce its chunk.
-template <typename S, bool REGEN, bool FUSED>
-__device__ __forceinline__ void update_body(const DevParams& P, const S* __restrict__ eps,
-                                             const S* __restrict__ dP, const S* __restrict__ Stot,
-                                             double* __restrict__ part, int NCH, const int a, const int t, const int ch,
-                                             const S* __restrict__ epart, uint64_t seed, uint32_t tick_arg,
-                                             const uint32_t* __restrict__ tick_ptr, int skip_light) {
+template <typename S, bool REGEN>
+__global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __restrict__ eps,
+                                                    const S* __restrict__ dP, const S* __restrict__ Stot,
+                                                    double* __restrict__ part, int NCH, int ch_first, int n_local,
+                                                    const S* __restrict__ epart, uint64_t seed, uint32_t tick_arg,
+                                                    const uint32_t* __restrict__ tick_ptr, int skip_light) {
     using R = S;
     constexpr int VEC = UpdCfg<S>::VEC, CH = UpdCfg<S>::CH;
     typedef S vec_t __attribute__((ext_vector_type(VEC)));
-    static_assert(!FUSED || (sizeof(S) == 4 && REGEN), "the fused tick runs the fp32-storage device-noise update");
+    // XCD-aware block -> (t, chunk) map.  Workgroups go to the 8 XCDs round-robin by linear id, and
+    // each XCD has its own L2: id = xcd + 8 * (t + T * group) puts all T blocks that share chunk
+    // column (8 * group + xcd) of Stot on ONE XCD, so that chunk crosses into L2 once per tick instead of once
+    // per XCD (placement only changes speed, never results).  Chunks are walked from the highest k down:
+    // the rollout kernel wrote the high-k columns last, they are what the Infinity Cache still holds.
+    // The columns of this launch are the (agent, chunk) pairs, numbered agent-major.
+    const int T_ = P.T;
+    const int id = blockIdx.x + (int)gridDim.x * blockIdx.y;  // grid = (8 * T, ceil(A * chunks / 8))
+    const int xcd = id & 7, q = id >> 3, t = q % T_, grp = q / T_;
+    const int col = grp * 8 + xcd;
+    if (col >= P.A * n_local) return;
+    const int a = col / n_local, local = col % n_local;
+    const int ch = ch_first + n_local - 1 - local;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const size_t Ks = (size_t)P.Ks;
     const S* v_row = dP + ((size_t)a * P.T + t) * Ks;   // exclusive cost prefix of row t
@@ -1076,7 +1038,7 @@ __device__ __forceinline__ void update_body(const DevParams& P, const S* __restr
     const int k_end = min(P.K, k_begin + CH);
     double* o = part + (((size_t)a * P.T + t) * NCH + ch) * kTupleW;
     if (k_end <= k_begin) {  // empty chunk (uniform)
-        if (tid == 0) { store_out<FUSED>(o + 0, (double)INFINITY); for (int i = 1; i < 8; ++i) store_out<FUSED>(o + i, 0.0); }
+        if (tid == 0) { o[0] = INFINITY; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = 0; o[7] = 0; }
         return;
     }
     __shared__ R red[4][6];
@@ -1086,34 +1048,23 @@ __device__ __forceinline__ void update_body(const DevParams& P, const S* __restr
         const size_t NW = Ks >> 6;
         const S* ep = epart + (((size_t)a * P.T + t) * 2) * NW;
         const int w_begin = k_begin >> 6, w_end = (k_end + 63) >> 6;
-        for (int w = w_begin + tid; w < w_end; w += 256) { E0 += load_in<FUSED>(ep + w); E1 += load_in<FUSED>(ep + NW + w); }
+        for (int w = w_begin + tid; w < w_end; w += 256) { E0 += ep[w]; E1 += ep[NW + w]; }
     }
 
     // pass 1: the chunk into registers, lane minimum
-    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<S*>(v_row), 0, (int)(Ks * sizeof(S)), 0x00020000);
-    const __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<S*>(s_row), 0, (int)(Ks * sizeof(S)), 0x00020000);
     S v[kUpdNV][VEC];
     R m = (R)INFINITY;
 #pragma unroll
     for (int j = 0; j < kUpdNV; ++j) {
         const int k = k_begin + (j * 256 + tid) * VEC;
         if (k + VEC <= k_end) {  // rows are 256-byte aligned and k % VEC == 0: 16-byte aligned loads
-            vec_t pv, sv;
-            if (FUSED) {   // 16-byte sc1 loads through the row's buffer descriptor (rows stay below 2 GiB: mppi_create checks)
-                typedef unsigned u4 __attribute__((ext_vector_type(4)));
-                const u4 pu = __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, (unsigned)k * (unsigned)sizeof(S), 0, kAuxSc1);
-                const u4 su = __builtin_amdgcn_raw_buffer_load_b128(s_rsrc, (unsigned)k * (unsigned)sizeof(S), 0, kAuxSc1);
-                __builtin_memcpy(&pv, &pu, 16);
-                __builtin_memcpy(&sv, &su, 16);
-            } else {
-                pv = *reinterpret_cast<const vec_t*>(v_row + k);
-                sv = *reinterpret_cast<const vec_t*>(s_row + k);
-            }
+            const vec_t pv = *reinterpret_cast<const vec_t*>(v_row + k);
+            const vec_t sv = *reinterpret_cast<const vec_t*>(s_row + k);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) v[j][i] = sv[i] - pv[i];
         } else {
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) v[j][i] = (k + i < k_end) ? load_in<FUSED>(s_row + k + i) - load_in<FUSED>(v_row + k + i) : (S)INFINITY;
+            for (int i = 0; i < VEC; ++i) v[j][i] = (k + i < k_end) ? s_row[k + i] - v_row[k + i] : (S)INFINITY;
         }
 #pragma unroll
         for (int i = 0; i < VEC; ++i) m = fmin(m, v[j][i]);
@@ -1144,7 +1095,7 @@ __device__ __forceinline__ void update_body(const DevParams& P, const S* __restr
     // carries weight) walks its values again from L2 and re-draws each candidate in place.
     // (the fp64 mode keeps half the queue: its 8-byte weights made the block's LDS 24.8 KB = six blocks per CU, and the kernel is
     // bound by the bytes it keeps in flight -- 107 us for 400 MB, 3.7 TB/s, against the fp32 mode's 5.2; with 12 KB the registers
-    // decide.  A chunk is 4096 samples there: 1024 candidates are a quarter of it, beyond that the block walks its values again)
+    // decide: seven blocks, 99.5 us.  A chunk is 4096 samples there: 1024 candidates are a quarter of it, beyond that the block walks its values again)
     constexpr int kQueue = sizeof(S) == 8 ? 1024 : 2048;
     __shared__ uint32_t q_k[REGEN ? kQueue : 1];
     __shared__ R q_e[REGEN ? kQueue : 1];
@@ -1211,7 +1162,7 @@ __device__ __forceinline__ void update_body(const DevParams& P, const S* __restr
             for (int idx = 0; idx < kUpdNV * VEC; ++idx) {
                 const int k = k_begin + ((idx / VEC) * 256 + tid) * VEC + idx % VEC;
                 if (k < k_end) {
-                    const R x = (M - (load_in<FUSED>(s_row + k) - load_in<FUSED>(v_row + k))) * scale;
+                    const R x = (M - (s_row[k] - v_row[k])) * scale;
                     if (x > cand) redraw((uint32_t)k, Exp2<R>::f(x));
                 }
             }
@@ -1225,35 +1176,13 @@ __device__ __forceinline__ void update_body(const DevParams& P, const S* __restr
     D = wave_sum(D); E0 = wave_sum(E0); E1 = wave_sum(E1);
     if (lane == 0) { red[wid][1] = D; redN[wid][0] = N0d; redN[wid][1] = N1d; red[wid][4] = E0; red[wid][5] = E1; }
     __syncthreads();
-    // (FUSED: the tuple may be read by a kernel that is already running -- the update stream's join -- so it goes out write-through)
     if (tid < 5) {
         const int c = tid + 1;
-        store_out<FUSED>(o + c, (c == 2 || c == 3) ? redN[0][c - 2] + redN[1][c - 2] + redN[2][c - 2] + redN[3][c - 2]
-                                                   : (double)red[0][c] + (double)red[1][c] + (double)red[2][c] + (double)red[3][c]);
+        o[c] = (c == 2 || c == 3) ? redN[0][c - 2] + redN[1][c - 2] + redN[2][c - 2] + redN[3][c - 2]
+                                  : (double)red[0][c] + (double)red[1][c] + (double)red[2][c] + (double)red[3][c];
     } else if (tid == 5) {
-        store_out<FUSED>(o + 0, (double)M); store_out<FUSED>(o + 6, (double)(k_end - k_begin)); store_out<FUSED>(o + 7, 0.0);
+        o[0] = (double)M; o[6] = (double)(k_end - k_begin); o[7] = 0.0;
     }
-}
-template <typename S, bool REGEN>
-__global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __restrict__ eps,
-                                                    const S* __restrict__ dP, const S* __restrict__ Stot,
-                                                    double* __restrict__ part, int NCH, int ch_first, int n_local,
-                                                    const S* __restrict__ epart, uint64_t seed, uint32_t tick_arg,
-                                                    const uint32_t* __restrict__ tick_ptr, int skip_light) {
-    // XCD-aware block -> (t, chunk) map.  Workgroups go to the 8 XCDs round-robin by linear id, and
-    // each XCD has its own L2: id = xcd + 8 * (t + T * group) puts all T blocks that share chunk
-    // column (8 * group + xcd) of Stot on ONE XCD, so that chunk crosses into L2 once per tick instead of once
-    // per XCD (placement only changes speed, never results).  Chunks are walked from the highest k down:
-    // the rollout kernel wrote the high-k columns last, they are what the Infinity Cache still holds.
-    // The columns of this launch are the (agent, chunk) pairs, numbered agent-major.
-    const int T_ = P.T;
-    const int id = blockIdx.x + (int)gridDim.x * blockIdx.y;  // grid = (8 * T, ceil(A * chunks / 8))
-    const int xcd = id & 7, q = id >> 3, t = q % T_, grp = q / T_;
-    const int col = grp * 8 + xcd;
-    if (col >= P.A * n_local) return;
-    const int a = col / n_local, local = col % n_local;
-    const int ch = ch_first + n_local - 1 - local;
-    update_body<S, REGEN, false>(P, eps, dP, Stot, part, NCH, a, t, ch, epart, seed, tick_arg, tick_ptr, skip_light);
 }
 
 // per-wave sums of eps for noise that did not come out of a rollout (mppi_upload_noise followed
@@ -1628,9 +1557,8 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
                                                double* outv, uint32_t* tick_ptr, int flags, uint32_t tick_set,
                                                double* host_out, uint32_t* host_seq, uint32_t seq, char* smem_raw,
                                                P2PWait wait) {
-    const bool fused_late = P.fstatus != nullptr && *P.fstatus != 0u;   // (uniform) a fused tick's work item ran into its deadline
-    if (wait.flags || fused_late) {  // peer-to-peer exchange: `gathered` is this rank's mailbox; wait until every peer's tuples are in
-        if (fused_late || !p2p_wait_block(wait)) {  // a peer never delivered: poison the outputs (mppi_get_outputs reports MPPI_E_TIMEOUT), touch nothing else
+    if (wait.flags) {  // peer-to-peer exchange: `gathered` is this rank's mailbox; wait until every peer's tuples are in
+        if (!p2p_wait_block(wait)) {  // a peer never delivered: poison the outputs (mppi_get_outputs reports MPPI_E_TIMEOUT), touch nothing else
             if (threadIdx.x == 0) {
                 outv[(size_t)a * 8 + 7] = 1.0;
                 if (host_out) {

@@ -72,30 +72,25 @@ inline bool rollout_pk_applies(double kth, double dt, double sigma, int T) {
     return T <= 256 && rollout_pk_guard(kth, dt, sigma) > 0.05f && (T + 1) * rollout_pk_step_bound(kth, dt, sigma) <= 2.0;
 }
 
-#if defined(MPPI_ROLLOUT_PK_TU) || defined(MPPI_FUSED_PK_TU)
+#ifdef MPPI_ROLLOUT_PK_TU
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 pk_med3(f2 v, float lo, float hi) {
     return f2{__builtin_amdgcn_fmed3f(v.x, lo, hi), __builtin_amdgcn_fmed3f(v.y, lo, hi)};
 }
 
-// rollout_pk_body: the work of one block (512 consecutive samples of agent a, starting at bx * 512); rollout_pk_kernel is its
-// stand-alone launch.  FUSED: a work item of tick_fused_kernel -- what update work items of the same launch read (dP, Stot, the
-// per-wave eps sums) is stored write-through (sc1), see rollout_body in mppi_kernels.hpp.
-template <int INLINE_NOM, bool FUSED>
-__device__ __forceinline__ void rollout_pk_body(const DevParams& P, const double* __restrict__ state,
-                                                const double* __restrict__ goal, double* __restrict__ tc,
-                                                float* __restrict__ dP, float* __restrict__ Stot, uint64_t seed,
-                                                uint32_t tick_arg, const uint32_t* __restrict__ tick_ptr,
-                                                float* __restrict__ epart, const double* __restrict__ unom,
-                                                double* __restrict__ base, float al_guard, const int bx, const int a,
-                                                const bool probe_block, const int prio_mode) {
+template <int INLINE_NOM, int WAVES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void rollout_pk_kernel(DevParams P, const double* __restrict__ state,
+                                                        const double* __restrict__ goal, double* __restrict__ tc,
+                                                        float* __restrict__ dP, float* __restrict__ Stot, uint64_t seed,
+                                                        uint32_t tick_arg, const uint32_t* __restrict__ tick_ptr,
+                                                        float* __restrict__ epart, const double* __restrict__ unom,
+                                                        double* __restrict__ base, float al_guard) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     PkRow* lt = reinterpret_cast<PkRow*>(smem_raw);  // [T]
     __shared__ double fin_sh[1];                      // the nominal trajectory's final heading (unwrapped)
-    const int tid = threadIdx.x, T = P.T;
-    constexpr int kAux = FUSED ? kAuxSc1 : 0;
-    ClockProbe probe(P, probe_block);
-    snapshot_inputs(P, state, goal, unom, a, bx);
+    const int tid = threadIdx.x, a = blockIdx.y, T = P.T;
+    ClockProbe probe(P);
+    snapshot_inputs(P, state, goal, unom, a);
     const double gx = goal[a * 3 + 0], gy = goal[a * 3 + 1], gth = goal[a * 3 + 2];
     {
         // the block runs the nominal rollout itself, lanes = timesteps (as rollout_kernel does), and derives the per-step
@@ -121,7 +116,7 @@ __device__ __forceinline__ void rollout_pk_body(const DevParams& P, const double
                 r.X2 = 2.0 * P.lean_f * (ex.X - gx); r.Y2 = 2.0 * P.lean_f * (ex.Y - gy);
                 lt[tid] = r;
                 if (tid == T - 1) fin_sh[0] = ex.th + ex.h;
-                if (bx == 0) {  // for mppi_download_value: V = base + Stot - dP
+                if (blockIdx.x == 0) {  // for mppi_download_value: V = base + Stot - dP
                     base[(size_t)a * T + tid] = base_t;
                     double* o = tc + ((size_t)a * T + tid) * kTcW;
 #pragma unroll
@@ -132,10 +127,10 @@ __device__ __forceinline__ void rollout_pk_body(const DevParams& P, const double
     }
     __syncthreads();
     const int lane = tid & 63;
-    const int kwave = bx * 512 + (tid >> 6) * 128;  // this wave's 128 consecutive samples
+    const int kwave = (int)blockIdx.x * 512 + (tid >> 6) * 128;  // this wave's 128 consecutive samples
     const int kA = kwave + 2 * lane;                             // this lane's two: kA, kA + 1
     const bool actA = kA < P.K, actB = kA + 1 < P.K;
-    const bool block_full = (bx + 1) * 512 <= P.K;  // (uniform)
+    const bool block_full = ((int)blockIdx.x + 1) * 512 <= P.K;  // (uniform)
     const size_t Ks = (size_t)P.Ks, NW = Ks >> 6;
     const uint64_t dP_a64 = reinterpret_cast<uint64_t>(dP + (size_t)a * T * Ks);
     float* const dP_a = reinterpret_cast<float*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(dP_a64 >> 32)) << 32) |
@@ -207,7 +202,7 @@ __device__ __forceinline__ void rollout_pk_body(const DevParams& P, const double
         const size_t slot = (size_t)(kwave >> 6) + half;
         const bool mine = lane < 32 && idx < (EXTRA ? 16 : 2 * U) && te < T && slot < NW;
         const size_t at = (((size_t)a * T + te) * 2 + (idx & 1)) * NW + slot;
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(half ? 0.f : tot), ep_rsrc, mine ? (unsigned)(at * 4) : 0xFFFFFFFFu, 0, kAux);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(half ? 0.f : tot), ep_rsrc, mine ? (unsigned)(at * 4) : 0xFFFFFFFFu, 0, 0);
     };
     auto step = [&](int t, f2 n0, f2 n1, auto full_tag, bool robust) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_tag)::value;
@@ -216,10 +211,10 @@ __device__ __forceinline__ void rollout_pk_body(const DevParams& P, const double
             const __amdgpu_buffer_rsrc_t row = __builtin_amdgcn_make_buffer_rsrc(dP_a + (size_t)t * Ks, 0, (int)(Ks * sizeof(float)), 0x00020000);
             const float pa = (float)pre[0], pb = (float)pre[1];
             if (FULL) {
-                __builtin_amdgcn_raw_buffer_store_b64(u2{__float_as_uint(pa), __float_as_uint(pb)}, row, (unsigned)kA * 4u, 0, kAux);
+                __builtin_amdgcn_raw_buffer_store_b64(u2{__float_as_uint(pa), __float_as_uint(pb)}, row, (unsigned)kA * 4u, 0, 0);
             } else {
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pa), row, actA ? (unsigned)kA * 4u : 0xFFFFFFFFu, 0, kAux);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pb), row, actB ? (unsigned)kA * 4u + 4u : 0xFFFFFFFFu, 0, kAux);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pa), row, actA ? (unsigned)kA * 4u : 0xFFFFFFFFu, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pb), row, actB ? (unsigned)kA * 4u + 4u : 0xFFFFFFFFu, 0, 0);
             }
         }
         // EXPLORE + CLIP (control/src/mppi:147-152) as deviations from the clipped nominal
@@ -288,7 +283,6 @@ __device__ __forceinline__ void rollout_pk_body(const DevParams& P, const double
     auto run = [&](auto full_tag) __attribute__((always_inline)) {
         const int t_loop = ride ? T4 - U : T4;
         for (int t0 = 0; t0 < t_loop; t0 += U) {
-            if (FUSED) prio_by_progress(prio_mode, t0, T);
             draw(t0);
             eps_sums(t0, full_tag, std::false_type{});
             chunk(t0, U, full_tag);
@@ -337,29 +331,12 @@ __device__ __forceinline__ void rollout_pk_body(const DevParams& P, const double
     }
     // value_fcn = reverse cumulative sum over t (control/src/mppi:175) = total - exclusive prefix
     if (block_full) {
-        if (FUSED) {   // one 8-byte agent-scope (write-through) store
-            const unsigned long long two = ((unsigned long long)__float_as_uint(tot[1]) << 32) | __float_as_uint(tot[0]);
-            __hip_atomic_store(reinterpret_cast<unsigned long long*>(Stot + (size_t)a * Ks + kA), two, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            *reinterpret_cast<f2*>(Stot + (size_t)a * Ks + kA) = f2{tot[0], tot[1]};
-        }
+        *reinterpret_cast<f2*>(Stot + (size_t)a * Ks + kA) = f2{tot[0], tot[1]};
     } else {
-        if (actA) store_out<FUSED>(Stot + (size_t)a * Ks + kA, tot[0]);
-        if (actB) store_out<FUSED>(Stot + (size_t)a * Ks + kA + 1, tot[1]);
+        if (actA) Stot[(size_t)a * Ks + kA] = tot[0];
+        if (actB) Stot[(size_t)a * Ks + kA + 1] = tot[1];
     }
     probe.stop(P);
-}
-#endif  // MPPI_ROLLOUT_PK_TU || MPPI_FUSED_PK_TU
-#ifdef MPPI_ROLLOUT_PK_TU
-template <int INLINE_NOM, int WAVES>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void rollout_pk_kernel(DevParams P, const double* __restrict__ state,
-                                                        const double* __restrict__ goal, double* __restrict__ tc,
-                                                        float* __restrict__ dP, float* __restrict__ Stot, uint64_t seed,
-                                                        uint32_t tick_arg, const uint32_t* __restrict__ tick_ptr,
-                                                        float* __restrict__ epart, const double* __restrict__ unom,
-                                                        double* __restrict__ base, float al_guard) {
-    rollout_pk_body<INLINE_NOM, false>(P, state, goal, tc, dP, Stot, seed, tick_arg, tick_ptr, epart, unom, base, al_guard, (int)blockIdx.x,
-                                       (int)blockIdx.y, blockIdx.x == (gridDim.x >> 1) && blockIdx.y == 0, 0);
 }
 
 hipError_t launch_rollout_pk(const RolloutPkArgs& a) {

@@ -418,10 +418,7 @@ class Engine(object):
                 "co_shards": n.value, "co_samples": [per[g] for g in range(n.value)],
                 "co_note": (self._lib.mppi_co_note(self._h) or b"").decode(),
                 # which kernel the last rollout launch was (include/mppi_hip.h MPPI_ROLLOUT_*)
-                "rollout_kernel": ("none", "fp64", "mixed", "scan")[kind.value],
-                # how the last tick ran its rollout + update: 0 two stand-alone launches one after the other, 1 work items of ONE
-                # launch (tick_fused_kernel), 2 the update stream (the update gets a head start under the rollout)
-                "tick_fused": self.get_option("last_tick_fused")}
+                "rollout_kernel": ("none", "fp64", "mixed", "scan")[kind.value]}
 
 
 class _NominalView(np.ndarray):

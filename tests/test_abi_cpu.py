@@ -116,39 +116,6 @@ def test_product_reads_no_test_hooks_from_the_environment():
     assert reads == ["MPPI_SYNC_TIMEOUT_MS"], reads
 
 
-def test_fused_tick_queue_map_is_a_valid_schedule():
-    """The ticket -> work item map of the fused tick (mppi_fused_decode = the function its workgroups call): over the 8
-    queues every rollout and update work item appears exactly once, a queue only holds its own columns, and an update item
-    comes after ALL rollout items of its column in the SAME queue -- the property that makes its wait deadlock-free
-    whatever the dispatch order.  Geometries: config 4 on both rollout kernels, the 125 000-sample share, config 5, one
-    column, a lag beyond the queue, no lag."""
-    from motion_planning_amd import _capi
-    lib = _capi.load()
-    it = (C.c_int32 * 4)()
-    for n_cols, nch, rb, t_items, lag in [(123, 123, 16, 50, 8), (123, 123, 32, 50, 5), (16, 16, 32, 50, 5), (128, 2, 16, 50, 8), (1, 1, 32, 50, 3),
-                                           (5, 5, 16, 100, 0), (9, 3, 16, 7, 100), (123, 123, 16, 50, 1)]:
-        seen = set()
-        for x in range(8):
-            assert lib.mppi_fused_decode(n_cols, nch, rb, t_items, lag, x, 0, it) == 0
-            qlen, rolled = it[3], {}
-            for n in range(qlen + 2):
-                lib.mppi_fused_decode(n_cols, nch, rb, t_items, lag, x, n, it)
-                kind, col, idx = it[0], it[1], it[2]
-                if n >= qlen:
-                    assert kind == 2
-                    continue
-                assert kind in (0, 1) and col % 8 == x and col < n_cols
-                if kind == 0:
-                    assert 0 <= idx < rb
-                    rolled[col] = rolled.get(col, 0) + 1
-                else:
-                    assert 0 <= idx < t_items and rolled.get(col, 0) == rb
-                assert (kind, col, idx) not in seen
-                seen.add((kind, col, idx))
-        assert len(seen) == n_cols * (rb + t_items)
-    assert lib.mppi_fused_decode(0, 1, 1, 1, 1, 0, 0, it) != 0 and lib.mppi_fused_decode(8, 1, 1, 1, 1, 8, 0, it) != 0
-
-
 def test_create_fails_loudly_without_gpu():
     """No silent CPU path: without a device the engine refuses to exist."""
     import torch
