@@ -1088,18 +1088,19 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
     double Na0 = 0.0, Na1 = 0.0;
     // REGEN (eps was never stored): a sample that carries weight needs its noise re-drawn -- one Philox call.  Far from the
     // goal a row has a handful of such samples; parked AT the goal a few per cent of a row carry weight.  The loop only
-    // NOTES them -- (index, weight) appended to ONE queue per block (a wave-aggregated LDS counter: one atomic per wave and
-    // value position that has any) -- and the re-draws happen afterwards, spread evenly over the block's 256 lanes:
-    // ceil(candidates / 256) Philox rounds per wave.  (Round 2 kept eight slots per lane: the rounds were the busiest
-    // lane's count, ~6 where the average lane had 2.)  A block whose queue overflows (sigma = 0, a flat cost: every sample
-    // carries weight) walks its values again from L2 and re-draws each candidate in place.
-    // (the fp64 mode keeps half the queue: its 8-byte weights made the block's LDS 24.8 KB = six blocks per CU, and the kernel is
-    // bound by the bytes it keeps in flight -- 107 us for 400 MB, 3.7 TB/s, against the fp32 mode's 5.2; with 12 KB the registers
-    // decide: seven blocks, 99.5 us.  A chunk is 4096 samples there: 1024 candidates are a quarter of it, beyond that the block walks its values again)
+    // NOTES them -- (index, weight) appended to a queue in LDS -- and the re-draws happen afterwards, spread evenly over the
+    // lanes: ceil(candidates / 64) Philox rounds per wave.  (Round 2 kept eight slots per lane: the rounds were the busiest
+    // lane's count, ~6 where the average lane had 2.  Round 3 kept ONE queue per block behind an LDS counter: one atomic with
+    // return per wave and 16-byte vector -- eight dependent LDS round trips per wave in the parked regime, where every vector
+    // holds candidates.  Round 4: one queue per WAVE, its fill count a wave-uniform register: no atomic, no barrier; the
+    // block's vectors are dealt to the waves in 1-KB pieces, so the four queues fill evenly.)  A wave whose queue overflows
+    // (sigma = 0, a flat cost: every sample carries weight) walks its own values again from L2 and re-draws each candidate
+    // in place.
     constexpr int kQueue = sizeof(S) == 8 ? 1024 : 2048;
+    constexpr int kQW = kQueue / 4;   // per wave
     __shared__ uint32_t q_k[REGEN ? kQueue : 1];
     __shared__ R q_e[REGEN ? kQueue : 1];
-    __shared__ int q_n;
+    int n_w = 0;   // (wave-uniform) candidates this wave has noted
     const uint32_t tick_now = REGEN ? (tick_ptr ? *tick_ptr : tick_arg) : 0u;
     auto redraw = [&](uint32_t kk, R e) {
         float f0, f1;  // the same Philox counter the rollout used for this (sample, step)
@@ -1108,10 +1109,6 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
         Na0 = fma((double)e, (double)(S)f0, Na0);   // exact products, fp64 sums: independent of how the queue orders them
         Na1 = fma((double)e, (double)(S)f1, Na1);
     };
-    if (REGEN) {
-        if (tid == 0) q_n = 0;
-        __syncthreads();
-    }
 #pragma unroll
     for (int j = 0; j < kUpdNV; ++j) {
         const int k = k_begin + (j * 256 + tid) * VEC;
@@ -1130,17 +1127,12 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
 #pragma unroll
         for (int i = 0; i < VEC; ++i) { es[i] = Exp2<R>::f(xs[i]); D += es[i]; }
         if (REGEN) {
-            // one queue reservation per wave and VECTOR (an LDS atomic with return is a round trip the wave waits for:
-            // one per value made 32 of them per row)
             if (n_here) {  // (uniform) skipped for almost every vector while the robot is far from its goal
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&q_n, n_here);
-                base = __builtin_amdgcn_readfirstlane(base);
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
-                    const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal[i] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal[i], 0u));
-                    if (xs[i] > cand && pos < kQueue) { q_k[pos] = (uint32_t)(k + i); q_e[pos] = es[i]; }
-                    base += (int)__popcll(bal[i]);
+                    const int pos = n_w + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal[i] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal[i], 0u));
+                    if (xs[i] > cand && pos < kQW) { q_k[wid * kQW + pos] = (uint32_t)(k + i); q_e[wid * kQW + pos] = es[i]; }
+                    n_w += (int)__popcll(bal[i]);
                 }
             }
         } else {
@@ -1153,10 +1145,13 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
         }
     }
     if (REGEN) {
-        __syncthreads();
-        const int total = q_n;  // (uniform)
-        if (total <= kQueue) {
-            for (int q = tid; q < total; q += 256) redraw(q_k[q], q_e[q]);
+        // the wave reads back what its own lanes queued: LDS operations of one wave complete in order, the fence keeps the compiler from
+        // moving the reads up
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (n_w <= kQW) {   // (wave-uniform)
+            for (int q = lane; q < n_w; q += 64) redraw(q_k[wid * kQW + q], q_e[wid * kQW + q]);
         } else {  // (rare) every candidate of the lane's own values, in place
 #pragma unroll 1
             for (int idx = 0; idx < kUpdNV * VEC; ++idx) {
