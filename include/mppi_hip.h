@@ -96,7 +96,11 @@ extern "C" {
  * working: after such a tick mppi_download_value / _noise / mppi_update re-run the rollout over all samples from a
  * snapshot of the tick's inputs, bit for bit what the shards computed.  AUTO = 2 shards for n_agents * samples >= 500000
  * on the lane-per-sample path with at least 32768 samples per agent and n_agents * horizon <= 256 rows (beyond that the
- * shards' publish kernels cost more than the overlap gains), else none.  mppi_tick_begin / _finish (the caller's own exchange), mppi_tick_graph and
+ * shards' publish kernels cost more than the overlap gains), fp32 storage only (the all-fp64 mode's two big kernels are both
+ * HBM-bound: split it measured slower), else none.  An AUTO handle builds its shards with its FIRST fused device-noise
+ * mppi_tick -- a handle that only runs the caller's own exchange (the ranks of an N > 1 run), graph replays or injected-noise
+ * ticks never pays for the second set of buffers; mppi_co_info reports the split from the start, mppi_co_note why a handle
+ * that should have split did not.  mppi_tick_begin / _finish (the caller's own exchange), mppi_tick_graph and
  * injected-noise ticks always run unsplit; mppi_p2p_create on such a handle dissolves the group. */
 
 /* kernels, for mppi_kernel_timing (the scan kernel is timed as MPPI_KERNEL_ROLLOUT) */

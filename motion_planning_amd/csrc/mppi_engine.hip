@@ -287,7 +287,10 @@ struct mppi_engine {
         }
         co_synced = true;
     }
-    void co_build();   // creates the subs (after init)
+    bool co_pending = false;   // co_shards AUTO decided to split: the shards are built with the first fused device-noise tick
+    int co_plan(bool& wanted) const;
+    void co_cuts(int G, std::vector<int>& cuts) const;
+    void co_build();   // creates the subs
     void co_tick(const double* state, const double* goal, uint64_t seed, uint32_t tick);
 
     // hipGraph of a whole tick
@@ -899,11 +902,11 @@ struct mppi_engine {
     catch (const std::exception& e) { (h)->err = e.what(); return MPPI_E_INTERNAL; } \
     catch (...) { (h)->err = "unknown error"; return MPPI_E_INTERNAL; }
 
-void mppi_engine::co_build() {
+// How many engines a fused device-noise tick of this handle runs on (1: unsplit).  wanted: asked for by name (co_shards >= 2).
+int mppi_engine::co_plan(bool& wanted) const {
     int G = cfg.co_shards;
-    if (G < 0 || G > 8) fail(MPPI_E_INVALID, "co_shards must be 0 (auto), 1 (off) or 2..8");
     const bool lanes = small_nb == 0;
-    const bool wanted = G > 1;
+    wanted = G > 1;
     // AUTO: two shards where the pair measured faster than the one engine (config 4: +7-9 % rollouts/s; nothing below
     // ~5e5 samples), on the lane-per-sample path only
     // (and while a second set of buffers is small change against the 288 GB: the subs hold another half of this engine's)
@@ -914,21 +917,36 @@ void mppi_engine::co_build() {
     // there is nothing complementary to overlap -- measured 0.277 ms split against 0.250 ms unsplit (profiles/r4_bench_c4_f64_*.json)
     if (G == 0) G = (lanes && !f64() && (long)cfg.n_agents * cfg.samples >= 500000 && cfg.samples >= 4 * CH && cfg.n_agents * cfg.horizon <= 256 &&
                      hbm_bytes < ((size_t)48 << 30)) ? 2 : 1;
-    if (G <= 1) return;
+    if (G <= 1) return 1;
     if (!lanes || cfg.samples < G * CH) {
         if (wanted) fail(MPPI_E_INVALID, "co_shards = %d needs the lane-per-sample tick path and at least %d samples per shard", G, CH);
-        return;
+        return 1;
     }
+    return G;
+}
+// shard boundaries [0, c1, ..., K] on multiples of the update kernel's chunk (no shard ends in a ragged chunk)
+void mppi_engine::co_cuts(int G, std::vector<int>& cuts) const {
+    cuts.assign(G + 1, 0);
+    for (int g = 1; g < G; ++g) cuts[g] = (int)(((long)g * cfg.samples / G + CH / 2) / CH) * CH;
+    // Two shards: 58 / 42.  Shard 0's launches go first, so the tick ends with shard 1's update + merge + finalize with nothing
+    // left to hide them under; a smaller shard 1 shortens that tail as long as its rollout still covers shard 0's update
+    // (same box, K = 10^6, tick us: 50/50 139.0, 55/45 136.4, 58/42 134.2, 60/40 135.4, 62/38 136, 65/35 137.1; 45/55 141.6)
+    if (G == 2) cuts[1] = std::max(CH, (int)(((long)cfg.samples * co_cut_pct / 100 + CH / 2) / CH) * CH);
+    cuts[G] = cfg.samples;
+    for (int g = 0; g < G; ++g) if (cuts[g + 1] <= cuts[g]) fail(MPPI_E_INVALID, "co_shards = %d: %d samples do not split", G, cfg.samples);
+}
+
+// Builds the shards.  Asked for by name (co_shards >= 2): at mppi_create, errors reported there.  AUTO: with the first fused
+// device-noise mppi_tick (co_pending) -- a handle that only ever runs the caller's own exchange (mppi_tick_begin / _finish: the
+// ranks of an N > 1 run), graph replays or injected-noise ticks never pays for the second set of buffers.
+void mppi_engine::co_build() {
+    co_pending = false;
+    bool wanted = false;
+    const int G = co_plan(wanted);
+    if (G <= 1) return;
     try {
-        // boundaries on multiples of the update kernel's chunk (no shard ends in a ragged chunk)
-        std::vector<int> cuts(G + 1, 0);
-        for (int g = 1; g < G; ++g) cuts[g] = (int)(((long)g * cfg.samples / G + CH / 2) / CH) * CH;
-        // Two shards: 58 / 42.  Shard 0's launches go first, so the tick ends with shard 1's update + merge + finalize with nothing
-        // left to hide them under; a smaller shard 1 shortens that tail as long as its rollout still covers shard 0's update
-        // (same box, K = 10^6, tick us: 50/50 139.0, 55/45 136.4, 58/42 134.2, 60/40 135.4, 62/38 136, 65/35 137.1; 45/55 141.6)
-        if (G == 2) cuts[1] = std::max(CH, (int)(((long)cfg.samples * co_cut_pct / 100 + CH / 2) / CH) * CH);
-        cuts[G] = cfg.samples;
-        for (int g = 0; g < G; ++g) if (cuts[g + 1] <= cuts[g]) fail(MPPI_E_INVALID, "co_shards = %d: %d samples do not split", G, cfg.samples);
+        std::vector<int> cuts;
+        co_cuts(G, cuts);
         co_k0 = cuts[1];
         for (int g = 1; g < G; ++g) {
             mppi_config c = cfg;
@@ -940,6 +958,17 @@ void mppi_engine::co_build() {
             subs.push_back(e);
             e->is_co_sub = true;
             e->init(c);
+            // what the handle was told since its creation (the shards may be built long after): the cost's sig matrix, the obstacle grid
+            // (shared: same device; a later mppi_set_obstacle_grid reaches the shards first and gives them their own copy), the shift
+            // fill, the deadline and the measurement switches.  Nominal controls / state / goal follow with the first tick (co_sync_subs).
+            if (sig_is_matrix) { for (int i = 0; i < 4; ++i) e->sig_cost[i] = sig_cost[i]; e->sig_is_matrix = true; e->refresh_params(); }
+            e->P.grid = P.grid; e->P.grid_w = P.grid_w; e->P.grid_h = P.grid_h; e->P.grid_res = P.grid_res; e->P.grid_ox = P.grid_ox;
+            e->P.grid_oy = P.grid_oy; e->P.grid_weight = P.grid_weight;
+            HIPCHK(hipMemcpyAsync(e->d_fill, d_fill, (size_t)cfg.n_agents * 2 * sizeof(double), hipMemcpyDeviceToDevice, stream));
+            wait_stream("co-scheduled shard set-up");
+            e->sync_timeout_ms = sync_timeout_ms;
+            e->store_eps_always = store_eps_always; e->use_pk = use_pk; e->upd_skip_light = upd_skip_light; e->pk_waves = pk_waves;
+            e->pk_min_set = pk_min_set; e->pk_min_samples = pk_min_samples;
         }
         std::vector<void*> ptrs(G, nullptr);
         std::vector<mppi_engine*> all{this};
@@ -951,7 +980,7 @@ void mppi_engine::co_build() {
         for (int g = 0; g < G; ++g)
             if (mppi_p2p_connect(all[g], nullptr, ptrs.data())) fail(MPPI_E_HIP, "co-scheduled shard %d: %s", g, all[g]->err.c_str());
         p2p_internal = true;
-        HIPCHK(hipEventCreateWithFlags(&ev_co, hipEventDisableTiming));
+        if (!ev_co) HIPCHK(hipEventCreateWithFlags(&ev_co, hipEventDisableTiming));
         co_synced = false;
     } catch (const EngineError& er) {
         co_release();
@@ -1032,7 +1061,8 @@ int mppi_create(const mppi_config* cfg, mppi_engine** out) {
     try {
         e = new mppi_engine();
         e->init(*cfg);
-        e->co_build();
+        if (cfg->co_shards == 0) { bool w; e->co_pending = e->co_plan(w) > 1; }   // AUTO: built with the first fused device-noise tick
+        else e->co_build();
         *out = e;
         return MPPI_OK;
     } catch (const EngineError& er) { g_create_error = er.msg; delete e; return er.code; }
@@ -1342,6 +1372,7 @@ int mppi_tick_finish(mppi_engine* h, const void* gathered_dev, int n_shards) {
 
 int mppi_p2p_create(mppi_engine* h, int n_ranks, int rank, void* ipc_handle_out) {
     API_BEGIN(h)
+    h->co_pending = false;   // (a handle on a caller's cross-GPU exchange runs unsplit)
     if (h->p2p_internal && h->co_active()) { h->wait_stream(__func__); for (auto* e__ : h->subs) e__->wait_stream(__func__); h->co_release(); }
     if (n_ranks < 1 || n_ranks > 8 || rank < 0 || rank >= n_ranks) fail(MPPI_E_INVALID, "p2p: 1 <= n_ranks <= 8, 0 <= rank < n_ranks");
     static_assert(sizeof(hipIpcMemHandle_t) <= MPPI_IPC_HANDLE_BYTES, "IPC handle does not fit the ABI's buffer");
@@ -1566,6 +1597,13 @@ static int tick_begin_fused(mppi_engine* h, const double* state, const double* g
     API_END(h)
 }
 
+static int co_build_now(mppi_engine* h) {
+    API_BEGIN(h)
+    h->wait_stream("co-scheduled shard set-up");
+    h->co_build();   // (AUTO: never throws -- on failure the one engine serves every call and mppi_co_note says why)
+    API_END(h)
+}
+
 // the fused tick of a handle that carries co-scheduled shards (device noise; injected noise lives in this engine's own buffer)
 static int tick_co(mppi_engine* h, const double* state, const double* goal, uint64_t seed, uint32_t tick_id) {
     API_BEGIN(h)
@@ -1588,6 +1626,10 @@ static int tick_co(mppi_engine* h, const double* state, const double* goal, uint
 int mppi_tick(mppi_engine* h, const double* state, const double* goal, int noise_mode, uint64_t seed, uint32_t tick_id,
               double* next_state, double* u_applied) {
     int rc;
+    if (h && h->co_pending && noise_mode == MPPI_NOISE_PHILOX) {
+        rc = co_build_now(h);
+        if (rc) return rc;
+    }
     if (h && h->co_active() && noise_mode == MPPI_NOISE_PHILOX) {
         rc = tick_co(h, state, goal, seed, tick_id);
     } else {
@@ -1742,12 +1784,21 @@ int mppi_shader_clock(mppi_engine* h, double* mhz) {
 
 int mppi_co_info(mppi_engine* h, int32_t* n_shards, int32_t* samples) {
     API_BEGIN(h)
-    const int G = 1 + (int)h->subs.size();
+    int G = 1 + (int)h->subs.size();
+    std::vector<int> cuts;
+    if (h->co_pending) {   // the shards are built with the first fused device-noise tick: report what that tick will run on
+        bool w;
+        G = h->co_plan(w);
+        if (G > 1) h->co_cuts(G, cuts);
+    }
     if (n_shards) *n_shards = G;
     if (samples) {
         for (int g = 0; g < 8; ++g) samples[g] = 0;
-        samples[0] = h->co_active() ? h->co_k0 : h->cfg.samples;
-        for (int g = 1; g < G; ++g) samples[g] = h->subs[g - 1]->cfg.samples;
+        if (!cuts.empty()) { for (int g = 0; g < G; ++g) samples[g] = cuts[g + 1] - cuts[g]; }
+        else {
+            samples[0] = h->co_active() ? h->co_k0 : h->cfg.samples;
+            for (int g = 1; g < G; ++g) samples[g] = h->subs[g - 1]->cfg.samples;
+        }
     }
     API_END(h)
 }

@@ -1007,7 +1007,7 @@ constexpr int kUpdNV = 8;  // 16-byte vectors per lane: chunk = 256 * kUpdNV * (
 template <typename S> struct UpdCfg { static constexpr int VEC = 16 / (int)sizeof(S); static constexpr int CH = 256 * kUpdNV * VEC; };
 
 template <typename S, bool REGEN>
-__global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __restrict__ eps,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(S) == 8 && REGEN ? 8 : 4, 8))) void update_kernel(DevParams P, const S* __restrict__ eps,
                                                     const S* __restrict__ dP, const S* __restrict__ Stot,
                                                     double* __restrict__ part, int NCH, int ch_first, int n_local,
                                                     const S* __restrict__ epart, uint64_t seed, uint32_t tick_arg,
