@@ -28,6 +28,8 @@ python tools/ab_rollout.py --rounds 2 > $O/ab_rollout_c4.jsonl 2>/dev/null
 g++ -O2 -std=c++17 -Iinclude tools/node_tail.cpp -o tools/node_tail -Lmotion_planning_amd/lib -lmppi_hip -Wl,-rpath,$R/motion_planning_amd/lib && ( ./tools/node_tail 10 100 5000 0; ./tools/node_tail 10 100 3000 500; ./tools/node_tail 1000 50 3000 0; ./tools/node_tail 10000 50 3000 0 ) > $O/node_tail.txt 2>&1
 timeout 120 python tools/node_latency.py > $O/node_latency.txt 2>&1
 timeout 60 ./tools/ubench > $O/ubench.txt 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/bwbench.hip -o tools/bwbench 2>/dev/null && timeout 120 ./tools/bwbench > $O/bwbench.txt 2>&1
+timeout 200 python bench.py --storage f64 --no-cpu-baseline --steps 100 2>/dev/null | tail -1 > $O/bench_c4_f64.json
 [ -n "$SKIP_HANG_HUNT" ] || timeout 300 bash tools/hang_hunt.sh 600 4 gpurun_out/final/hang 2>&1 | tail -5
 python3 - <<PY
 import csv, glob, json, collections
