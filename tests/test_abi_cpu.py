@@ -208,3 +208,47 @@ def test_committed_bench_line_has_the_contract_fields():
     drv = json.load(open(os.path.join(ROOT, "profiles", "r2_bench_c4_driver_flags.json")))
     assert drv["steps"] == 20 and drv["warmup"] == 5
     assert abs(drv["ms_per_step"] / line["ms_per_step"] - 1.0) < 0.03      # a 20-step run is steady-state too
+
+
+def test_committed_round4_bench_line_says_what_bounds_the_kernels():
+    """profiles/r4_bench_c4.json (the line bench.py printed on the GPU box with the round's final build): the roofline record
+    leads with the roof the dominant kernel is ON -- VALU issue, at the measured clock and at the 2.4 GHz peak --, gives the HBM
+    fraction of the rollout and of the update from counter bytes over live durations, keeps SURVEY 8(d)'s accounting figure
+    under its own name, and states the tick's floor; all of it self-consistent."""
+    import json
+    path = os.path.join(ROOT, "profiles", "r4_bench_c4.json")
+    if not os.path.exists(path):
+        pytest.skip("the round's bench line is committed with the final profile refresh")
+    line = json.load(open(path))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["vs_baseline"] is None and line["unit"] == "rollouts/s" and line["dtype"] == "f32"
+    assert "K=1000000 T=50" in line["config"]["workload"] and "model" not in line["config"]
+    assert abs(line["value"] - line["config"]["samples_total"] / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+    roof = line["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "hbm", "accounting_8d", "tick_floor_us", "tick_frac", "valu"):
+        assert key in roof, key
+    assert roof["bound"] == "valu-issue" and roof["unit"] == "G wave-inst/s" and roof["kernel"] == "rollout_pk_kernel"
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and 0.5 < roof["frac_at_peak_clock"] <= roof["frac"] * 1.1 < 1.1
+    wave_steps = line["config"]["state_steps_per_tick"] / 64.0
+    t_min = roof["valu"]["issue_cycles_per_step"] * wave_steps / 1024 / (roof["clock_mhz_under_load"] * 1e6)
+    assert abs(roof["frac"] - t_min / (roof["avg_launch_us"] * 1e-6)) < 1e-9 and abs(roof["min_launch_us"] - 1e6 * t_min) < 1e-6
+    acc = roof["accounting_8d"]      # SURVEY 8(d): 12 B / state-step / kernel over the launch duration, against 8 TB/s
+    assert acc["bound"] == "hbm" and acc["peak"] == 8000.0 and acc["algorithmic_bytes_per_launch"] == 12 * line["config"]["state_steps_per_tick"]
+    assert abs(acc["achieved"] - acc["algorithmic_bytes_per_launch"] / (roof["avg_launch_us"] * 1e-6) / 1e9) < 1e-6 * acc["achieved"]
+    hbm = roof["hbm"]                # what the kernels really move: counter bytes over live durations
+    for k in ("rollout", "update"):
+        h = hbm[k]
+        assert abs(h["achieved"] - h["counter_bytes"] / (h["avg_launch_us"] * 1e-6) / 1e9) < 1e-6 * h["achieved"] and abs(h["frac"] - h["achieved"] / 8000.0) < 1e-12
+        assert h["vs_algorithmic"] < 0.5                                  # eps is never stored: about a third of the accounting bytes exist
+    assert roof["traffic"] == hbm["rollout"]["counter_bytes"] and 0.15 < hbm["rollout"]["frac"] < 0.4 and 0.5 < hbm["update"]["frac"] < 0.8
+    assert abs(hbm["update"]["frac_of_achievable"] - hbm["update"]["achieved"] / 6300.0) < 1e-12
+    terms = roof["tick_floor_terms"]
+    floor = max(terms["rollout_issue_us"], terms["update_bytes_over_achievable_hbm_us"]) + terms["merge_us_measured"] + terms["finalize_us_measured"]
+    assert abs(roof["tick_floor_us"] - floor) < 1e-6 and abs(roof["tick_frac"] - floor / terms["tick_us"]) < 1e-9 and 0.4 < roof["tick_frac"] < 1.0
+    assert roof["tick_level"]["accounting_8d"]["frac"] > 0.9           # the contract's tick-level figure: most of its bytes never exist
+    one = line["one_engine"]
+    assert one["self_check"]["max_abs_diff_u"] <= 1e-10 and one["ms_per_step"] >= line["ms_per_step"] * 0.95
+    cpu = line["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0
