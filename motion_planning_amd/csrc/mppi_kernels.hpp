@@ -1003,14 +1003,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(S) =
 //   with e > 2^-kCand: N += e * eps  (predicated scalar loads, wave-uniformly skipped otherwise).
 // grid = (8 T, ceil(A * chunks of this launch / 8)) x 256 threads; part[a][t][ch] = {M, D, N0, N1, E0, E1, count, 0}.
 // ---------------------------------------------------------------------------------------------
-#ifndef MPPI_UPD64_WAVES
-#define MPPI_UPD64_WAVES 8   // waves per SIMD the fp64-storage update kernel is compiled for (same-box A/B: -DMPPI_UPD64_WAVES=4 lets the registers decide: 7)
-#endif
 constexpr int kUpdNV = 8;  // 16-byte vectors per lane: chunk = 256 * kUpdNV * (16 / sizeof(S)) samples
 template <typename S> struct UpdCfg { static constexpr int VEC = 16 / (int)sizeof(S); static constexpr int CH = 256 * kUpdNV * VEC; };
 
 template <typename S, bool REGEN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(S) == 8 && REGEN ? MPPI_UPD64_WAVES : 4, 8))) void update_kernel(DevParams P, const S* __restrict__ eps,
+// (fp64 storage: 70 VGPRs, seven blocks per CU.  Forcing 64 VGPRs for an eighth block spilled five registers and measured SLOWER on
+// the same box: update 110-117 us against 95-103, tick 0.233-0.239 ms against 0.221-0.225 -- the registers decide.)
+__global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __restrict__ eps,
                                                     const S* __restrict__ dP, const S* __restrict__ Stot,
                                                     double* __restrict__ part, int NCH, int ch_first, int n_local,
                                                     const S* __restrict__ epart, uint64_t seed, uint32_t tick_arg,
