@@ -934,6 +934,30 @@ def test_full_size_oracle_replay(orc, tick_path, cfg, storage, record_property):
     assert m["du_max"] <= du_cap, (cfg, storage, m)
 
 
+def test_full_size_replay_of_the_mixed_rollout_at_a_long_horizon(orc, tick_path, record_property):
+    """The mixed-precision rollout at the far end of the horizons it serves (T = 254 of its 256: the accumulation its V tolerance
+    allows for grows like T^1.5, V_ABS_PK) on the engine's own kernel choice (393 216 samples = three rounds of its waves): 10^8
+    state steps replayed IN FULL on the oracle, V per sample against the stated tolerance and an EMPIRICAL cap on the controls
+    next to the analytic bound (nothing pinned the growth with T beyond the small-size cases)."""
+    if tick_path == "scan":
+        pytest.skip("lane kernels only at this size")
+    K, T = 393216, 254
+    u0 = np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
+    state, goal = [0.0, 0.0, 0.0], [0.0, -1.0, 0.0]
+    with _engine(K, T, "f32") as e:
+        e.set_nominal(u0)
+        nxt, ua = e.tick(state, goal, noise="philox", seed=2, tick_id=1)
+        assert e.info()["rollout_kernel"] == "mixed"
+        V = e.download_value()[0]
+        eps = e.download_noise()[0]
+        lat = e.get_nominal()
+    m = _replay_full(orc, V, eps, nxt[0], ua[0], lat, state, goal, u0, T, "f32")
+    for k, v in m.items():
+        record_property(k, v)
+    print("full-size replay of the mixed rollout, K = %d, T = %d: %s (stated absolute V term %.2e)" % (K, T, m, _v_abs_pk(T)))
+    assert m["du_max"] <= 1e-6, m      # empirical cap (the analytic bound of this scene is m["tol_max"])
+
+
 PK_SMALL = [(1, 26), (2, 27), (511, 28), (513, 29), (1025, 30), (2049, 31), (777, 32), (1300, 49), (900, 50), (1100, 51), (640, 100),
             (515, 255), (300, 256)]
 
