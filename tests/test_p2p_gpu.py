@@ -429,6 +429,43 @@ def test_co_scheduled_shards_behind_one_handle(K, shards, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_callers_p2p_calls_leave_an_internal_group_alone():
+    """a handle that never called mppi_p2p_create may still carry mailboxes -- those of its co-scheduled group.  The
+    caller-facing exchange calls must not act on them: mppi_p2p_destroy is the no-op it always was on an unconnected handle
+    (it used to free shard 0's mailbox under the other shard's raw pointers), publish / finish / selftest refuse with
+    MPPI_E_STATE (they used to bump one shard's epoch and hang the next tick), the mailbox pointer reads NULL -- and the handle
+    keeps ticking co-scheduled, equal to the unsplit engine."""
+    from motion_planning_amd.mppi import Engine
+    from motion_planning_amd._capi import MppiError
+    K = 600000
+    outs = {}
+    for co in (None, 1):
+        with Engine(K, T, storage="f32", tick_path="lanes", co_shards=co, options={"pk_min_samples": 400000}) as e:
+            e.set_nominal(_u0())
+            e.tick([0, 0, 0], [0, -1, 0], noise="philox", seed=8, tick_id=0)
+            if co is None:
+                assert e.info()["co_shards"] == 2
+                e.p2p_destroy()                                   # not the caller's mailboxes: left alone
+                assert e.p2p_mailbox_ptr() is None or e.p2p_mailbox_ptr() == 0
+                e.tick_begin(None, None, noise="philox", seed=8, tick_id=1)
+                for call in (e.p2p_publish, e.tick_finish_p2p, e.tick_exchange_p2p, e.p2p_selftest):
+                    with pytest.raises(MppiError) as err:
+                        call()
+                    assert err.value.code == -3, call              # MPPI_E_STATE
+                e.tick_finish()
+            else:
+                e.tick_begin(None, None, noise="philox", seed=8, tick_id=1)
+                e.tick_finish()
+            traj = []
+            for i in range(3):
+                st, ua = e.tick(None, None, noise="philox", seed=8, tick_id=2 + i)
+                traj.append(np.concatenate([st[0], ua[0]]))
+            assert e.info()["co_shards"] == (2 if co is None else 1)
+            outs[co] = np.array(traj)
+    assert np.abs(outs[None] - outs[1]).max() < 1e-10
+
+
+@pytest.mark.gpu
 def test_auto_co_shards_are_built_lazily_and_inherit_the_handles_settings():
     """co_shards AUTO: the handle reports its split from the start but builds the second engine only with its first fused
     device-noise tick -- a handle that runs the split tick_begin / tick_finish path (what a rank of an N > 1 run does) never pays for
