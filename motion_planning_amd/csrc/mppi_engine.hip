@@ -447,7 +447,7 @@ struct mppi_engine {
         // -- 1.9 ceil(r_mixed) < ceil(r_fp64) picks the faster kernel at 21 of the 23 sizes measured (300 000 ... 1 200 000; 0.7 % and 2.2 % slower at the other two).
         // Below three rounds the long waves lose to latency whatever the rounds say (250 000: 34.5 vs 36.1 us).  Shards of a
         // co-scheduled handle fill each other's gaps and keep the plain size rule (measured: 138-139 us against 142-145 per tick);
-        // so does an engine whose MPPI_PK_MIN_SAMPLES is set (tests, A/B runs).  (pick_pk)
+        // so does an engine whose option "pk_min_samples" is set (tests, A/B runs).  (pick_pk)
         const bool pk = pick_pk(ph, store, k0, k1);
         last_rollout_pk = pk;
         last_rollout_kind = pk ? MPPI_ROLLOUT_MIXED : MPPI_ROLLOUT_FP64;

@@ -181,6 +181,44 @@ def make_hip_ticker(samples_total, horizon, n_agents=1, storage="f32", local_ran
     return ticker, eng
 
 
+class P2PTicker(object):
+    """One rank of a K-sharded controller on the engine's own peer-to-peer exchange, WITHOUT torch: the rank's engine, connected
+    to its peers by mppi_p2p_rendezvous (IPC handles through files), ticking tick_begin -> publish -> finalize-behind-the-flags.
+    What ShardedTicker(exchange="p2p") does once a process group has carried the handles -- for launchers that have no process
+    group (a ROS launch file starting one node per GPU, mpirun, a shell loop): rank and world size come from the caller."""
+
+    exchange = "p2p"
+
+    def __init__(self, engine, world, rank):
+        self.engine, self.world, self.rank = engine, int(world), int(rank)
+
+    def tick_async(self, state=None, goal=None, noise="philox", seed=0, tick_id=0):
+        self.engine.tick_begin(state, goal, noise=noise, seed=seed, tick_id=tick_id)
+        self.engine.tick_exchange_p2p()
+
+    def tick(self, state=None, goal=None, noise="philox", seed=0, tick_id=0):
+        self.tick_async(state, goal, noise, seed, tick_id)
+        return self.engine.get_outputs()
+
+
+def make_p2p_ticker(samples_total, horizon, rank, world, rendezvous_prefix, n_agents=1, storage="f32", device=0,
+                    timeout_ms=60000, selftest_rounds=2, **engine_kw):
+    """This rank's slice of the samples (global sample offsets) + the exchange, no torch and no process group: every rank calls this
+    with the same `rendezvous_prefix` (a path inside a directory the launcher made for THIS run; the files `<prefix>.<rank>` are left
+    for the launcher to remove).  Returns (ticker, engine)."""
+    from .mppi import Engine
+    lo, hi = shard_range(samples_total, world, rank)
+    eng = Engine(hi - lo, horizon, n_agents=n_agents, storage=storage, device=device, sample_offset=lo, co_shards=1, **engine_kw)
+    try:
+        eng.p2p_rendezvous(rendezvous_prefix, world, rank, timeout_ms)
+        if selftest_rounds:
+            eng.p2p_selftest(selftest_rounds)   # collective: round trips of a known pattern, consumed by a kernel the way finalize does
+    except Exception:
+        eng.close()
+        raise
+    return P2PTicker(eng, world, rank), eng
+
+
 def make_replica_ticker(samples, horizon, n_agents, storage="f32", local_rank=0, **engine_kw):
     """Independent agents (BASELINE config 5): this rank's agents in one engine, no exchange.  Pass ``agent_offset`` = the global
     index of this rank's first agent: the device-noise streams are keyed by the global agent index, so the ranks together draw

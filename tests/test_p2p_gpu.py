@@ -262,6 +262,45 @@ def test_config5_as_eight_replica_ranks_against_the_oracle():
     assert np.abs(ua - ua8).max() <= 1e-4 and np.abs(nxt - nxt8).max() <= 1e-6, (np.abs(ua - ua8).max(), np.abs(nxt - nxt8).max())
 
 
+def _torchless_worker(rank, world, prefix, q):
+    sys.path.insert(0, ROOT)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from motion_planning_amd import sharded
+    ticker, eng = sharded.make_p2p_ticker(K, T, rank, world, prefix, storage="f32", tick_path="lanes")
+    eng.set_nominal(_u0())
+    outs = []
+    for i in range(NT):
+        nxt, ua = ticker.tick([[0, 0, 0]] if i == 0 else None, [[0, -1, 0]] if i == 0 else None, "philox", SEED, i)
+        outs.append(np.concatenate([nxt[0], ua[0]]))
+    lat = eng.get_nominal()
+    eng.p2p_selftest(1)                    # doubles as the barrier: nobody unmaps a mailbox a peer may still be writing to
+    q.put((rank, np.array(outs), lat, "torch" in sys.modules))
+    eng.close()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_p2p_ranks_without_torch(world, tmp_path):
+    """The K-sharded controller from Python WITHOUT torch or a process group: sharded.make_p2p_ticker -- the
+    IPC handles meet through files (mppi_p2p_rendezvous), rank and world size come from the launcher.  Two and eight processes on the
+    one GPU reproduce the unsharded engine like the process-group form does, and never import torch."""
+    import multiprocessing as mp
+    ref, ref_lat = _reference()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    prefix = str(tmp_path / "mbox")
+    procs = [ctx.Process(target=_torchless_worker, args=(r, world, prefix, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    tol = 1e-10 if world <= 2 else 1e-8      # (fp32 chunk sums group the samples differently for every split, see _run_ranks)
+    for rank, outs, lat, torch_loaded in res:
+        assert not torch_loaded
+        assert np.abs(outs - ref).max() < tol and np.abs(lat - ref_lat).max() < tol, (rank, np.abs(outs - ref).max())
+
+
 def _visible_devices():
     import subprocess
     out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True).stdout.strip()
