@@ -597,7 +597,7 @@ def main():
             contract defines it; it is an accounting figure, not a distance to a roof.
             `tick_floor_us`: max(rollout issue time, update bytes / achievable HBM rate) + measured merge + finalize."""
             steps = A * k_launch * T
-            share = (A * k_launch) / float(A * K_local)          # a co-scheduled shard's launch moves its share of the bytes
+            share = (A * k_launch) / float(A_total * K_total)    # the PMC passes covered ALL samples of the workload: a shard's (or a rank's) launch moves its share
             # `kind`: what the engine says its last tick launched (mppi_rollout_kernel), not a copy of its rule
             name = {"mixed": "rollout_pk_kernel", "fp64": "rollout_kernel", "scan": "scan_tick_kernel"}[kind]
             gbs = BYTES_PER_STEP_PER_KERNEL * steps / avg_s / 1e9
