@@ -1445,12 +1445,16 @@ int mppi_p2p_rendezvous(mppi_engine* h, const char* prefix, int n_ranks, int ran
     API_BEGIN(h)
     const std::string base(prefix);
     auto name = [&](int r) { return base + "." + std::to_string(r); };
+    // file = {magic, n_ranks, rank, bytes of one mailbox} + the handle: a reader refuses a file that is not this group's
+    struct Head { char magic[8]; int32_t n_ranks, rank; uint64_t mbox_bytes; };
+    auto head_of = [&](int r) { Head hd{}; std::memcpy(hd.magic, "MPPIMBX1", 8); hd.n_ranks = n_ranks; hd.rank = r; hd.mbox_bytes = h->p2p_bytes; return hd; };
     {
         const std::string tmp = name(rank) + ".tmp";
         FILE* f = std::fopen(tmp.c_str(), "wb");
         if (!f) fail(MPPI_E_INVALID, "p2p rendezvous: cannot write %s", tmp.c_str());
-        const size_t w = std::fwrite(mine, 1, sizeof(mine), f);
-        if (std::fclose(f) != 0 || w != sizeof(mine) || std::rename(tmp.c_str(), name(rank).c_str()) != 0)
+        const Head hd = head_of(rank);
+        const size_t w = std::fwrite(&hd, 1, sizeof(hd), f) + std::fwrite(mine, 1, sizeof(mine), f);
+        if (std::fclose(f) != 0 || w != sizeof(hd) + sizeof(mine) || std::rename(tmp.c_str(), name(rank).c_str()) != 0)
             fail(MPPI_E_INVALID, "p2p rendezvous: cannot publish %s", name(rank).c_str());
     }
     std::vector<unsigned char> all((size_t)n_ranks * MPPI_IPC_HANDLE_BYTES, 0);
@@ -1460,9 +1464,17 @@ int mppi_p2p_rendezvous(mppi_engine* h, const char* prefix, int n_ranks, int ran
         for (;;) {
             FILE* f = std::fopen(name(r).c_str(), "rb");
             if (f) {
-                const size_t got = std::fread(all.data() + (size_t)r * MPPI_IPC_HANDLE_BYTES, 1, MPPI_IPC_HANDLE_BYTES, f);
+                Head hd{};
+                const size_t got = std::fread(&hd, 1, sizeof(hd), f) + std::fread(all.data() + (size_t)r * MPPI_IPC_HANDLE_BYTES, 1, MPPI_IPC_HANDLE_BYTES, f);
                 std::fclose(f);
-                if (got == MPPI_IPC_HANDLE_BYTES) break;
+                if (got == sizeof(hd) + MPPI_IPC_HANDLE_BYTES) {
+                    const Head want = head_of(r);
+                    if (std::memcmp(&hd, &want, sizeof(hd)) != 0)
+                        fail(MPPI_E_INVALID, "p2p rendezvous: %s belongs to another group (ranks %d / rank %d / mailbox %llu bytes; this group: %d / %d / %llu): "
+                             "a stale file of an earlier run, or engines of different shapes", name(r).c_str(), hd.n_ranks, hd.rank,
+                             (unsigned long long)hd.mbox_bytes, n_ranks, r, (unsigned long long)h->p2p_bytes);
+                    break;
+                }
             }
             const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
             if (timeout_ms > 0 && ms > timeout_ms) fail(MPPI_E_TIMEOUT, "p2p rendezvous: rank %d's handle (%s) did not appear within %d ms", r, name(r).c_str(), timeout_ms);
