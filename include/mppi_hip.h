@@ -309,8 +309,6 @@ int mppi_synchronize(mppi_engine *h);
  *   "pk_min_samples"  >= 0: a plain size rule for the mixed-precision rollout; -1 (default): chosen by rounds of waves
  *   "pk_waves"        4 | 5: the mixed-precision rollout's 5-waves-per-SIMD build
  *   "upd_skip"        0: the update forms exp() for every sample (default 1: wave-vectors without a weight above the cut are skipped)
- *   "upd_group"       chunks of 8192 samples one update workgroup walks: -1 (default) ceil(chunks / 16) -- a row is left with at most
- *                     16 tuples, no merge launch in a tick --, 0 one chunk per workgroup + the merge launch (round 3), n that many
  *   "store_eps"       1: the tick path stores its noise like mppi_rollout does
  *   "co_cut_pct"      share of shard 0 of a two-shard co-scheduled handle in per cent (default 58); re-cuts the group
  * Unknown keys and out-of-range values return MPPI_E_INVALID.

@@ -549,24 +549,14 @@ struct mppi_engine {
         HIPCHK(hipGetLastError());
         epart_ready = true;
     }
-    // chunks one update block walks (update_kernel GROUPS): on the tick paths a row is left with at most kDirectTuples tuples, so no
-    // merge launch follows; option "upd_group": -1 that rule, 0 one chunk per block (round 3), n > 0 that many
-    int upd_group_mode = -1;
-    int upd_per_group() const {
-        if (upd_group_mode == 0) return 1;
-        if (upd_group_mode > 0) return std::min(upd_group_mode, NCH);
-        return (NCH + kDirectTuples - 1) / kDirectTuples;
-    }
-    // per_group chunks per block: the launch writes ceil(NCH / per_group) tuples per row into d_part
-    void launch_update(hipStream_t st, int per_group, const uint32_t* tick_ptr = nullptr) {
+    void launch_update(hipStream_t st, int ch0, int nch, const uint32_t* tick_ptr = nullptr) {
         ensure_epart(st);
         Scope sc(this, MPPI_KERNEL_UPDATE, st);
-        const int ng = (NCH + per_group - 1) / per_group;
-        dim3 grid(8 * cfg.horizon, (cfg.n_agents * ng + 7) / 8);  // XCD-aware decode inside the kernel
+        dim3 grid(8 * cfg.horizon, (cfg.n_agents * nch + 7) / 8);  // XCD-aware decode inside the kernel
 #define LAUNCH_UPD(TYPE, REGEN)                                                                                  \
     hipLaunchKernelGGL((mppi::update_kernel<TYPE, REGEN>), grid, dim3(256), 0, st, P, static_cast<const TYPE*>(d_eps), \
-                       static_cast<const TYPE*>(d_dP), static_cast<const TYPE*>(d_stot), d_part, ng, 0, ng,        \
-                       static_cast<const TYPE*>(d_epart), lazy_seed, lazy_tick, tick_ptr, upd_skip_light, per_group, NCH)
+                       static_cast<const TYPE*>(d_dP), static_cast<const TYPE*>(d_stot), d_part, NCH, ch0, nch,    \
+                       static_cast<const TYPE*>(d_epart), lazy_seed, lazy_tick, tick_ptr, upd_skip_light)
         if (f64()) { if (eps_lazy) LAUNCH_UPD(double, true); else LAUNCH_UPD(double, false); }
         else { if (eps_lazy) LAUNCH_UPD(float, true); else LAUNCH_UPD(float, false); }
 #undef LAUNCH_UPD
@@ -628,12 +618,11 @@ struct mppi_engine {
             noise_ready = true; value_ready = false; value_lazy = true; partials_ready = true; epart_ready = false;
             return;
         }
-        const int pg = upd_per_group(), ng = (NCH + pg - 1) / pg;
-        merge_skipped = (skip_small_merge || (p2p_connected && !p2p_internal)) && ng <= kDirectTuples;
-        direct_n = ng;
+        merge_skipped = (skip_small_merge || (p2p_connected && !p2p_internal)) && NCH <= kDirectTuples;
+        direct_n = NCH;
         launch_rollout(stream, 0, cfg.samples, ph, store, seed, tick, tick_ptr);
-        launch_update(stream, pg, tick_ptr);
-        if (!merge_skipped) launch_merge(ng);
+        launch_update(stream, 0, NCH, tick_ptr);
+        if (!merge_skipped) launch_merge(NCH);
         noise_ready = true; value_ready = true; value_lazy = false; partials_ready = true; epart_ready = true;
     }
     // T <= 256: the nominal rollout runs inside every rollout block (lanes = timesteps)
@@ -655,7 +644,7 @@ struct mppi_engine {
         materialise_value();
         if (!noise_ready || !value_ready) fail(MPPI_E_STATE, "update needs a rollout (or uploaded V and eps) first");
         materialise_eps();
-        launch_update(stream, 1);
+        launch_update(stream, 0, NCH);
         launch_merge(NCH);
         merge_skipped = false;  // (an earlier fused tick may have left its tuples unmerged: these are merged)
         partials_ready = true;
@@ -979,7 +968,7 @@ void mppi_engine::co_build() {
             wait_stream("co-scheduled shard set-up");
             e->sync_timeout_ms = sync_timeout_ms;
             e->store_eps_always = store_eps_always; e->use_pk = use_pk; e->upd_skip_light = upd_skip_light; e->pk_waves = pk_waves;
-            e->pk_min_set = pk_min_set; e->pk_min_samples = pk_min_samples; e->upd_group_mode = upd_group_mode;
+            e->pk_min_set = pk_min_set; e->pk_min_samples = pk_min_samples;
         }
         std::vector<void*> ptrs(G, nullptr);
         std::vector<mppi_engine*> all{this};
@@ -1713,7 +1702,6 @@ int mppi_set_option(mppi_engine* h, const char* key, int64_t value) {
     if (k == "store_eps") { h->settle_lazy_state(); h->store_eps_always = value != 0; h->destroy_graph(); }
     else if (k == "rollout_pk") { h->settle_lazy_state(); h->use_pk = value != 0; h->destroy_graph(); }
     else if (k == "upd_skip") h->upd_skip_light = value != 0;
-    else if (k == "upd_group") { if (value < -1 || value > 4096) fail(MPPI_E_INVALID, "upd_group: -1 auto, 0 one chunk per block, n chunks per block"); h->upd_group_mode = (int)value; h->destroy_graph(); }
     else if (k == "pk_waves") { if (value != 4 && value != 5) fail(MPPI_E_INVALID, "pk_waves: 4 or 5"); h->pk_waves = (int)value; }
     else if (k == "pk_min_samples") { h->settle_lazy_state(); h->pk_min_set = value >= 0; h->pk_min_samples = value >= 0 ? (long)value : 400000; h->destroy_graph(); }
     else if (k == "co_cut_pct") {
@@ -1730,7 +1718,7 @@ int mppi_set_option(mppi_engine* h, const char* key, int64_t value) {
             try { h->co_build(); } catch (...) { h->cfg.co_shards = asked; throw; }
             h->cfg.co_shards = asked;
             for (auto* e : h->subs) {   // the new shards take over this handle's switches
-                e->store_eps_always = h->store_eps_always; e->use_pk = h->use_pk; e->upd_skip_light = h->upd_skip_light; e->pk_waves = h->pk_waves; e->upd_group_mode = h->upd_group_mode;
+                e->store_eps_always = h->store_eps_always; e->use_pk = h->use_pk; e->upd_skip_light = h->upd_skip_light; e->pk_waves = h->pk_waves;
                 e->pk_min_set = h->pk_min_set; e->pk_min_samples = h->pk_min_samples; e->sync_timeout_ms = h->sync_timeout_ms;
             }
         }
@@ -1746,7 +1734,6 @@ int mppi_get_option(mppi_engine* h, const char* key, int64_t* value) {
     if (k == "store_eps") *value = h->store_eps_always;
     else if (k == "rollout_pk") *value = h->use_pk;
     else if (k == "upd_skip") *value = h->upd_skip_light;
-    else if (k == "upd_group") *value = h->upd_group_mode;
     else if (k == "pk_waves") *value = h->pk_waves;
     else if (k == "pk_min_samples") *value = h->pk_min_set ? h->pk_min_samples : -1;
     else if (k == "co_cut_pct") *value = h->co_cut_pct;
@@ -1843,7 +1830,7 @@ int mppi_engine_info(mppi_engine* h, size_t* hbm_bytes, int32_t* rollout_blocks,
     // what a tick launches: the scan kernel alone (no update kernel), or rollout + update
     const bool scan = h->small_nb > 0;
     if (rollout_blocks) *rollout_blocks = (scan ? h->small_nb : h->roll_blocks) * h->cfg.n_agents;
-    if (update_blocks) *update_blocks = scan ? 0 : ((h->NCH + h->upd_per_group() - 1) / h->upd_per_group()) * h->cfg.horizon * h->cfg.n_agents;
+    if (update_blocks) *update_blocks = scan ? 0 : h->NCH * h->cfg.horizon * h->cfg.n_agents;
     API_END(h)
 }
 

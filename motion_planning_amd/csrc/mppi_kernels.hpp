@@ -1003,26 +1003,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(S) =
 //   with e > 2^-kCand: N += e * eps  (predicated scalar loads, wave-uniformly skipped otherwise).
 // grid = (8 T, ceil(A * chunks of this launch / 8)) x 256 threads; part[a][t][ch] = {M, D, N0, N1, E0, E1, count, 0}.
 // ---------------------------------------------------------------------------------------------
-// exp((a - b) / lambda) for the online tuple fold of update_kernel: kept out of line so that the software fp64 exp does not
-// stretch the register allocation of the streaming loop around it (inlined it took the fp32 kernel from 54 to 88 VGPRs)
-__device__ __attribute__((noinline)) double fold_scale(double a, double b, double inv_lambda) { return exp((a - b) * inv_lambda); }
 constexpr int kUpdNV = 8;  // 16-byte vectors per lane: chunk = 256 * kUpdNV * (16 / sizeof(S)) samples
 template <typename S> struct UpdCfg { static constexpr int VEC = 16 / (int)sizeof(S); static constexpr int CH = 256 * kUpdNV * VEC; };
 
 template <typename S, bool REGEN>
 // (fp64 storage: 70 VGPRs, seven blocks per CU.  Forcing 64 VGPRs for an eighth block spilled five registers and measured SLOWER on
 // the same box: update 110-117 us against 95-103, tick 0.233-0.239 ms against 0.221-0.225 -- the registers decide.)
-// GROUPS (round 4).  A block owns a GROUP of `per_group` consecutive chunks of its row, walks them from the highest down and folds
-// each chunk's tuple into its running one (the exact tuple merge, in fp64, online) -- part[a][t][group].  The engine picks
-// per_group = ceil(chunks / 16) on the tick paths, so a row never has more than 16 tuples and whoever consumes them (the finalize
-// kernel, the merging publish kernel) merges them itself: the merge LAUNCH is gone from the tick (4.7 us of every tick with more
-// than 131 072 samples), and the 800 resident blocks of config 4 stream their chunks back to back instead of three rounds of
-// 2048 short-lived ones.  per_group = 1 is the round-3 kernel, bit for bit (the first fold multiplies by exp(0) = 1).
 __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __restrict__ eps,
                                                     const S* __restrict__ dP, const S* __restrict__ Stot,
-                                                    double* __restrict__ part, int NG, int g_first, int n_local,
+                                                    double* __restrict__ part, int NCH, int ch_first, int n_local,
                                                     const S* __restrict__ epart, uint64_t seed, uint32_t tick_arg,
-                                                    const uint32_t* __restrict__ tick_ptr, int skip_light, int per_group, int NCH) {
+                                                    const uint32_t* __restrict__ tick_ptr, int skip_light) {
     using R = S;
     constexpr int VEC = UpdCfg<S>::VEC, CH = UpdCfg<S>::CH;
     typedef S vec_t __attribute__((ext_vector_type(VEC)));
@@ -1031,32 +1022,28 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
     // column (8 * group + xcd) of Stot on ONE XCD, so that chunk crosses into L2 once per tick instead of once
     // per XCD (placement only changes speed, never results).  Chunks are walked from the highest k down:
     // the rollout kernel wrote the high-k columns last, they are what the Infinity Cache still holds.
-    // The columns of this launch are the (agent, group) pairs, numbered agent-major.
+    // The columns of this launch are the (agent, chunk) pairs, numbered agent-major.
     const int T_ = P.T;
-    const int id = blockIdx.x + (int)gridDim.x * blockIdx.y;  // grid = (8 * T, ceil(A * groups / 8))
+    const int id = blockIdx.x + (int)gridDim.x * blockIdx.y;  // grid = (8 * T, ceil(A * chunks / 8))
     const int xcd = id & 7, q = id >> 3, t = q % T_, grp = q / T_;
     const int col = grp * 8 + xcd;
     if (col >= P.A * n_local) return;
     const int a = col / n_local, local = col % n_local;
-    const int g = g_first + n_local - 1 - local;
+    const int ch = ch_first + n_local - 1 - local;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const size_t Ks = (size_t)P.Ks;
     const S* v_row = dP + ((size_t)a * P.T + t) * Ks;   // exclusive cost prefix of row t
     const S* s_row = Stot + (size_t)a * Ks;               // per-sample totals (L2-resident, re-read per t)
     const S* e0_row = eps + (((size_t)a * P.T + t) * 2 + 0) * Ks;
     const S* e1_row = e0_row + Ks;
-    double* o = part + (((size_t)a * P.T + t) * NG + g) * kTupleW;
-    __shared__ R red[4][6];
-    __shared__ double redN[4][2];
-    __shared__ double run[kTupleW];   // the group's running tuple {M, D, N0, N1, E0, E1, count, 0}
-    if (tid < kTupleW) run[tid] = tid == 0 ? (double)INFINITY : 0.0;
-    const int ch_lo = g * per_group, ch_hi = min(NCH, ch_lo + per_group);   // (uniform) this group's chunks
-#pragma unroll 1
-    for (int ch = ch_hi - 1; ch >= ch_lo; --ch) {
     const int k_begin = ch * CH;
     const int k_end = min(P.K, k_begin + CH);
-    if (k_end <= k_begin) continue;  // empty chunk (uniform)
-    __syncthreads();   // (the LDS scratch of the chunk before this one has been read)
+    double* o = part + (((size_t)a * P.T + t) * NCH + ch) * kTupleW;
+    if (k_end <= k_begin) {  // empty chunk (uniform)
+        if (tid == 0) { o[0] = INFINITY; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = 0; o[7] = 0; }
+        return;
+    }
+    __shared__ R red[4][6];
     // E = sum_k eps of this chunk from the per-wave sums (CH/64 entries per wheel, a few hundred bytes)
     R E0 = 0, E1 = 0;
     {
@@ -1181,31 +1168,18 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
     // sum_k e * eps across the block in fp64: a thread holds a few products at most (the queue spreads the candidates over
     // the block -- a handful of them all sit in wave 0), and an fp32 tree would let the row's dominant term absorb the small
     // ones differently for every way of splitting the samples over chunks / shards
+    __shared__ double redN[4][2];
     const double N0d = wave_sum((double)N0 + Na0), N1d = wave_sum((double)N1 + Na1);
     D = wave_sum(D); E0 = wave_sum(E0); E1 = wave_sum(E1);
     if (lane == 0) { red[wid][1] = D; redN[wid][0] = N0d; redN[wid][1] = N1d; red[wid][4] = E0; red[wid][5] = E1; }
     __syncthreads();
-    // fold this chunk's tuple into the group's (the tuple merge of the header comment: M = min; D, N rescaled by exp(-(m - M)/lam); E, count
-    // add).  Lanes 1..5 of wave 0 each own one component; all of them form the two rescaling factors (same wave: no extra time).
-    if (tid >= 1 && tid <= 6) {
-        const int c = tid;
-        const double mine = c == 6 ? (double)(k_end - k_begin)
-                          : (c == 2 || c == 3) ? redN[0][c - 2] + redN[1][c - 2] + redN[2][c - 2] + redN[3][c - 2]
-                                               : (double)red[0][c] + (double)red[1][c] + (double)red[2][c] + (double)red[3][c];
-        const double Mr = run[0], Mc = (double)M, Mn = fmin(Mr, Mc);
-        if (c <= 3) {
-            const double sr = Mr == Mn ? 1.0 : (Mr == INFINITY ? 0.0 : fold_scale(Mn, Mr, P.inv_lambda));
-            const double sc = Mc == Mn ? 1.0 : fold_scale(Mn, Mc, P.inv_lambda);
-            run[c] = run[c] * sr + mine * sc;
-        } else {
-            run[c] += mine;
-        }
+    if (tid < 5) {
+        const int c = tid + 1;
+        o[c] = (c == 2 || c == 3) ? redN[0][c - 2] + redN[1][c - 2] + redN[2][c - 2] + redN[3][c - 2]
+                                  : (double)red[0][c] + (double)red[1][c] + (double)red[2][c] + (double)red[3][c];
+    } else if (tid == 5) {
+        o[0] = (double)M; o[6] = (double)(k_end - k_begin); o[7] = 0.0;
     }
-    __syncthreads();
-    if (tid == 0) run[0] = fmin(run[0], (double)M);
-    }   // chunks of the group
-    __syncthreads();
-    if (tid < kTupleW) o[tid] = run[tid];
 }
 
 // per-wave sums of eps for noise that did not come out of a rollout (mppi_upload_noise followed
