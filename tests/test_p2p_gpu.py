@@ -301,6 +301,53 @@ def test_p2p_ranks_without_torch(world, tmp_path):
         assert np.abs(outs - ref).max() < tol and np.abs(lat - ref_lat).max() < tol, (rank, np.abs(outs - ref).max())
 
 
+def test_rendezvous_refuses_stale_and_missing_files(tmp_path):
+    """mppi_p2p_rendezvous: a file that is not this group's (a stale one of an earlier run, a group of another size, an engine of
+    another shape) is refused by name, a rank that never shows up is a time-out -- never a mapped garbage handle."""
+    from motion_planning_amd.mppi import Engine
+    from motion_planning_amd._capi import MppiError
+    prefix = str(tmp_path / "mbox")
+    with Engine(6000, T, storage="f32", tick_path="lanes") as e:
+        with pytest.raises(MppiError) as err:                       # nobody else: time-out after 300 ms
+            e.p2p_rendezvous(prefix, 2, 0, timeout_ms=300)
+        assert err.value.code == -5 and "did not appear" in str(err.value)
+        with open(prefix + ".1", "wb") as f:                         # a file of the old, header-less format
+            f.write(b"\0" * 64)
+        with pytest.raises(MppiError) as err:
+            e.p2p_rendezvous(prefix, 2, 0, timeout_ms=300)
+        assert err.value.code == -5                                   # too short to be a complete file: treated as not there yet
+        with open(prefix + ".1", "wb") as f:                         # complete, but of a group of three
+            f.write(b"MPPIMBX1" + (3).to_bytes(4, "little") + (1).to_bytes(4, "little") + (0).to_bytes(8, "little") + b"\0" * 64)
+        with pytest.raises(MppiError) as err:
+            e.p2p_rendezvous(prefix, 2, 0, timeout_ms=300)
+        assert err.value.code == -1 and "another group" in str(err.value)
+        nxt, ua = e.tick([0, 0, 0], [0, -1, 0], noise="philox", seed=1, tick_id=0)   # the handle still ticks (unconnected mailbox: plain tick)
+        assert np.isfinite(ua).all()
+
+
+def test_options_are_per_handle_and_checked():
+    """mppi_set_option / mppi_get_option: round trips, unknown keys and out-of-range values are MPPI_E_INVALID, and a switch set on
+    one handle does not leak into another (round 3 read these from the process environment)."""
+    from motion_planning_amd.mppi import Engine
+    from motion_planning_amd._capi import MppiError
+    with Engine(4096, T, tick_path="lanes") as a, Engine(4096, T, tick_path="lanes") as b:
+        assert a.get_option("rollout_pk") == 1 and a.get_option("pk_min_samples") == -1 and a.get_option("co_cut_pct") == 58
+        a.set_option("rollout_pk", 0); a.set_option("pk_min_samples", 1); a.set_option("upd_skip", 0); a.set_option("pk_waves", 5)
+        assert (a.get_option("rollout_pk"), a.get_option("pk_min_samples"), a.get_option("upd_skip"), a.get_option("pk_waves")) == (0, 1, 0, 5)
+        assert (b.get_option("rollout_pk"), b.get_option("pk_min_samples"), b.get_option("upd_skip"), b.get_option("pk_waves")) == (1, -1, 1, 4)
+        for key, val in (("no_such_switch", 1), ("pk_waves", 6), ("co_cut_pct", 0), ("co_cut_pct", 100)):
+            with pytest.raises(MppiError) as err:
+                a.set_option(key, val)
+            assert err.value.code == -1, (key, val)
+        with pytest.raises(MppiError):
+            a.get_option("no_such_switch")
+        a.set_nominal(_u0()); b.set_nominal(_u0())
+        a.tick([0, 0, 0], [0, -1, 0], noise="philox", seed=1, tick_id=0)
+        b.set_option("pk_min_samples", 1)
+        b.tick([0, 0, 0], [0, -1, 0], noise="philox", seed=1, tick_id=0)
+        assert a.info()["rollout_kernel"] == "fp64" and b.info()["rollout_kernel"] == "mixed"   # a: the mixed kernel switched off
+
+
 def _visible_devices():
     import subprocess
     out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True).stdout.strip()
