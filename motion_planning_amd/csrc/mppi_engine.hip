@@ -1410,7 +1410,10 @@ int mppi_p2p_connect(mppi_engine* h, const void* ipc_handles, void* const* local
         if (g == h->p2p_rank) { h->p2p_peer[g] = h->p2p_mbox; continue; }
         if (local_ptrs && local_ptrs[g]) {   // an engine of THIS process -- possibly on another GPU of the node
             hipPointerAttribute_t at{};
-            if (hipPointerGetAttributes(&at, local_ptrs[g]) != hipSuccess) { (void)hipGetLastError(); fail(MPPI_E_INVALID, "p2p connect: local_ptrs[%d] is not a device pointer", g); }
+            if (hipPointerGetAttributes(&at, local_ptrs[g]) != hipSuccess || at.type != hipMemoryTypeDevice) {
+                (void)hipGetLastError();
+                fail(MPPI_E_INVALID, "p2p connect: local_ptrs[%d] is not a device pointer (pass mppi_p2p_mailbox_ptr of the peer engine)", g);
+            }
             if (at.device != h->device) {
                 int can = 0;
                 HIPCHK(hipDeviceCanAccessPeer(&can, h->device, at.device));

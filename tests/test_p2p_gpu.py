@@ -325,6 +325,26 @@ def test_rendezvous_refuses_stale_and_missing_files(tmp_path):
         assert np.isfinite(ua).all()
 
 
+def test_connect_checks_the_pointers_it_is_given():
+    """mppi_p2p_connect(local_ptrs): a mailbox pointer of an engine of THIS process -- on this or another GPU (peer access is enabled
+    on the way; round 3 used the pointer raw, which faults across devices).  What is not device memory is refused before any kernel
+    could store through it."""
+    import ctypes as C
+    from motion_planning_amd.mppi import Engine
+    from motion_planning_amd._capi import MppiError
+    host = np.zeros(4096)
+    with Engine(6000, T, storage="f32", tick_path="lanes") as e:
+        e.p2p_create(2, 0)
+        with pytest.raises(MppiError) as err:
+            e.p2p_connect(local_ptrs=[e.p2p_mailbox_ptr(), host.ctypes.data])
+        assert err.value.code == -1 and "not a device pointer" in str(err.value)
+        with pytest.raises(MppiError):                               # still unconnected: nothing to publish into
+            e.tick_begin([0, 0, 0], [0, -1, 0], noise="philox", seed=1, tick_id=0); e.tick_exchange_p2p()
+        e.p2p_destroy()
+        nxt, ua = e.tick([0, 0, 0], [0, -1, 0], noise="philox", seed=1, tick_id=1)
+        assert np.isfinite(ua).all()
+
+
 def test_options_are_per_handle_and_checked():
     """mppi_set_option / mppi_get_option: round trips, unknown keys and out-of-range values are MPPI_E_INVALID, and a switch set on
     one handle does not leak into another (round 3 read these from the process environment)."""
