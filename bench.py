@@ -562,6 +562,40 @@ def main():
             raise SystemExit("bench self-check FAILED: the timed region of the headline run and of the one-engine run ended in "
                              "different states / controls: %r" % one_line["self_check"])
 
+    # The optional 16-bit noise packing (option "noise_packing" = 1: one Philox call serves four steps instead of three) next to
+    # the default stream: N = 1, config 4, fp32 storage only; the handle's own co-scheduling, then one engine with its rollout timed.
+    pack_line = None
+    if (rank == 0 and world == 1 and args.workload == "c4" and args.storage == "f32" and not args.samples and not args.graph
+            and not args.no_f64_line and one_line is not None):
+        from motion_planning_amd.mppi import Engine
+        pack_line = {"option": "noise_packing = 1 (not the default: Box-Muller radius cut at 4.85 sigma instead of 5.53, 2^16 directions)"}
+        for name, co in (("co_scheduled", None), ("one_engine", 1)):
+            with Engine(K_total, T, storage="f32", device=local_rank, tick_path=args.tick_path, co_shards=co,
+                        options={"noise_packing": 1}) as ep:
+                ep.set_nominal(nominal_warm(T))
+                ep.tick_async(np.zeros((1, 3)), np.array([goal]), "philox", 0, 0)
+                t_w, i = time.perf_counter(), 1
+                while time.perf_counter() - t_w < 0.3 or i < 20:
+                    ep.tick_async(None, None, "philox", 0, i)
+                    i += 1
+                    if i % 16 == 0:
+                        ep.synchronize()
+                ep.set_nominal(nominal_warm(T))
+                ep.tick_async(np.zeros((1, 3)), np.array([goal]), "philox", 0, 1_000_000)
+                if co == 1:
+                    ep.kernel_timing(("rollout",), period=4)
+                ep.synchronize()
+                t0 = time.perf_counter()
+                for j in range(100):
+                    ep.tick_async(None, None, "philox", 0, 1_000_001 + j)
+                ep.synchronize()
+                elq = time.perf_counter() - t0
+                pack_line[name] = {"ms_per_step": 1e3 * elq / 100, "value": K_total / (elq / 100), "steps": 100}
+                if co == 1:
+                    kq = ep.kernel_times()
+                    pack_line[name]["rollout_us"] = kq["rollout"][0] * 1e3 / max(kq["rollout"][1], 1)
+                    ep.kernel_timing(())
+
     if rank == 0:
         lanes = info.get("tick_kernels", "lanes") == "lanes"
         mixes = load_profile(PROFILE_ROUND + "_valu_mix.json") or load_profile("r3_valu_mix.json") or {}
@@ -744,7 +778,7 @@ def main():
             "final_state": [float(x) for x in final_nxt[0]], "final_u": [float(x) for x in final_ua[0]],
             "sync_tick_us": sync_tick_us,
             "kernels_us": kernels_us, "exchange_us": exchange_us, "per_rank": per_rank,
-            "roofline": roofline, "cpu_baseline": cpu, "f64_storage": f64_line, "one_engine": one_line,
+            "roofline": roofline, "cpu_baseline": cpu, "f64_storage": f64_line, "one_engine": one_line, "noise_packing_1": pack_line,
         }
         line.update(extra)
         # the other regime of the closed loop at the top level too: the robot parked at its goal

@@ -311,6 +311,13 @@ int mppi_synchronize(mppi_engine *h);
  *   "upd_skip"        0: the update forms exp() for every sample (default 1: wave-vectors without a weight above the cut are skipped)
  *   "store_eps"       1: the tick path stores its noise like mppi_rollout does
  *   "co_cut_pct"      share of shard 0 of a two-shard co-scheduled handle in per cent (default 58); re-cuts the group
+ * and one that selects another noise STREAM (same generator, same counters, other use of its bits):
+ *   "noise_packing"   0 (default): one Philox4x32-10 call serves three steps (2 x 21-bit uniforms per step: Box-Muller radius
+ *                     <= 5.53 sigma, 2^21 directions); 1: four steps (word j of call t / 4 serves step t: its low 16 bits the radius
+ *                     uniform, radius <= 4.85 sigma, its high 16 bits the direction) -- a quarter fewer calls, the mixed-precision
+ *                     rollout 6 % shorter.  Drawn by that kernel only: fp32 storage, the lane kernels, the node's cost and model,
+ *                     noise not stored; MPPI_E_INVALID where it cannot be served (from the option call, or from the tick that
+ *                     would need another kernel).  mppi_download_noise, mppi_update and the oracle's twin follow the option.
  * Unknown keys and out-of-range values return MPPI_E_INVALID.
  */
 int mppi_set_option(mppi_engine *h, const char *key, int64_t value);

@@ -113,6 +113,7 @@ struct mppi_engine {
     bool last_rollout_pk = false;  // which kernel the last rollout launch was
     int last_rollout_kind = MPPI_ROLLOUT_NONE;   // ... as mppi_rollout_kernel reports it
     bool co_shards_pk = false;     // ... and the one the shards of the last co-scheduled tick ran
+    int noise_pack = 0;             // option "noise_packing": how a Philox call's bits become normals (mppi::NoisePack): 0 three steps per call, 1 four
     int upd_skip_light = 1;         // option "upd_skip" = 0: the update kernel forms exp() for every sample (same-box A/B)
     bool use_pk = true;             // option "rollout_pk" = 0: keep the all-fp64 rollout kernel on the tick path (same-box A/B measurements)
     double* d_tc = nullptr;  // [A][T][8]
@@ -449,6 +450,9 @@ struct mppi_engine {
         // co-scheduled handle fill each other's gaps and keep the plain size rule (measured: 138-139 us against 142-145 per tick);
         // so does an engine whose option "pk_min_samples" is set (tests, A/B runs).  (pick_pk)
         const bool pk = pick_pk(ph, store, k0, k1);
+        if (noise_pack && ph && !pk)
+            fail(MPPI_E_INVALID, "noise_packing 1 is drawn by the mixed-precision rollout only: all samples of an fp32-storage engine, noise not stored "
+                                 "(option store_eps 0), the node's cost (Q = diag(q, q, 0), no obstacle grid), rk4 / diff drive, T <= 256 with sigma small enough for its series");
         last_rollout_pk = pk;
         last_rollout_kind = pk ? MPPI_ROLLOUT_MIXED : MPPI_ROLLOUT_FP64;
         if (pk) {
@@ -457,7 +461,7 @@ struct mppi_engine {
             b.state = a.state; b.goal = a.goal; b.unom = a.unom; b.tc = d_tc; b.base = d_base;
             b.dP = static_cast<float*>(d_dP); b.stot = static_cast<float*>(d_stot); b.epart = static_cast<float*>(d_epart);
             b.al_guard = mppi::rollout_pk_guard(P.kth, P.dt, P.sigma);
-            b.waves = pk_waves;
+            b.waves = pk_waves; b.noise_pack = noise_pack;
             b.ev_start = a.ev_start; b.ev_stop = a.ev_stop;
             e = mppi::launch_rollout_pk(b);
         } else
@@ -536,8 +540,10 @@ struct mppi_engine {
         inputs_consumed();
     }
     void launch_regen(hipStream_t st, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
-        dim3 g((cfg.samples + 255) / 256, (cfg.horizon + mppi::kStepsPerDraw - 1) / mppi::kStepsPerDraw, cfg.n_agents);
+        const int spd = noise_pack ? mppi::NoisePack<1>::kSteps : mppi::NoisePack<0>::kSteps;
+        dim3 g((cfg.samples + 255) / 256, (cfg.horizon + spd - 1) / spd, cfg.n_agents);
         if (f64()) hipLaunchKernelGGL(mppi::eps_regen_kernel<double>, g, dim3(256), 0, st, P, static_cast<double*>(d_eps), seed, tick, tick_ptr);
+        else if (noise_pack) hipLaunchKernelGGL((mppi::eps_regen_kernel<float, 1>), g, dim3(256), 0, st, P, static_cast<float*>(d_eps), seed, tick, tick_ptr);
         else hipLaunchKernelGGL(mppi::eps_regen_kernel<float>, g, dim3(256), 0, st, P, static_cast<float*>(d_eps), seed, tick, tick_ptr);
         HIPCHK(hipGetLastError());
     }
@@ -558,6 +564,10 @@ struct mppi_engine {
                        static_cast<const TYPE*>(d_dP), static_cast<const TYPE*>(d_stot), d_part, NCH, ch0, nch,    \
                        static_cast<const TYPE*>(d_epart), lazy_seed, lazy_tick, tick_ptr, upd_skip_light)
         if (f64()) { if (eps_lazy) LAUNCH_UPD(double, true); else LAUNCH_UPD(double, false); }
+        else if (eps_lazy && noise_pack)
+            hipLaunchKernelGGL((mppi::update_kernel<float, true, 1>), grid, dim3(256), 0, st, P, static_cast<const float*>(d_eps),
+                               static_cast<const float*>(d_dP), static_cast<const float*>(d_stot), d_part, NCH, ch0, nch,
+                               static_cast<const float*>(d_epart), lazy_seed, lazy_tick, tick_ptr, upd_skip_light);
         else { if (eps_lazy) LAUNCH_UPD(float, true); else LAUNCH_UPD(float, false); }
 #undef LAUNCH_UPD
         HIPCHK(hipGetLastError());
@@ -581,14 +591,15 @@ struct mppi_engine {
     // which of the two lane-per-sample rollouts a device-noise tick of this engine takes (see launch_rollout)
     bool pick_pk(bool ph, bool store, int k0, int k1) const {
         bool pk_size;
-        if (force_pk >= 0) pk_size = force_pk != 0;
+        if (noise_pack) pk_size = true;   // (the only kernel that draws that stream)
+        else if (force_pk >= 0) pk_size = force_pk != 0;
         else if (pk_min_set || co_active() || is_co_sub) pk_size = (long)cfg.n_agents * cfg.samples >= pk_min_samples;
         else {
             const long r_pk = ((long)cfg.n_agents * ((cfg.samples + 511) / 512) + 255) / 256;
             const long r_64 = ((long)cfg.n_agents * ((cfg.samples + 255) / 256) + 255) / 256;
             pk_size = r_pk >= 3 && 19 * r_pk < 10 * r_64;
         }
-        return use_pk && !f64() && ph && !store && inline_nominal() && !general_cost() && k0 == 0 && k1 == cfg.samples && pk_size &&
+        return (use_pk || noise_pack) && !f64() && ph && !store && inline_nominal() && !general_cost() && k0 == 0 && k1 == cfg.samples && pk_size &&
                mppi::rollout_pk_applies(P.kth, P.dt, P.sigma, cfg.horizon);
     }
     // rollout + update + merge of one tick
@@ -636,7 +647,10 @@ struct mppi_engine {
     }
     void run_rollout(int noise_mode, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
         check_noise_mode(noise_mode);
-        launch_rollout(stream, 0, cfg.samples, noise_mode == MPPI_NOISE_PHILOX, true, seed, tick, tick_ptr);
+        const bool ph = noise_mode == MPPI_NOISE_PHILOX;
+        // (the 16-bit packing is drawn by the mixed-precision kernel, which does not store its noise: the re-draw kernel leaves the same bits in d_eps)
+        launch_rollout(stream, 0, cfg.samples, ph, !(ph && noise_pack), seed, tick, tick_ptr);
+        if (ph && noise_pack) launch_regen(stream, seed, tick, tick_ptr);
         eps_lazy = false; injected_ready = true;
         noise_ready = true; value_ready = true; value_lazy = false; partials_ready = false; epart_ready = true;
     }
@@ -968,7 +982,7 @@ void mppi_engine::co_build() {
             wait_stream("co-scheduled shard set-up");
             e->sync_timeout_ms = sync_timeout_ms;
             e->store_eps_always = store_eps_always; e->use_pk = use_pk; e->upd_skip_light = upd_skip_light; e->pk_waves = pk_waves;
-            e->pk_min_set = pk_min_set; e->pk_min_samples = pk_min_samples;
+            e->pk_min_set = pk_min_set; e->pk_min_samples = pk_min_samples; e->noise_pack = noise_pack;
         }
         std::vector<void*> ptrs(G, nullptr);
         std::vector<mppi_engine*> all{this};
@@ -1705,6 +1719,12 @@ int mppi_set_option(mppi_engine* h, const char* key, int64_t value) {
     if (k == "store_eps") { h->settle_lazy_state(); h->store_eps_always = value != 0; h->destroy_graph(); }
     else if (k == "rollout_pk") { h->settle_lazy_state(); h->use_pk = value != 0; h->destroy_graph(); }
     else if (k == "upd_skip") h->upd_skip_light = value != 0;
+    else if (k == "noise_packing") {
+        if (value != 0 && value != 1) fail(MPPI_E_INVALID, "noise_packing: 0 (three steps per Philox call, the default stream) or 1 (four)");
+        if (value && (h->f64() || h->small_nb > 0 || !h->inline_nominal()))
+            fail(MPPI_E_INVALID, "noise_packing 1 is drawn by the mixed-precision rollout only: fp32 storage, the lane kernels (tick_path lanes), rk4 / diff drive, T <= 256");
+        h->settle_lazy_state(); h->noise_pack = (int)value; h->destroy_graph();
+    }
     else if (k == "pk_waves") { if (value != 4 && value != 5) fail(MPPI_E_INVALID, "pk_waves: 4 or 5"); h->pk_waves = (int)value; }
     else if (k == "pk_min_samples") { h->settle_lazy_state(); h->pk_min_set = value >= 0; h->pk_min_samples = value >= 0 ? (long)value : 400000; h->destroy_graph(); }
     else if (k == "co_cut_pct") {
@@ -1723,6 +1743,7 @@ int mppi_set_option(mppi_engine* h, const char* key, int64_t value) {
             for (auto* e : h->subs) {   // the new shards take over this handle's switches
                 e->store_eps_always = h->store_eps_always; e->use_pk = h->use_pk; e->upd_skip_light = h->upd_skip_light; e->pk_waves = h->pk_waves;
                 e->pk_min_set = h->pk_min_set; e->pk_min_samples = h->pk_min_samples; e->sync_timeout_ms = h->sync_timeout_ms;
+                e->noise_pack = h->noise_pack;
             }
         }
     }
@@ -1737,6 +1758,7 @@ int mppi_get_option(mppi_engine* h, const char* key, int64_t* value) {
     if (k == "store_eps") *value = h->store_eps_always;
     else if (k == "rollout_pk") *value = h->use_pk;
     else if (k == "upd_skip") *value = h->upd_skip_light;
+    else if (k == "noise_packing") *value = h->noise_pack;
     else if (k == "pk_waves") *value = h->pk_waves;
     else if (k == "pk_min_samples") *value = h->pk_min_set ? h->pk_min_samples : -1;
     else if (k == "co_cut_pct") *value = h->co_cut_pct;

@@ -608,31 +608,62 @@ __device__ __forceinline__ void box_muller(uint32_t a21, uint32_t ang_mant, floa
     e1 = cs.y;
 }
 
-// The noise of global sample `gk`, agent a, steps 3*triple .. 3*triple+2: e[2j], e[2j+1] = (eps0, eps1)
-// of step 3*triple + j.  One Philox call = 128 bits = three pairs of 21-bit uniforms (the top 21 bits of
-// the four words, plus the 2 x 21 bits assembled from their low 11): 1/3 call per step instead of 1/2.
-constexpr int kStepsPerDraw = 3;
-__device__ __forceinline__ void philox_normals(uint32_t gk, uint32_t triple, uint32_t tick, uint32_t a, uint32_t key0,
-                                               uint32_t key1, float sigf, float (&e)[6]) {
-    uint32_t o[4];
-    philox4x32_10(gk, triple, tick, a, key0, key1, o);
-    const float nscale = -1.3862943611198906f * (sigf * sigf);
-    box_muller(o[0] >> 11, (o[1] >> 9) & 0x7FFFFCu, nscale, e[0], e[1]);
-    box_muller(o[2] >> 11, (o[3] >> 9) & 0x7FFFFCu, nscale, e[2], e[3]);
-    box_muller(((o[0] & 0x7FFu) << 10) | ((o[1] & 0x7FFu) >> 1), ((o[2] & 0x7FFu) << 12) | ((o[3] & 0x7FEu) << 1),
-               nscale, e[4], e[5]);
+// The same from ONE word: its low 16 bits the radius uniform u1 = (a + 1/2) / 2^16 (radius <= 4.85 sigma), its high 16
+// bits the angle (65 536 directions) -- the 16-bit packing of option "noise_packing" = 1.
+__device__ __forceinline__ void box_muller16(uint32_t w, float nscale, float& e0, float& e1) {
+    const float u1 = __builtin_fmaf((float)(w & 0xFFFFu), 1.0f / 65536.0f, 1.0f / 131072.0f);
+    const float rev = __uint_as_float(0x3F800000u | ((w >> 9) & 0x7FFF80u));
+    const float r = __builtin_amdgcn_sqrtf(nscale * __builtin_amdgcn_logf(u1));
+    float2v cs = {__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev)};
+    cs *= r;
+    e0 = cs.x;
+    e1 = cs.y;
 }
 
-// the same stream addressed by (sample, t): only step t's pair of its draw's three
+// How the 128 bits of one Philox call become normals (option "noise_packing", PACK):
+//   0  the default stream: THREE steps per call -- three pairs of 21-bit uniforms (the top 21 bits of the four words, plus the
+//      2 x 21 bits assembled from their low 11): 1/3 call per step instead of 1/2;
+//   1  FOUR steps per call: word j serves step 4 * draw + j (box_muller16).  A quarter fewer calls and no splicing:
+//      the mixed-precision rollout runs 6 % shorter with it (same box, 102.0 -> 96.0 us at 10^6 x 50).  Its price is the
+//      distribution's resolution (tails cut at 4.85 sigma instead of 5.53), which is why it is an option and not the default;
+//      served where the mixed-precision rollout is (fp32 storage, lane kernels, the node's cost).
+template <int PACK> struct NoisePack { static constexpr int kSteps = PACK ? 4 : 3; };
+constexpr int kStepsPerDraw = NoisePack<0>::kSteps;
+// The noise of global sample `gk`, agent a, steps kSteps * draw .. kSteps * draw + kSteps - 1: e[2j], e[2j+1] = (eps0, eps1)
+// of step kSteps * draw + j.
+template <int PACK = 0>
+__device__ __forceinline__ void philox_normals(uint32_t gk, uint32_t draw, uint32_t tick, uint32_t a, uint32_t key0,
+                                               uint32_t key1, float sigf, float (&e)[2 * NoisePack<PACK>::kSteps]) {
+    uint32_t o[4];
+    philox4x32_10(gk, draw, tick, a, key0, key1, o);
+    const float nscale = -1.3862943611198906f * (sigf * sigf);
+    if constexpr (PACK == 0) {
+        box_muller(o[0] >> 11, (o[1] >> 9) & 0x7FFFFCu, nscale, e[0], e[1]);
+        box_muller(o[2] >> 11, (o[3] >> 9) & 0x7FFFFCu, nscale, e[2], e[3]);
+        box_muller(((o[0] & 0x7FFu) << 10) | ((o[1] & 0x7FFu) >> 1), ((o[2] & 0x7FFu) << 12) | ((o[3] & 0x7FEu) << 1),
+                   nscale, e[4], e[5]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) box_muller16(o[j], nscale, e[2 * j], e[2 * j + 1]);
+    }
+}
+
+// the same stream addressed by (sample, t): only step t's pair of its draw's three (four)
+template <int PACK = 0>
 __device__ __forceinline__ void philox_normal_pair(uint32_t gk, uint32_t t, uint32_t tick, uint32_t a, uint32_t key0,
                                                    uint32_t key1, float sigf, float& e0, float& e1) {
+    constexpr uint32_t kS = NoisePack<PACK>::kSteps;
     uint32_t o[4];
-    philox4x32_10(gk, t / kStepsPerDraw, tick, a, key0, key1, o);
-    const uint32_t j = t % kStepsPerDraw;
-    const uint32_t a21 = j == 0 ? o[0] >> 11 : (j == 1 ? o[2] >> 11 : ((o[0] & 0x7FFu) << 10) | ((o[1] & 0x7FFu) >> 1));
-    const uint32_t mant = j == 0 ? (o[1] >> 9) & 0x7FFFFCu
-                                 : (j == 1 ? (o[3] >> 9) & 0x7FFFFCu : ((o[2] & 0x7FFu) << 12) | ((o[3] & 0x7FEu) << 1));
-    box_muller(a21, mant, -1.3862943611198906f * (sigf * sigf), e0, e1);
+    philox4x32_10(gk, t / kS, tick, a, key0, key1, o);
+    const uint32_t j = t % kS;
+    if constexpr (PACK == 0) {
+        const uint32_t a21 = j == 0 ? o[0] >> 11 : (j == 1 ? o[2] >> 11 : ((o[0] & 0x7FFu) << 10) | ((o[1] & 0x7FFu) >> 1));
+        const uint32_t mant = j == 0 ? (o[1] >> 9) & 0x7FFFFCu
+                                     : (j == 1 ? (o[3] >> 9) & 0x7FFFFCu : ((o[2] & 0x7FFu) << 12) | ((o[3] & 0x7FEu) << 1));
+        box_muller(a21, mant, -1.3862943611198906f * (sigf * sigf), e0, e1);
+    } else {
+        box_muller16(j == 0 ? o[0] : (j == 1 ? o[1] : (j == 2 ? o[2] : o[3])), -1.3862943611198906f * (sigf * sigf), e0, e1);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1006,7 +1037,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(S) =
 constexpr int kUpdNV = 8;  // 16-byte vectors per lane: chunk = 256 * kUpdNV * (16 / sizeof(S)) samples
 template <typename S> struct UpdCfg { static constexpr int VEC = 16 / (int)sizeof(S); static constexpr int CH = 256 * kUpdNV * VEC; };
 
-template <typename S, bool REGEN>
+template <typename S, bool REGEN, int PACK = 0>
 // (fp64 storage: 70 VGPRs, seven blocks per CU.  Forcing 64 VGPRs for an eighth block spilled five registers and measured SLOWER on
 // the same box: update 110-117 us against 95-103, tick 0.233-0.239 ms against 0.221-0.225 -- the registers decide.)
 __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __restrict__ eps,
@@ -1106,7 +1137,7 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
     const uint32_t tick_now = REGEN ? (tick_ptr ? *tick_ptr : tick_arg) : 0u;
     auto redraw = [&](uint32_t kk, R e) {
         float f0, f1;  // the same Philox counter the rollout used for this (sample, step)
-        philox_normal_pair(P.sample_offset + kk, (uint32_t)t, tick_now, P.agent_offset + (uint32_t)a, (uint32_t)seed, (uint32_t)(seed >> 32),
+        philox_normal_pair<PACK>(P.sample_offset + kk, (uint32_t)t, tick_now, P.agent_offset + (uint32_t)a, (uint32_t)seed, (uint32_t)(seed >> 32),
                            (float)P.sigma, f0, f1);
         Na0 = fma((double)e, (double)(S)f0, Na0);   // exact products, fp64 sums: independent of how the queue orders them
         Na1 = fma((double)e, (double)(S)f1, Na1);
@@ -1196,20 +1227,21 @@ __global__ __launch_bounds__(256) void eps_wavesum_kernel(DevParams P, const S* 
 // The device noise as a kernel of its own, one lane per (sample, step pair): materialises the
 // noise of a rollout that did not store it (mppi_download_noise, or a separate mppi_update after a
 // tick).  (Drawing the noise first and rolling out on the stored eps was tried as a small-K tick
-// path: slower than the fused rollout at every K from 1e4 to 5e5.)   grid = (ceil(K/256), ceil(T/3), A)
-template <typename S>
+// path: slower than the fused rollout at every K from 1e4 to 5e5.)   grid = (ceil(K/256), ceil(T / steps per draw), A)
+template <typename S, int PACK = 0>
 __global__ __launch_bounds__(256) void eps_regen_kernel(DevParams P, S* __restrict__ eps, uint64_t seed, uint32_t tick_arg,
                                                        const uint32_t* __restrict__ tick_ptr) {
+    constexpr int kS = NoisePack<PACK>::kSteps;
     const int k = blockIdx.x * 256 + threadIdx.x, triple = blockIdx.y, a = blockIdx.z;
     if (k >= P.K) return;
     const uint32_t tick = tick_ptr ? *tick_ptr : tick_arg;
-    float e[6];
-    philox_normals(P.sample_offset + (uint32_t)k, (uint32_t)triple, tick, P.agent_offset + (uint32_t)a, (uint32_t)seed,
-                   (uint32_t)(seed >> 32), (float)P.sigma, e);
+    float e[2 * kS];
+    philox_normals<PACK>(P.sample_offset + (uint32_t)k, (uint32_t)triple, tick, P.agent_offset + (uint32_t)a, (uint32_t)seed,
+                         (uint32_t)(seed >> 32), (float)P.sigma, e);
     const size_t Ks = (size_t)P.Ks;
 #pragma unroll
-    for (int i = 0; i < kStepsPerDraw; ++i) {
-        const int t = kStepsPerDraw * triple + i;
+    for (int i = 0; i < kS; ++i) {
+        const int t = kS * triple + i;
         if (t < P.T) {
             S* row = eps + (((size_t)a * P.T + t) * 2) * Ks + k;
             row[0] = (S)e[2 * i]; row[Ks] = (S)e[2 * i + 1];

@@ -60,6 +60,7 @@ struct RolloutPkArgs {
     float *dP, *stot, *epart;
     float al_guard;
     int waves;            // 4: the compiler's own allocation (no spills); 5: one more wave per SIMD at the price of a few spills
+    int noise_pack;       // option "noise_packing": 0 three steps per Philox call (the default stream), 1 four (NoisePack, mppi_kernels.hpp)
     hipEvent_t ev_start, ev_stop;
 };
 hipError_t launch_rollout_pk(const RolloutPkArgs& a);
@@ -78,7 +79,7 @@ __device__ __forceinline__ f2 pk_med3(f2 v, float lo, float hi) {
     return f2{__builtin_amdgcn_fmed3f(v.x, lo, hi), __builtin_amdgcn_fmed3f(v.y, lo, hi)};
 }
 
-template <int INLINE_NOM, int WAVES>
+template <int INLINE_NOM, int WAVES, int PACK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void rollout_pk_kernel(DevParams P, const double* __restrict__ state,
                                                         const double* __restrict__ goal, double* __restrict__ tc,
                                                         float* __restrict__ dP, float* __restrict__ Stot, uint64_t seed,
@@ -143,9 +144,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
     const uint32_t tick = tick_ptr ? *tick_ptr : tick_arg;
     const float sigf = (float)P.sigma;
 
-    constexpr int U = 6;  // steps per chunk = two Philox draws per sample (wave_sum16 carries the 12 eps sums)
-    float nz[U][4];       // the chunk's noise: [step]{wheel 0 of kA, wheel 0 of kA + 1, wheel 1 of kA, wheel 1 of kA + 1}
-    float tz[kStepsPerDraw][4];
+    constexpr int SPD = NoisePack<PACK>::kSteps;   // steps per Philox draw: 3 (the default stream) | 4 (16-bit packing)
+    constexpr int U = 2 * SPD;  // steps per chunk = two Philox draws per sample (wave_sum16 carries the chunk's 12 | 16 eps sums)
+    float nz[U][4];             // the chunk's noise: [step]{wheel 0 of kA, wheel 0 of kA + 1, wheel 1 of kA, wheel 1 of kA + 1}
+    float tz[SPD][4];
     double th[2] = {0.0, 0.0}, dX[2] = {0.0, 0.0}, dY[2] = {0.0, 0.0}, pre[2] = {0.0, 0.0};
     f2 thf = {0.f, 0.f};  // (float)th at the start of the step
 
@@ -153,31 +155,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
     // is bit-identical to what the update kernel's re-draw and mppi_download_noise produce): the exactly rounded steps run
     // packed and the results land as (kA, kA + 1) pairs -- no register shuffling between the draw and the packed dynamics
     const float nscale = -1.3862943611198906f * (sigf * sigf);
+    constexpr float kU1 = PACK ? 1.0f / 65536.0f : 1.0f / 2097152.0f;   // (box_muller | box_muller16)
     auto bm2 = [&](uint32_t a21a, uint32_t manta, uint32_t a21b, uint32_t mantb, f2& w0, f2& w1) __attribute__((always_inline)) {
-        const f2 u1 = pk_fma(f2{(float)a21a, (float)a21b}, f2{1.0f / 2097152.0f, 1.0f / 2097152.0f}, f2{1.0f / 4194304.0f, 1.0f / 4194304.0f});
+        const f2 u1 = pk_fma(f2{(float)a21a, (float)a21b}, f2{kU1, kU1}, f2{0.5f * kU1, 0.5f * kU1});
         const f2 lg = f2{__builtin_amdgcn_logf(u1.x), __builtin_amdgcn_logf(u1.y)} * f2{nscale, nscale};
         const f2 r = f2{__builtin_amdgcn_sqrtf(lg.x), __builtin_amdgcn_sqrtf(lg.y)};
         const float ra = __uint_as_float(0x3F800000u | manta), rb = __uint_as_float(0x3F800000u | mantb);
         w0 = f2{__builtin_amdgcn_cosf(ra), __builtin_amdgcn_cosf(rb)} * r;
         w1 = f2{__builtin_amdgcn_sinf(ra), __builtin_amdgcn_sinf(rb)} * r;
     };
-    // the noise of steps 3 * triple .. 3 * triple + 2 of both samples (philox_normals for two counters)
-    auto draw3 = [&](uint32_t triple, f2 (&w0)[kStepsPerDraw], f2 (&w1)[kStepsPerDraw]) __attribute__((always_inline)) {
+    // the noise of steps SPD * d .. SPD * d + SPD - 1 of both samples (philox_normals<PACK> for two counters)
+    auto draw3 = [&](uint32_t d, f2 (&w0)[SPD], f2 (&w1)[SPD]) __attribute__((always_inline)) {
         uint32_t oa[4], ob[4];
-        philox4x32_10(ctrA, triple, tick, P.agent_offset + (uint32_t)a, key0, key1, oa);
-        philox4x32_10(ctrA + 1u, triple, tick, P.agent_offset + (uint32_t)a, key0, key1, ob);
-        bm2(oa[0] >> 11, (oa[1] >> 9) & 0x7FFFFCu, ob[0] >> 11, (ob[1] >> 9) & 0x7FFFFCu, w0[0], w1[0]);
-        bm2(oa[2] >> 11, (oa[3] >> 9) & 0x7FFFFCu, ob[2] >> 11, (ob[3] >> 9) & 0x7FFFFCu, w0[1], w1[1]);
-        bm2(((oa[0] & 0x7FFu) << 10) | ((oa[1] & 0x7FFu) >> 1), ((oa[2] & 0x7FFu) << 12) | ((oa[3] & 0x7FEu) << 1),
-            ((ob[0] & 0x7FFu) << 10) | ((ob[1] & 0x7FFu) >> 1), ((ob[2] & 0x7FFu) << 12) | ((ob[3] & 0x7FEu) << 1), w0[2], w1[2]);
+        philox4x32_10(ctrA, d, tick, P.agent_offset + (uint32_t)a, key0, key1, oa);
+        philox4x32_10(ctrA + 1u, d, tick, P.agent_offset + (uint32_t)a, key0, key1, ob);
+        if constexpr (PACK == 0) {
+            bm2(oa[0] >> 11, (oa[1] >> 9) & 0x7FFFFCu, ob[0] >> 11, (ob[1] >> 9) & 0x7FFFFCu, w0[0], w1[0]);
+            bm2(oa[2] >> 11, (oa[3] >> 9) & 0x7FFFFCu, ob[2] >> 11, (ob[3] >> 9) & 0x7FFFFCu, w0[1], w1[1]);
+            bm2(((oa[0] & 0x7FFu) << 10) | ((oa[1] & 0x7FFu) >> 1), ((oa[2] & 0x7FFu) << 12) | ((oa[3] & 0x7FEu) << 1),
+                ((ob[0] & 0x7FFu) << 10) | ((ob[1] & 0x7FFu) >> 1), ((ob[2] & 0x7FFu) << 12) | ((ob[3] & 0x7FEu) << 1), w0[2], w1[2]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bm2(oa[i] & 0xFFFFu, (oa[i] >> 9) & 0x7FFF80u, ob[i] & 0xFFFFu, (ob[i] >> 9) & 0x7FFF80u, w0[i], w1[i]);
+        }
     };
-    auto draw = [&](int t0) __attribute__((always_inline)) {
+    // (nsteps < U, uniform: the ragged tail only makes the draws its steps need)
+    auto draw = [&](int t0, int nsteps) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < U; j += kStepsPerDraw) {
-            f2 w0[kStepsPerDraw], w1[kStepsPerDraw];
-            draw3((uint32_t)((t0 + j) / kStepsPerDraw), w0, w1);
+        for (int j = 0; j < U; j += SPD) {
+            f2 w0[SPD], w1[SPD];
+            if (j < nsteps) draw3((uint32_t)((t0 + j) / SPD), w0, w1);
+            else {
 #pragma unroll
-            for (int i = 0; i < kStepsPerDraw; ++i) { nz[j + i][0] = w0[i].x; nz[j + i][1] = w0[i].y; nz[j + i][2] = w1[i].x; nz[j + i][3] = w1[i].y; }
+                for (int i = 0; i < SPD; ++i) { w0[i] = f2{0.f, 0.f}; w1[i] = f2{0.f, 0.f}; }
+            }
+#pragma unroll
+            for (int i = 0; i < SPD; ++i) { nz[j + i][0] = w0[i].x; nz[j + i][1] = w0[i].y; nz[j + i][2] = w1[i].x; nz[j + i][3] = w1[i].y; }
         }
     };
     // per-wave sums of eps (the E of the softmax floor term, control/src/mppi:193) for the chunk's steps x 2 wheels: the
@@ -193,11 +206,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
             ev[2 * j + 1] = FULL ? nz[j][2] + nz[j][3] : (actA ? nz[j][2] : 0.f) + (actB ? nz[j][3] : 0.f);
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < (U == 6 ? 2 : 0); ++j) {   // (the four spare slots of a 6-step chunk)
             ev[12 + 2 * j] = !EXTRA ? 0.f : (FULL ? tz[j][0] + tz[j][1] : (actA ? tz[j][0] : 0.f) + (actB ? tz[j][1] : 0.f));
             ev[13 + 2 * j] = !EXTRA ? 0.f : (FULL ? tz[j][2] + tz[j][3] : (actA ? tz[j][2] : 0.f) + (actB ? tz[j][3] : 0.f));
         }
-        const float tot = wave_sum16<EXTRA>(ev, lane);
+        const float tot = wave_sum16<(EXTRA || U == 8)>(ev, lane);   // (an 8-step chunk fills all sixteen slots)
         const int idx = sum16_index(lane), te = t0 + (idx >> 1), half = lane >> 4;
         const size_t slot = (size_t)(kwave >> 6) + half;
         const bool mine = lane < 32 && idx < (EXTRA ? 16 : 2 * U) && te < T && slot < NW;
@@ -279,22 +292,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
     const int T4 = T - T % U;
     // T = 6 n + 1 or 6 n + 2 (the node's 50): the steps behind the last full chunk ride along with it (their draw is made
     // with the chunk's two, their eps sums fill the reduce-scatter's four spare slots)
-    const bool ride = T4 >= U && (T - T4 == 1 || T - T4 == 2);  // (uniform)
+    // (a chunk of 8 steps -- PACK 1 -- fills all sixteen slots: its tail is a chunk of its own)
+    const bool ride = U == 6 && T4 >= U && (T - T4 == 1 || T - T4 == 2);  // (uniform)
     auto run = [&](auto full_tag) __attribute__((always_inline)) {
         const int t_loop = ride ? T4 - U : T4;
         for (int t0 = 0; t0 < t_loop; t0 += U) {
-            draw(t0);
+            draw(t0, U);
             eps_sums(t0, full_tag, std::false_type{});
             chunk(t0, U, full_tag);
         }
         if (ride) {
             const int t0 = T4 - U;
-            draw(t0);
+            draw(t0, U);
             {
-                f2 w0[kStepsPerDraw], w1[kStepsPerDraw];
-                draw3((uint32_t)(T4 / kStepsPerDraw), w0, w1);
+                f2 w0[SPD], w1[SPD];
+                draw3((uint32_t)(T4 / SPD), w0, w1);
 #pragma unroll
-                for (int i = 0; i < kStepsPerDraw; ++i) {  // steps at or beyond T carry no noise (they are never integrated)
+                for (int i = 0; i < SPD; ++i) {  // steps at or beyond T carry no noise (they are never integrated)
                     const bool in = T4 + i < T;
                     tz[i][0] = in ? w0[i].x : 0.f; tz[i][1] = in ? w0[i].y : 0.f;
                     tz[i][2] = in ? w1[i].x : 0.f; tz[i][3] = in ? w1[i].y : 0.f;
@@ -303,12 +317,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
             eps_sums(t0, full_tag, std::true_type{});
             chunk(t0, U, full_tag);
 #pragma unroll
-            for (int j = 0; j < kStepsPerDraw; ++j)
+            for (int j = 0; j < SPD; ++j)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) nz[j][c] = tz[j][c];
             chunk(T4, T - T4, full_tag);
         } else if (T4 < T) {  // ragged tail: sums of steps at or beyond T are never stored, their noise is never integrated
-            draw(T4);
+            draw(T4, T - T4);
             eps_sums(T4, full_tag, std::false_type{});
             chunk(T4, T - T4, full_tag);
         }
@@ -342,18 +356,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
 hipError_t launch_rollout_pk(const RolloutPkArgs& a) {
     dim3 grid((a.P.K + 511) / 512, a.P.A);
     const unsigned lds = (unsigned)((size_t)a.P.T * sizeof(PkRow));
-#define MPPI_PK_GO(IN, W)                                                                                                      \
+#define MPPI_PK_GO_(IN, W, PK)                                                                                                    \
     do {                                                                                                                      \
         if (a.ev_start)                                                                                                       \
-            hipExtLaunchKernelGGL((rollout_pk_kernel<IN, W>), grid, dim3(256), lds, a.stream, a.ev_start, a.ev_stop, 0, a.P, a.state, \
+            hipExtLaunchKernelGGL((rollout_pk_kernel<IN, W, PK>), grid, dim3(256), lds, a.stream, a.ev_start, a.ev_stop, 0, a.P, a.state, \
                                   a.goal, a.tc, a.dP, a.stot, a.seed, a.tick, a.tick_ptr, a.epart, a.unom, a.base, a.al_guard); \
         else                                                                                                                  \
-            hipLaunchKernelGGL((rollout_pk_kernel<IN, W>), grid, dim3(256), lds, a.stream, a.P, a.state, a.goal, a.tc, a.dP, a.stot, \
+            hipLaunchKernelGGL((rollout_pk_kernel<IN, W, PK>), grid, dim3(256), lds, a.stream, a.P, a.state, a.goal, a.tc, a.dP, a.stot, \
                                a.seed, a.tick, a.tick_ptr, a.epart, a.unom, a.base, a.al_guard);                              \
     } while (0)
+#define MPPI_PK_GO(IN, W) do { if (a.noise_pack) MPPI_PK_GO_(IN, W, 1); else MPPI_PK_GO_(IN, W, 0); } while (0)
     if (a.waves == 5) { if (a.inline_nominal == 2) MPPI_PK_GO(2, 5); else MPPI_PK_GO(1, 5); }
     else { if (a.inline_nominal == 2) MPPI_PK_GO(2, 4); else MPPI_PK_GO(1, 4); }
 #undef MPPI_PK_GO
+#undef MPPI_PK_GO_
     return hipGetLastError();
 }
 #endif  // MPPI_ROLLOUT_PK_TU

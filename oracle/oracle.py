@@ -193,10 +193,12 @@ def philox4x32_10(ctr, key):
     return [int(x) for x in o]
 
 
-def philox_noise(seed, agent, tick, k_off, K_local, T, sigma):
+def philox_noise(seed, agent, tick, k_off, K_local, T, sigma, packing=0):
+    """The device noise's CPU twin; packing = the engine's option "noise_packing" (0: three steps per Philox call, 1: four)."""
     eps = np.zeros((T, 2, K_local))
-    lib().orc_philox_noise(C.c_uint64(int(seed)), C.c_uint32(int(agent)), C.c_uint32(int(tick)),
-                           C.c_uint32(int(k_off)), int(K_local), int(T), C.c_double(sigma), _p(eps))
+    fn = lib().orc_philox_noise16 if packing else lib().orc_philox_noise
+    fn(C.c_uint64(int(seed)), C.c_uint32(int(agent)), C.c_uint32(int(tick)),
+       C.c_uint32(int(k_off)), int(K_local), int(T), C.c_double(sigma), _p(eps))
     return eps
 
 

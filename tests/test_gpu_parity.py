@@ -1000,6 +1000,98 @@ def test_mixed_precision_rollout_at_small_sizes(orc, monkeypatch, tick_path, K, 
     print("mixed kernel K=%d T=%d %s: %s" % (K, T, scene, m))
 
 
+PK16 = [(1, 26), (513, 27), (1025, 28), (777, 29), (300, 30), (2049, 31), (640, 32), (515, 33), (900, 50), (1100, 100), (300, 255), (515, 256)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene", ["under_way", "parked"])
+@pytest.mark.parametrize("K,T", PK16)
+def test_noise_packing_16bit_against_its_twin_and_the_oracle(orc, tick_path, K, T, scene):
+    """Option "noise_packing" = 1 (round 4): one Philox call serves FOUR steps, 16 + 16 bits each, drawn by the mixed-precision
+    rollout in chunks of eight steps.  Every horizon class mod 8 (26 ... 33), the node's 50, the longest the kernel serves; one
+    sample, odd K, K around the 512-sample block.  (a) the noise the tick drew (mppi_download_noise: the re-draw kernel) is the
+    CPU twin's 16-bit stream -- same Philox words, Box-Muller to fp32 rounding -- and not the default stream; (b) the tick
+    replayed IN FULL on the oracle on that noise: V per sample, du, applied controls, next state -- which also ties the
+    rollout's own draws and the update kernel's re-draws (both on the tick's path) to the downloaded noise."""
+    if tick_path == "scan":
+        pytest.skip("a lane-kernel option")
+    if scene == "under_way":
+        u0 = np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
+        state, goal = [0.0, 0.0, 0.2], [0.4, -0.3, 0.0]
+    else:
+        u0 = np.zeros((2, T))
+        state, goal = [0.3, 0.1, -0.4], [0.3, 0.1, -0.4]
+    seed, tick = 5, 9
+    with _engine(K, T, "f32", tick_path="lanes", options={"noise_packing": 1}) as e:
+        assert e.get_option("noise_packing") == 1
+        e.set_nominal(u0)
+        nxt, ua = e.tick(state, goal, noise="philox", seed=seed, tick_id=tick)
+        assert e.info()["rollout_kernel"] == "mixed"      # whatever the size: the only kernel that draws this stream
+        V = e.download_value()[0]
+        eps = e.download_noise()[0]
+        lat = e.get_nominal()
+    twin = orc.philox_noise(seed, 0, tick, 0, K, T, SIG, packing=1)
+    assert np.abs(eps - twin).max() < 2e-6
+    assert np.abs(eps).max() <= 4.86 * SIG * 1.0000001            # the 16-bit radius
+    assert np.abs(eps - orc.philox_noise(seed, 0, tick, 0, K, T, SIG)).max() > 0.1
+    m = _replay_full(orc, V, eps, nxt[0], ua[0], lat, state, goal, u0, T, "f32")
+    print("16-bit packing K=%d T=%d %s: %s" % (K, T, scene, m))
+
+
+@pytest.mark.gpu
+def test_noise_packing_16bit_full_size_shards_and_refusals(orc, tick_path):
+    """The 16-bit packing at config 4's size on the co-scheduled handle and on one engine (equal to the split-invariance
+    bound, the same noise bit for bit, the noise shard-invariant: sample ids are global), switched on a live handle, and
+    refused -- MPPI_E_INVALID, the handle left usable -- wherever the mixed-precision rollout cannot serve it."""
+    if tick_path == "scan":
+        pytest.skip("a lane-kernel option")
+    from motion_planning_amd._capi import MppiError
+    K, T = 1000000, 50
+    u0 = np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
+    outs = {}
+    for co in (1, None):
+        with _engine(K, T, "f32", tick_path="lanes", co_shards=co) as e:
+            e.set_nominal(u0)
+            s0, a0 = e.tick([0, 0, 0], [0, -1, 0], noise="philox", seed=3, tick_id=0)     # the default stream first
+            e.set_option("noise_packing", 1)
+            e.set_nominal(u0)
+            s1, a1 = e.tick([0, 0, 0], [0, -1, 0], noise="philox", seed=3, tick_id=0)
+            s2, a2 = e.tick(None, None, noise="philox", seed=3, tick_id=1)
+            assert e.info()["co_shards"] == (1 if co == 1 else 2)
+            eps = e.download_noise()[0][:, :, ::4099]
+            outs[co] = (np.concatenate([s1[0], a1[0], s2[0], a2[0]]), eps, np.concatenate([s0[0], a0[0]]))
+    assert np.abs(outs[1][0] - outs[None][0]).max() < 1e-9
+    assert np.array_equal(outs[1][1], outs[None][1])
+    assert np.abs(outs[1][0][:5] - outs[1][2]).max() > 1e-6          # another stream, another tick
+    twin = orc.philox_noise(3, 0, 1, 0, K, T, SIG, packing=1)[:, :, ::4099]
+    assert np.abs(outs[1][1] - twin).max() < 2e-6
+    # a shard draws what the whole engine draws for its samples
+    with _engine(3000, T, "f32", tick_path="lanes", sample_offset=7000, options={"noise_packing": 1}) as e:
+        e.rollout([0, 0, 0], [0, -1, 0], noise="philox", seed=3, tick_id=1)
+        part = e.download_noise()[0]
+    assert np.abs(part - orc.philox_noise(3, 0, 1, 7000, 3000, T, SIG, packing=1)).max() < 2e-6
+    # refusals
+    for kw in (dict(storage="f64"), dict(tick_path="scan"), dict(T=257), dict(model="euler")):
+        kw = dict(kw)
+        st, Tk = kw.pop("storage", "f32"), kw.pop("T", 50)
+        kw.setdefault("tick_path", "lanes")
+        with _engine(600, Tk, st, **kw) as e:
+            with pytest.raises(MppiError):
+                e.set_option("noise_packing", 1)
+            assert e.get_option("noise_packing") == 0
+            e.tick([0.0, 0.0, 0.0], [0.3, 0.2, 0.0], noise="philox", seed=1, tick_id=0)
+    for kw, opt in ((dict(q=(1e3, 1e3, 5.0)), {}), ({}, {"store_eps": 1}), (dict(T=20), {})):   # refused by the tick that would need another kernel
+        kw = dict(kw)
+        Tk = kw.pop("T", 50)
+        with _engine(600, Tk, "f32", tick_path="lanes", options=dict(opt, noise_packing=1), **kw) as e:
+            with pytest.raises(MppiError) as err:
+                e.tick([0.0, 0.0, 0.0], [0.3, 0.2, 0.0], noise="philox", seed=1, tick_id=0)
+            assert "noise_packing" in str(err.value)
+            e.set_option("noise_packing", 0)
+            e.tick([0.0, 0.0, 0.0], [0.3, 0.2, 0.0], noise="philox", seed=1, tick_id=0)
+            assert e.info()["rollout_kernel"] == "fp64"
+
+
 def test_the_mixed_rollout_hands_over_where_it_does_not_apply(monkeypatch, tick_path):
     """Beyond T = 256 (no inline nominal rollout), below T = 26 (steps too long for its series), in fp64 storage, with the heading weight or the euler model the tick runs
     the all-fp64 kernel even when the size rule says mixed; the small-K path reports the scan kernel."""
