@@ -575,7 +575,7 @@ def main():
                 ep.set_nominal(nominal_warm(T))
                 ep.tick_async(np.zeros((1, 3)), np.array([goal]), "philox", 0, 0)
                 t_w, i = time.perf_counter(), 1
-                while time.perf_counter() - t_w < 0.3 or i < 20:
+                while time.perf_counter() - t_w < args.min_warmup_s or i < args.warmup:   # (the headline's own protocol)
                     ep.tick_async(None, None, "philox", 0, i)
                     i += 1
                     if i % 16 == 0:
@@ -586,11 +586,11 @@ def main():
                     ep.kernel_timing(("rollout",), period=4)
                 ep.synchronize()
                 t0 = time.perf_counter()
-                for j in range(100):
+                for j in range(args.steps):
                     ep.tick_async(None, None, "philox", 0, 1_000_001 + j)
                 ep.synchronize()
                 elq = time.perf_counter() - t0
-                pack_line[name] = {"ms_per_step": 1e3 * elq / 100, "value": K_total / (elq / 100), "steps": 100}
+                pack_line[name] = {"ms_per_step": 1e3 * elq / args.steps, "value": K_total / (elq / args.steps), "steps": args.steps}
                 if co == 1:
                     kq = ep.kernel_times()
                     pack_line[name]["rollout_us"] = kq["rollout"][0] * 1e3 / max(kq["rollout"][1], 1)

@@ -315,9 +315,14 @@ int mppi_synchronize(mppi_engine *h);
  *   "noise_packing"   0 (default): one Philox4x32-10 call serves three steps (2 x 21-bit uniforms per step: Box-Muller radius
  *                     <= 5.53 sigma, 2^21 directions); 1: four steps (word j of call t / 4 serves step t: its low 16 bits the radius
  *                     uniform, radius <= 4.85 sigma, its high 16 bits the direction) -- a quarter fewer calls, the mixed-precision
- *                     rollout 6 % shorter.  Drawn by that kernel only: fp32 storage, the lane kernels, the node's cost and model,
- *                     noise not stored; MPPI_E_INVALID where it cannot be served (from the option call, or from the tick that
- *                     would need another kernel).  mppi_download_noise, mppi_update and the oracle's twin follow the option.
+ *                     rollout 7 % shorter; 2: hipRAND's own normals -- two steps per call, mppi_download_noise / sigma =
+ *                     hiprand_normal4() of a hiprandStatePhilox4_32_10_t initialised with hiprand_init(seed, agent << 32 | tick,
+ *                     4 * ((t / 2) << 32 | global sample)), bit for bit: values (x, y) step t even, (z, w) step t odd, wheels 0, 1
+ *                     (32-bit uniforms, radius <= 6.66 sigma, the device library's logf / sqrtf: the rollout a third longer).
+ *                     1 and 2 are drawn by the mixed-precision rollout only: fp32 storage, the lane kernels, the node's cost and
+ *                     model (2: T >= 32 at dt = 1 / T and sigma = 0.9); MPPI_E_INVALID where they cannot be served (from the option
+ *                     call, or from the tick that would need another kernel).  mppi_rollout, mppi_download_noise, mppi_update and
+ *                     the oracle's twins follow the option.
  * Unknown keys and out-of-range values return MPPI_E_INVALID.
  */
 int mppi_set_option(mppi_engine *h, const char *key, int64_t value);

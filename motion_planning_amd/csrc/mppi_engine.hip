@@ -113,7 +113,7 @@ struct mppi_engine {
     bool last_rollout_pk = false;  // which kernel the last rollout launch was
     int last_rollout_kind = MPPI_ROLLOUT_NONE;   // ... as mppi_rollout_kernel reports it
     bool co_shards_pk = false;     // ... and the one the shards of the last co-scheduled tick ran
-    int noise_pack = 0;             // option "noise_packing": how a Philox call's bits become normals (mppi::NoisePack): 0 three steps per call, 1 four
+    int noise_pack = 0;             // option "noise_packing": how a Philox call's bits become normals (mppi::NoisePack): 0 three steps per call, 1 four, 2 hipRAND's normals (two)
     int upd_skip_light = 1;         // option "upd_skip" = 0: the update kernel forms exp() for every sample (same-box A/B)
     bool use_pk = true;             // option "rollout_pk" = 0: keep the all-fp64 rollout kernel on the tick path (same-box A/B measurements)
     double* d_tc = nullptr;  // [A][T][8]
@@ -451,7 +451,7 @@ struct mppi_engine {
         // so does an engine whose option "pk_min_samples" is set (tests, A/B runs).  (pick_pk)
         const bool pk = pick_pk(ph, store, k0, k1);
         if (noise_pack && ph && !pk)
-            fail(MPPI_E_INVALID, "noise_packing 1 is drawn by the mixed-precision rollout only: all samples of an fp32-storage engine, noise not stored "
+            fail(MPPI_E_INVALID, "noise_packing 1 / 2 is drawn by the mixed-precision rollout only: all samples of an fp32-storage engine, noise not stored "
                                  "(option store_eps 0), the node's cost (Q = diag(q, q, 0), no obstacle grid), rk4 / diff drive, T <= 256 with sigma small enough for its series");
         last_rollout_pk = pk;
         last_rollout_kind = pk ? MPPI_ROLLOUT_MIXED : MPPI_ROLLOUT_FP64;
@@ -460,7 +460,7 @@ struct mppi_engine {
             b.P = P; b.stream = st; b.inline_nominal = a.inline_nominal; b.seed = seed; b.tick = tick; b.tick_ptr = tick_ptr;
             b.state = a.state; b.goal = a.goal; b.unom = a.unom; b.tc = d_tc; b.base = d_base;
             b.dP = static_cast<float*>(d_dP); b.stot = static_cast<float*>(d_stot); b.epart = static_cast<float*>(d_epart);
-            b.al_guard = mppi::rollout_pk_guard(P.kth, P.dt, P.sigma);
+            b.al_guard = mppi::rollout_pk_guard(P.kth, P.dt, P.sigma, noise_pack);
             b.waves = pk_waves; b.noise_pack = noise_pack;
             b.ev_start = a.ev_start; b.ev_stop = a.ev_stop;
             e = mppi::launch_rollout_pk(b);
@@ -540,10 +540,11 @@ struct mppi_engine {
         inputs_consumed();
     }
     void launch_regen(hipStream_t st, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
-        const int spd = noise_pack ? mppi::NoisePack<1>::kSteps : mppi::NoisePack<0>::kSteps;
+        const int spd = noise_pack == 1 ? mppi::NoisePack<1>::kSteps : (noise_pack == 2 ? mppi::NoisePack<2>::kSteps : mppi::NoisePack<0>::kSteps);
         dim3 g((cfg.samples + 255) / 256, (cfg.horizon + spd - 1) / spd, cfg.n_agents);
         if (f64()) hipLaunchKernelGGL(mppi::eps_regen_kernel<double>, g, dim3(256), 0, st, P, static_cast<double*>(d_eps), seed, tick, tick_ptr);
-        else if (noise_pack) hipLaunchKernelGGL((mppi::eps_regen_kernel<float, 1>), g, dim3(256), 0, st, P, static_cast<float*>(d_eps), seed, tick, tick_ptr);
+        else if (noise_pack == 1) hipLaunchKernelGGL((mppi::eps_regen_kernel<float, 1>), g, dim3(256), 0, st, P, static_cast<float*>(d_eps), seed, tick, tick_ptr);
+        else if (noise_pack == 2) hipLaunchKernelGGL((mppi::eps_regen_kernel<float, 2>), g, dim3(256), 0, st, P, static_cast<float*>(d_eps), seed, tick, tick_ptr);
         else hipLaunchKernelGGL(mppi::eps_regen_kernel<float>, g, dim3(256), 0, st, P, static_cast<float*>(d_eps), seed, tick, tick_ptr);
         HIPCHK(hipGetLastError());
     }
@@ -563,12 +564,15 @@ struct mppi_engine {
     hipLaunchKernelGGL((mppi::update_kernel<TYPE, REGEN>), grid, dim3(256), 0, st, P, static_cast<const TYPE*>(d_eps), \
                        static_cast<const TYPE*>(d_dP), static_cast<const TYPE*>(d_stot), d_part, NCH, ch0, nch,    \
                        static_cast<const TYPE*>(d_epart), lazy_seed, lazy_tick, tick_ptr, upd_skip_light)
+#define LAUNCH_UPD_PACK(PK)                                                                                               \
+    hipLaunchKernelGGL((mppi::update_kernel<float, true, PK>), grid, dim3(256), 0, st, P, static_cast<const float*>(d_eps), \
+                       static_cast<const float*>(d_dP), static_cast<const float*>(d_stot), d_part, NCH, ch0, nch,           \
+                       static_cast<const float*>(d_epart), lazy_seed, lazy_tick, tick_ptr, upd_skip_light)
         if (f64()) { if (eps_lazy) LAUNCH_UPD(double, true); else LAUNCH_UPD(double, false); }
-        else if (eps_lazy && noise_pack)
-            hipLaunchKernelGGL((mppi::update_kernel<float, true, 1>), grid, dim3(256), 0, st, P, static_cast<const float*>(d_eps),
-                               static_cast<const float*>(d_dP), static_cast<const float*>(d_stot), d_part, NCH, ch0, nch,
-                               static_cast<const float*>(d_epart), lazy_seed, lazy_tick, tick_ptr, upd_skip_light);
+        else if (eps_lazy && noise_pack == 1) LAUNCH_UPD_PACK(1);
+        else if (eps_lazy && noise_pack == 2) LAUNCH_UPD_PACK(2);
         else { if (eps_lazy) LAUNCH_UPD(float, true); else LAUNCH_UPD(float, false); }
+#undef LAUNCH_UPD_PACK
 #undef LAUNCH_UPD
         HIPCHK(hipGetLastError());
     }
@@ -600,7 +604,7 @@ struct mppi_engine {
             pk_size = r_pk >= 3 && 19 * r_pk < 10 * r_64;
         }
         return (use_pk || noise_pack) && !f64() && ph && !store && inline_nominal() && !general_cost() && k0 == 0 && k1 == cfg.samples && pk_size &&
-               mppi::rollout_pk_applies(P.kth, P.dt, P.sigma, cfg.horizon);
+               mppi::rollout_pk_applies(P.kth, P.dt, P.sigma, cfg.horizon, noise_pack);
     }
     // rollout + update + merge of one tick
     // The merge launch is skipped when whoever consumes the tuples can merge a handful per row itself -- one launch and
@@ -1720,9 +1724,9 @@ int mppi_set_option(mppi_engine* h, const char* key, int64_t value) {
     else if (k == "rollout_pk") { h->settle_lazy_state(); h->use_pk = value != 0; h->destroy_graph(); }
     else if (k == "upd_skip") h->upd_skip_light = value != 0;
     else if (k == "noise_packing") {
-        if (value != 0 && value != 1) fail(MPPI_E_INVALID, "noise_packing: 0 (three steps per Philox call, the default stream) or 1 (four)");
+        if (value < 0 || value > 2) fail(MPPI_E_INVALID, "noise_packing: 0 (three steps per Philox call, the default stream), 1 (four) or 2 (hipRAND's normals: two)");
         if (value && (h->f64() || h->small_nb > 0 || !h->inline_nominal()))
-            fail(MPPI_E_INVALID, "noise_packing 1 is drawn by the mixed-precision rollout only: fp32 storage, the lane kernels (tick_path lanes), rk4 / diff drive, T <= 256");
+            fail(MPPI_E_INVALID, "noise_packing 1 / 2 is drawn by the mixed-precision rollout only: fp32 storage, the lane kernels (tick_path lanes), rk4 / diff drive, T <= 256");
         h->settle_lazy_state(); h->noise_pack = (int)value; h->destroy_graph();
     }
     else if (k == "pk_waves") { if (value != 4 && value != 5) fail(MPPI_E_INVALID, "pk_waves: 4 or 5"); h->pk_waves = (int)value; }

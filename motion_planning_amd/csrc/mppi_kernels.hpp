@@ -620,6 +620,20 @@ __device__ __forceinline__ void box_muller16(uint32_t w, float nscale, float& e0
     e1 = cs.y;
 }
 
+// hipRAND's own normals (option "noise_packing" = 2): rocrand_device::detail::box_muller of <rocrand/rocrand_normal.h> restated --
+// u = 2^-32 + x 2^-32, v = (2 pi) 2^-32 (1 + y), s = sqrtf(-2 logf(u)), (sin v, cos v) s with the same library functions
+// (logf / sqrtf of the device library, __sincosf), then sigma: hiprand_normal4() of a Philox4_32_10 state positioned on the
+// call's counter returns {e[0], e[1], e[2], e[3]} / sigma bit for bit (tests/native/hiprand_normal4.hip, compiled by the test).
+__device__ __forceinline__ void box_muller_hiprand(uint32_t x, uint32_t y, float sigf, float& e0, float& e1) {
+    const float u = 2.3283064e-10f + ((float)x * 2.3283064e-10f);
+    const float v = 1.46291807e-09f + ((float)y * 1.46291807e-09f);
+    const float s = sqrtf(-2.0f * logf(u));
+    float sn, cs;
+    __sincosf(v, &sn, &cs);
+    e0 = sigf * (sn * s);
+    e1 = sigf * (cs * s);
+}
+
 // How the 128 bits of one Philox call become normals (option "noise_packing", PACK):
 //   0  the default stream: THREE steps per call -- three pairs of 21-bit uniforms (the top 21 bits of the four words, plus the
 //      2 x 21 bits assembled from their low 11): 1/3 call per step instead of 1/2;
@@ -627,7 +641,10 @@ __device__ __forceinline__ void box_muller16(uint32_t w, float nscale, float& e0
 //      the mixed-precision rollout runs 6 % shorter with it (same box, 102.0 -> 96.0 us at 10^6 x 50).  Its price is the
 //      distribution's resolution (tails cut at 4.85 sigma instead of 5.53), which is why it is an option and not the default;
 //      served where the mixed-precision rollout is (fp32 storage, lane kernels, the node's cost).
-template <int PACK> struct NoisePack { static constexpr int kSteps = PACK ? 4 : 3; };
+//   2  hipRAND's normals themselves: TWO steps per call, hiprand_normal4's four values in order (box_muller_hiprand) -- 32-bit
+//      uniforms, radius <= 6.66 sigma, the device library's logf / sqrtf: the literal reading of "noise from hipRAND", at the
+//      price of half again as many calls as the default and a longer transform.  Served where 1 is.
+template <int PACK> struct NoisePack { static constexpr int kSteps = PACK == 1 ? 4 : (PACK == 2 ? 2 : 3); };
 constexpr int kStepsPerDraw = NoisePack<0>::kSteps;
 // The noise of global sample `gk`, agent a, steps kSteps * draw .. kSteps * draw + kSteps - 1: e[2j], e[2j+1] = (eps0, eps1)
 // of step kSteps * draw + j.
@@ -642,9 +659,12 @@ __device__ __forceinline__ void philox_normals(uint32_t gk, uint32_t draw, uint3
         box_muller(o[2] >> 11, (o[3] >> 9) & 0x7FFFFCu, nscale, e[2], e[3]);
         box_muller(((o[0] & 0x7FFu) << 10) | ((o[1] & 0x7FFu) >> 1), ((o[2] & 0x7FFu) << 12) | ((o[3] & 0x7FEu) << 1),
                    nscale, e[4], e[5]);
-    } else {
+    } else if constexpr (PACK == 1) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) box_muller16(o[j], nscale, e[2 * j], e[2 * j + 1]);
+    } else {
+        box_muller_hiprand(o[0], o[1], sigf, e[0], e[1]);
+        box_muller_hiprand(o[2], o[3], sigf, e[2], e[3]);
     }
 }
 
@@ -661,8 +681,10 @@ __device__ __forceinline__ void philox_normal_pair(uint32_t gk, uint32_t t, uint
         const uint32_t mant = j == 0 ? (o[1] >> 9) & 0x7FFFFCu
                                      : (j == 1 ? (o[3] >> 9) & 0x7FFFFCu : ((o[2] & 0x7FFu) << 12) | ((o[3] & 0x7FEu) << 1));
         box_muller(a21, mant, -1.3862943611198906f * (sigf * sigf), e0, e1);
-    } else {
+    } else if constexpr (PACK == 1) {
         box_muller16(j == 0 ? o[0] : (j == 1 ? o[1] : (j == 2 ? o[2] : o[3])), -1.3862943611198906f * (sigf * sigf), e0, e1);
+    } else {
+        box_muller_hiprand(j == 0 ? o[0] : o[2], j == 0 ? o[1] : o[3], sigf, e0, e1);
     }
 }
 

@@ -60,17 +60,23 @@ struct RolloutPkArgs {
     float *dP, *stot, *epart;
     float al_guard;
     int waves;            // 4: the compiler's own allocation (no spills); 5: one more wave per SIMD at the price of a few spills
-    int noise_pack;       // option "noise_packing": 0 three steps per Philox call (the default stream), 1 four (NoisePack, mppi_kernels.hpp)
+    int noise_pack;       // option "noise_packing": 0 three steps per Philox call (the default stream), 1 four, 2 hipRAND's normals, two (NoisePack, mppi_kernels.hpp)
     hipEvent_t ev_start, ev_stop;
 };
 hipError_t launch_rollout_pk(const RolloutPkArgs& a);
-// |2 dphi| of one step is at most 2 hk (|e0| + |e1|) <= 2 hk sqrt2 * 5.53 sigma (Box-Muller radius of a 22-bit uniform)
-inline double rollout_pk_step_bound(double kth, double dt, double sigma) { return 2.0 * (0.5 * kth * dt) * 1.41421356237 * 5.53 * sigma; }
+// |2 dphi| of one step is at most 2 hk (|e0| + |e1|) <= 2 hk sqrt2 * radius * sigma; the Box-Muller radius of the packing: 5.53 for
+// a 22-bit uniform (4.85 for the 16-bit one), 6.66 for hipRAND's 32-bit one
+inline double rollout_pk_radius(int noise_pack) { return noise_pack == 2 ? 6.67 : 5.53; }
+inline double rollout_pk_step_bound(double kth, double dt, double sigma, int noise_pack) {
+    return 2.0 * (0.5 * kth * dt) * 1.41421356237 * rollout_pk_radius(noise_pack) * sigma;
+}
 // largest |th| at the start of a chunk (<= 8 steps) for which the short series are valid
-inline float rollout_pk_guard(double kth, double dt, double sigma) { return (float)(0.5 - 8.0 * rollout_pk_step_bound(kth, dt, sigma)); }
+inline float rollout_pk_guard(double kth, double dt, double sigma, int noise_pack) {
+    return (float)(0.5 - 8.0 * rollout_pk_step_bound(kth, dt, sigma, noise_pack));
+}
 // the long series hold for |alpha| <= 2: the heading deviation can never leave that range over the whole horizon
-inline bool rollout_pk_applies(double kth, double dt, double sigma, int T) {
-    return T <= 256 && rollout_pk_guard(kth, dt, sigma) > 0.05f && (T + 1) * rollout_pk_step_bound(kth, dt, sigma) <= 2.0;
+inline bool rollout_pk_applies(double kth, double dt, double sigma, int T, int noise_pack) {
+    return T <= 256 && rollout_pk_guard(kth, dt, sigma, noise_pack) > 0.05f && (T + 1) * rollout_pk_step_bound(kth, dt, sigma, noise_pack) <= 2.0;
 }
 
 #ifdef MPPI_ROLLOUT_PK_TU
@@ -144,8 +150,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
     const uint32_t tick = tick_ptr ? *tick_ptr : tick_arg;
     const float sigf = (float)P.sigma;
 
-    constexpr int SPD = NoisePack<PACK>::kSteps;   // steps per Philox draw: 3 (the default stream) | 4 (16-bit packing)
-    constexpr int U = 2 * SPD;  // steps per chunk = two Philox draws per sample (wave_sum16 carries the chunk's 12 | 16 eps sums)
+    constexpr int SPD = NoisePack<PACK>::kSteps;   // steps per Philox draw: 3 (the default stream) | 4 (16-bit packing) | 2 (hipRAND's normals)
+    constexpr int U = PACK ? 8 : 6;  // steps per chunk = two (hipRAND's normals: four) Philox draws per sample; wave_sum16 carries the chunk's 12 | 16 eps sums
     float nz[U][4];             // the chunk's noise: [step]{wheel 0 of kA, wheel 0 of kA + 1, wheel 1 of kA, wheel 1 of kA + 1}
     float tz[SPD][4];
     double th[2] = {0.0, 0.0}, dX[2] = {0.0, 0.0}, dY[2] = {0.0, 0.0}, pre[2] = {0.0, 0.0};
@@ -174,9 +180,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
             bm2(oa[2] >> 11, (oa[3] >> 9) & 0x7FFFFCu, ob[2] >> 11, (ob[3] >> 9) & 0x7FFFFCu, w0[1], w1[1]);
             bm2(((oa[0] & 0x7FFu) << 10) | ((oa[1] & 0x7FFu) >> 1), ((oa[2] & 0x7FFu) << 12) | ((oa[3] & 0x7FEu) << 1),
                 ((ob[0] & 0x7FFu) << 10) | ((ob[1] & 0x7FFu) >> 1), ((ob[2] & 0x7FFu) << 12) | ((ob[3] & 0x7FEu) << 1), w0[2], w1[2]);
-        } else {
+        } else if constexpr (PACK == 1) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) bm2(oa[i] & 0xFFFFu, (oa[i] >> 9) & 0x7FFF80u, ob[i] & 0xFFFFu, (ob[i] >> 9) & 0x7FFF80u, w0[i], w1[i]);
+        } else {   // hipRAND's own transform, sample by sample
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float a0, a1, b0, b1;
+                box_muller_hiprand(oa[2 * i], oa[2 * i + 1], sigf, a0, a1);
+                box_muller_hiprand(ob[2 * i], ob[2 * i + 1], sigf, b0, b1);
+                w0[i] = f2{a0, b0}; w1[i] = f2{a1, b1};
+            }
         }
     };
     // (nsteps < U, uniform: the ragged tail only makes the draws its steps need)
@@ -365,7 +379,7 @@ hipError_t launch_rollout_pk(const RolloutPkArgs& a) {
             hipLaunchKernelGGL((rollout_pk_kernel<IN, W, PK>), grid, dim3(256), lds, a.stream, a.P, a.state, a.goal, a.tc, a.dP, a.stot, \
                                a.seed, a.tick, a.tick_ptr, a.epart, a.unom, a.base, a.al_guard);                              \
     } while (0)
-#define MPPI_PK_GO(IN, W) do { if (a.noise_pack) MPPI_PK_GO_(IN, W, 1); else MPPI_PK_GO_(IN, W, 0); } while (0)
+#define MPPI_PK_GO(IN, W) do { if (a.noise_pack == 2) MPPI_PK_GO_(IN, W, 2); else if (a.noise_pack == 1) MPPI_PK_GO_(IN, W, 1); else MPPI_PK_GO_(IN, W, 0); } while (0)
     if (a.waves == 5) { if (a.inline_nominal == 2) MPPI_PK_GO(2, 5); else MPPI_PK_GO(1, 5); }
     else { if (a.inline_nominal == 2) MPPI_PK_GO(2, 4); else MPPI_PK_GO(1, 4); }
 #undef MPPI_PK_GO

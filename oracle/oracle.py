@@ -194,9 +194,10 @@ def philox4x32_10(ctr, key):
 
 
 def philox_noise(seed, agent, tick, k_off, K_local, T, sigma, packing=0):
-    """The device noise's CPU twin; packing = the engine's option "noise_packing" (0: three steps per Philox call, 1: four)."""
+    """The device noise's CPU twin; packing = the engine's option "noise_packing" (0: three steps per Philox call, 1: four,
+    2: hipRAND's own normals, two)."""
     eps = np.zeros((T, 2, K_local))
-    fn = lib().orc_philox_noise16 if packing else lib().orc_philox_noise
+    fn = {0: lib().orc_philox_noise, 1: lib().orc_philox_noise16, 2: lib().orc_philox_noise_hiprand}[int(packing)]
     fn(C.c_uint64(int(seed)), C.c_uint32(int(agent)), C.c_uint32(int(tick)),
        C.c_uint32(int(k_off)), int(K_local), int(T), C.c_double(sigma), _p(eps))
     return eps

@@ -1004,17 +1004,21 @@ PK16 = [(1, 26), (513, 27), (1025, 28), (777, 29), (300, 30), (2049, 31), (640, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("packing", [1, 2])
 @pytest.mark.parametrize("scene", ["under_way", "parked"])
 @pytest.mark.parametrize("K,T", PK16)
-def test_noise_packing_16bit_against_its_twin_and_the_oracle(orc, tick_path, K, T, scene):
-    """Option "noise_packing" = 1 (round 4): one Philox call serves FOUR steps, 16 + 16 bits each, drawn by the mixed-precision
-    rollout in chunks of eight steps.  Every horizon class mod 8 (26 ... 33), the node's 50, the longest the kernel serves; one
-    sample, odd K, K around the 512-sample block.  (a) the noise the tick drew (mppi_download_noise: the re-draw kernel) is the
-    CPU twin's 16-bit stream -- same Philox words, Box-Muller to fp32 rounding -- and not the default stream; (b) the tick
-    replayed IN FULL on the oracle on that noise: V per sample, du, applied controls, next state -- which also ties the
-    rollout's own draws and the update kernel's re-draws (both on the tick's path) to the downloaded noise."""
+def test_noise_packing_against_its_twin_and_the_oracle(orc, tick_path, K, T, scene, packing):
+    """Option "noise_packing" (round 4).  1: one Philox call serves FOUR steps, 16 + 16 bits each; 2: hipRAND's own normals, TWO
+    steps per call; both drawn by the mixed-precision rollout in chunks of eight steps.  Every horizon class mod 8 (26 ... 33), the
+    node's 50, the longest the kernel serves; one sample, odd K, K around the 512-sample block.  (a) the noise the tick drew
+    (mppi_download_noise: the re-draw kernel) is the CPU twin's stream of that packing -- same Philox words, the transform to
+    fp32 rounding -- and not the default stream; (b) the tick replayed IN FULL on the oracle on that noise: V per sample, du,
+    applied controls, next state -- which also ties the rollout's own draws and the update kernel's re-draws (both on the
+    tick's path) to the downloaded noise."""
     if tick_path == "scan":
         pytest.skip("a lane-kernel option")
+    if packing == 2 and T < 32:
+        pytest.skip("hipRAND's 32-bit uniform reaches 6.66 sigma: the mixed-precision rollout serves it from T = 32 at dt = 1 / T (rollout_pk_applies)")
     if scene == "under_way":
         u0 = np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
         state, goal = [0.0, 0.0, 0.2], [0.4, -0.3, 0.0]
@@ -1022,25 +1026,61 @@ def test_noise_packing_16bit_against_its_twin_and_the_oracle(orc, tick_path, K, 
         u0 = np.zeros((2, T))
         state, goal = [0.3, 0.1, -0.4], [0.3, 0.1, -0.4]
     seed, tick = 5, 9
-    with _engine(K, T, "f32", tick_path="lanes", options={"noise_packing": 1}) as e:
-        assert e.get_option("noise_packing") == 1
+    with _engine(K, T, "f32", tick_path="lanes", options={"noise_packing": packing}) as e:
+        assert e.get_option("noise_packing") == packing
         e.set_nominal(u0)
         nxt, ua = e.tick(state, goal, noise="philox", seed=seed, tick_id=tick)
         assert e.info()["rollout_kernel"] == "mixed"      # whatever the size: the only kernel that draws this stream
         V = e.download_value()[0]
         eps = e.download_noise()[0]
         lat = e.get_nominal()
-    twin = orc.philox_noise(seed, 0, tick, 0, K, T, SIG, packing=1)
-    assert np.abs(eps - twin).max() < 2e-6
-    assert np.abs(eps).max() <= 4.86 * SIG * 1.0000001            # the 16-bit radius
+    twin = orc.philox_noise(seed, 0, tick, 0, K, T, SIG, packing=packing)
+    # (2: the library's __sincosf scales the angle to revolutions in fp32 first: 4e-7 rad at the far end, times the radius)
+    assert np.abs(eps - twin).max() < (2e-6 if packing == 1 else 1e-5)
+    assert np.abs(eps).max() <= (4.86 if packing == 1 else 6.67) * SIG * 1.0000001            # the packing's radius
     assert np.abs(eps - orc.philox_noise(seed, 0, tick, 0, K, T, SIG)).max() > 0.1
     m = _replay_full(orc, V, eps, nxt[0], ua[0], lat, state, goal, u0, T, "f32")
-    print("16-bit packing K=%d T=%d %s: %s" % (K, T, scene, m))
+    print("noise packing %d K=%d T=%d %s: %s" % (packing, K, T, scene, m))
 
 
 @pytest.mark.gpu
-def test_noise_packing_16bit_full_size_shards_and_refusals(orc, tick_path):
-    """The 16-bit packing at config 4's size on the co-scheduled handle and on one engine (equal to the split-invariance
+def test_noise_packing_2_is_hiprand_normal4_bit_for_bit(tick_path, tmp_path):
+    """north_star: "Gaussian control perturbation from hipRAND".  Option "noise_packing" = 2 makes that literal: what the engine
+    draws for (global sample, steps 2 d and 2 d + 1, tick, agent) is sigma x hiprand_normal4() of hipRAND's own Philox4_32_10 device
+    state initialised on the same counter (hiprand_init(seed, agent << 32 | tick, 4 * (d << 32 | sample))) -- compared BIT FOR BIT
+    with a helper compiled here against <hiprand/hiprand_kernel.h>, on every sample and step of three engines (a shard with a
+    sample offset, a second agent, odd horizon)."""
+    if tick_path == "scan":
+        pytest.skip("a lane-kernel option")
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "hiprand_normal4")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", os.path.join(root, "tests", "native", "hiprand_normal4.hip"),
+                    "-o", exe], check=True, capture_output=True, timeout=300)
+    for K, T, A, off, seed, tick in ((300, 50, 1, 0, 11, 3), (129, 33, 2, 70001, 2**63 + 5, 2**31 + 7), (64, 40, 1, 2**32 - 64, 0, 0)):
+        with _engine(K, T, "f32", n_agents=A, tick_path="lanes", sample_offset=off, options={"noise_packing": 2}) as e:
+            e.rollout(np.zeros((A, 3)), np.tile([0.0, -1.0, 0.0], (A, 1)), noise="philox", seed=seed, tick_id=tick)
+            eps = e.download_noise()                                        # [A][T][2][K]
+        n_draws = (T + 1) // 2
+        lines = "".join("%d %d %d\n" % (seed, (a << 32) | tick, (d << 32) | ((off + k) & 0xFFFFFFFF))
+                        for a in range(A) for d in range(n_draws) for k in range(K))
+        out = subprocess.run([exe], input=lines, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        bits = np.array([[int(x) for x in l.split()] for l in out.stdout.splitlines()], dtype=np.uint32)
+        n4 = bits.view(np.float32).reshape(A, n_draws, K, 4)
+        want = np.empty((A, 2 * n_draws, 2, K), dtype=np.float32)
+        want[:, 0::2, 0], want[:, 0::2, 1] = n4[..., 0], n4[..., 1]
+        want[:, 1::2, 0], want[:, 1::2, 1] = n4[..., 2], n4[..., 3]
+        want = (np.float32(SIG) * want)[:, :T]
+        got = eps.astype(np.float32)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (K, T, A, np.abs(got - want).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("packing", [1, 2])
+def test_noise_packing_full_size_shards_and_refusals(orc, tick_path, packing):
+    """The other noise packings at config 4's size on the co-scheduled handle and on one engine (equal to the split-invariance
     bound, the same noise bit for bit, the noise shard-invariant: sample ids are global), switched on a live handle, and
     refused -- MPPI_E_INVALID, the handle left usable -- wherever the mixed-precision rollout cannot serve it."""
     if tick_path == "scan":
@@ -1053,7 +1093,7 @@ def test_noise_packing_16bit_full_size_shards_and_refusals(orc, tick_path):
         with _engine(K, T, "f32", tick_path="lanes", co_shards=co) as e:
             e.set_nominal(u0)
             s0, a0 = e.tick([0, 0, 0], [0, -1, 0], noise="philox", seed=3, tick_id=0)     # the default stream first
-            e.set_option("noise_packing", 1)
+            e.set_option("noise_packing", packing)
             e.set_nominal(u0)
             s1, a1 = e.tick([0, 0, 0], [0, -1, 0], noise="philox", seed=3, tick_id=0)
             s2, a2 = e.tick(None, None, noise="philox", seed=3, tick_id=1)
@@ -1063,27 +1103,29 @@ def test_noise_packing_16bit_full_size_shards_and_refusals(orc, tick_path):
     assert np.abs(outs[1][0] - outs[None][0]).max() < 1e-9
     assert np.array_equal(outs[1][1], outs[None][1])
     assert np.abs(outs[1][0][:5] - outs[1][2]).max() > 1e-6          # another stream, another tick
-    twin = orc.philox_noise(3, 0, 1, 0, K, T, SIG, packing=1)[:, :, ::4099]
-    assert np.abs(outs[1][1] - twin).max() < 2e-6
+    twin = orc.philox_noise(3, 0, 1, 0, K, T, SIG, packing=packing)[:, :, ::4099]
+    tol = 2e-6 if packing == 1 else 1e-5
+    assert np.abs(outs[1][1] - twin).max() < tol
     # a shard draws what the whole engine draws for its samples
-    with _engine(3000, T, "f32", tick_path="lanes", sample_offset=7000, options={"noise_packing": 1}) as e:
+    with _engine(3000, T, "f32", tick_path="lanes", sample_offset=7000, options={"noise_packing": packing}) as e:
         e.rollout([0, 0, 0], [0, -1, 0], noise="philox", seed=3, tick_id=1)
         part = e.download_noise()[0]
-    assert np.abs(part - orc.philox_noise(3, 0, 1, 7000, 3000, T, SIG, packing=1)).max() < 2e-6
+    assert np.abs(part - orc.philox_noise(3, 0, 1, 7000, 3000, T, SIG, packing=packing)).max() < tol
     # refusals
     for kw in (dict(storage="f64"), dict(tick_path="scan"), dict(T=257), dict(model="euler")):
         kw = dict(kw)
         st, Tk = kw.pop("storage", "f32"), kw.pop("T", 50)
         kw.setdefault("tick_path", "lanes")
         with _engine(600, Tk, st, **kw) as e:
-            with pytest.raises(MppiError):
-                e.set_option("noise_packing", 1)
+            for val in (packing, 3, -1):
+                with pytest.raises(MppiError):
+                    e.set_option("noise_packing", val)
             assert e.get_option("noise_packing") == 0
             e.tick([0.0, 0.0, 0.0], [0.3, 0.2, 0.0], noise="philox", seed=1, tick_id=0)
     for kw, opt in ((dict(q=(1e3, 1e3, 5.0)), {}), ({}, {"store_eps": 1}), (dict(T=20), {})):   # refused by the tick that would need another kernel
         kw = dict(kw)
         Tk = kw.pop("T", 50)
-        with _engine(600, Tk, "f32", tick_path="lanes", options=dict(opt, noise_packing=1), **kw) as e:
+        with _engine(600, Tk, "f32", tick_path="lanes", options=dict(opt, noise_packing=packing), **kw) as e:
             with pytest.raises(MppiError) as err:
                 e.tick([0.0, 0.0, 0.0], [0.3, 0.2, 0.0], noise="philox", seed=1, tick_id=0)
             assert "noise_packing" in str(err.value)
