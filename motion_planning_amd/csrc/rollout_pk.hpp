@@ -154,8 +154,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
     constexpr int U = PACK ? 8 : 6;  // steps per chunk = two (hipRAND's normals: four) Philox draws per sample; wave_sum16 carries the chunk's 12 | 16 eps sums
     float nz[U][4];             // the chunk's noise: [step]{wheel 0 of kA, wheel 0 of kA + 1, wheel 1 of kA, wheel 1 of kA + 1}
     float tz[SPD][4];
-    double th[2] = {0.0, 0.0}, dX[2] = {0.0, 0.0}, dY[2] = {0.0, 0.0}, pre[2] = {0.0, 0.0};
-    f2 thf = {0.f, 0.f};  // (float)th at the start of the step
+    double dX[2] = {0.0, 0.0}, dY[2] = {0.0, 0.0}, pre[2] = {0.0, 0.0};
+    // the heading deviation: a compensated (Kahan) fp32 sum of the steps' 2 dphi -- thf is what the next step's series take (it was
+    // (float) of an fp64 running sum until round 4: a conversion each way and an fp64 add per sample and step), thf - thc the sum to
+    // ~2^-46 relative for the terminal cost
+    f2 thf = {0.f, 0.f}, thc = {0.f, 0.f};
+    // the noise-cost part of the cost prefix, lam (un . Sig) eps summed in fp32 next to the fp64 prefix (~0.007 per step: 2e-8 of
+    // rounding over the horizon, three orders below this kernel's V tolerance) -- a conversion and an fp64 add less per sample and step
+    f2 ncs = {0.f, 0.f};
 
     // Box-Muller for the lane's two samples at once (same arithmetic as box_muller(), operation by operation, so the noise
     // is bit-identical to what the update kernel's re-draw and mppi_download_noise produce): the exactly rounded steps run
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
         const PkRow& r = lt[t];
         {   // dP[t] = the exclusive cost prefix (control/src/mppi:175 as total minus prefix)
             const __amdgpu_buffer_rsrc_t row = __builtin_amdgcn_make_buffer_rsrc(dP_a + (size_t)t * Ks, 0, (int)(Ks * sizeof(float)), 0x00020000);
-            const float pa = (float)pre[0], pb = (float)pre[1];
+            const float pa = (float)pre[0] + ncs.x, pb = (float)pre[1] + ncs.y;
             if (FULL) {
                 __builtin_amdgcn_raw_buffer_store_b64(u2{__float_as_uint(pa), __float_as_uint(pb)}, row, (unsigned)kA * 4u, 0, 0);
             } else {
@@ -249,9 +255,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
         const f2 dp1 = pk_med3(pk_fma(n1, f2{hkf, hkf}, f2{r.d1, r.d1}), r.lo1, r.hi1);
         const f2 dphi = dp1 - dp0, dPs = dp0 + dp1;
         const f2 al = thf + dphi;
-        th[0] = fma(2.0, (double)dphi.x, th[0]);
-        th[1] = fma(2.0, (double)dphi.y, th[1]);
-        thf = f2{(float)th[0], (float)th[1]};
+        {
+            const f2 y = pk_fma(f2{2.f, 2.f}, dphi, -thc), t = thf + y;
+            thc = (t - thf) - y;
+            thf = t;
+        }
         f2 S, Cm;
         const f2 z = al * al;
         if (robust) {  // (uniform, practically never) |alpha| <= 2: eight terms each, truncation < 4e-10
@@ -283,12 +291,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
             dY[i] = fma(s1n, ad, fma(c1n, bd, dY[i]));
         }
         // get_cost (control/src/mppi:180-184) minus the nominal stage cost: u = NOMINAL, eps = UNCLIPPED
-        const f2 dcn = pk_fma(n0, f2{r.w0, r.w0}, n1 * f2{r.w1, r.w1});
+        ncs = pk_fma(n0, f2{r.w0, r.w0}, pk_fma(n1, f2{r.w1, r.w1}, ncs));
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             pre[i] = fma(dX[i], X2 + dX[i], pre[i]);
             pre[i] = fma(dY[i], Y2 + dY[i], pre[i]);
-            pre[i] += (double)(i ? dcn.y : dcn.x);
         }
     };
     auto chunk = [&](int t0, int nsteps, auto full_tag) __attribute__((always_inline)) {
@@ -351,11 +358,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
     float tot[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const double ths = thn + th[i];
+        const double ths = thn + ((double)(i ? thf.y : thf.x) - (double)(i ? thc.y : thc.x));
         const double thw = (ths > M_PI || ths <= -M_PI) ? wrap_theta(ths) : ths;
         const double dths = thw - gth;
         const double term = inv_f2 * (P.p0 * dX[i] * (rT.X2 + dX[i]) + P.p1 * dY[i] * (rT.Y2 + dY[i])) + P.p2 * (dths * dths - dthn * dthn);
-        tot[i] = (float)(pre[i] + term);
+        tot[i] = (float)(pre[i] + term + (double)(i ? ncs.y : ncs.x));
     }
     // value_fcn = reverse cumulative sum over t (control/src/mppi:175) = total - exclusive prefix
     if (block_full) {
