@@ -141,6 +141,10 @@ class Engine(object):
         self.dt = 1.0 / self.T if dt is None else float(dt)
         self.storage = "f64" if cfg.storage == MPPI_STORE_F64 else "f32"
         self.sigma, self.lam = cfg.sigma, cfg.lambda_
+        # staging buffers of the blocking tick with their ctypes pointers made once (ndarray.ctypes.data_as costs 2 us a time:
+        # four of them were a tenth of the node's 20 us call)
+        self._io = [np.zeros((self.A, 3)), np.zeros((self.A, 3)), np.empty((self.A, 3)), np.empty((self.A, 2))]
+        self._io_ptr = [_capi.dptr(a) for a in self._io]
         for key, val in dict(self.default_options, **(options or {})).items():
             self.set_option(key, val)
 
@@ -365,20 +369,33 @@ class Engine(object):
 
     def tick(self, state=None, goal=None, noise="philox", seed=0, tick_id=0):
         """One blocking control tick: mppi_tick (= tick_begin + tick_finish + get_outputs in one call)."""
-        s, g = self._sg(state, goal)
+        sp, gp = self._stage(state, goal)
         mode = MPPI_NOISE_PHILOX if noise == "philox" else MPPI_NOISE_INJECTED
-        nxt, ua = np.empty((self.A, 3)), np.empty((self.A, 2))
-        self._ck(self._lib.mppi_tick(self._h, _capi.dptr(s), _capi.dptr(g), mode, int(seed), int(tick_id),
-                                     _capi.dptr(nxt), _capi.dptr(ua)))
-        return nxt, ua
+        rc = self._lib.mppi_tick(self._h, sp, gp, mode, int(seed), int(tick_id), self._io_ptr[2], self._io_ptr[3])
+        if rc:
+            _capi.check(rc, self._h)
+        return self._io[2].copy(), self._io[3].copy()
+
+    def _stage(self, state, goal):
+        """state / goal copied into the engine object's own staging arrays (the library reads them during the call)."""
+        sp = gp = None
+        if state is not None:
+            self._io[0][...] = np.asarray(state, dtype=np.float64).reshape(self.A, 3)
+            sp = self._io_ptr[0]
+        if goal is not None:
+            self._io[1][...] = np.asarray(goal, dtype=np.float64).reshape(self.A, 3)
+            gp = self._io_ptr[1]
+        return sp, gp
 
     def tick_async(self, state=None, goal=None, noise="philox", seed=0, tick_id=0):
         """The fused tick without waiting for its outputs (mppi_tick with NULL outputs): everything is enqueued, nothing
         blocks; get_outputs() later.  Unlike tick_begin + tick_finish it has no exchange point, so the engine may take
         its shortcuts (zero-copy inputs, no merge launch for a handful of tuples)."""
-        s, g = self._sg(state, goal)
+        sp, gp = self._stage(state, goal)
         mode = MPPI_NOISE_PHILOX if noise == "philox" else MPPI_NOISE_INJECTED
-        self._ck(self._lib.mppi_tick(self._h, _capi.dptr(s), _capi.dptr(g), mode, int(seed), int(tick_id), None, None))
+        rc = self._lib.mppi_tick(self._h, sp, gp, mode, int(seed), int(tick_id), None, None)
+        if rc:
+            _capi.check(rc, self._h)
 
     def tick_graph(self, seed=0):
         self._ck(self._lib.mppi_tick_graph(self._h, int(seed)))
@@ -481,7 +498,9 @@ class MPPI(object):
         self.dt = 1.0 / float(horizon)
         self._eng = None
         self._weights_sent = None
+        self._weights_raw = None        # the raw bytes of Q, R, P1 when they were last validated (the per-tick fast path)
         self._fill_sent = np.zeros(2)   # the engine starts with a zero fill
+        self._path_buf = self._uvec_buf = None
         self.Q = np.array([[1e3, 0.0, 0.0], [0.0, 1e3, 0.0], [0.0, 0.0, 0.0]])
         self.R = np.array([[1.0, 0.0], [0.0, 1.0]])
         self.P1 = np.array([[1e3, 0.0, 0.0], [0.0, 1e3, 0.0], [0.0, 0.0, 1e3]])
@@ -500,6 +519,14 @@ class MPPI(object):
     # arrays; every call that rolls out hands their current diagonals to the engine first (mppi_set_weights) when they
     # differ from what it has.  The kernels implement diagonal weights: anything else is refused by name.
     def _sync_weights(self):
+        # fast path (every tick of the node): the three attributes are still float64 arrays holding the bytes last validated and sent
+        raw = self._weights_raw
+        if raw is not None:
+            q, r, p1 = self.Q, self.R, self.P1
+            if (type(q) is np.ndarray and type(r) is np.ndarray and type(p1) is np.ndarray and q.dtype == np.float64 and
+                    r.dtype == np.float64 and p1.dtype == np.float64 and q.tobytes() == raw[0] and r.tobytes() == raw[1] and
+                    p1.tobytes() == raw[2]):
+                return
         mats = []
         for name, n in (("Q", 3), ("R", 2), ("P1", 3)):
             m = np.asarray(getattr(self, name), dtype=np.float64)
@@ -513,10 +540,15 @@ class MPPI(object):
         if key != self._weights_sent:
             self._eng.set_weights(*mats)
             self._weights_sent = key
+        self._weights_raw = tuple(np.asarray(getattr(self, name), dtype=np.float64).tobytes() for name in ("Q", "R", "P1"))
 
     # uvec_init[:, 0] is what every receding-horizon shift appends, read live on each get_path (control/src/mppi:101): an
     # assignment to m.uvec_init (or into it) between calls must reach the engine without an initialize()
     def _sync_fill(self):
+        init = self.uvec_init
+        if (type(init) is np.ndarray and init.dtype == np.float64 and init.ndim == 2 and init.shape[0] == 2 and init.shape[1] >= 1
+                and self._fill_sent is not None and init[0, 0] == self._fill_sent[0] and init[1, 0] == self._fill_sent[1]):
+            return   # (every tick of the node)
         init = np.asarray(self.uvec_init, dtype=np.float64)
         if init.ndim != 2 or init.shape[0] != 2 or init.shape[1] < 1:
             raise ValueError("uvec_init must be [2, horizon] (control/src/mppi:65)")
@@ -544,6 +576,36 @@ class MPPI(object):
         self._load_uvec_init(init)           # latest_uvec = uvec_init (:81); every later shift appends uvec_init[:, 0] (:101)
         self.uvec = np.array([init[:, 0]])
         self.path = np.array([self.start])
+
+    # path [n][3] and uvec [n][2] grow by one row per get_path (control/src/mppi:97-98: np.concatenate, O(n) per tick).  They are
+    # views of buffers that double when full; assigning to the attributes works as it does on the reference's plain arrays.
+    @staticmethod
+    def _grown(buf, n, row):
+        if buf is None or n >= buf.shape[0]:
+            new = np.empty((max(64, 2 * n), len(row)))
+            if buf is not None:
+                new[:n] = buf[:n]
+            buf = new
+        buf[n] = row
+        return buf
+
+    @property
+    def path(self):
+        return self._path_buf[:self._path_n]
+
+    @path.setter
+    def path(self, value):
+        value = np.array(value, dtype=np.float64, ndmin=2)
+        self._path_buf, self._path_n = value, value.shape[0]
+
+    @property
+    def uvec(self):
+        return self._uvec_buf[:self._uvec_n]
+
+    @uvec.setter
+    def uvec(self, value):
+        value = np.array(value, dtype=np.float64, ndmin=2)
+        self._uvec_buf, self._uvec_n = value, value.shape[0]
 
     @property
     def latest_uvec(self):
@@ -580,8 +642,10 @@ class MPPI(object):
             nxt, ua = self._eng.tick(state, goal, noise="philox", seed=self.seed, tick_id=self._tick)
         self._tick += 1
         state = nxt[0]
-        self.path = np.concatenate((self.path, np.array([state])))
-        self.uvec = np.concatenate((self.uvec, np.array([ua[0]])))
+        self._path_buf = self._grown(self._path_buf, self._path_n, state)       # :97
+        self._path_n += 1
+        self._uvec_buf = self._grown(self._uvec_buf, self._uvec_n, ua[0])       # :98
+        self._uvec_n += 1
         self.fin_time.append(self.fin_time[-1] + self.dt)
         return state
 
