@@ -621,7 +621,7 @@ def main():
                         return {"read": rd[0], "write": wr[0], "valu_insts": c.get("SQ_INSTS_VALU")}
             return None
 
-        def kernel_roofline(k_launch, avg_s, mhz, n_timed, kind, upd_us=None, merge_us=None, fin_us=None, tick_s=None):
+        def kernel_roofline(k_launch, avg_s, mhz, n_timed, kind, upd_us=None, merge_us=None, fin_us=None, tick_s=None, a_launch=None):
             """The dominant kernel of a launch over k_launch samples per agent.
             TOP LEVEL = the roof it is on: VALU issue -- wave-instructions of the steady-state loop from the compiler's own assembly
             (tools/valu_mix.py), each class at its measured issue cost (tools/ubench.hip, shader clock read in-kernel), over 1024
@@ -630,8 +630,9 @@ def main():
             `accounting_8d`: SURVEY 8(d)'s figure -- 12 algorithmic B / state-step / kernel over the launch duration -- kept as the
             contract defines it; it is an accounting figure, not a distance to a roof.
             `tick_floor_us`: max(rollout issue time, update bytes / achievable HBM rate) + measured merge + finalize."""
-            steps = A * k_launch * T
-            share = (A * k_launch) / float(A_total * K_total)    # the PMC passes covered ALL samples of the workload: a shard's (or a rank's) launch moves its share
+            A_l = a_launch or A              # agents one launch covers (a handle that splits its AGENTS over two engines: half of them)
+            steps = A_l * k_launch * T
+            share = (A_l * k_launch) / float(A_total * K_total)    # the PMC passes covered ALL samples of the workload: a shard's (or a rank's) launch moves its share
             # `kind`: what the engine says its last tick launched (mppi_rollout_kernel), not a copy of its rule
             name = {"mixed": "rollout_pk_kernel", "fp64": "rollout_kernel", "scan": "scan_tick_kernel"}[kind]
             gbs = BYTES_PER_STEP_PER_KERNEL * steps / avg_s / 1e9
@@ -641,7 +642,7 @@ def main():
                            "kernel, 24 per tick.  NOT the distance to a roof: eps is never stored (it is re-drawn from its Philox counter), so the "
                            "kernels move about a third of these bytes (`hbm`), and the tick-level figure can exceed 1"}
             r = {"kernel": name, "bound": "valu-issue", "achieved": None, "peak": None, "unit": "G wave-inst/s", "frac": None, "traffic": None,
-                 "samples_per_launch": A * k_launch, "avg_launch_us": avg_s * 1e6, "launches_timed": n_timed, "accounting_8d": acc}
+                 "samples_per_launch": A_l * k_launch, "avg_launch_us": avg_s * 1e6, "launches_timed": n_timed, "accounting_8d": acc}
             mix = mixes.get(name)
             if mix and lanes and args.storage == "f32":
                 wave_steps = steps / 64.0          # sample-steps per 64 lanes (the pk kernel's waves carry 128 samples)
@@ -687,19 +688,22 @@ def main():
 
         co_n = info.get("co_shards", 1)
         k_launch = info["co_samples"][0] if co_n > 1 else K_local    # the launches this handle's events time: its own shard
+        # co_samples all equal to K: the handle splits its AGENTS (config 5), engine 0 carries the first ceil(A / 2) of them
+        agent_split = co_n > 1 and A > 1 and all(k == K_local for k in info["co_samples"])
+        a_launch = (A + 1) // 2 if agent_split else None
         ms, n = ktimes["rollout"]
         if n == 0:  # hipGraph replay: launches are not individually bracketed
             ms, n = dtimes["rollout"] if dtimes["rollout"][1] else (float("nan"), 1)
         avg_s = ms * 1e-3 / max(n, 1)
         tick_s = elapsed / args.steps
         roofline = kernel_roofline(k_launch, avg_s, clock_mhz, n, info["rollout_kernel"], upd_us=kernels_us.get("update"),
-                                   merge_us=kernels_us.get("merge"), fin_us=kernels_us.get("finalize"), tick_s=tick_s)
+                                   merge_us=kernels_us.get("merge"), fin_us=kernels_us.get("finalize"), tick_s=tick_s, a_launch=a_launch)
         tick_bytes = 2 * BYTES_PER_STEP_PER_KERNEL * A * K_local * T
         if co_n > 1:
             roofline["concurrent_launches"] = co_n
             roofline["concurrency_note"] = ("this handle runs its fused tick as %d co-scheduled engines: each shard's rollout launch covers %d of the %d samples and "
                                             "runs NEXT TO the other shards' launches (own streams), so its own duration says little about the kernel; the "
-                                            "per-kernel figures of this line are those of the one-engine leg" % (co_n, A * k_launch, A * K_local))
+                                            "per-kernel figures of this line are those of the one-engine leg" % (co_n, (a_launch or A) * k_launch, A * K_local))
         tick_level = {"accounting_8d": {"algorithmic_bytes": tick_bytes, "achieved": tick_bytes / tick_s / 1e9, "frac": tick_bytes / tick_s / 1e9 / HBM_PEAK_GBS,
                                         "note": "24 B/state-step x all samples of the tick / tick time: both kernels (and, co-scheduled, both engines) together; above 1 "
                                                 "means what the note of accounting_8d says -- most of these bytes never exist"}}

@@ -97,7 +97,12 @@ extern "C" {
  * snapshot of the tick's inputs, bit for bit what the shards computed.  AUTO = 2 shards for n_agents * samples >= 500000
  * on the lane-per-sample path with at least 32768 samples per agent and n_agents * horizon <= 256 rows (beyond that the
  * shards' publish kernels cost more than the overlap gains), fp32 storage only (the all-fp64 mode's two big kernels are both
- * HBM-bound: split it measured slower), else none.  An AUTO handle builds its shards with its FIRST fused device-noise
+ * HBM-bound: split it measured slower).  A handle of MANY agents (n_agents * horizon > 256 rows: config 5's 64 x 16 384) splits its
+ * AGENTS instead, where each half still holds >= 400 000 sample-agents: two complete engines, agents [0, ceil(A / 2)) and the rest,
+ * NOTHING exchanged (agents are independent controllers) -- per agent bit for bit the one engine's results (the noise streams are
+ * keyed by the global agent index), config 5 +8-10 % rollouts/s.  Only the fused tick runs split; any other call first copies the
+ * second engine's results of the last tick (nominal / filtered controls, state, outputs, V) into the handle's own arrays, and the
+ * next split tick hands over what changed.  Else none.  An AUTO handle builds its shards with its FIRST fused device-noise
  * mppi_tick -- a handle that only runs the caller's own exchange (the ranks of an N > 1 run), graph replays or injected-noise
  * ticks never pays for the second set of buffers; mppi_co_info reports the split from the start, mppi_co_note why a handle
  * that should have split did not.  mppi_tick_begin / _finish (the caller's own exchange), mppi_tick_graph and
@@ -352,7 +357,8 @@ int mppi_kernel_times(mppi_engine *h, double *ms /*[MPPI_KERNEL_COUNT]*/,
 int mppi_shader_clock(mppi_engine *h, double *mhz);
 
 /* How the fused device-noise mppi_tick of this handle runs: n_shards co-scheduled engines (1: unsplit) and the samples
- * each owns (samples [8], zero-filled behind n_shards). */
+ * each owns (samples [8], zero-filled behind n_shards).  A handle that splits its AGENTS reports mppi_config.samples for every
+ * engine (each rolls out all samples of its agents: engine 0 the first ceil(n_agents / 2) of them). */
 int mppi_co_info(mppi_engine *h, int32_t *n_shards, int32_t *samples);
 /* Why this handle runs unsplit although co_shards AUTO would have split it (the second set of buffers could not be
  * built), or why a group was dissolved (a co-scheduled tick failed half-way): "" when there is nothing to report.  Never NULL. */

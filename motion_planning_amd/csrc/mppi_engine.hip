@@ -262,6 +262,7 @@ struct mppi_engine {
         for (auto* e : subs) delete e;
         subs.clear();
         if (p2p_internal) { p2p_release(); p2p_internal = false; }
+        co_agents = false; co_dirty = false;
     }
     bool p2p_internal = false;  // the mailboxes belong to the co-scheduled group, not to a caller's cross-GPU exchange
     std::string co_fallback = "";   // why this handle runs unsplit although co-scheduling was possible (mppi_co_note)
@@ -288,8 +289,28 @@ struct mppi_engine {
         }
         co_synced = true;
     }
+    // ---- the second way of co-scheduling: by AGENTS (a handle of many independent agents, config 5) -------------------------
+    // Two complete engines, agents [0, co_a0) on this one and the rest on the sub: nothing is exchanged -- agents are independent
+    // (control/src/mppi:296-342: one controller per robot) -- each engine runs rollout, update and finalize for its own agents
+    // on its own stream, and one engine's HBM-bound update runs under the other's VALU-bound rollout.  The handle stays the one
+    // owner of every per-agent array towards the API: only the fused device-noise mppi_tick runs split; whatever else is called
+    // first pulls the sub's results into this engine's arrays (co_pull), and the next split tick pushes what changed (co_push_agents).
+    bool co_agents = false;    // the group splits the agents, not the samples
+    int co_a0 = 0;             // agents of this engine while a split tick is enqueued
+    bool co_dirty = false;     // the sub holds newer nominal controls / state / V of its agents than this engine's arrays
+    double* out_view_ext = nullptr;   // (a sub of an agent split) where its finalize drops the outputs: the handle's pinned rows
+    uint32_t* seq_view_ext = nullptr;
+    uint32_t seq_ext = 0;
+    struct AgentView {   // this engine's view of its own agents while a split tick is enqueued
+        mppi_engine* e; int A;
+        explicit AgentView(mppi_engine* e_) : e(e_), A(e_->cfg.n_agents) { e->cfg.n_agents = e->co_a0; e->P.A = e->co_a0; }
+        ~AgentView() { e->cfg.n_agents = A; e->P.A = A; }
+    };
+    void co_push_agents();
+    void co_pull();
+    void co_tick_agents(const double* state, const double* goal, uint64_t seed, uint32_t tick);
     bool co_pending = false;   // co_shards AUTO decided to split: the shards are built with the first fused device-noise tick
-    int co_plan(bool& wanted) const;
+    int co_plan(bool& wanted, bool* by_agents = nullptr) const;
     void co_cuts(int G, std::vector<int>& cuts) const;
     void co_build();   // creates the subs
     void co_tick(const double* state, const double* goal, uint64_t seed, uint32_t tick);
@@ -698,14 +719,15 @@ struct mppi_engine {
         // eager ticks also drop their outputs into the pinned host buffer (a graph replay cannot: its sequence number
         // would be frozen at capture time -- it keeps the D2H copy)
         const bool host_out = (flags & 1) && !(flags & 4) && !capturing;
-        if (host_out) out_seq += 1u;
+        const bool ext = host_out && out_view_ext != nullptr;   // a sub of an agent split: the outputs land in the handle's pinned rows
+        if (host_out && !ext) out_seq += 1u;
         if (slot_unclaimed >= 0) {
-            if (host_out) { slot_seq[slot_unclaimed] = out_seq; slot_seq_valid[slot_unclaimed] = true; slot_unclaimed = -1; }
+            if (host_out && !ext) { slot_seq[slot_unclaimed] = out_seq; slot_seq_valid[slot_unclaimed] = true; slot_unclaimed = -1; }
             else release_unclaimed_slot();
         }
         hipLaunchKernelGGL(mppi::finalize_kernel, dim3(cfg.n_agents), dim3(fin_threads), lds,
                            stream, P, gathered, G, lay, d_S, d_unom, d_ufilt, d_state, d_out, d_tick, flags, tick_set,
-                           host_out ? d_out_view : nullptr, d_seq_view, out_seq, wait);
+                           ext ? out_view_ext : (host_out ? d_out_view : nullptr), ext ? seq_view_ext : d_seq_view, ext ? seq_ext : out_seq, wait);
         if (flags & 1) out_via_host = host_out;
         HIPCHK(hipGetLastError());
         partials_ready = false;
@@ -909,10 +931,14 @@ struct mppi_engine {
 // --------------------------------------------------------------------------------------------
 // C ABI
 // --------------------------------------------------------------------------------------------
-#define API_BEGIN(h)                                   \
+#define API_BEGIN_FAST(h)                              \
     if (!(h)) return MPPI_E_INVALID;                   \
     try {                                              \
         DeviceGuard dev_guard__((h)->device);
+// every call but the split tick itself, the outputs' read-back and the read-only queries first makes this engine's arrays whole again
+#define API_BEGIN(h)                                   \
+    API_BEGIN_FAST(h)                                  \
+        if ((h)->co_dirty) (h)->co_pull();
 #define API_END(h)                                                                  \
         return MPPI_OK;                                                             \
     } catch (const EngineError& e) { (h)->err = e.msg; return e.code; }             \
@@ -921,10 +947,11 @@ struct mppi_engine {
     catch (...) { (h)->err = "unknown error"; return MPPI_E_INTERNAL; }
 
 // How many engines a fused device-noise tick of this handle runs on (1: unsplit).  wanted: asked for by name (co_shards >= 2).
-int mppi_engine::co_plan(bool& wanted) const {
+int mppi_engine::co_plan(bool& wanted, bool* by_agents) const {
     int G = cfg.co_shards;
     const bool lanes = small_nb == 0;
     wanted = G > 1;
+    if (by_agents) *by_agents = false;
     // AUTO: two shards where the pair measured faster than the one engine (config 4: +7-9 % rollouts/s; nothing below
     // ~5e5 samples), on the lane-per-sample path only
     // (and while a second set of buffers is small change against the 288 GB: the subs hold another half of this engine's)
@@ -935,6 +962,15 @@ int mppi_engine::co_plan(bool& wanted) const {
     // there is nothing complementary to overlap -- measured 0.277 ms split against 0.250 ms unsplit (profiles/r4_bench_c4_f64_*.json)
     if (G == 0) G = (lanes && !f64() && (long)cfg.n_agents * cfg.samples >= 500000 && cfg.samples >= 4 * CH && cfg.n_agents * cfg.horizon <= 256 &&
                      hbm_bytes < ((size_t)48 << 30)) ? 2 : 1;
+    // AUTO, many agents (config 5: 64 x 16 384): the split by samples does not pay (every shard's publish walks all A * T rows; asked
+    // for by name it measured 0.297 against 0.154 ms) -- the agents are split instead: two engines of A / 2 agents, nothing exchanged.
+    // Same box, one process, tick us: one engine 150.8 | 32 + 32 agents 134.5 | 38 + 26 139.3 | 40 + 24 140.1 | 22 + 21 + 21 132.4.
+    // Each half must still be a size the mixed-precision rollout is chosen for (shards choose it by size: 400 000 sample-agents).
+    if (G <= 1 && cfg.co_shards == 0 && lanes && !f64() && cfg.n_agents >= 2 && cfg.n_agents * cfg.horizon > 256 &&
+        (long)(cfg.n_agents / 2) * cfg.samples >= 400000 && hbm_bytes < ((size_t)48 << 30)) {
+        if (by_agents) *by_agents = true;
+        return 2;
+    }
     if (G <= 1) return 1;
     if (!lanes || cfg.samples < G * CH) {
         if (wanted) fail(MPPI_E_INVALID, "co_shards = %d needs the lane-per-sample tick path and at least %d samples per shard", G, CH);
@@ -959,9 +995,40 @@ void mppi_engine::co_cuts(int G, std::vector<int>& cuts) const {
 // ranks of an N > 1 run), graph replays or injected-noise ticks never pays for the second set of buffers.
 void mppi_engine::co_build() {
     co_pending = false;
-    bool wanted = false;
-    const int G = co_plan(wanted);
+    bool wanted = false, by_agents = false;
+    const int G = co_plan(wanted, &by_agents);
     if (G <= 1) return;
+    if (by_agents) {   // (AUTO only)
+        try {
+            mppi_config c = cfg;
+            co_a0 = (cfg.n_agents + 1) / 2;
+            c.n_agents = cfg.n_agents - co_a0;
+            c.agent_offset = cfg.agent_offset + (uint32_t)co_a0;   // the noise streams are keyed by the global agent index
+            c.co_shards = 1;
+            c.tick_path = MPPI_TICK_LANES;
+            mppi_engine* e = new mppi_engine();
+            subs.push_back(e);
+            e->is_co_sub = true;
+            e->init(c);
+            if (sig_is_matrix) { for (int i = 0; i < 4; ++i) e->sig_cost[i] = sig_cost[i]; e->sig_is_matrix = true; e->refresh_params(); }
+            e->P.grid = P.grid; e->P.grid_w = P.grid_w; e->P.grid_h = P.grid_h; e->P.grid_res = P.grid_res; e->P.grid_ox = P.grid_ox;
+            e->P.grid_oy = P.grid_oy; e->P.grid_weight = P.grid_weight;
+            e->sync_timeout_ms = sync_timeout_ms;
+            e->store_eps_always = store_eps_always; e->use_pk = use_pk; e->upd_skip_light = upd_skip_light; e->pk_waves = pk_waves;
+            e->pk_min_set = pk_min_set; e->pk_min_samples = pk_min_samples; e->noise_pack = noise_pack;
+            e->out_view_ext = d_out_view + (size_t)co_a0 * 8;
+            e->seq_view_ext = d_seq_view + co_a0;
+            if (!ev_co) HIPCHK(hipEventCreateWithFlags(&ev_co, hipEventDisableTiming));
+            co_agents = true; co_synced = false; co_dirty = false;
+        } catch (const EngineError& er) {
+            co_release();
+            co_fallback = "co_shards AUTO (agents) fell back to one engine: " + er.msg;
+        } catch (...) {
+            co_release();
+            co_fallback = "co_shards AUTO (agents) fell back to one engine (allocation failed)";
+        }
+        return;
+    }
     try {
         std::vector<int> cuts;
         co_cuts(G, cuts);
@@ -1011,7 +1078,72 @@ void mppi_engine::co_build() {
     }
 }
 
+// what this engine's arrays hold for the sub's agents -> the sub (only after something other than a split tick touched them)
+void mppi_engine::co_push_agents() {
+    if (co_synced) return;
+    mppi_engine* e = subs[0];
+    const size_t A1 = e->cfg.n_agents, T_ = cfg.horizon, a0 = (size_t)co_a0;
+    HIPCHK(hipEventRecord(ev_co, stream));
+    HIPCHK(hipStreamWaitEvent(e->stream, ev_co, 0));
+    HIPCHK(hipMemcpyAsync(e->d_unom, d_unom + a0 * 2 * T_, A1 * 2 * T_ * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d_state, d_state + a0 * 3, A1 * 3 * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d_goal, d_goal + a0 * 3, A1 * 3 * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d_fill, d_fill + a0 * 2, A1 * 2 * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    e->have_state = have_state; e->have_goal = have_goal;
+    co_synced = true;
+}
+
+// the sub's results of the last split tick(s) -> this engine's arrays: nominal and filtered controls, state, outputs, and the
+// tick's V (cost prefix, totals, nominal cost-to-go, per-step table, per-wave eps sums).  The noise is not copied: it is a
+// function of (seed, tick, GLOBAL agent, sample, t) and re-drawn here on demand.
+void mppi_engine::co_pull() {
+    if (!co_dirty) return;
+    co_dirty = false;
+    co_synced = false;   // whoever called may change this engine's arrays: the next split tick hands them over again
+    mppi_engine* e = subs[0];
+    const size_t A1 = e->cfg.n_agents, T_ = cfg.horizon, a0 = (size_t)co_a0, Ks = (size_t)P.Ks, NW = Ks >> 6;
+    const size_t es = f64() ? sizeof(double) : sizeof(float);
+    HIPCHK(hipEventRecord(ev_co, e->stream));
+    HIPCHK(hipStreamWaitEvent(stream, ev_co, 0));
+    auto pull = [&](void* dst, const void* src, size_t per_agent_bytes) {
+        HIPCHK(hipMemcpyAsync(static_cast<char*>(dst) + a0 * per_agent_bytes, src, A1 * per_agent_bytes, hipMemcpyDeviceToDevice, stream));
+    };
+    pull(d_unom, e->d_unom, 2 * T_ * sizeof(double));
+    pull(d_ufilt, e->d_ufilt, 2 * T_ * sizeof(double));
+    pull(d_state, e->d_state, 3 * sizeof(double));
+    pull(d_out, e->d_out, 8 * sizeof(double));
+    pull(d_dP, e->d_dP, T_ * Ks * es);
+    pull(d_stot, e->d_stot, Ks * es);
+    pull(d_base, e->d_base, T_ * sizeof(double));
+    pull(d_tc, e->d_tc, T_ * mppi::kTcW * sizeof(double));
+    pull(d_epart, e->d_epart, T_ * 2 * NW * es);
+    // (the sub's stream must not run ahead of these copies: its next launches come after co_push_agents' event)
+    out_via_host = false;   // d_out is whole; the pinned rows are too, but a later non-split finalize rewrites only d_out's sequence
+    wait_stream("co-scheduled agents: results pulled");
+}
+
+// the fused device-noise tick of a handle whose agents are split over two engines
+void mppi_engine::co_tick_agents(const double* state, const double* goal, uint64_t seed, uint32_t tick) {
+    mppi_engine* e = subs[0];
+    co_push_agents();
+    set_inputs(state, goal);
+    e->set_inputs(state ? state + (size_t)3 * co_a0 : nullptr, goal ? goal + (size_t)3 * co_a0 : nullptr);
+    {
+        AgentView view(this);
+        run_nominal();
+        run_pipeline(MPPI_NOISE_PHILOX, seed, tick, nullptr, /*skip_small_merge=*/true);
+        run_finalize(nullptr, 1, 1 | 2);
+    }
+    e->seq_ext = out_seq;   // the one sequence number mppi_get_outputs waits for, on every agent's row
+    e->run_nominal();
+    e->run_pipeline(MPPI_NOISE_PHILOX, seed, tick, nullptr, /*skip_small_merge=*/true);
+    e->run_finalize(nullptr, 1, 1 | 2);
+    co_dirty = true;
+    co_last = false;
+}
+
 void mppi_engine::co_tick(const double* state, const double* goal, uint64_t seed, uint32_t tick) {
+    if (co_agents) { co_tick_agents(state, goal, seed, tick); return; }
     co_sync_subs();
     set_inputs(state, goal);
     for (auto* e : subs) e->set_inputs(state, goal);
@@ -1104,7 +1236,7 @@ int mppi_set_stream(mppi_engine* h, void* hip_stream) {
 }
 
 int mppi_get_stream(mppi_engine* h, void** hip_stream) {
-    API_BEGIN(h)
+    API_BEGIN_FAST(h)
     if (!hip_stream) fail(MPPI_E_INVALID, "hip_stream is NULL");
     *hip_stream = static_cast<void*>(h->stream);
     API_END(h)
@@ -1152,7 +1284,7 @@ int mppi_set_weights(mppi_engine* h, const double* q, const double* r, const dou
 }
 
 int mppi_set_sync_timeout(mppi_engine* h, int milliseconds) {
-    API_BEGIN(h)
+    API_BEGIN_FAST(h)
     for (auto* sub__ : h->subs) if (int rc__ = mppi_set_sync_timeout(sub__, milliseconds)) fail(rc__, "co-scheduled shard: %s", sub__->err.c_str());
     if (milliseconds < 0) fail(MPPI_E_INVALID, "timeout must be >= 0 (0 = wait forever)");
     h->sync_timeout_ms = milliseconds;
@@ -1207,7 +1339,8 @@ int mppi_set_obstacle_grid(mppi_engine* h, const int8_t* cells, int32_t width, i
 
 int mppi_reset(mppi_engine* h, int agent) {
     API_BEGIN(h)
-    for (auto* sub__ : h->subs) if (int rc__ = mppi_reset(sub__, agent)) fail(rc__, "co-scheduled shard: %s", sub__->err.c_str());
+    h->co_synced = h->co_synced && !h->co_agents;   // (an agent split takes this engine's arrays over with its next tick)
+    if (!h->co_agents) for (auto* sub__ : h->subs) if (int rc__ = mppi_reset(sub__, agent)) fail(rc__, "co-scheduled shard: %s", sub__->err.c_str());
     const size_t row = (size_t)2 * h->cfg.horizon * sizeof(double);
     if (agent < 0) HIPCHK(hipMemsetAsync(h->d_unom, 0, row * h->cfg.n_agents, h->stream));
     else if (agent < h->cfg.n_agents) HIPCHK(hipMemsetAsync(h->d_unom + (size_t)agent * 2 * h->cfg.horizon, 0, row, h->stream));
@@ -1217,7 +1350,8 @@ int mppi_reset(mppi_engine* h, int agent) {
 
 int mppi_set_shift_fill(mppi_engine* h, int agent, const double* fill) {
     API_BEGIN(h)
-    for (auto* sub__ : h->subs) if (int rc__ = mppi_set_shift_fill(sub__, agent, fill)) fail(rc__, "co-scheduled shard: %s", sub__->err.c_str());
+    h->co_synced = h->co_synced && !h->co_agents;   // (an agent split takes this engine's arrays over with its next tick)
+    if (!h->co_agents) for (auto* sub__ : h->subs) if (int rc__ = mppi_set_shift_fill(sub__, agent, fill)) fail(rc__, "co-scheduled shard: %s", sub__->err.c_str());
     if (!fill || agent < 0 || agent >= h->cfg.n_agents) fail(MPPI_E_INVALID, "bad agent/fill");
     HIPCHK(hipMemcpyAsync(h->d_fill + (size_t)agent * 2, fill, 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
     h->wait_stream(__func__);
@@ -1226,7 +1360,8 @@ int mppi_set_shift_fill(mppi_engine* h, int agent, const double* fill) {
 
 int mppi_set_nominal(mppi_engine* h, int agent, const double* uvec) {
     API_BEGIN(h)
-    for (auto* sub__ : h->subs) if (int rc__ = mppi_set_nominal(sub__, agent, uvec)) fail(rc__, "co-scheduled shard: %s", sub__->err.c_str());
+    h->co_synced = h->co_synced && !h->co_agents;   // (an agent split takes this engine's arrays over with its next tick)
+    if (!h->co_agents) for (auto* sub__ : h->subs) if (int rc__ = mppi_set_nominal(sub__, agent, uvec)) fail(rc__, "co-scheduled shard: %s", sub__->err.c_str());
     if (!uvec || agent < 0 || agent >= h->cfg.n_agents) fail(MPPI_E_INVALID, "bad agent/uvec");
     const size_t n = (size_t)2 * h->cfg.horizon;
     HIPCHK(hipMemcpyAsync(h->d_unom + agent * n, uvec, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -1391,7 +1526,7 @@ int mppi_tick_finish(mppi_engine* h, const void* gathered_dev, int n_shards) {
 int mppi_p2p_create(mppi_engine* h, int n_ranks, int rank, void* ipc_handle_out) {
     API_BEGIN(h)
     h->co_pending = false;   // (a handle on a caller's cross-GPU exchange runs unsplit)
-    if (h->p2p_internal && h->co_active()) { h->wait_stream(__func__); for (auto* e__ : h->subs) e__->wait_stream(__func__); h->co_release(); }
+    if ((h->p2p_internal || h->co_agents) && h->co_active()) { h->wait_stream(__func__); for (auto* e__ : h->subs) e__->wait_stream(__func__); h->co_release(); }
     if (n_ranks < 1 || n_ranks > 8 || rank < 0 || rank >= n_ranks) fail(MPPI_E_INVALID, "p2p: 1 <= n_ranks <= 8, 0 <= rank < n_ranks");
     static_assert(sizeof(hipIpcMemHandle_t) <= MPPI_IPC_HANDLE_BYTES, "IPC handle does not fit the ABI's buffer");
     h->wait_stream(__func__);
@@ -1593,7 +1728,7 @@ int mppi_p2p_selftest(mppi_engine* h, int rounds) {
 }
 
 int mppi_get_outputs(mppi_engine* h, double* next_state, double* u_applied) {
-    API_BEGIN(h)
+    API_BEGIN_FAST(h)
     const int A = h->cfg.n_agents;
     const double* o = h->h_out;
     if (h->out_via_host) {
@@ -1631,7 +1766,7 @@ static int tick_begin_fused(mppi_engine* h, const double* state, const double* g
 }
 
 static int co_build_now(mppi_engine* h) {
-    API_BEGIN(h)
+    API_BEGIN_FAST(h)
     h->wait_stream("co-scheduled shard set-up");
     h->co_build();   // (AUTO: never throws -- on failure the one engine serves every call and mppi_co_note says why)
     API_END(h)
@@ -1639,7 +1774,7 @@ static int co_build_now(mppi_engine* h) {
 
 // the fused tick of a handle that carries co-scheduled shards (device noise; injected noise lives in this engine's own buffer)
 static int tick_co(mppi_engine* h, const double* state, const double* goal, uint64_t seed, uint32_t tick_id) {
-    API_BEGIN(h)
+    API_BEGIN_FAST(h)
     try {
         h->co_tick(state, goal, seed, tick_id);
     } catch (...) {
@@ -1756,7 +1891,7 @@ int mppi_set_option(mppi_engine* h, const char* key, int64_t value) {
 }
 
 int mppi_get_option(mppi_engine* h, const char* key, int64_t* value) {
-    API_BEGIN(h)
+    API_BEGIN_FAST(h)
     if (!key || !value) fail(MPPI_E_INVALID, "NULL argument");
     const std::string k(key);
     if (k == "store_eps") *value = h->store_eps_always;
@@ -1771,7 +1906,7 @@ int mppi_get_option(mppi_engine* h, const char* key, int64_t* value) {
 }
 
 int mppi_synchronize(mppi_engine* h) {
-    API_BEGIN(h)
+    API_BEGIN_FAST(h)
     h->wait_stream(__func__);
     for (auto* e : h->subs) e->wait_stream(__func__);
     API_END(h)
@@ -1788,7 +1923,7 @@ int mppi_savgol_matrix(int horizon, double* S) {
 }
 
 int mppi_kernel_timing(mppi_engine* h, uint32_t mask) {
-    API_BEGIN(h)
+    API_BEGIN_FAST(h)
     h->drain_timing();
     h->time_mask = mask;
     for (int i = 0; i < MPPI_KERNEL_COUNT; ++i) { h->t_ms[i] = 0.0; h->t_n[i] = 0; h->time_seen[i] = 0; }
@@ -1796,14 +1931,14 @@ int mppi_kernel_timing(mppi_engine* h, uint32_t mask) {
 }
 
 int mppi_kernel_timing_period(mppi_engine* h, int period) {
-    API_BEGIN(h)
+    API_BEGIN_FAST(h)
     if (period < 1) fail(MPPI_E_INVALID, "period must be >= 1");
     h->time_period = period;
     API_END(h)
 }
 
 int mppi_kernel_times(mppi_engine* h, double* ms, int64_t* launches) {
-    API_BEGIN(h)
+    API_BEGIN_FAST(h)
     h->drain_timing();
     for (int i = 0; i < MPPI_KERNEL_COUNT; ++i) {
         if (ms) ms[i] = h->t_ms[i];
@@ -1813,7 +1948,7 @@ int mppi_kernel_times(mppi_engine* h, double* ms, int64_t* launches) {
 }
 
 int mppi_shader_clock(mppi_engine* h, double* mhz) {
-    API_BEGIN(h)
+    API_BEGIN_FAST(h)
     if (!mhz) fail(MPPI_E_INVALID, "mhz is NULL");
     unsigned long long v[2] = {0, 0};
     HIPCHK(hipMemcpyAsync(v, h->d_clk, sizeof(v), hipMemcpyDeviceToHost, h->stream));
@@ -1824,18 +1959,20 @@ int mppi_shader_clock(mppi_engine* h, double* mhz) {
 }
 
 int mppi_co_info(mppi_engine* h, int32_t* n_shards, int32_t* samples) {
-    API_BEGIN(h)
+    API_BEGIN_FAST(h)
     int G = 1 + (int)h->subs.size();
     std::vector<int> cuts;
+    bool by_agents = h->co_agents;
     if (h->co_pending) {   // the shards are built with the first fused device-noise tick: report what that tick will run on
         bool w;
-        G = h->co_plan(w);
-        if (G > 1) h->co_cuts(G, cuts);
+        G = h->co_plan(w, &by_agents);
+        if (G > 1 && !by_agents) h->co_cuts(G, cuts);
     }
     if (n_shards) *n_shards = G;
     if (samples) {
         for (int g = 0; g < 8; ++g) samples[g] = 0;
         if (!cuts.empty()) { for (int g = 0; g < G; ++g) samples[g] = cuts[g + 1] - cuts[g]; }
+        else if (by_agents) { for (int g = 0; g < G; ++g) samples[g] = h->cfg.samples; }   // the AGENTS are split: every engine rolls out all samples of its agents
         else {
             samples[0] = h->co_active() ? h->co_k0 : h->cfg.samples;
             for (int g = 1; g < G; ++g) samples[g] = h->subs[g - 1]->cfg.samples;
@@ -1847,14 +1984,14 @@ int mppi_co_info(mppi_engine* h, int32_t* n_shards, int32_t* samples) {
 const char* mppi_co_note(const mppi_engine* h) { return h ? h->co_fallback.c_str() : ""; }
 
 int mppi_rollout_kernel(mppi_engine* h, int32_t* kind) {
-    API_BEGIN(h)
+    API_BEGIN_FAST(h)
     if (!kind) fail(MPPI_E_INVALID, "NULL argument");
     *kind = h->last_rollout_kind;
     API_END(h)
 }
 
 int mppi_engine_info(mppi_engine* h, size_t* hbm_bytes, int32_t* rollout_blocks, int32_t* update_blocks) {
-    API_BEGIN(h)
+    API_BEGIN_FAST(h)
     if (hbm_bytes) { *hbm_bytes = h->hbm_bytes; for (auto* e : h->subs) *hbm_bytes += e->hbm_bytes; }
     // what a tick launches: the scan kernel alone (no update kernel), or rollout + update
     const bool scan = h->small_nb > 0;
