@@ -1056,6 +1056,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(S) =
 //   with e > 2^-kCand: N += e * eps  (predicated scalar loads, wave-uniformly skipped otherwise).
 // grid = (8 T, ceil(A * chunks of this launch / 8)) x 256 threads; part[a][t][ch] = {M, D, N0, N1, E0, E1, count, 0}.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float uniform_value(float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); }
+__device__ __forceinline__ double uniform_value(double v) {
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
 constexpr int kUpdNV = 8;  // 16-byte vectors per lane: chunk = 256 * kUpdNV * (16 / sizeof(S)) samples
 template <typename S> struct UpdCfg { static constexpr int VEC = 16 / (int)sizeof(S); static constexpr int CH = 256 * kUpdNV * VEC; };
 
@@ -1097,14 +1103,6 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
         return;
     }
     __shared__ R red[4][6];
-    // E = sum_k eps of this chunk from the per-wave sums (CH/64 entries per wheel, a few hundred bytes)
-    R E0 = 0, E1 = 0;
-    {
-        const size_t NW = Ks >> 6;
-        const S* ep = epart + (((size_t)a * P.T + t) * 2) * NW;
-        const int w_begin = k_begin >> 6, w_end = (k_end + 63) >> 6;
-        for (int w = w_begin + tid; w < w_end; w += 256) { E0 += ep[w]; E1 += ep[NW + w]; }
-    }
 
     // pass 1: the chunk into registers, lane minimum
     S v[kUpdNV][VEC];
@@ -1127,7 +1125,9 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
     m = wave_min(m);
     if (lane == 0) red[wid][0] = m;
     __syncthreads();
-    const R M = fmin(fmin(red[0][0], red[1][0]), fmin(red[2][0], red[3][0]));
+    // (the block minimum is uniform: kept in scalar registers -- in the fp64 mode the two vector registers it would hold are what
+    // stands between seven and eight blocks per CU)
+    const R M = uniform_value(fmin(fmin(red[0][0], red[1][0]), fmin(red[2][0], red[3][0])));
     __syncthreads();
 
     // pass 2: weights relative to the block minimum; eps only where the weight is representable
@@ -1221,6 +1221,15 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
     // sum_k e * eps across the block in fp64: a thread holds a few products at most (the queue spreads the candidates over
     // the block -- a handful of them all sit in wave 0), and an fp32 tree would let the row's dominant term absorb the small
     // ones differently for every way of splitting the samples over chunks / shards
+    // E = sum_k eps of this chunk from the per-wave sums (CH/64 entries per wheel, a few hundred bytes) -- formed here, behind the loops,
+    // so that it does not hold registers through them
+    R E0 = 0, E1 = 0;
+    {
+        const size_t NW = Ks >> 6;
+        const S* ep = epart + (((size_t)a * P.T + t) * 2) * NW;
+        const int w_begin = k_begin >> 6, w_end = (k_end + 63) >> 6;
+        for (int w = w_begin + tid; w < w_end; w += 256) { E0 += ep[w]; E1 += ep[NW + w]; }
+    }
     __shared__ double redN[4][2];
     const double N0d = wave_sum((double)N0 + Na0), N1d = wave_sum((double)N1 + Na1);
     D = wave_sum(D); E0 = wave_sum(E0); E1 = wave_sum(E1);
