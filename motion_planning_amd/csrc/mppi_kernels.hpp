@@ -1066,8 +1066,9 @@ constexpr int kUpdNV = 8;  // 16-byte vectors per lane: chunk = 256 * kUpdNV * (
 template <typename S> struct UpdCfg { static constexpr int VEC = 16 / (int)sizeof(S); static constexpr int CH = 256 * kUpdNV * VEC; };
 
 template <typename S, bool REGEN, int PACK = 0>
-// (fp64 storage: 70 VGPRs, seven blocks per CU.  Forcing 64 VGPRs for an eighth block spilled five registers and measured SLOWER on
-// the same box: update 110-117 us against 95-103, tick 0.233-0.239 ms against 0.221-0.225 -- the registers decide.)
+// (fp64 storage: 64 VGPRs, eight blocks per CU -- since the eps sums are read behind the loops and the block minimum sits in scalar
+// registers; 70 before, and FORCING 64 then spilled five registers and measured slower on the same box, update 110-117 us against
+// 95-103.  Without spills the eighth block changes nothing: 99-100 us for its 400 MB either way.)
 __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __restrict__ eps,
                                                     const S* __restrict__ dP, const S* __restrict__ Stot,
                                                     double* __restrict__ part, int NCH, int ch_first, int n_local,
