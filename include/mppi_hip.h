@@ -97,8 +97,8 @@ extern "C" {
  * snapshot of the tick's inputs, bit for bit what the shards computed.  AUTO = 2 shards for n_agents * samples >= 500000
  * on the lane-per-sample path with at least 32768 samples per agent and n_agents * horizon <= 256 rows (beyond that the
  * shards' publish kernels cost more than the overlap gains), fp32 storage only (the all-fp64 mode's two big kernels are both
- * HBM-bound: split it measured slower).  A handle of MANY agents (n_agents * horizon > 256 rows: config 5's 64 x 16 384) splits its
- * AGENTS instead, where each half still holds >= 400 000 sample-agents: two complete engines, agents [0, ceil(A / 2)) and the rest,
+ * HBM-bound: split it measured slower).  A handle of SEVERAL agents splits its AGENTS instead (AUTO prefers this wherever each
+ * half still holds >= 400 000 sample-agents: config 5's 64 x 16 384, 2 x 500 000 ...): two complete engines, agents [0, ceil(A / 2)) and the rest,
  * NOTHING exchanged (agents are independent controllers) -- per agent bit for bit the one engine's results (the noise streams are
  * keyed by the global agent index), config 5 +8-10 % rollouts/s.  Only the fused tick runs split; any other call first copies the
  * second engine's results of the last tick (nominal / filtered controls, state, outputs, V) into the handle's own arrays, and the

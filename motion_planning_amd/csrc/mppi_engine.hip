@@ -952,6 +952,16 @@ int mppi_engine::co_plan(bool& wanted, bool* by_agents) const {
     const bool lanes = small_nb == 0;
     wanted = G > 1;
     if (by_agents) *by_agents = false;
+    // AUTO, several agents: the AGENTS are split -- two engines of A / 2 agents, nothing exchanged (agents are independent controllers).
+    // It beats the split by samples wherever both apply, and applies where that one does not pay (config 5: every shard's publish
+    // would walk all A * T rows; asked for by name it measured 0.297 against 0.154 ms).  Same box, one process, tick us, one engine |
+    // split by samples | by agents: 2 x 500 000 147.7 | 135.2 | 128.9; 4 x 250 000 147.9 | 146.2 | 129.4; 8 x 131 072 148.8 | -- | 132.1;
+    // 64 x 16 384 150.8 | -- | 134.5 (38 + 26 agents 139.3, 40 + 24 140.1, three engines 22 + 21 + 21 132.4).
+    // Each half must still be a size the mixed-precision rollout is chosen for (shards choose it by size: 400 000 sample-agents).
+    if (G == 0 && lanes && !f64() && cfg.n_agents >= 2 && (long)(cfg.n_agents / 2) * cfg.samples >= 400000 && hbm_bytes < ((size_t)48 << 30)) {
+        if (by_agents) *by_agents = true;
+        return 2;
+    }
     // AUTO: two shards where the pair measured faster than the one engine (config 4: +7-9 % rollouts/s; nothing below
     // ~5e5 samples), on the lane-per-sample path only
     // (and while a second set of buffers is small change against the 288 GB: the subs hold another half of this engine's)
@@ -962,15 +972,6 @@ int mppi_engine::co_plan(bool& wanted, bool* by_agents) const {
     // there is nothing complementary to overlap -- measured 0.277 ms split against 0.250 ms unsplit (profiles/r4_bench_c4_f64_*.json)
     if (G == 0) G = (lanes && !f64() && (long)cfg.n_agents * cfg.samples >= 500000 && cfg.samples >= 4 * CH && cfg.n_agents * cfg.horizon <= 256 &&
                      hbm_bytes < ((size_t)48 << 30)) ? 2 : 1;
-    // AUTO, many agents (config 5: 64 x 16 384): the split by samples does not pay (every shard's publish walks all A * T rows; asked
-    // for by name it measured 0.297 against 0.154 ms) -- the agents are split instead: two engines of A / 2 agents, nothing exchanged.
-    // Same box, one process, tick us: one engine 150.8 | 32 + 32 agents 134.5 | 38 + 26 139.3 | 40 + 24 140.1 | 22 + 21 + 21 132.4.
-    // Each half must still be a size the mixed-precision rollout is chosen for (shards choose it by size: 400 000 sample-agents).
-    if (G <= 1 && cfg.co_shards == 0 && lanes && !f64() && cfg.n_agents >= 2 && cfg.n_agents * cfg.horizon > 256 &&
-        (long)(cfg.n_agents / 2) * cfg.samples >= 400000 && hbm_bytes < ((size_t)48 << 30)) {
-        if (by_agents) *by_agents = true;
-        return 2;
-    }
     if (G <= 1) return 1;
     if (!lanes || cfg.samples < G * CH) {
         if (wanted) fail(MPPI_E_INVALID, "co_shards = %d needs the lane-per-sample tick path and at least %d samples per shard", G, CH);

@@ -631,10 +631,10 @@ def test_co_scheduled_value_is_bit_identical_to_the_unsplit_engine(monkeypatch):
         assert e.info()["co_shards"] == 2
     with Engine(100000, 100) as e:
         assert e.info()["co_shards"] == 1
-    # the AUTO rule over agents: two agents x 500 000 split their SAMPLES (100 rows for the publish kernels to walk); eight x 131 072
-    # and config 5 (400 / 3200 rows: that split measured slower than one engine) split their AGENTS instead -- every engine rolls
-    # out all samples of its half of the agents, nothing is exchanged; six x 100 000 is too small for either
-    for A, K, want, samples in [(2, 500000, 2, [286720, 213280]), (8, 131072, 2, [131072, 131072]), (64, 16384, 2, [16384, 16384]),
+    # the AUTO rule over agents: a handle of several agents splits its AGENTS -- every engine rolls out all samples of its half of
+    # the agents, nothing is exchanged (faster than the split by samples wherever both apply, and config 5's only one); six x 100 000
+    # is too small for either
+    for A, K, want, samples in [(2, 500000, 2, [500000, 500000]), (8, 131072, 2, [131072, 131072]), (64, 16384, 2, [16384, 16384]),
                                 (6, 100000, 1, [100000])]:
         with Engine(K, T, n_agents=A) as e:
             assert e.info()["co_shards"] == want and e.info()["co_samples"] == samples, (A, K, e.info())
@@ -709,7 +709,7 @@ def test_agents_split_over_two_engines_equals_the_one_engine():
     blocking tick with fresh inputs every call.  (Oracle parity of such a handle: test_config5_64_agents_full_size and the
     eight-replica test run on it by default.)"""
     from motion_planning_amd.mppi import Engine
-    for A, K in ((9, 120000), (64, 16384)):
+    for A, K in ((9, 120000), (64, 16384), (2, 500000)):
         rng = np.random.RandomState(A)
         st0 = rng.uniform(-0.3, 0.3, (A, 3)); goals = rng.uniform(-1.0, 1.0, (A, 3)); goals2 = rng.uniform(-1.0, 1.0, (A, 3))
         outs = {}
@@ -730,7 +730,7 @@ def test_agents_split_over_two_engines_equals_the_one_engine():
                 log += [V[0, :, ::97], V[A - 1, :, ::97], eps[A - 1, :, :, ::97]]
                 e.set_nominal(_u0() * 0.5, agent=A - 1)                      # an agent of the second engine
                 e.set_nominal(_u0() * 0.25, agent=0)
-                e.reset(agent=A // 2 + 1)
+                e.reset(agent=min(A - 1, A // 2 + 1))
                 st, ua = e.tick(None, goals2, noise="philox", seed=4, tick_id=4)   # pushed, then split again
                 log += [st, ua]
                 for i in range(5, 8):                                   # the node's pattern: a blocking call with the state it got back
