@@ -19,6 +19,12 @@ for i in 1 2 3; do
 done
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_co -- python $R/bench.py --no-cpu-baseline --no-f64-line > $O/stats_co.log 2>&1
 cp $O/stats_co/*/*kernel_stats.csv $O/kernel_stats_co_headline.csv 2>/dev/null
+# config 5 on its two agent-split engines (kernels of two streams next to each other), and on one engine
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c5 -- python $R/bench.py --workload c5 --no-cpu-baseline > $O/stats_c5.log 2>&1
+cp $O/stats_c5/*/*kernel_stats.csv $O/kernel_stats_c5_agents_split.csv 2>/dev/null
+timeout 300 python $R/bench.py --workload c5 --co-shards 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_c5_one_engine.json
+timeout 200 python $R/tools/ab_option.py --option noise_packing --values 0,1,2 --rounds 2 > $O/ab_noise_packing_one_engine.jsonl 2>/dev/null
+timeout 200 python $R/tools/ab_option.py --option noise_packing --values 0,1,2 --rounds 2 --co-shards 0 > $O/ab_noise_packing_co_scheduled.jsonl 2>/dev/null
 timeout 300 python $R/bench.py --co-shards 1 --no-cpu-baseline --no-f64-line 2>/dev/null | tail -1 > $O/bench_c4_one_engine.json
 cd $R
 timeout 900 bash tools/pmc.sh final/pmc --co-shards 1 > $O/pmc.log 2>&1; tail -4 $O/pmc.log
