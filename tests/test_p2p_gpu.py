@@ -745,3 +745,60 @@ def test_agents_split_over_two_engines_equals_the_one_engine():
         for x, y in zip(outs[1][0], outs[None][0]):
             assert np.array_equal(x, y)
         assert np.array_equal(outs[1][1], outs[None][1]) and np.array_equal(outs[1][2], outs[None][2])
+
+
+@pytest.mark.gpu
+def test_agent_split_handle_follows_parameter_changes():
+    """Setters reach both engines of a handle that splits its agents: other cost weights (both engines then run the general-cost
+    all-fp64 rollout), another sig / lambda, an obstacle grid set and removed, a per-agent shift fill on either side, a reset, the
+    16-bit noise packing -- after each change the handle's fused ticks still equal the one engine's BIT FOR BIT (per agent the same
+    kernels on the same noise), and mppi_p2p_create dissolves the group and leaves a working engine holding every agent's latest state."""
+    from motion_planning_amd.mppi import Engine
+    A, K = 6, 160000
+    rng = np.random.RandomState(3)
+    st0 = rng.uniform(-0.2, 0.2, (A, 3)); goals = rng.uniform(-1.0, 1.0, (A, 3))
+    cells = np.zeros((40, 40), dtype=np.int8)
+    cells[10:30, 5:20] = 100
+    outs = []
+    for co in (1, None):
+        with Engine(K, T, n_agents=A, storage="f32", tick_path="lanes", co_shards=co, options={"pk_min_samples": 100000}) as e:
+            assert e.info()["co_shards"] == (1 if co == 1 else 2)
+            for a in range(A):
+                e.set_nominal(_u0() * (1.0 - 0.1 * a), agent=a)
+            traj = []
+
+            def ticks(first, n, base):
+                for i in range(n):
+                    nxt, ua = e.tick(st0 if (first and i == 0) else None, goals if (first and i == 0) else None,
+                                     noise="philox", seed=9, tick_id=base + i)
+                    traj.append(np.concatenate([nxt, ua], axis=1))
+            ticks(True, 2, 0)
+            e.set_weights(q=[350.0, 900.0, 15.0], r=[0.5, 2.0], p1=[800.0, 1200.0, 300.0])
+            ticks(False, 2, 10)
+            kinds = e.info()["rollout_kernel"]
+            e.set_sig(np.array([[0.7, 0.1], [0.0, 0.5]]), 0.004)
+            ticks(False, 2, 20)
+            e.set_obstacle_grid(cells, 0.05, (-1.0, -1.5), 25.0)
+            ticks(False, 2, 30)
+            e.set_obstacle_grid(None, 1.0, (0, 0), 0.0)
+            e.set_weights(q=[1e3, 1e3, 0.0], r=[1.0, 1.0], p1=[1e3, 1e3, 1e3])
+            e.set_sig(0.9, 0.001)
+            e.set_shift_fill([0.3, -0.2], agent=0)
+            e.set_shift_fill([-0.1, 0.4], agent=A - 1)
+            ticks(False, 2, 40)
+            assert np.all(e.get_nominal(0)[:, -1] == [0.3, -0.2]) and np.all(e.get_nominal(A - 1)[:, -1] == [-0.1, 0.4])
+            assert np.all(e.get_nominal(1)[:, -1] == 0.0)
+            e.reset()
+            ticks(False, 2, 50)
+            e.set_option("noise_packing", 1)
+            ticks(False, 2, 60)
+            e.set_option("noise_packing", 0)
+            if co is None:
+                assert e.info()["co_shards"] == 2 and kinds == "fp64"
+                e.p2p_create(1, 0)                       # a caller's own exchange: the group dissolves (its results pulled first)
+                assert e.info()["co_shards"] == 1
+                e.p2p_destroy()
+            ticks(False, 2, 70)
+            traj.append(np.stack([e.get_nominal(a) for a in range(A)]).reshape(A, -1)[:, :5])
+            outs.append(np.array(traj))
+    assert np.array_equal(outs[0], outs[1])
