@@ -99,40 +99,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
     ClockProbe probe(P);
     snapshot_inputs(P, state, goal, unom, a);
     const double gx = goal[a * 3 + 0], gy = goal[a * 3 + 1], gth = goal[a * 3 + 2];
-    {
-        // the block runs the nominal rollout itself, lanes = timesteps (as rollout_kernel does), and derives the per-step
-        // constants of the deviation form from it
-        __shared__ double nom_sh[4];
-        if (INLINE_NOM == 2 || tid < 64) {
-            double row[5], base_t;
-            NomExtra ex;
-            nominal_lanes<(INLINE_NOM == 2 ? 4 : 1)>(P, state, goal, unom, a, tid, row, base_t, nom_sh, nullptr, &ex);
-            if (tid < T) {
-                const double hk = 0.5 * P.kth * P.dt, phin = 0.5 * ex.h;
-                double sp, cp;
-                if (fabs(phin) <= 0.25) small_sincos<7>(phin, sp, cp);
-                else sincos(phin, &sp, &cp);
-                PkRow r;
-                r.d0 = (float)(hk * (row[0] - ex.u0c)); r.d1 = (float)(hk * (row[1] - ex.u1c));
-                r.lo0 = (float)(hk * (-P.u_max - ex.u0c)); r.hi0 = (float)(hk * (P.u_max - ex.u0c));
-                r.lo1 = (float)(hk * (-P.u_max - ex.u1c)); r.hi1 = (float)(hk * (P.u_max - ex.u1c));
-                r.A1 = (float)(-2.0 * sp * P.lean_rho); r.Cn = (float)(-cp * P.lean_rho);
-                r.Wn = (float)((4.0 + 2.0 * cp) * P.lean_rho); r.Pn = (float)(hk * (ex.u0c + ex.u1c));
-                r.w0 = (float)row[2]; r.w1 = (float)row[3];
-                r.c1n = ex.c1; r.s1n = ex.s1;
-                r.X2 = 2.0 * P.lean_f * (ex.X - gx); r.Y2 = 2.0 * P.lean_f * (ex.Y - gy);
-                lt[tid] = r;
-                if (tid == T - 1) fin_sh[0] = ex.th + ex.h;
-                if (blockIdx.x == 0) {  // for mppi_download_value: V = base + Stot - dP
-                    base[(size_t)a * T + tid] = base_t;
-                    double* o = tc + ((size_t)a * T + tid) * kTcW;
-#pragma unroll
-                    for (int i = 0; i < 5; ++i) o[i] = row[i];
-                }
-            }
-        }
-    }
-    __syncthreads();
     const int lane = tid & 63;
     const int kwave = (int)blockIdx.x * 512 + (tid >> 6) * 128;  // this wave's 128 consecutive samples
     const int kA = kwave + 2 * lane;                             // this lane's two: kA, kA + 1
@@ -154,6 +120,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
     constexpr int U = PACK ? 8 : 6;  // steps per chunk = two (hipRAND's normals: four) Philox draws per sample; wave_sum16 carries the chunk's 12 | 16 eps sums
     float nz[U][4];             // the chunk's noise: [step]{wheel 0 of kA, wheel 0 of kA + 1, wheel 1 of kA, wheel 1 of kA + 1}
     float tz[SPD][4];
+    bool drawn0 = false;   // (wave-uniform) this wave drew its first chunk's noise before the barrier
     double dX[2] = {0.0, 0.0}, dY[2] = {0.0, 0.0}, pre[2] = {0.0, 0.0};
     // the heading deviation: a compensated (Kahan) fp32 sum of the steps' 2 dphi -- thf is what the next step's series take (it was
     // (float) of an fp64 running sum until round 4: a conversion each way and an fp64 add per sample and step), thf - thc the sum to
@@ -213,6 +180,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
             for (int i = 0; i < SPD; ++i) { nz[j + i][0] = w0[i].x; nz[j + i][1] = w0[i].y; nz[j + i][2] = w1[i].x; nz[j + i][3] = w1[i].y; }
         }
     };
+    {
+        // the block runs the nominal rollout itself, lanes = timesteps (as rollout_kernel does), and derives the per-step
+        // constants of the deviation form from it
+        __shared__ double nom_sh[4];
+        // (a scalar condition: the two sides are real branches, the noise registers of one are not live through the other)
+        const bool prologue_wave = INLINE_NOM == 2 || __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
+        if (prologue_wave) {
+            double row[5], base_t;
+            NomExtra ex;
+            nominal_lanes<(INLINE_NOM == 2 ? 4 : 1)>(P, state, goal, unom, a, tid, row, base_t, nom_sh, nullptr, &ex);
+            if (tid < T) {
+                const double hk = 0.5 * P.kth * P.dt, phin = 0.5 * ex.h;
+                double sp, cp;
+                if (fabs(phin) <= 0.25) small_sincos<7>(phin, sp, cp);
+                else sincos(phin, &sp, &cp);
+                PkRow r;
+                r.d0 = (float)(hk * (row[0] - ex.u0c)); r.d1 = (float)(hk * (row[1] - ex.u1c));
+                r.lo0 = (float)(hk * (-P.u_max - ex.u0c)); r.hi0 = (float)(hk * (P.u_max - ex.u0c));
+                r.lo1 = (float)(hk * (-P.u_max - ex.u1c)); r.hi1 = (float)(hk * (P.u_max - ex.u1c));
+                r.A1 = (float)(-2.0 * sp * P.lean_rho); r.Cn = (float)(-cp * P.lean_rho);
+                r.Wn = (float)((4.0 + 2.0 * cp) * P.lean_rho); r.Pn = (float)(hk * (ex.u0c + ex.u1c));
+                r.w0 = (float)row[2]; r.w1 = (float)row[3];
+                r.c1n = ex.c1; r.s1n = ex.s1;
+                r.X2 = 2.0 * P.lean_f * (ex.X - gx); r.Y2 = 2.0 * P.lean_f * (ex.Y - gy);
+                lt[tid] = r;
+                if (tid == T - 1) fin_sh[0] = ex.th + ex.h;
+                if (blockIdx.x == 0) {  // for mppi_download_value: V = base + Stot - dP
+                    base[(size_t)a * T + tid] = base_t;
+                    double* o = tc + ((size_t)a * T + tid) * kTcW;
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) o[i] = row[i];
+                }
+            }
+        } else {
+            // T <= 64: one wave runs the nominal rollout, the other three would wait at the barrier behind it -- and the blocks of a CU
+            // run in lockstep, so twice per launch every SIMD would host one working wave and three waiting ones (4.1 us of the
+            // launch, measured).  They draw the noise of their first chunk meanwhile (it depends on nothing the prologue computes).
+            draw(0, U);
+            drawn0 = true;
+        }
+    }
+    __syncthreads();
     // per-wave sums of eps (the E of the softmax floor term, control/src/mppi:193) for the chunk's steps x 2 wheels: the
     // lane's two samples are added first, one 16-value reduce-scatter serves 128 samples.  epart keeps its
     // [A][T][2][Ks/64] layout: the wave's total goes to the slot of its first 64 samples, 0 to the slot of the other 64
@@ -317,7 +326,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
     const bool ride = U == 6 && T4 >= U && (T - T4 == 1 || T - T4 == 2);  // (uniform)
     auto run = [&](auto full_tag) __attribute__((always_inline)) {
         const int t_loop = ride ? T4 - U : T4;
-        for (int t0 = 0; t0 < t_loop; t0 += U) {
+        // (the first chunk stands in front of the loop: the waves that waited at the barrier have drawn its noise there)
+        if (t_loop > 0) {
+            if (!drawn0) draw(0, U);   // (uniform)
+            eps_sums(0, full_tag, std::false_type{});
+            chunk(0, U, full_tag);
+        }
+        for (int t0 = U; t0 < t_loop; t0 += U) {
             draw(t0, U);
             eps_sums(t0, full_tag, std::false_type{});
             chunk(t0, U, full_tag);
