@@ -303,3 +303,44 @@ def test_sig_matrix_not_isotropic(orc, golden, tag):
         assert np.abs(st - golden[tag + "_seq_states"][i]).max() < 1e-10, i
         assert np.abs(ua - golden[tag + "_seq_u"][i]).max() < 1e-9, i
     assert np.abs(lat - golden[tag + "_seq_latest_uvec"]).max() < 1e-9
+
+
+@pytest.mark.parametrize("packing", [0, 1, 2])
+def test_device_noise_twins_use_the_philox_words_as_documented(orc, packing):
+    """The CPU twins of the engine's three noise packings (include/mppi_hip.h, option "noise_packing") restated once more in numpy
+    from the raw Philox4x32-10 words: which bits of which call serve which step, the Box-Muller radius each packing can reach, and
+    -- on 2 x 10^5 draws -- zero mean, variance sigma^2, uncorrelated wheels.  (The GPU suite ties the device noise to these twins,
+    and packing 2 to hiprand_normal4() bit for bit.)"""
+    sigma, seed, agent, tick, k_off, K, T = 0.9, (7 << 32) | 12345, 3, 41, 1000, 96, 23
+    eps = orc.philox_noise(seed, agent, tick, k_off, K, T, sigma, packing=packing)
+    assert eps.shape == (T, 2, K) and np.isfinite(eps).all()
+    spd = {0: 3, 1: 4, 2: 2}[packing]
+    key = [seed & 0xFFFFFFFF, seed >> 32]
+    for k in (0, 1, K - 1):
+        for t in (0, 1, 2, 3, 4, 5, 7, T - 1):
+            o = orc.philox4x32_10([k_off + k, t // spd, tick, agent], key)
+            j = t % spd
+            if packing == 0:
+                a = [o[0] >> 11, o[2] >> 11, ((o[0] & 0x7FF) << 10) | ((o[1] & 0x7FF) >> 1)][j]
+                b = [o[1] >> 11, o[3] >> 11, ((o[2] & 0x7FF) << 10) | ((o[3] & 0x7FF) >> 1)][j]
+                u1, u2 = (a + 0.5) / 2**21, b / 2**21
+            elif packing == 1:
+                u1, u2 = ((o[j] & 0xFFFF) + 0.5) / 2**16, (o[j] >> 16) / 2**16
+            else:   # rocRAND's box_muller: u = 2^-32 + x 2^-32, v = 2 pi 2^-32 (1 + y), (sin v, cos v) sqrt(-2 ln u), in fp32
+                x, y = np.float32(o[2 * j]), np.float32(o[2 * j + 1])
+                u = np.float32(np.float64(x) * np.float64(np.float32(2.3283064e-10)) + np.float64(np.float32(2.3283064e-10)))
+                v = np.float32(np.float64(y) * np.float64(np.float32(1.46291807e-09)) + np.float64(np.float32(1.46291807e-09)))
+                s = np.sqrt(-2.0 * np.log(np.float64(u)))
+                want = np.array([np.sin(np.float64(v)) * s, np.cos(np.float64(v)) * s]) * sigma
+                assert np.abs(eps[t, :, k] - want).max() < 2e-6 * max(1.0, s)
+                continue
+            r = sigma * np.sqrt(-2.0 * np.log(u1))
+            want = np.array([r * np.cos(2 * np.pi * u2), r * np.sin(2 * np.pi * u2)])
+            assert np.abs(eps[t, :, k] - want).max() < 1e-6
+    big = orc.philox_noise(seed, 0, 0, 0, 4096, 25, sigma, packing=packing)          # 204 800 normals
+    radius = {0: 5.53, 1: 4.86, 2: 6.67}[packing]
+    assert np.abs(big).max() <= radius * sigma * 1.000001
+    n = big.size
+    assert abs(big.mean()) < 4 * sigma / np.sqrt(n)
+    assert abs(big.var() / sigma**2 - 1.0) < 0.02
+    assert abs(np.corrcoef(big[:, 0].ravel(), big[:, 1].ravel())[0, 1]) < 0.02
