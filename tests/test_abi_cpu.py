@@ -252,3 +252,63 @@ def test_committed_round4_bench_line_says_what_bounds_the_kernels():
     assert one["self_check"]["max_abs_diff_u"] <= 1e-10 and one["ms_per_step"] >= line["ms_per_step"] * 0.95
     cpu = line["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0
+
+
+def test_python_shell_fast_paths_still_see_every_change():
+    """The reference reads Q, R, P1 and uvec_init[:, 0] on every get_path (control/src/mppi:69-73, :101) and grows path / uvec by
+    np.concatenate (:97-98).  The shell keeps those semantics on fast paths (a byte comparison of the attributes, buffers that
+    double): in-place edits, rebinding, dtype changes and invalid matrices must all still be seen; path / uvec must still be
+    plain arrays of the right shape that can be assigned to.  (Host logic only: the engine is a recording stand-in.)"""
+    from motion_planning_amd import mppi as M
+
+    class Recorder:
+        sigma = lam = None
+        def __init__(self): self.calls = []
+        def set_weights(self, q, r, p1): self.calls.append(("weights", q.copy(), r.copy(), p1.copy()))
+        def set_shift_fill(self, f): self.calls.append(("fill", np.array(f)))
+        def set_sig(self, sig, lam): pass
+        def set_nominal(self, u): self.calls.append(("nominal",))
+        def reset(self): self.calls.append(("reset",))
+        def tick(self, state, goal, **kw): return np.array([[1.0, 2.0, 3.0]]) * (len(self.calls) + 1), np.array([[0.5, -0.5]])
+
+    m = M.MPPI.__new__(M.MPPI)
+    m.horizon, m.samples, m.thresh, m.rng, m.seed, m._tick, m.dt = 8, 4, 0.05, "philox", 0, 0, 0.125
+    m.Q, m.R, m.P1 = np.diag([1e3, 1e3, 0.0]), np.diag([1.0, 1.0]), np.diag([1e3, 1e3, 1e3])
+    m.uvec_init = np.zeros((2, 8))
+    m._weights_sent = m._weights_raw = None
+    m._fill_sent = np.zeros(2)
+    m._path_buf = m._uvec_buf = None
+    m._eng = eng = Recorder()
+    m.start, m.goal = np.zeros(3), np.array([1.0, 0.0, 0.0])
+    m.initialize()
+    n = lambda kind: sum(c[0] == kind for c in eng.calls)
+    m.get_path(m.start, m.goal); m.get_path(m.start, m.goal)
+    assert n("weights") == 1 and n("fill") == 0                      # sent once, then the fast path
+    m.Q[2, 2] = 5.0                                                   # in place
+    m.get_path(m.start, m.goal)
+    assert n("weights") == 2 and eng.calls[-1][1][2] == 5.0
+    m.R = [[2.0, 0.0], [0.0, 3.0]]                                    # rebound to a list
+    m.get_path(m.start, m.goal); m.get_path(m.start, m.goal)
+    assert n("weights") == 3 and list(eng.calls[-1][2]) == [2.0, 3.0]
+    m.P1 = np.diag([1, 2, 3]).astype(np.int64)                       # another dtype
+    m.get_path(m.start, m.goal)
+    assert n("weights") == 4 and list(eng.calls[-1][3]) == [1.0, 2.0, 3.0]
+    m.Q = np.ones((3, 3))
+    with pytest.raises(ValueError):
+        m.get_path(m.start, m.goal)
+    m.Q = np.diag([1e3, 1e3, 0.0])
+    m.uvec_init[:, 0] = [0.3, -0.2]                                   # in place: the shift fill of the next tick
+    m.get_path(m.start, m.goal)
+    assert n("fill") == 1 and list(eng.calls[-1][1]) == [0.3, -0.2]
+    m.get_path(m.start, m.goal)
+    assert n("fill") == 1
+    # path / uvec: one row per get_path behind the initial one, plain arrays, assignable
+    assert m.path.shape == (9, 3) and m.uvec.shape == (9, 2) and len(m.fin_time) == 9
+    assert np.all(m.uvec[-1] == [0.5, -0.5]) and np.all(m.path[0] == 0.0)
+    old = m.path
+    for _ in range(200):                                              # across several doublings of the buffers
+        m.get_path(m.start, m.goal)
+    assert m.path.shape == (209, 3) and np.array_equal(m.path[:9], old) and old.shape == (9, 3)
+    m.path = np.zeros((1, 3)); m.uvec = [[1.0, 2.0]]
+    m.get_path(m.start, m.goal)
+    assert m.path.shape == (2, 3) and m.uvec.shape == (2, 2) and np.all(m.uvec[0] == [1.0, 2.0])
