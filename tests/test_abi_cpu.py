@@ -250,6 +250,9 @@ def test_committed_round4_bench_line_says_what_bounds_the_kernels():
     assert roof["tick_level"]["accounting_8d"]["frac"] > 0.9           # the contract's tick-level figure: most of its bytes never exist
     one = line["one_engine"]
     assert one["self_check"]["max_abs_diff_u"] <= 1e-10 and one["ms_per_step"] >= line["ms_per_step"] * 0.95
+    pack = line["noise_packing_1"]    # the optional 16-bit noise packing next to the default stream, the headline's protocol
+    assert pack["one_engine"]["steps"] == line["steps"] and 0.8 * one["rollout_us"] < pack["one_engine"]["rollout_us"] < one["rollout_us"]
+    assert pack["co_scheduled"]["ms_per_step"] < one["ms_per_step"] and "not the default" in pack["option"]
     cpu = line["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0
 
