@@ -217,8 +217,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
             // T <= 64: one wave runs the nominal rollout, the other three would wait at the barrier behind it -- and the blocks of a CU
             // run in lockstep, so twice per launch every SIMD would host one working wave and three waiting ones (4.1 us of the
             // launch, measured).  They draw the noise of their first chunk meanwhile (it depends on nothing the prologue computes).
-            draw(0, U);
-            drawn0 = true;
+            // (the default stream only: with the eight-step chunks of the other packings the 32 noise registers held across the barrier
+            // cost spills -- 19 dwords -- and the launch got longer, 92.2 -> 93.8 us)
+            if constexpr (PACK == 0) {
+                draw(0, U);
+                drawn0 = true;
+            }
         }
     }
     __syncthreads();
