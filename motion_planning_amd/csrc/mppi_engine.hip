@@ -1118,6 +1118,7 @@ void mppi_engine::co_pull() {
     pull(d_base, e->d_base, T_ * sizeof(double));
     pull(d_tc, e->d_tc, T_ * mppi::kTcW * sizeof(double));
     pull(d_epart, e->d_epart, T_ * 2 * NW * es);
+    if (!eps_lazy && injected_ready) pull(d_eps, e->d_eps, T_ * 2 * Ks * es);   // (option store_eps: the tick's noise is resident, not re-drawn on demand)
     // (the sub's stream must not run ahead of these copies: its next launches come after co_push_agents' event)
     out_via_host = false;   // d_out is whole; the pinned rows are too, but a later non-split finalize rewrites only d_out's sequence
     wait_stream("co-scheduled agents: results pulled");

@@ -793,6 +793,10 @@ def test_agent_split_handle_follows_parameter_changes():
             e.set_option("noise_packing", 1)
             ticks(False, 2, 60)
             e.set_option("noise_packing", 0)
+            e.set_option("store_eps", 1)                 # the tick's noise resident instead of re-drawn: it is pulled with V
+            ticks(False, 2, 65)
+            traj.append(np.concatenate([e.download_noise()[A - 1, 3, :, ::4001][:, :5], e.download_value()[A - 1, :4, ::4001][:, :5]], axis=0))   # [2 + 4][5]
+            e.set_option("store_eps", 0)
             if co is None:
                 assert e.info()["co_shards"] == 2 and kinds == "fp64"
                 e.p2p_create(1, 0)                       # a caller's own exchange: the group dissolves (its results pulled first)
