@@ -9,15 +9,17 @@
 // block's prologue computes in fp64 (nominal_lanes) and leaves in LDS as one 80-byte row per step:
 //     dp_i   = hk (clip(un_i + eps_i) - clip(un_i))             wheel-speed deviations (hk = kth dt / 2), exact clip
 //     dphi   = dp1 - dp0,  dPs = dp0 + dp1                       rotation / speed deviation of the step
-//     th    += 2 dphi                                            heading deviation                      [fp64 running sum]
+//     th    += 2 dphi                                            heading deviation          [compensated fp32 sum: thf - thc]
 //     alpha  = th_start + dphi                                   mid-step heading deviation
 //     S = sin alpha, Cm = cos alpha - 1                          series, |alpha| <= 0.5 (guarded per chunk, see below)
 //     G  = rho (Pn + dPs) W(phin + dphi),  dG = G - Gn           Simpson-weighted speed and its deviation
 //     (a, b) = (G Cm + dG, G S)                                  increment deviation in the nominal mid-step heading frame
 //     dX += c1n a - s1n b,  dY += s1n a + c1n b                  position deviation (scaled by sqrt(q/2)) [fp64 running sums]
-//     pre += dX (2 Xn + dX) + dY (2 Yn + dY) + lam un.Sig.eps    stage cost minus nominal stage cost     [fp64 running sum]
-// fp32 (packed): the clip, the series, the speed / Simpson-weight deviations and the noise cost -- 28 packed operations
-// per step for two samples; fp64: the three running sums, the rotation into the world frame (it feeds the position sum
+//     pre += dX (2 Xn + dX) + dY (2 Yn + dY)                     stage cost minus nominal stage cost     [fp64 running sum]
+//     ncs += lam un.Sig.eps                                      its noise-cost part                     [fp32 running sum]
+// fp32 (packed): the clip, the series, the speed / Simpson-weight deviations, the heading sum (Kahan: round 4 -- it was an fp64
+// sum converted each way per step) and the noise cost with its running sum -- 32 packed operations per step for two samples;
+// fp64: the position and cost sums, the rotation into the world frame (it feeds the position sum
 // directly: as cheap as a packed rotation plus two conversions, and it keeps the increments' rounding out of the sum)
 // and the quadratic cost.  Every fp32 rounding error is proportional to a DEVIATION (none to the nominal's magnitude).
 // Measured against the fp64 oracle (tools/pk_error_model.py is this arithmetic in numpy; tests replay the kernel):
@@ -27,6 +29,10 @@
 // Box-Muller radius is bounded), so a chunk whose lanes all start with |th| <= al_guard = 0.5 - that bound runs the
 // short series; otherwise (never at the node's sigma: 7 standard deviations) the same step runs series that hold for
 // |alpha| <= 2.  The engine selects this kernel only when T times that per-step bound is <= 2 (rollout_pk_applies).
+//
+// PACK (option "noise_packing", NoisePack in mppi_kernels.hpp): how a Philox call's bits become normals -- 0 three steps per call
+// (chunks of six steps), 1 four (16-bit uniforms), 2 hipRAND's own normals, two (both: chunks of eight steps).
+// T <= 64: one wave runs the block's nominal prologue; the other three draw their first chunk's noise meanwhile (PACK 0).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
