@@ -41,7 +41,8 @@
  *     so results do not depend on the shard count).
  *
  * Environment: MPPI_SYNC_TIMEOUT_MS (default deadline of the blocking waits) is the only variable the library reads.
- * Measurement and test switches are per-handle options: mppi_set_option / mppi_get_option below.
+ * Measurement and test switches are per-handle options: mppi_set_option / mppi_get_option in include/mppi_hip_diag.h,
+ * the measurement surface (kernel timing, shader clock, launch geometry, option switches) that no binding of the node needs.
  */
 #ifndef MPPI_HIP_H
 #define MPPI_HIP_H
@@ -53,7 +54,7 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 4
+#define MPPI_ABI_VERSION 5
 
 /* error codes */
 #define MPPI_OK 0
@@ -108,18 +109,13 @@ extern "C" {
  * that should have split did not.  mppi_tick_begin / _finish (the caller's own exchange), mppi_tick_graph and
  * injected-noise ticks always run unsplit; mppi_p2p_create on such a handle dissolves the group. */
 
-/* kernels, for mppi_kernel_timing (the scan kernel is timed as MPPI_KERNEL_ROLLOUT) */
-#define MPPI_KERNEL_NOMINAL 0
-#define MPPI_KERNEL_ROLLOUT 1
-#define MPPI_KERNEL_UPDATE 2
-#define MPPI_KERNEL_MERGE 3
-#define MPPI_KERNEL_FINALIZE 4
-#define MPPI_KERNEL_EXCHANGE 5 /* the p2p publish kernel (the wait for the peers is inside MPPI_KERNEL_FINALIZE) */
-#define MPPI_KERNEL_COUNT 6
-
 typedef struct mppi_engine mppi_engine;
 
 typedef struct mppi_config {
+    uint32_t struct_size;  /* sizeof(mppi_config) as the CALLER compiled it (mppi_default_config fills it in).  mppi_create
+                              reads exactly that many bytes over its own defaults: a caller built against an older, shorter
+                              struct keeps working when fields are appended (they take their defaults), a size the library
+                              does not know (0, shorter than MPPI_CONFIG_SIZE_V5, longer than its own) is MPPI_E_INVALID    */
     int32_t n_agents;      /* A >= 1 independent controllers batched in one engine           */
     int32_t samples;       /* K >= 1 rollouts per agent owned by this engine (MPPI samples=)  */
     int32_t horizon;       /* T >= 5 (Savitzky-Golay window T-1 > 3, control/src/mppi:202; odd T as scipy >= 1.x) */
@@ -128,9 +124,10 @@ typedef struct mppi_config {
     uint32_t sample_offset;/* global index of local sample 0                                  */
     int32_t model;         /* MPPI_MODEL_*: the `model=` ctor argument (control/src/mppi:62)   */
     int32_t tick_path;     /* MPPI_TICK_*: which kernels a tick runs; default MPPI_TICK_AUTO          */
-    int32_t co_shards;     /* co-scheduled shards of the fused mppi_tick: 0 auto | 1 off | 2..8 (below)  */
+    int32_t co_shards;     /* co-scheduled shards of the fused mppi_tick: 0 auto | 1 off | 2..8 (above)  */
     int32_t agent_offset;  /* global index of local agent 0 (independent agents split over engines / GPUs: the device-RNG streams
                               are keyed by the GLOBAL agent index, so a replica rank draws what the one big engine would)   */
+    int32_t reserved0;     /* 0 (keeps the doubles below 8-byte aligned without compiler padding)                            */
     double dt;             /* <= 0: 1/T  (control/src/mppi:67)                                */
     double sigma;          /* noise std-dev = sig[0,0] (control/src/mppi:145); default 0.9    */
     double lambda;         /* temperature; default 0.001 (control/src/mppi:89)                */
@@ -142,8 +139,10 @@ typedef struct mppi_config {
     double wheel_base;     /* WHEEL_BASE     (control/src/mppi:20)                            */
     double floor_w;        /* weight floor 1e-8 (control/src/mppi:193)                        */
 } mppi_config;
+/* the struct as ABI version 5 introduced it: the shortest struct_size mppi_create accepts (fields are only ever appended) */
+#define MPPI_CONFIG_SIZE_V5 168u
 
-/* Fill *cfg with the reference defaults (K=10, T=100, constants above). */
+/* Fill *cfg with the reference defaults (K=10, T=100, constants above) and struct_size = sizeof(mppi_config). */
 int mppi_default_config(mppi_config *cfg);
 
 int mppi_abi_version(void);
@@ -172,6 +171,11 @@ int mppi_set_sig_matrix(mppi_engine *h, const double *sig /*[4]*/, double lambda
  * call, :168, :183) as their diagonals q[3], r[2], p1[3]; NULL keeps the current values.  Takes effect with the next
  * rollout. */
 int mppi_set_weights(mppi_engine *h, const double *q, const double *r, const double *p1);
+/* The same as the FULL row-major matrices the reference multiplies -- (state - desired).T.dot(Q).dot(state - desired),
+ * u.T.dot(R).dot(u) (control/src/mppi:181-184), .dot(P1) (:168): Q [3][3], R [2][2], P1 [3][3]; NULL keeps the current one.
+ * A quadratic form only sees the symmetric part of its matrix, so (M + M') / 2 is what the kernels carry.  Matrices with
+ * off-diagonal terms run the general-cost rollout (all fp64); diagonal ones keep whatever kernel mppi_set_weights would pick. */
+int mppi_set_weight_matrices(mppi_engine *h, const double *Q /*[9]*/, const double *R /*[4]*/, const double *P1 /*[9]*/);
 
 /* Deadline of the blocking waits, in milliseconds (0 = wait forever).  See MPPI_E_TIMEOUT. */
 int mppi_set_sync_timeout(mppi_engine *h, int milliseconds);
@@ -307,78 +311,9 @@ int mppi_set_tick_counter(mppi_engine *h, uint32_t next_tick_id);
 
 int mppi_synchronize(mppi_engine *h);
 
-/*
- * Per-handle switches for measurements and tests (none changes results beyond rounding); a co-scheduled handle passes them
- * on to its shards.  Keys of mppi_set_option (value) / mppi_get_option:
- *   "rollout_pk"      0: fp32-storage ticks stay on the all-fp64 rollout (same-box A/B against the mixed-precision one)
- *   "pk_min_samples"  >= 0: a plain size rule for the mixed-precision rollout; -1 (default): chosen by rounds of waves
- *   "pk_waves"        4 | 5: the mixed-precision rollout's 5-waves-per-SIMD build
- *   "upd_skip"        0: the update forms exp() for every sample (default 1: wave-vectors without a weight above the cut are skipped)
- *   "store_eps"       1: the tick path stores its noise like mppi_rollout does
- *   "co_cut_pct"      share of shard 0 of a two-shard co-scheduled handle in per cent (default 58); re-cuts the group
- * and one that selects another noise STREAM (same generator, same counters, other use of its bits):
- *   "noise_packing"   0 (default): one Philox4x32-10 call serves three steps (2 x 21-bit uniforms per step: Box-Muller radius
- *                     <= 5.53 sigma, 2^21 directions); 1: four steps (word j of call t / 4 serves step t: its low 16 bits the radius
- *                     uniform, radius <= 4.85 sigma, its high 16 bits the direction) -- a quarter fewer calls, the mixed-precision
- *                     rollout 7 % shorter; 2: hipRAND's own normals -- two steps per call, mppi_download_noise / sigma =
- *                     hiprand_normal4() of a hiprandStatePhilox4_32_10_t initialised with hiprand_init(seed, agent << 32 | tick,
- *                     4 * ((t / 2) << 32 | global sample)), bit for bit: values (x, y) step t even, (z, w) step t odd, wheels 0, 1
- *                     (32-bit uniforms, radius <= 6.66 sigma, the device library's logf / sqrtf: the rollout a third longer).
- *                     1 and 2 are drawn by the mixed-precision rollout only: fp32 storage, the lane kernels, the node's cost and
- *                     model (2: T >= 32 at dt = 1 / T and sigma = 0.9); MPPI_E_INVALID where they cannot be served (from the option
- *                     call, or from the tick that would need another kernel).  mppi_rollout, mppi_download_noise, mppi_update and
- *                     the oracle's twins follow the option.
- * Unknown keys and out-of-range values return MPPI_E_INVALID.
- */
-int mppi_set_option(mppi_engine *h, const char *key, int64_t value);
-int mppi_get_option(mppi_engine *h, const char *key, int64_t *value);
-
 /* Savitzky-Golay operator S [T][T] with u_f = u @ S, as savgol_filter(u, T-1, 3, axis=1)
  * (mode='interp') applies it at control/src/mppi:202.  Host only. */
 int mppi_savgol_matrix(int horizon, double *S);
-
-/*
- * Kernel timing with HIP events on the engine's stream.  mask = OR of (1 << MPPI_KERNEL_*)
- * to time, 0 = off.  mppi_kernel_times synchronises and returns, per kernel, the summed
- * duration (ms) and the number of launches since timing was (re)enabled.  The rollout kernel's
- * events ride on its own launch (dispatch begin / end timestamps, no marker packets in the
- * stream); the small kernels are bracketed by recorded events.
- */
-int mppi_kernel_timing(mppi_engine *h, uint32_t mask);
-/* Bracket only every `period`-th launch of each selected kernel (default 1 = every launch):
- * an event pair costs a few microseconds of stream time, sampling keeps a timed region honest. */
-int mppi_kernel_timing_period(mppi_engine *h, int period);
-int mppi_kernel_times(mppi_engine *h, double *ms /*[MPPI_KERNEL_COUNT]*/,
-                      int64_t *launches /*[MPPI_KERNEL_COUNT]*/);
-
-/* Shader clock (MHz) the last lane-per-sample rollout launch ran at: one lane of that launch's middle workgroup reads
- * the shader cycle counter (s_memtime) and the constant-rate counter (s_memrealtime) when its wave starts and ends.
- * 0 before the first such launch.  Synchronises.  (Measurement aid: prices the VALU-issue roofline of bench.py.) */
-int mppi_shader_clock(mppi_engine *h, double *mhz);
-
-/* How the fused device-noise mppi_tick of this handle runs: n_shards co-scheduled engines (1: unsplit) and the samples
- * each owns (samples [8], zero-filled behind n_shards).  A handle that splits its AGENTS reports mppi_config.samples for every
- * engine (each rolls out all samples of its agents: engine 0 the first ceil(n_agents / 2) of them). */
-int mppi_co_info(mppi_engine *h, int32_t *n_shards, int32_t *samples);
-/* Why this handle runs unsplit although co_shards AUTO would have split it (the second set of buffers could not be
- * built), or why a group was dissolved (a co-scheduled tick failed half-way): "" when there is nothing to report.  Never NULL. */
-const char *mppi_co_note(const mppi_engine *h);
-
-/* Which rollout kernel this handle's last tick / mppi_rollout launched (a co-scheduled handle: its shards all take the same
- * one; the re-run behind a later mppi_download_value does not count):
- * MPPI_ROLLOUT_NONE before the first; _FP64 the one-sample-per-lane kernel (all arithmetic fp64); _MIXED the
- * mixed-precision two-samples-per-lane kernel (fp32 storage, device noise, the node's cost and model, T <= 256, at the sizes
- * where it is the faster of the two -- from about 262 000 samples); _SCAN the single-kernel small-K tick.  What tests and bench.py label their numbers with. */
-#define MPPI_ROLLOUT_NONE 0
-#define MPPI_ROLLOUT_FP64 1
-#define MPPI_ROLLOUT_MIXED 2
-#define MPPI_ROLLOUT_SCAN 3
-int mppi_rollout_kernel(mppi_engine *h, int32_t *kind);
-
-/* Bytes of HBM held by the engine, and the launch geometry (blocks) of a tick's kernels: rollout +
- * update on the lane-per-sample path; the scan kernel and update_blocks = 0 on the small-K path. */
-int mppi_engine_info(mppi_engine *h, size_t *hbm_bytes, int32_t *rollout_blocks,
-                     int32_t *update_blocks);
 
 #ifdef __cplusplus
 }

@@ -1,4 +1,4 @@
-"""ctypes binding of include/mppi_hip.h (libmppi_hip.so).  This is the whole FFI: the
+"""ctypes binding of include/mppi_hip.h and include/mppi_hip_diag.h (libmppi_hip.so).  This is the whole FFI: the
 reference has none (its controller is a single Python script, control/src/mppi), so this
 file is the binding INTEGRATION.md tells a maintainer to add."""
 import ctypes as C
@@ -14,14 +14,15 @@ MPPI_TICK_AUTO, MPPI_TICK_LANES, MPPI_TICK_SCAN = 0, 1, 2
 MPPI_E_TIMEOUT = -5
 IPC_HANDLE_BYTES = 64
 KERNELS = ("nominal", "rollout", "update", "merge", "finalize", "exchange")
-ABI_VERSION = 4
+ABI_VERSION = 5
+PROBE_MARKS = 30
 
 
 class MppiConfig(C.Structure):
-    _fields_ = [("n_agents", C.c_int32), ("samples", C.c_int32), ("horizon", C.c_int32),
+    _fields_ = [("struct_size", C.c_uint32), ("n_agents", C.c_int32), ("samples", C.c_int32), ("horizon", C.c_int32),
                 ("storage", C.c_int32), ("device", C.c_int32), ("sample_offset", C.c_uint32),
                 ("model", C.c_int32), ("tick_path", C.c_int32), ("co_shards", C.c_int32), ("agent_offset", C.c_int32),
-                ("dt", C.c_double), ("sigma", C.c_double), ("lambda_", C.c_double),
+                ("reserved0", C.c_int32), ("dt", C.c_double), ("sigma", C.c_double), ("lambda_", C.c_double),
                 ("q", C.c_double * 3), ("r", C.c_double * 2), ("p1", C.c_double * 3),
                 ("u_max", C.c_double), ("wheel_radius", C.c_double), ("wheel_base", C.c_double),
                 ("floor_w", C.c_double)]
@@ -36,7 +37,7 @@ class MppiError(RuntimeError):
 _dp = C.POINTER(C.c_double)
 _H = C.c_void_p
 
-# name -> (restype, argtypes); every symbol include/mppi_hip.h declares
+# name -> (restype, argtypes); every symbol include/mppi_hip.h and include/mppi_hip_diag.h declare
 SIGNATURES = {
     "mppi_default_config": (C.c_int, [C.POINTER(MppiConfig)]),
     "mppi_abi_version": (C.c_int, []),
@@ -48,6 +49,7 @@ SIGNATURES = {
     "mppi_set_sigma_lambda": (C.c_int, [_H, C.c_double, C.c_double]),
     "mppi_set_sig_matrix": (C.c_int, [_H, _dp, C.c_double]),
     "mppi_set_weights": (C.c_int, [_H, _dp, _dp, _dp]),
+    "mppi_set_weight_matrices": (C.c_int, [_H, _dp, _dp, _dp]),
     "mppi_set_sync_timeout": (C.c_int, [_H, C.c_int]),
     "mppi_set_tick_counter": (C.c_int, [_H, C.c_uint32]),
     "mppi_stream_wait_partials": (C.c_int, [_H, C.c_void_p]),
@@ -89,6 +91,7 @@ SIGNATURES = {
     "mppi_kernel_timing_period": (C.c_int, [_H, C.c_int]),
     "mppi_kernel_times": (C.c_int, [_H, _dp, C.POINTER(C.c_int64)]),
     "mppi_shader_clock": (C.c_int, [_H, _dp]),
+    "mppi_probe_timeline": (C.c_int, [_H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "mppi_co_info": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "mppi_co_note": (C.c_char_p, [_H]),
     "mppi_rollout_kernel": (C.c_int, [_H, C.POINTER(C.c_int32)]),

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/mppi_hip.h"
+#include "../../include/mppi_hip_diag.h"
 #include "mppi_kernels.hpp"
 #include "rollout_launch.hpp"
 #include "rollout_pk.hpp"
@@ -116,8 +117,24 @@ struct mppi_engine {
     int noise_pack = 0;             // option "noise_packing": how a Philox call's bits become normals (mppi::NoisePack): 0 three steps per call, 1 four, 2 hipRAND's normals (two)
     int upd_skip_light = 1;         // option "upd_skip" = 0: the update kernel forms exp() for every sample (same-box A/B)
     bool use_pk = true;             // option "rollout_pk" = 0: keep the all-fp64 rollout kernel on the tick path (same-box A/B measurements)
-    double* d_tc = nullptr;  // [A][T][8]
-    double* d_base = nullptr;
+    double* d_tc = nullptr;  // [A][T][8]   the nominal trajectory's table the LAST rollout used (= tcb[tab])
+    double* d_base = nullptr;   //             (= baseb[tab])
+    // The table exists twice: a tick's finalize kernel writes the NEXT tick's table (nominal_table_lanes) into the other set while
+    // d_tc / d_base still describe the tick just run (mppi_download_value: V = base + Stot - dP); a rollout launch that loads its
+    // table takes that set and makes it the current one.
+    double* tcb[2] = {nullptr, nullptr};
+    double* baseb[2] = {nullptr, nullptr};
+    mppi::PkRow* pkb[2] = {nullptr, nullptr};   // [A][T] the deviation-form rows (rollout_pk.hpp) of the same tables
+    int tab = 0;
+    bool table_valid = false;   // set tab ^ 1 holds the table of (d_state, d_goal, d_unom) as they are now
+    bool hoist = true;          // option "table_hoist"
+    int fin_threads_opt = 0;    // option "fin_threads"
+    int k_pieces_opt = 0;       // option "k_pieces"
+    int low_occ_opt = -1;       // option "low_occ"
+    int graph_tab = 0;
+    bool table_taken = false;   // this tick's rollout launches already switched to the set they load
+    void use_table_set(int t) { tab = t; d_tc = tcb[t]; d_base = baseb[t]; }
+    void invalidate_table() { table_valid = false; table_taken = false; }   // (whatever changes d_state / d_goal / d_unom or what the table derives from them)
     double* d_unom = nullptr;
     double* d_ufilt = nullptr;
     double* d_state = nullptr;
@@ -158,6 +175,7 @@ struct mppi_engine {
 
     bool noise_ready = false, value_ready = false, partials_ready = false, have_state = false, have_goal = false;
     bool injected_ready = false;   // d_eps holds noise a MPPI_NOISE_INJECTED rollout may read (uploaded, or stored by a rollout)
+    double w_off[7] = {0, 0, 0, 0, 0, 0, 0};  // off-diagonal terms of the symmetric parts of Q (01, 02, 12), R (01), P1 (01, 02, 12): mppi_set_weight_matrices
     double sig_cost[4] = {0, 0, 0, 0};  // the sig matrix of the stage cost (sigma * I unless mppi_set_sig_matrix)
     bool sig_is_matrix = false;
     uint32_t last_tick_id = 0;     // id of the last eager tick (its successor is written to d_tick by tick_finish)
@@ -286,6 +304,7 @@ struct mppi_engine {
             HIPCHK(hipMemcpyAsync(e->d_state, d_state, A_ * 3 * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
             HIPCHK(hipMemcpyAsync(e->d_goal, d_goal, A_ * 3 * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
             e->have_state = have_state; e->have_goal = have_goal;
+            e->invalidate_table();
         }
         co_synced = true;
     }
@@ -398,6 +417,7 @@ struct mppi_engine {
     // (two copies were 14 of the 47 us of a K = 10 tick); that kernel refreshes d_state / d_goal for the later ones.
     void set_inputs(const double* state, const double* goal, bool zero_copy = false) {
         const size_t n = (size_t)cfg.n_agents * 3;
+        if (state || goal) invalidate_table();   // a fresh pose / goal: not what the last finalize kernel prepared the table for
         in_state = d_state; in_goal = d_goal; in_slot = -1;
         if (zero_copy && (state || goal)) {
             release_unclaimed_slot();
@@ -439,7 +459,9 @@ struct mppi_engine {
         }
     }
 
-    void launch_rollout(hipStream_t st, int k0, int k1, bool ph, bool store, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
+    // dp_shift: this launch's cost prefix goes to columns [k0 - dp_shift, k1 - dp_shift) of the rows of d_dP (k_pieces: every piece of a
+    // tick in the same region of the buffer)
+    void launch_rollout(hipStream_t st, int k0, int k1, bool ph, bool store, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr, int dp_shift = 0) {
         mppi::RolloutArgs a{};
         // timing: the launch carries its own start / stop events (no marker packets in the stream)
         if ((time_mask & (1u << MPPI_KERNEL_ROLLOUT)) && (time_seen[MPPI_KERNEL_ROLLOUT]++ % time_period) == 0) {
@@ -448,12 +470,16 @@ struct mppi_engine {
         }
         a.P = P; a.stream = st; a.k0 = k0; a.k1 = k1; a.philox = ph; a.store_eps = store;
         a.model = cfg.model;
-        a.inline_nominal = !inline_nominal() ? 0 : (cfg.horizon <= 64 ? 1 : 2);
+        // the table the previous tick's finalize kernel left for exactly these inputs: load it (no prologue); that set becomes the
+        // current one (d_tc / d_base: what mppi_download_value adds to the stored offsets)
+        const bool load_table = hoist && table_valid && inline_nominal() && !ro_state && !ro_goal && !ro_unom && !capturing;
+        if (load_table && !table_taken) { use_table_set(tab ^ 1); table_taken = true; }
+        a.inline_nominal = !inline_nominal() || load_table ? 0 : (cfg.horizon <= 64 ? 1 : 2);
         a.general = general_cost();
         a.seed = seed; a.tick = tick; a.tick_ptr = tick_ptr;
         a.state = ro_state ? ro_state : d_state; a.goal = ro_goal ? ro_goal : d_goal;
         a.unom = ro_unom ? ro_unom : d_unom; a.tc = d_tc; a.base = d_base;
-        a.eps = d_eps; a.dP = d_dP; a.stot = d_stot; a.epart = d_epart;
+        a.eps = d_eps; a.dP = static_cast<char*>(d_dP) - (size_t)dp_shift * esz(); a.stot = d_stot; a.epart = d_epart;
         hipError_t e;
         // the tick path of an fp32-storage engine with the node's own cost and model: the mixed-precision kernel, two
         // samples per lane on the packed-fp32 pipe (rollout_pk.hpp); its heading series need the noise's reach bounded
@@ -482,6 +508,7 @@ struct mppi_engine {
             b.state = a.state; b.goal = a.goal; b.unom = a.unom; b.tc = d_tc; b.base = d_base;
             b.dP = static_cast<float*>(d_dP); b.stot = static_cast<float*>(d_stot); b.epart = static_cast<float*>(d_epart);
             b.al_guard = mppi::rollout_pk_guard(P.kth, P.dt, P.sigma, noise_pack);
+            b.pkrows = pkb[tab];
             b.waves = pk_waves; b.noise_pack = noise_pack;
             b.ev_start = a.ev_start; b.ev_stop = a.ev_stop;
             e = mppi::launch_rollout_pk(b);
@@ -577,17 +604,18 @@ struct mppi_engine {
         HIPCHK(hipGetLastError());
         epart_ready = true;
     }
-    void launch_update(hipStream_t st, int ch0, int nch, const uint32_t* tick_ptr = nullptr) {
+    void launch_update(hipStream_t st, int ch0, int nch, const uint32_t* tick_ptr = nullptr, int dp_shift = 0) {
         ensure_epart(st);
+        const char* dP_at = static_cast<const char*>(d_dP) - (size_t)dp_shift * esz();
         Scope sc(this, MPPI_KERNEL_UPDATE, st);
         dim3 grid(8 * cfg.horizon, (cfg.n_agents * nch + 7) / 8);  // XCD-aware decode inside the kernel
 #define LAUNCH_UPD(TYPE, REGEN)                                                                                  \
     hipLaunchKernelGGL((mppi::update_kernel<TYPE, REGEN>), grid, dim3(256), 0, st, P, static_cast<const TYPE*>(d_eps), \
-                       static_cast<const TYPE*>(d_dP), static_cast<const TYPE*>(d_stot), d_part, NCH, ch0, nch,    \
+                       reinterpret_cast<const TYPE*>(dP_at), static_cast<const TYPE*>(d_stot), d_part, NCH, ch0, nch,    \
                        static_cast<const TYPE*>(d_epart), lazy_seed, lazy_tick, tick_ptr, upd_skip_light)
 #define LAUNCH_UPD_PACK(PK)                                                                                               \
     hipLaunchKernelGGL((mppi::update_kernel<float, true, PK>), grid, dim3(256), 0, st, P, static_cast<const float*>(d_eps), \
-                       static_cast<const float*>(d_dP), static_cast<const float*>(d_stot), d_part, NCH, ch0, nch,           \
+                       reinterpret_cast<const float*>(dP_at), static_cast<const float*>(d_stot), d_part, NCH, ch0, nch,           \
                        static_cast<const float*>(d_epart), lazy_seed, lazy_tick, tick_ptr, upd_skip_light)
         if (f64()) { if (eps_lazy) LAUNCH_UPD(double, true); else LAUNCH_UPD(double, false); }
         else if (eps_lazy && noise_pack == 1) LAUNCH_UPD_PACK(1);
@@ -611,7 +639,7 @@ struct mppi_engine {
     bool general_cost() const {
         // the lean rollout instantiations are written for the node's cost: Q = diag(q, q, 0), q > 0 (and sane: they scale
         // positions by sqrt(q/2)), no obstacle grid
-        return P.q2 != 0.0 || P.grid_weight != 0.0 || P.q0 != P.q1 || !(P.q0 > 1e-100 && P.q0 < 1e100);
+        return P.q2 != 0.0 || P.grid_weight != 0.0 || P.q0 != P.q1 || !(P.q0 > 1e-100 && P.q0 < 1e100) || P.offdiag != 0;
     }
     // which of the two lane-per-sample rollouts a device-noise tick of this engine takes (see launch_rollout)
     bool pick_pk(bool ph, bool store, int k0, int k1) const {
@@ -656,10 +684,41 @@ struct mppi_engine {
         }
         merge_skipped = (skip_small_merge || (p2p_connected && !p2p_internal)) && NCH <= kDirectTuples;
         direct_n = NCH;
+        const int pieces = tick_pieces(ph, store);
+        if (pieces > 1) {
+            // Infinity-Cache-sized pieces: rollout + update per piece, every piece's cost prefix in the same columns of d_dP -- what the
+            // rollout wrote is read back before anything evicts it, and the next piece overwrites it in place (nothing of it ever has
+            // to reach HBM).  The tick's V exists piece by piece only: re-run from the snapshot on demand (materialise_value).
+            double* const snap_was = P.snap;
+            P.snap = d_prev;
+            const int per = (NCH + pieces - 1) / pieces;   // chunks per piece
+            try {
+                for (int c0 = 0; c0 < NCH; c0 += per) {
+                    const int c1 = std::min(NCH, c0 + per), k0 = c0 * CH, k1 = std::min(cfg.samples, c1 * CH);
+                    launch_rollout(stream, k0, k1, ph, store, seed, tick, tick_ptr, k0);
+                    launch_update(stream, c0, c1 - c0, tick_ptr, k0);
+                }
+            } catch (...) { P.snap = snap_was; throw; }
+            P.snap = snap_was;
+            if (!merge_skipped) launch_merge(NCH);
+            noise_ready = true; value_ready = false; value_lazy = true; partials_ready = true; epart_ready = true;
+            return;
+        }
         launch_rollout(stream, 0, cfg.samples, ph, store, seed, tick, tick_ptr);
         launch_update(stream, 0, NCH, tick_ptr);
         if (!merge_skipped) launch_merge(NCH);
         noise_ready = true; value_ready = true; value_lazy = false; partials_ready = true; epart_ready = true;
+    }
+    // How many pieces a lane-per-sample tick runs its samples in (option "k_pieces"; include/mppi_hip_diag.h).  AUTO: fp64 storage whose
+    // cost prefix does not fit the Infinity Cache next to everything else -- pieces of at most 144 MB.
+    int tick_pieces(bool ph, bool store) const {
+        if (!ph || store || small_nb > 0 || NCH < 2 || noise_pack) return 1;
+        int n = k_pieces_opt;
+        if (n == 0) {
+            const size_t bytes = (size_t)cfg.n_agents * cfg.horizon * P.Ks * esz();
+            n = f64() && bytes > ((size_t)208 << 20) ? (int)((bytes + ((size_t)144 << 20) - 1) / ((size_t)144 << 20)) : 1;
+        }
+        return std::max(1, std::min(n, NCH));
     }
     // T <= 256: the nominal rollout runs inside every rollout block (lanes = timesteps)
     bool inline_nominal() const { return cfg.horizon <= 256 && cfg.model == MPPI_MODEL_DIFFDRIVE_RK4; }
@@ -713,7 +772,11 @@ struct mppi_engine {
             flags |= 8;
         }
         // 16 lanes per row for the tuple merge, one wave per filter coefficient (16 of them): T = 50 -> 1024 threads; at least 256
-        const int fin_threads = std::min(1024, std::max(256, ((2 * T * std::max(1, 1024 / (2 * T)) + 63) / 64) * 64));
+        int fin_threads = std::min(1024, std::max(256, ((2 * T * std::max(1, 1024 / (2 * T)) + 63) / 64) * 64));
+        if (fin_threads_opt) fin_threads = fin_threads_opt;
+        // the next tick's nominal table on the way out (lane-per-sample ticks that run the plant step and the shift; a graph replay
+        // keeps its prologue: its launches are frozen)
+        if ((flags & 3) == 3 && !(flags & 4) && hoist && inline_nominal() && small_nb == 0 && !capturing) flags |= 32;
         uint32_t tick_set = 0;
         if ((flags & 1) && !(flags & 4) && last_tick_eager) { flags |= 16; tick_set = last_tick_id + 1u; }
         // eager ticks also drop their outputs into the pinned host buffer (a graph replay cannot: its sequence number
@@ -727,16 +790,22 @@ struct mppi_engine {
         }
         hipLaunchKernelGGL(mppi::finalize_kernel, dim3(cfg.n_agents), dim3(fin_threads), lds,
                            stream, P, gathered, G, lay, d_S, d_unom, d_ufilt, d_state, d_out, d_tick, flags, tick_set,
-                           ext ? out_view_ext : (host_out ? d_out_view : nullptr), ext ? seq_view_ext : d_seq_view, ext ? seq_ext : out_seq, wait);
+                           ext ? out_view_ext : (host_out ? d_out_view : nullptr), ext ? seq_view_ext : d_seq_view, ext ? seq_ext : out_seq, wait,
+                           (const double*)d_goal, tcb[tab ^ 1], baseb[tab ^ 1], pkb[tab ^ 1]);
         if (flags & 1) out_via_host = host_out;
         HIPCHK(hipGetLastError());
         partials_ready = false;
+        table_valid = (flags & 32) != 0;   // (this launch rewrote the nominal controls: a table it did not refresh is stale)
+        table_taken = false;
     }
 
     void refresh_weights() {   // the cost weights and what the lean rollout step derives from them
         P.q0 = cfg.q[0]; P.q1 = cfg.q[1]; P.q2 = cfg.q[2];
         P.r0 = cfg.r[0]; P.r1 = cfg.r[1];
         P.p0 = cfg.p1[0]; P.p1 = cfg.p1[1]; P.p2 = cfg.p1[2];
+        P.q01 = w_off[0]; P.q02 = w_off[1]; P.q12 = w_off[2]; P.r01 = w_off[3]; P.p01 = w_off[4]; P.p02 = w_off[5]; P.p12 = w_off[6];
+        P.offdiag = 0;
+        for (double v : w_off) if (v != 0.0) P.offdiag = 1;
         P.lean_f = std::sqrt(0.5 * P.q0);
         P.lean_rho = P.lean_f * (P.dt * P.rhalf * (1.0 / 6.0)) / (0.5 * P.kth * P.dt);
         P.lean_inv_f = 1.0 / P.lean_f;
@@ -832,8 +901,12 @@ struct mppi_engine {
             HIPCHK(hipMalloc(&p, bytes)); hbm_bytes += bytes; d_epart = p;
             HIPCHK(hipMemsetAsync(d_epart, 0, bytes, stream));
         }
-        d_tc = dev_alloc<double>((size_t)A * T * mppi::kTcW, hbm_bytes);
-        d_base = dev_alloc<double>((size_t)A * T, hbm_bytes);
+        for (int i = 0; i < 2; ++i) {
+            tcb[i] = dev_alloc<double>((size_t)A * T * mppi::kTcW, hbm_bytes);
+            baseb[i] = dev_alloc<double>((size_t)A * T, hbm_bytes);
+            pkb[i] = dev_alloc<mppi::PkRow>((size_t)A * T, hbm_bytes);
+        }
+        use_table_set(0);
         d_unom = dev_alloc<double>((size_t)A * 2 * T, hbm_bytes);
         d_ufilt = dev_alloc<double>((size_t)A * 2 * T, hbm_bytes);
         d_state = dev_alloc<double>((size_t)A * 3, hbm_bytes);
@@ -864,8 +937,8 @@ struct mppi_engine {
         d_S = dev_alloc<double>((size_t)4 * (T - 1) + 4, hbm_bytes);   // the Savitzky-Golay operator's orthonormal basis [4][T-1] (+ its four values at the even window's half-integer position)
         d_out = dev_alloc<double>((size_t)A * 8, hbm_bytes);
         d_tick = dev_alloc<uint32_t>(1, hbm_bytes);
-        d_clk = dev_alloc<unsigned long long>(2, hbm_bytes);
-        HIPCHK(hipMemsetAsync(d_clk, 0, 2 * sizeof(unsigned long long), stream));
+        d_clk = dev_alloc<unsigned long long>(2 + mppi::kProbeMarks, hbm_bytes);
+        HIPCHK(hipMemsetAsync(d_clk, 0, (2 + mppi::kProbeMarks) * sizeof(unsigned long long), stream));
         P.clk = d_clk;
         d_fill = dev_alloc<double>((size_t)A * 2, hbm_bytes);
         HIPCHK(hipMemsetAsync(d_fill, 0, (size_t)A * 2 * sizeof(double), stream));
@@ -922,7 +995,7 @@ struct mppi_engine {
         if (h_stage) hipHostFree(h_stage);
         if (h_out) hipHostFree(h_out);
         if (h_seq) hipHostFree(h_seq);
-        void* bufs[] = {d_eps, d_dP, d_stot, d_epart, d_tc, d_base, d_unom, d_ufilt, d_state, d_goal, d_part, d_merged, d_S, d_out, d_tick, d_tmp, d_grid, d_prev, d_clk, d_fill};
+        void* bufs[] = {d_eps, d_dP, d_stot, d_epart, tcb[0], tcb[1], baseb[0], baseb[1], pkb[0], pkb[1], d_unom, d_ufilt, d_state, d_goal, d_part, d_merged, d_S, d_out, d_tick, d_tmp, d_grid, d_prev, d_clk, d_fill};
         for (void* b : bufs) if (b) hipFree(b);
         if (own_stream) hipStreamDestroy(own_stream);
     }
@@ -1017,6 +1090,9 @@ void mppi_engine::co_build() {
             e->sync_timeout_ms = sync_timeout_ms;
             e->store_eps_always = store_eps_always; e->use_pk = use_pk; e->upd_skip_light = upd_skip_light; e->pk_waves = pk_waves;
             e->pk_min_set = pk_min_set; e->pk_min_samples = pk_min_samples; e->noise_pack = noise_pack;
+            e->fin_threads_opt = fin_threads_opt; e->k_pieces_opt = k_pieces_opt; e->hoist = hoist; e->low_occ_opt = low_occ_opt;
+            for (int i = 0; i < 7; ++i) e->w_off[i] = w_off[i];
+            e->refresh_weights();
             e->out_view_ext = d_out_view + (size_t)co_a0 * 8;
             e->seq_view_ext = d_seq_view + co_a0;
             if (!ev_co) HIPCHK(hipEventCreateWithFlags(&ev_co, hipEventDisableTiming));
@@ -1055,6 +1131,9 @@ void mppi_engine::co_build() {
             e->sync_timeout_ms = sync_timeout_ms;
             e->store_eps_always = store_eps_always; e->use_pk = use_pk; e->upd_skip_light = upd_skip_light; e->pk_waves = pk_waves;
             e->pk_min_set = pk_min_set; e->pk_min_samples = pk_min_samples; e->noise_pack = noise_pack;
+            e->fin_threads_opt = fin_threads_opt; e->k_pieces_opt = k_pieces_opt; e->hoist = hoist; e->low_occ_opt = low_occ_opt;
+            for (int i = 0; i < 7; ++i) e->w_off[i] = w_off[i];
+            e->refresh_weights();
         }
         std::vector<void*> ptrs(G, nullptr);
         std::vector<mppi_engine*> all{this};
@@ -1091,6 +1170,7 @@ void mppi_engine::co_push_agents() {
     HIPCHK(hipMemcpyAsync(e->d_goal, d_goal + a0 * 3, A1 * 3 * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->d_fill, d_fill + a0 * 2, A1 * 2 * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
     e->have_state = have_state; e->have_goal = have_goal;
+    e->invalidate_table();
     co_synced = true;
 }
 
@@ -1100,6 +1180,7 @@ void mppi_engine::co_push_agents() {
 void mppi_engine::co_pull() {
     if (!co_dirty) return;
     co_dirty = false;
+    invalidate_table();   // (the sub's agents' controls / poses arrive in this engine's arrays: its own table knows nothing of them)
     co_synced = false;   // whoever called may change this engine's arrays: the next split tick hands them over again
     mppi_engine* e = subs[0];
     const size_t A1 = e->cfg.n_agents, T_ = cfg.horizon, a0 = (size_t)co_a0, Ks = (size_t)P.Ks, NW = Ks >> 6;
@@ -1179,6 +1260,7 @@ int mppi_abi_version(void) { return MPPI_ABI_VERSION; }
 int mppi_default_config(mppi_config* cfg) {
     if (!cfg) return MPPI_E_INVALID;
     std::memset(cfg, 0, sizeof(*cfg));
+    cfg->struct_size = (uint32_t)sizeof(*cfg);
     cfg->n_agents = 1;
     cfg->samples = 10;   // control/src/mppi:62
     cfg->horizon = 100;  // control/src/mppi:62
@@ -1211,9 +1293,18 @@ int mppi_create(const mppi_config* cfg, mppi_engine** out) {
     const bool have_prev = hipGetDevice(&prev_dev) == hipSuccess;
     struct Restore { bool on; int dev; ~Restore() { if (on) (void)hipSetDevice(dev); } } restore{have_prev, prev_dev};
     try {
+        // the caller's struct may be an older, shorter one: its bytes over this library's defaults (fields are only ever appended)
+        static_assert(sizeof(mppi_config) >= MPPI_CONFIG_SIZE_V5, "mppi_config shrank");
+        if (cfg->struct_size < MPPI_CONFIG_SIZE_V5 || cfg->struct_size > sizeof(mppi_config))
+            fail(MPPI_E_INVALID, "mppi_config.struct_size = %u: this library knows %u ... %zu bytes (start from mppi_default_config; "
+                                 "a caller compiled against a NEWER header than the library it loads?)", cfg->struct_size, MPPI_CONFIG_SIZE_V5, sizeof(mppi_config));
+        mppi_config full;
+        mppi_default_config(&full);
+        std::memcpy(&full, cfg, cfg->struct_size);
+        full.struct_size = (uint32_t)sizeof(full);
         e = new mppi_engine();
-        e->init(*cfg);
-        if (cfg->co_shards == 0) { bool w; e->co_pending = e->co_plan(w) > 1; }   // AUTO: built with the first fused device-noise tick
+        e->init(full);
+        if (full.co_shards == 0) { bool w; e->co_pending = e->co_plan(w) > 1; }   // AUTO: built with the first fused device-noise tick
         else e->co_build();
         *out = e;
         return MPPI_OK;
@@ -1246,6 +1337,7 @@ int mppi_get_stream(mppi_engine* h, void** hip_stream) {
 
 int mppi_set_sigma_lambda(mppi_engine* h, double sigma, double lambda) {
     API_BEGIN(h)
+    h->invalidate_table();
     for (auto* sub__ : h->subs) if (int rc__ = mppi_set_sigma_lambda(sub__, sigma, lambda)) fail(rc__, "co-scheduled shard: %s", sub__->err.c_str());
     if (!(lambda > 0.0) || !(sigma >= 0.0)) fail(MPPI_E_INVALID, "lambda must be > 0 and sigma >= 0");
     h->settle_lazy_state();
@@ -1258,6 +1350,7 @@ int mppi_set_sigma_lambda(mppi_engine* h, double sigma, double lambda) {
 
 int mppi_set_sig_matrix(mppi_engine* h, const double* sig, double lambda) {
     API_BEGIN(h)
+    h->invalidate_table();
     if (!sig) fail(MPPI_E_INVALID, "sig is NULL");
     for (auto* sub__ : h->subs) if (int rc__ = mppi_set_sig_matrix(sub__, sig, lambda)) fail(rc__, "co-scheduled shard: %s", sub__->err.c_str());
     if (!(lambda > 0.0) || !(sig[0] >= 0.0)) fail(MPPI_E_INVALID, "lambda must be > 0 and sig[0][0] >= 0");
@@ -1277,10 +1370,34 @@ int mppi_set_weights(mppi_engine* h, const double* q, const double* r, const dou
     for (int i = 0; i < 3; ++i) if ((q && !std::isfinite(q[i])) || (p1 && !std::isfinite(p1[i]))) fail(MPPI_E_INVALID, "cost weights must be finite");
     for (int i = 0; i < 2; ++i) if (r && !std::isfinite(r[i])) fail(MPPI_E_INVALID, "cost weights must be finite");
     h->settle_lazy_state();   // the last tick's V may exist only as "re-run with these weights"
-    if (q) for (int i = 0; i < 3; ++i) h->cfg.q[i] = q[i];
-    if (r) for (int i = 0; i < 2; ++i) h->cfg.r[i] = r[i];
-    if (p1) for (int i = 0; i < 3; ++i) h->cfg.p1[i] = p1[i];
+    // (a matrix given by its diagonal IS diagonal: whatever mppi_set_weight_matrices left off it goes)
+    if (q) { for (int i = 0; i < 3; ++i) h->cfg.q[i] = q[i]; h->w_off[0] = h->w_off[1] = h->w_off[2] = 0.0; }
+    if (r) { for (int i = 0; i < 2; ++i) h->cfg.r[i] = r[i]; h->w_off[3] = 0.0; }
+    if (p1) { for (int i = 0; i < 3; ++i) h->cfg.p1[i] = p1[i]; h->w_off[4] = h->w_off[5] = h->w_off[6] = 0.0; }
     h->refresh_weights();
+    h->invalidate_table();
+    h->destroy_graph();
+    API_END(h)
+}
+
+int mppi_set_weight_matrices(mppi_engine* h, const double* Q, const double* R, const double* P1) {
+    API_BEGIN(h)
+    for (auto* sub__ : h->subs) if (int rc__ = mppi_set_weight_matrices(sub__, Q, R, P1)) fail(rc__, "co-scheduled shard: %s", sub__->err.c_str());
+    for (int i = 0; i < 9; ++i) if ((Q && !std::isfinite(Q[i])) || (P1 && !std::isfinite(P1[i]))) fail(MPPI_E_INVALID, "cost weights must be finite");
+    for (int i = 0; i < 4; ++i) if (R && !std::isfinite(R[i])) fail(MPPI_E_INVALID, "cost weights must be finite");
+    h->settle_lazy_state();   // the last tick's V may exist only as "re-run with these weights"
+    // x' M x sees the symmetric part of M only: diagonal as given, off-diagonal (M[i][j] + M[j][i]) / 2
+    if (Q) {
+        for (int i = 0; i < 3; ++i) h->cfg.q[i] = Q[4 * i];
+        h->w_off[0] = 0.5 * (Q[1] + Q[3]); h->w_off[1] = 0.5 * (Q[2] + Q[6]); h->w_off[2] = 0.5 * (Q[5] + Q[7]);
+    }
+    if (R) { h->cfg.r[0] = R[0]; h->cfg.r[1] = R[3]; h->w_off[3] = 0.5 * (R[1] + R[2]); }
+    if (P1) {
+        for (int i = 0; i < 3; ++i) h->cfg.p1[i] = P1[4 * i];
+        h->w_off[4] = 0.5 * (P1[1] + P1[3]); h->w_off[5] = 0.5 * (P1[2] + P1[6]); h->w_off[6] = 0.5 * (P1[5] + P1[7]);
+    }
+    h->refresh_weights();
+    h->invalidate_table();
     h->destroy_graph();
     API_END(h)
 }
@@ -1341,6 +1458,7 @@ int mppi_set_obstacle_grid(mppi_engine* h, const int8_t* cells, int32_t width, i
 
 int mppi_reset(mppi_engine* h, int agent) {
     API_BEGIN(h)
+    h->invalidate_table();
     h->co_synced = h->co_synced && !h->co_agents;   // (an agent split takes this engine's arrays over with its next tick)
     if (!h->co_agents) for (auto* sub__ : h->subs) if (int rc__ = mppi_reset(sub__, agent)) fail(rc__, "co-scheduled shard: %s", sub__->err.c_str());
     const size_t row = (size_t)2 * h->cfg.horizon * sizeof(double);
@@ -1352,6 +1470,7 @@ int mppi_reset(mppi_engine* h, int agent) {
 
 int mppi_set_shift_fill(mppi_engine* h, int agent, const double* fill) {
     API_BEGIN(h)
+    h->invalidate_table();
     h->co_synced = h->co_synced && !h->co_agents;   // (an agent split takes this engine's arrays over with its next tick)
     if (!h->co_agents) for (auto* sub__ : h->subs) if (int rc__ = mppi_set_shift_fill(sub__, agent, fill)) fail(rc__, "co-scheduled shard: %s", sub__->err.c_str());
     if (!fill || agent < 0 || agent >= h->cfg.n_agents) fail(MPPI_E_INVALID, "bad agent/fill");
@@ -1362,6 +1481,7 @@ int mppi_set_shift_fill(mppi_engine* h, int agent, const double* fill) {
 
 int mppi_set_nominal(mppi_engine* h, int agent, const double* uvec) {
     API_BEGIN(h)
+    h->invalidate_table();
     h->co_synced = h->co_synced && !h->co_agents;   // (an agent split takes this engine's arrays over with its next tick)
     if (!h->co_agents) for (auto* sub__ : h->subs) if (int rc__ = mppi_set_nominal(sub__, agent, uvec)) fail(rc__, "co-scheduled shard: %s", sub__->err.c_str());
     if (!uvec || agent < 0 || agent >= h->cfg.n_agents) fail(MPPI_E_INVALID, "bad agent/uvec");
@@ -1477,6 +1597,7 @@ int mppi_update(mppi_engine* h, double* uvec_out) {
 
 int mppi_plant_step(mppi_engine* h, const double* state, double* next_state) {
     API_BEGIN(h)
+    h->invalidate_table();
     h->co_synced = false;   // (the co-scheduled shards no longer hold this engine's nominal controls / state)
     const int A = h->cfg.n_agents;
     if (state) { h->stage_upload(state, h->d_state, (size_t)A * 3); h->have_state = true; }
@@ -1496,6 +1617,7 @@ int mppi_plant_step(mppi_engine* h, const double* state, double* next_state) {
 
 int mppi_shift(mppi_engine* h) {
     API_BEGIN(h)
+    h->invalidate_table();
     h->co_synced = false;   // (the co-scheduled shards no longer hold this engine's nominal controls / state)
     hipLaunchKernelGGL(mppi::shift_kernel, dim3(h->cfg.n_agents * 2), dim3(256), (size_t)h->cfg.horizon * sizeof(double), h->stream, h->P, h->d_unom);
     HIPCHK(hipGetLastError());
@@ -1814,6 +1936,7 @@ int mppi_tick(mppi_engine* h, const double* state, const double* goal, int noise
 
 int mppi_tick_graph(mppi_engine* h, uint64_t seed) {
     API_BEGIN(h)
+    h->invalidate_table();
     h->co_synced = false;   // (the co-scheduled shards no longer hold this engine's nominal controls / state)
     if (!h->have_state || !h->have_goal) fail(MPPI_E_STATE, "tick_graph needs a resident state and goal (run one mppi_tick first)");
     if (h->stream == nullptr) fail(MPPI_E_STATE, "graph capture is not possible on the null stream");
@@ -1823,6 +1946,7 @@ int mppi_tick_graph(mppi_engine* h, uint64_t seed) {
         h->time_mask = 0;
         HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
         h->capturing = true;
+        h->graph_tab = h->tab;   // the captured launches write THIS table set
         try {
             h->run_nominal();
             h->run_pipeline(MPPI_NOISE_PHILOX, seed, 0, h->d_tick, /*skip_small_merge=*/true);
@@ -1841,9 +1965,10 @@ int mppi_tick_graph(mppi_engine* h, uint64_t seed) {
         h->graph_seed = seed;
         h->time_mask = saved;
     }
+    h->use_table_set(h->graph_tab);   // (eager ticks in between may have switched sets: the replay's rollout rewrites the captured one)
     HIPCHK(hipGraphLaunch(h->graph_exec, h->stream));
     h->out_via_host = false;
-    const bool small = h->small_nb > 0;
+    const bool small = h->small_nb > 0 || h->tick_pieces(true, h->store_eps_always) > 1;   // (V not resident: re-run from the snapshot on demand)
     h->noise_ready = true; h->value_ready = !small; h->value_lazy = small; h->partials_ready = false; h->epart_ready = !small;
     h->eps_lazy = small || !h->store_eps_always; h->lazy_seed = seed; h->lazy_from_counter = true; h->lazy_counter_bumped = true;
     h->injected_ready = !h->eps_lazy; h->last_tick_eager = false;
@@ -1866,6 +1991,19 @@ int mppi_set_option(mppi_engine* h, const char* key, int64_t value) {
             fail(MPPI_E_INVALID, "noise_packing 1 / 2 is drawn by the mixed-precision rollout only: fp32 storage, the lane kernels (tick_path lanes), rk4 / diff drive, T <= 256");
         h->settle_lazy_state(); h->noise_pack = (int)value; h->destroy_graph();
     }
+    else if (k == "fin_threads") {
+        if (value != 0 && value != 256 && value != 512 && value != 1024) fail(MPPI_E_INVALID, "fin_threads: 0 (the engine's rule), 256, 512 or 1024");
+        h->fin_threads_opt = (int)value; h->destroy_graph();
+    }
+    else if (k == "k_pieces") {
+        if (value < 0 || value > 16) fail(MPPI_E_INVALID, "k_pieces: 0 (the engine's rule) or 1..16");
+        h->settle_lazy_state(); h->k_pieces_opt = (int)value; h->destroy_graph();
+    }
+    else if (k == "table_hoist") { h->hoist = value != 0; h->invalidate_table(); }
+    else if (k == "low_occ") {
+        if (value < -1 || value > 1) fail(MPPI_E_INVALID, "low_occ: -1 (by launch size), 0 or 1");
+        h->low_occ_opt = (int)value; h->destroy_graph();
+    }
     else if (k == "pk_waves") { if (value != 4 && value != 5) fail(MPPI_E_INVALID, "pk_waves: 4 or 5"); h->pk_waves = (int)value; }
     else if (k == "pk_min_samples") { h->settle_lazy_state(); h->pk_min_set = value >= 0; h->pk_min_samples = value >= 0 ? (long)value : 400000; h->destroy_graph(); }
     else if (k == "co_cut_pct") {
@@ -1885,6 +2023,7 @@ int mppi_set_option(mppi_engine* h, const char* key, int64_t value) {
                 e->store_eps_always = h->store_eps_always; e->use_pk = h->use_pk; e->upd_skip_light = h->upd_skip_light; e->pk_waves = h->pk_waves;
                 e->pk_min_set = h->pk_min_set; e->pk_min_samples = h->pk_min_samples; e->sync_timeout_ms = h->sync_timeout_ms;
                 e->noise_pack = h->noise_pack;
+                e->fin_threads_opt = h->fin_threads_opt; e->k_pieces_opt = h->k_pieces_opt; e->hoist = h->hoist; e->low_occ_opt = h->low_occ_opt;
             }
         }
     }
@@ -1901,6 +2040,10 @@ int mppi_get_option(mppi_engine* h, const char* key, int64_t* value) {
     else if (k == "upd_skip") *value = h->upd_skip_light;
     else if (k == "noise_packing") *value = h->noise_pack;
     else if (k == "pk_waves") *value = h->pk_waves;
+    else if (k == "fin_threads") *value = h->fin_threads_opt;
+    else if (k == "k_pieces") *value = h->k_pieces_opt;
+    else if (k == "table_hoist") *value = h->hoist;
+    else if (k == "low_occ") *value = h->low_occ_opt;
     else if (k == "pk_min_samples") *value = h->pk_min_set ? h->pk_min_samples : -1;
     else if (k == "co_cut_pct") *value = h->co_cut_pct;
     else fail(MPPI_E_INVALID, "unknown option '%s'", key);
@@ -1957,6 +2100,19 @@ int mppi_shader_clock(mppi_engine* h, double* mhz) {
     h->wait_stream(__func__);
     // v[1] counts the constant-rate wall clock (hipDeviceAttributeWallClockRate, kHz)
     *mhz = v[1] ? (double)v[0] / (double)v[1] * (double)h->wall_clock_khz * 1e-3 : 0.0;
+    API_END(h)
+}
+
+int mppi_probe_timeline(mppi_engine* h, uint64_t* cycles, uint64_t* total) {
+    API_BEGIN_FAST(h)
+    static_assert(MPPI_PROBE_MARKS == mppi::kProbeMarks, "header and kernels disagree on the number of stamps");
+    if (!cycles) fail(MPPI_E_INVALID, "cycles is NULL");
+    unsigned long long v[2 + mppi::kProbeMarks] = {};
+    HIPCHK(hipMemcpyAsync(v, h->d_clk, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+    h->wait_stream(__func__);
+    for (int i = 0; i < mppi::kProbeMarks; ++i) cycles[i] = v[2 + i];
+    if (total) *total = v[0];
+    HIPCHK(hipMemsetAsync(h->d_clk + 2, 0, mppi::kProbeMarks * sizeof(unsigned long long), h->stream));
     API_END(h)
 }
 

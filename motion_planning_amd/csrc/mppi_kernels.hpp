@@ -48,6 +48,10 @@ struct DevParams {
     uint32_t agent_offset;    // global index of local agent 0: the device-noise streams are keyed by the GLOBAL agent index
     double dt, sigma, lambda, inv_lambda;
     double q0, q1, q2, r0, r1, p0, p1, p2;
+    // the off-diagonal terms of the SYMMETRIC parts of Q, R, P1 (mppi_set_weight_matrices: the reference multiplies whole
+    // matrices, control/src/mppi:168, :181-184); offdiag = any of them is non-zero (a uniform branch around their arithmetic)
+    double q01, q02, q12, r01, p01, p02, p12;
+    int offdiag;
     double u_max, kth, rhalf, floor_w;  // kth = wheel_radius / wheel_base, rhalf = wheel_radius / 2
     // the `sig` matrix of get_cost (control/src/mppi:184: lam * u . sig . eps), row-major; sigma above is the
     // std-dev the noise is drawn with (= sig[0,0], :143-146).  sigma * I unless mppi_set_sig_matrix was called.
@@ -81,6 +85,7 @@ __device__ __forceinline__ void snapshot_inputs(const DevParams& P, const double
         P.snap[(size_t)P.A * 2 * T + (size_t)P.A * 3 + a * 3 + threadIdx.x] = goal[a * 3 + threadIdx.x];
     }
 }
+constexpr int kProbeMarks = 30;   // stamps of a diagnostic build's timeline (ClockProbe::mark)
 struct ClockProbe {
     unsigned long long c0 = 0, w0 = 0;
     bool on;
@@ -90,6 +95,16 @@ struct ClockProbe {
     }
     __device__ __forceinline__ void stop(const DevParams& P) {
         if (on) { P.clk[0] = clock64() - c0; P.clk[1] = wall_clock64() - w0; }
+    }
+    // diagnostic builds only (make PROBE=1 -> libmppi_hip_probe.so; tools/probe_timeline.py): shader-cycle stamps of the probe
+    // wave at points of its life -- behind the prologue's barrier, behind every chunk -- in clk[2 ...]; the product build
+    // compiles this to nothing
+    __device__ __forceinline__ void mark(const DevParams& P, int i) {
+#ifdef MPPI_PROBE_TIMELINE
+        if (on && i < kProbeMarks) P.clk[2 + i] = clock64() - c0;
+#else
+        (void)P; (void)i;
+#endif
     }
 };
 
@@ -107,6 +122,10 @@ __device__ __forceinline__ void cost_noise_weights(const DevParams& P, double un
 }
 
 __device__ __forceinline__ double clampd(double v, double lim) { return fmin(fmax(v, -lim), lim); }
+// what the off-diagonal terms add to x' M x: 2 (m01 x y + m02 x z + m12 y z)
+__device__ __forceinline__ double cross3(double m01, double m02, double m12, double x, double y, double z) {
+    return 2.0 * (m01 * x * y + m02 * x * z + m12 * y * z);
+}
 // the same clip as ONE fp64 instruction (v_min_f64 with |v|) plus a 32-bit sign copy (v_bfi_b32)
 __device__ __forceinline__ double clamp_sym(double v, double lim) { return copysign(fmin(fabs(v), lim), v); }
 // 2 * v for a normal, finite v: exponent + 1 (a 32-bit integer add instead of an fp64 instruction)
@@ -221,14 +240,20 @@ __global__ __launch_bounds__(kNomThreads) void nominal_kernel(DevParams P, const
         if (valid) {
             const double thn = (P.model == 1) ? th + h : wrap_theta(th + h);
             const double dx = X - gx, dy = Y - gy, dth = thn - gth;
-            const double xqx = P.q0 * dx * dx + P.q1 * dy * dy + P.q2 * dth * dth;
-            const double uru = P.r0 * un0 * un0 + P.r1 * un1 * un1;
+            double xqx = P.q0 * dx * dx + P.q1 * dy * dy + P.q2 * dth * dth;
+            double uru = P.r0 * un0 * un0 + P.r1 * un1 * un1;
+            if (P.offdiag) { xqx += cross3(P.q01, P.q02, P.q12, dx, dy, dth); uru += 2.0 * (P.r01 * un0 * un1); }
             double cst = 0.5 * (xqx + uru);
-            if (t == T - 1) cst += P.p0 * dx * dx + P.p1 * dy * dy + P.p2 * dth * dth;
+            if (t == T - 1) {
+                cst += P.p0 * dx * dx + P.p1 * dy * dy + P.p2 * dth * dth;
+                if (P.offdiag) cst += cross3(P.p01, P.p02, P.p12, dx, dy, dth);
+            }
             double* o = tc + ((size_t)a * T + t) * kTcW;
             o[0] = un0; o[1] = un1;
             cost_noise_weights(P, un0, un1, o[2], o[3]);
-            o[4] = 0.5 * uru - cst; o[5] = 0.0; o[6] = 0.0; o[7] = 0.0;
+            o[4] = 0.5 * uru - cst;
+            if (t != 0) { o[5] = 0.0; o[6] = 0.0; o[7] = 0.0; }
+            else { o[5] = c0; o[6] = s0; o[7] = 0.0; }   // (cos, sin) of the pose's heading: read by every lane of a rollout launch (t = 0: th is the pose's theta exactly)
             cstage[t] = cst;
         }
         car_th += tot_h; car_x += tot_x; car_y += tot_y;
@@ -491,6 +516,7 @@ __device__ __forceinline__ double wave_scan_incl(double v, int /*lane*/) {
 
 // inclusive prefix sum over NWAVES * 64 consecutive lanes: shuffles inside each wave, the wave totals
 // through LDS (two barriers; none for a single wave).  `total` = sum over all lanes.
+// NWAVES == 0: every wave of the block takes part, their number read from blockDim.x (<= 16: sh holds 16 doubles)
 template <int NWAVES>
 __device__ __forceinline__ double lanes_scan_incl(double v, int t, double* sh, double& total) {
     const int lane = t & 63;
@@ -500,8 +526,13 @@ __device__ __forceinline__ double lanes_scan_incl(double v, int t, double* sh, d
     if (lane == 63) sh[wid] = v;
     __syncthreads();
     double carry = 0.0, tot = 0.0;
+    if (NWAVES == 0) {
+        const int nw = (int)blockDim.x >> 6;
+        for (int w = 0; w < nw; ++w) { const double x = sh[w]; tot += x; if (w < wid) carry += x; }
+    } else {
 #pragma unroll
-    for (int w = 0; w < NWAVES; ++w) { const double x = sh[w]; tot += x; if (w < wid) carry += x; }
+        for (int w = 0; w < NWAVES; ++w) { const double x = sh[w]; tot += x; if (w < wid) carry += x; }
+    }
     __syncthreads();
     total = tot;
     return v + carry;
@@ -513,20 +544,20 @@ __device__ __forceinline__ double lanes_scan_incl(double v, int t, double* sh, d
 // what the deviation-form rollout (rollout_pk_kernel) needs of the nominal trajectory beyond the table row: lane t's
 // clipped wheel speeds, its step's rotation h = 2 phi, the mid-step heading vector and the post-step position
 struct NomExtra { double u0c, u1c, h, th, c1, s1, X, Y; };
+// nominal_lanes_v: the same on VALUES -- the pose (sx, sy, sth), the goal, and this lane's nominal controls (un0, un1; lanes t >= T
+// pass anything) -- for callers whose inputs are not in global memory yet (the finalize kernel preparing the NEXT tick's table).
 template <int NWAVES>
-__device__ __forceinline__ void nominal_lanes(const DevParams& P, const double* __restrict__ state,
-                                              const double* __restrict__ goal, const double* __restrict__ unom,
-                                              int a, int t, double (&row)[5], double& base_t, double* sh,
-                                              double* head0 = nullptr, NomExtra* ex = nullptr) {
+__device__ __forceinline__ void nominal_lanes_v(const DevParams& P, double sx, double sy, double sth, double gx, double gy, double gth,
+                                                double un0_in, double un1_in, int t, double (&row)[5], double& base_t, double* sh,
+                                                double* head0 = nullptr, NomExtra* ex = nullptr) {
     const int T = P.T;
     double tot_;
     const bool valid = t < T;
-    const double gx = goal[a * 3 + 0], gy = goal[a * 3 + 1], gth = goal[a * 3 + 2];
-    const double un0 = valid ? unom[(a * 2 + 0) * T + t] : 0.0;
-    const double un1 = valid ? unom[(a * 2 + 1) * T + t] : 0.0;
+    const double un0 = valid ? un0_in : 0.0;
+    const double un1 = valid ? un1_in : 0.0;
     const double u0 = clampd(un0, P.u_max), u1 = clampd(un1, P.u_max);
     const double h = valid ? (P.model == 1 ? P.dt * u1 : P.kth * P.dt * (u1 - u0)) : 0.0;
-    const double th = state[a * 3 + 2] + (lanes_scan_incl<NWAVES>(h, t, sh, tot_) - h);
+    const double th = sth + (lanes_scan_incl<NWAVES>(h, t, sh, tot_) - h);
     double s0, c0, ix, iy;
     sincos(th, &s0, &c0);
     if (head0 && t == 0) { head0[0] = c0; head0[1] = s0; }  // lane 0: th = the state's theta exactly (its exclusive scan is 0)
@@ -547,24 +578,90 @@ __device__ __forceinline__ void nominal_lanes(const DevParams& P, const double* 
         ix = aa * (c0 + 4.0 * c1 + c2); iy = aa * (s0 + 4.0 * s1 + s2);
         if (ex) { ex->c1 = c1; ex->s1 = s1; }
     }
-    const double X = state[a * 3 + 0] + lanes_scan_incl<NWAVES>(valid ? ix : 0.0, t, sh, tot_);
-    const double Y = state[a * 3 + 1] + lanes_scan_incl<NWAVES>(valid ? iy : 0.0, t, sh, tot_);
+    const double X = sx + lanes_scan_incl<NWAVES>(valid ? ix : 0.0, t, sh, tot_);
+    const double Y = sy + lanes_scan_incl<NWAVES>(valid ? iy : 0.0, t, sh, tot_);
     if (ex) { ex->u0c = u0; ex->u1c = u1; ex->h = h; ex->th = th; ex->X = X; ex->Y = Y; }
     double cst = 0.0;
     row[0] = un0; row[1] = un1; row[2] = 0.0; row[3] = 0.0; row[4] = 0.0;
     if (valid) {
         const double thn = (P.model == 1) ? th + h : wrap_theta(th + h);
         const double dx = X - gx, dy = Y - gy, dth = thn - gth;
-        const double xqx = P.q0 * dx * dx + P.q1 * dy * dy + P.q2 * dth * dth;
-        const double uru = P.r0 * un0 * un0 + P.r1 * un1 * un1;
+        double xqx = P.q0 * dx * dx + P.q1 * dy * dy + P.q2 * dth * dth;
+        double uru = P.r0 * un0 * un0 + P.r1 * un1 * un1;
+        if (P.offdiag) { xqx += cross3(P.q01, P.q02, P.q12, dx, dy, dth); uru += 2.0 * (P.r01 * un0 * un1); }
         cst = 0.5 * (xqx + uru);
-        if (t == T - 1) cst += P.p0 * dx * dx + P.p1 * dy * dy + P.p2 * dth * dth;
+        if (t == T - 1) {
+            cst += P.p0 * dx * dx + P.p1 * dy * dy + P.p2 * dth * dth;
+            if (P.offdiag) cst += cross3(P.p01, P.p02, P.p12, dx, dy, dth);
+        }
         cost_noise_weights(P, un0, un1, row[2], row[3]);
         row[4] = 0.5 * uru - cst;
     }
     double tot;
     const double inc = lanes_scan_incl<NWAVES>(cst, t, sh, tot);
     base_t = tot - (inc - cst);
+}
+template <int NWAVES>
+__device__ __forceinline__ void nominal_lanes(const DevParams& P, const double* __restrict__ state,
+                                              const double* __restrict__ goal, const double* __restrict__ unom,
+                                              int a, int t, double (&row)[5], double& base_t, double* sh,
+                                              double* head0 = nullptr, NomExtra* ex = nullptr) {
+    const int T = P.T;
+    const bool valid = t < T;
+    nominal_lanes_v<NWAVES>(P, state[a * 3 + 0], state[a * 3 + 1], state[a * 3 + 2], goal[a * 3 + 0], goal[a * 3 + 1], goal[a * 3 + 2],
+                            valid ? unom[(a * 2 + 0) * T + t] : 0.0, valid ? unom[(a * 2 + 1) * T + t] : 0.0, t, row, base_t, sh, head0, ex);
+}
+
+// One step of the nominal trajectory as the deviation-form rollout (rollout_pk.hpp) reads it from LDS: five 16-byte words.
+struct __attribute__((aligned(16))) PkRow {
+    float d0, d1, lo0, hi0;   // hk (un_i - clip(un_i)); clip bounds of the deviation: hk (-+u_max - clip(un_i))
+    float lo1, hi1, A1, Cn;   // dW = dphi (A1 + Cn dphi): A1 = -2 rho sin phin, Cn = -rho cos phin
+    float Wn, Pn, w0, w1;     // rho (4 + 2 cos phin); hk (u0c + u1c); lam (un . Sig) -- the noise-cost weights
+    double c1n, s1n;          // nominal mid-step heading
+    double X2, Y2;            // 2 * scaled nominal position after the step (relative to the goal)
+};
+static_assert(sizeof(PkRow) == 80, "PkRow is read as five 16-byte LDS words");
+__device__ __forceinline__ PkRow make_pkrow(const DevParams& P, const double (&row)[5], const NomExtra& ex, double gx, double gy) {
+    const double hk = 0.5 * P.kth * P.dt, phin = 0.5 * ex.h;
+    double sp, cp;
+    if (fabs(phin) <= 0.25) small_sincos<7>(phin, sp, cp);
+    else sincos(phin, &sp, &cp);
+    PkRow r;
+    r.d0 = (float)(hk * (row[0] - ex.u0c)); r.d1 = (float)(hk * (row[1] - ex.u1c));
+    r.lo0 = (float)(hk * (-P.u_max - ex.u0c)); r.hi0 = (float)(hk * (P.u_max - ex.u0c));
+    r.lo1 = (float)(hk * (-P.u_max - ex.u1c)); r.hi1 = (float)(hk * (P.u_max - ex.u1c));
+    r.A1 = (float)(-2.0 * sp * P.lean_rho); r.Cn = (float)(-cp * P.lean_rho);
+    r.Wn = (float)((4.0 + 2.0 * cp) * P.lean_rho); r.Pn = (float)(hk * (ex.u0c + ex.u1c));
+    r.w0 = (float)row[2]; r.w1 = (float)row[3];
+    r.c1n = ex.c1; r.s1n = ex.s1;
+    r.X2 = 2.0 * P.lean_f * (ex.X - gx); r.Y2 = 2.0 * P.lean_f * (ex.Y - gy);
+    return r;
+}
+
+// The nominal trajectory's table in GLOBAL memory, for rollout launches that load it instead of computing it in every workgroup's
+// prologue (INLINE_NOM 0): lane t writes
+//     tc[a][t][0..4] = the row,  base[a][t],  pk[a][t] = the deviation-form row (rk4 / diff drive only),
+//     tc[a][0][5..6] = (cos, sin) of the pose's heading,  tc[a][0][7] = the trajectory's final heading (unwrapped).
+// Written by the finalize kernel for the NEXT tick (from the pose its plant step predicts and the controls it shifted:
+// finalize_block) -- valid for a tick whose inputs are those outputs, which the engine tracks on the host (table_valid).
+// NWAVES 1: one wave (T <= 64), 0: every thread of the block (T <= 256 <= blockDim.x, barriers inside).
+template <int NWAVES>
+__device__ __forceinline__ void nominal_table_lanes(const DevParams& P, int a, double sx, double sy, double sth, double gx, double gy,
+                                                    double gth, double un0, double un1, int t, double* sh, double* __restrict__ tc,
+                                                    double* __restrict__ base, PkRow* __restrict__ pk) {
+    const int T = P.T;
+    double row[5], base_t;
+    NomExtra ex;
+    double* row0 = tc + (size_t)a * T * kTcW;
+    nominal_lanes_v<NWAVES>(P, sx, sy, sth, gx, gy, gth, un0, un1, t, row, base_t, sh, row0 + 5, &ex);
+    if (t < T) {
+        double* o = row0 + (size_t)t * kTcW;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) o[i] = row[i];
+        base[(size_t)a * T + t] = base_t;
+        if (P.model == 0 && pk != nullptr) pk[(size_t)a * T + t] = make_pkrow(P, row, ex, gx, gy);
+        if (t == T - 1) row0[7] = ex.th + ex.h;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -756,21 +853,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(S) =
             }
         }
     } else {
+        // the table from memory: nominal_kernel's (T > 256, euler), or the one the previous tick's finalize kernel left for this one
         for (int i = tid; i < T * 5; i += blockDim.x) {
             const double v = tc[((size_t)a * T + i / 5) * kTcW + i % 5];
             lt[i] = (LEAN && i % 5 < 2) ? v * (0.5 * P.kth * P.dt) : v;
         }
+        if (tid < 2) head_sh[tid] = tc[(size_t)a * T * kTcW + 5 + tid];
+        if (tid == 2) head_sh[2] = P.lean_inv_f;
     }
     __syncthreads();
+    int mk = 0;   // (timeline marks of a diagnostic build; dead code in the product)
+    probe.mark(P, mk++);
     const int k = k_first + blockIdx.x * 256 + tid;  // this launch covers samples [k_first, k_last)
     const bool active = k < k_last;
     const size_t Ks = (size_t)P.Ks;
     double gx = goal[a * 3 + 0], gy = goal[a * 3 + 1];
     const double gth = goal[a * 3 + 2];
     double x = state[a * 3 + 0], y = state[a * 3 + 1], th = state[a * 3 + 2];
-    double c, s;
-    if (INLINE_NOM) { c = head_sh[0]; s = head_sh[1]; }
-    else sincos(th, &s, &c);
+    double c = head_sh[0], s = head_sh[1];
     if (LEAN) {
         const double f = P.lean_f, rho = P.lean_rho;
         x = (x - gx) * f; y = (y - gy) * f;  // position is carried relative to the goal
@@ -973,10 +1073,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(S) =
                 dc = fma(w0, e0, dc);
                 dc = fma(w1, e1, dc);
                 if (GENERAL) {
-                    if (hq2 != 0.0) {  // Q[2,2] = 0 in the node
+                    if (hq2 != 0.0 || P.offdiag) {  // Q[2,2] = 0 and Q diagonal in the node
                         const double thw = (MODEL == 0 && (th > M_PI || th <= -M_PI)) ? wrap_theta(th) : th;
                         const double dth = thw - gth;
                         dc = fma(hq2 * dth, dth, dc);
+                        if (P.offdiag) dc += 0.5 * cross3(P.q01, P.q02, P.q12, dx, dy, dth);
                     }
                     if (P.grid_weight != 0.0) dc += obstacle_cost(P, x, y);  // extension, off in the node
                 }
@@ -989,9 +1090,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(S) =
     // sample's terminal cost only enters the total
     auto terminal = [&]() {
         const double thw = (MODEL == 0 && (th > M_PI || th <= -M_PI)) ? wrap_theta(th) : th;
-        const double inv_sq = !LEAN ? 1.0 : (INLINE_NOM ? head_sh[2] : P.lean_inv_f);  // LEAN: x, y are sqrt(q0 / 2) * position
+        const double inv_sq = !LEAN ? 1.0 : head_sh[2];  // LEAN: x, y are sqrt(q0 / 2) * position
         const double dx = (x - gx) * inv_sq, dy = (y - gy) * inv_sq, dth = thw - gth;
         pre += P.p0 * dx * dx + P.p1 * dy * dy + P.p2 * dth * dth;
+        if (GENERAL && P.offdiag) pre += cross3(P.p01, P.p02, P.p12, dx, dy, dth);
     };
     const int T4 = T - T % U;  // steps covered by full chunks
     // T = 6 n + 1 or 6 n + 2 (the node's T = 50, 20): the one or two steps behind the last full chunk do not get a chunk of their
@@ -1009,6 +1111,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(S) =
 #pragma unroll
                 for (int j = 0; j < U; ++j) { cur[j][0] = nxt[j][0]; cur[j][1] = nxt[j][1]; }
             }
+            probe.mark(P, mk++);
         }
         if (PHILOX && ride) {
             const int t0 = T4 - U;
@@ -1041,6 +1144,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(S) =
     terminal();
     // value_fcn = reverse cumulative sum over t (control/src/mppi:175) = total - exclusive prefix
     if (active) Stot[(size_t)a * Ks + k] = (S)pre;
+    probe.mark(P, mk++);
     probe.stop(P);
 }
 
@@ -1376,7 +1480,7 @@ __global__ __launch_bounds__(256) void scan_tick_kernel(DevParams P, const doubl
             if (goal_keep != goal) goal_keep[a * 3 + tid] = goal[a * 3 + tid];
         }
     }
-    const double half_uru = 0.5 * (P.r0 * un0 * un0 + P.r1 * un1 * un1);
+    const double half_uru = 0.5 * (P.r0 * un0 * un0 + P.r1 * un1 * un1 + (P.offdiag ? 2.0 * (P.r01 * un0 * un1) : 0.0));
     double w0, w1;
     cost_noise_weights(P, un0, un1, w0, w1);
     double sth0, cth0;
@@ -1450,8 +1554,12 @@ __global__ __launch_bounds__(256) void scan_tick_kernel(DevParams P, const doubl
             const double thn = (P.model == 0 && (the > M_PI || the <= -M_PI)) ? wrap_theta(the) : the;
             const double dx = X - gx, dy = Y - gy, dth = thn - gth;
             cst = 0.5 * (P.q0 * dx * dx + P.q1 * dy * dy + P.q2 * dth * dth) + half_uru + (w0 * e0 + w1 * e1);
+            if (P.offdiag) cst += 0.5 * cross3(P.q01, P.q02, P.q12, dx, dy, dth);
             if (P.grid_weight != 0.0) cst += obstacle_cost(P, X, Y);
-            if (t == T - 1) cst += P.p0 * dx * dx + P.p1 * dy * dy + P.p2 * dth * dth;
+            if (t == T - 1) {
+                cst += P.p0 * dx * dx + P.p1 * dy * dy + P.p2 * dth * dth;
+                if (P.offdiag) cst += cross3(P.p01, P.p02, P.p12, dx, dy, dth);
+            }
         }
         double tot;
         const double inc = lanes_scan_incl<NWAVES>(cst, t, sh_scan, tot);
@@ -1517,7 +1625,8 @@ __device__ __forceinline__ void rk4_exact(const DevParams& P, const double x0[3]
 // finalize_kernel: the tail of update_action (control/src/mppi:196-208) and of get_path
 // (:91-101) for one agent per block.
 //   gathered [G][A][T][8] shard partials (G = 1: this engine's own)
-//   flags: bit0 plant step (perform_action :210-213), bit1 receding-horizon shift (:100-101),
+//   flags: bit5 (with bits 0 and 1) the NEXT tick's nominal table (nominal_table_lanes) from the pose and controls this tick leaves;
+//          bit0 plant step (perform_action :210-213), bit1 receding-horizon shift (:100-101),
 //          bit2 bump the device tick counter (graph replay), bit3 the filter's basis staged in LDS (4*(T-1) more doubles),
 //          bit4 set the device tick counter to tick_set (eager ticks: the id after the one just run, so a
 //          later mppi_tick_graph continues the stream instead of re-drawing it)
@@ -1617,7 +1726,8 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
                                                const double* __restrict__ Smat, double* unom, double* ufilt, double* state,
                                                double* outv, uint32_t* tick_ptr, int flags, uint32_t tick_set,
                                                double* host_out, uint32_t* host_seq, uint32_t seq, char* smem_raw,
-                                               P2PWait wait) {
+                                               P2PWait wait, const double* __restrict__ goal = nullptr, double* __restrict__ tc = nullptr,
+                                               double* __restrict__ base = nullptr, PkRow* __restrict__ pk = nullptr) {
     if (wait.flags) {  // peer-to-peer exchange: `gathered` is this rank's mailbox; wait until every peer's tuples are in
         if (!p2p_wait_block(wait)) {  // a peer never delivered: poison the outputs (mppi_get_outputs reports MPPI_E_TIMEOUT), touch nothing else
             if (threadIdx.x == 0) {
@@ -1634,6 +1744,8 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
     double* uf = un + 2 * P.T;                          // [2][T] filtered + clipped
     double* Sl = uf + 2 * P.T;                          // [4][T-1] + [4]: staged copy of the filter's basis (flags bit3)
     __shared__ double trig[3][2];
+    __shared__ double nx_sh[3];     // the pose the plant step predicts (flags bit5: the next tick's table starts from it)
+    __shared__ double tab_sh[16];   // scan scratch of nominal_table_lanes
     const int tid = threadIdx.x, T = P.T;
     // the filter operator does not depend on anything this kernel waits for: fetch it now, all loads in
     // flight at once, and read it from LDS when the updated controls are ready
@@ -1752,6 +1864,7 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
             double* o = outv + (size_t)a * 8;
             o[0] = xn[0]; o[1] = xn[1]; o[2] = xn[2]; o[3] = uf[0]; o[4] = uf[T];
             state[a * 3 + 0] = xn[0]; state[a * 3 + 1] = xn[1]; state[a * 3 + 2] = xn[2];
+            nx_sh[0] = xn[0]; nx_sh[1] = xn[1]; nx_sh[2] = xn[2];
             if (host_out) {
                 // zero-copy output: the five results go straight into the caller's pinned host buffer, then the
                 // sequence word (system-scope release) -- mppi_get_outputs polls that word instead of issuing a D2H copy
@@ -1764,6 +1877,22 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
         if ((flags & 4) && a == 0 && tick_ptr) *tick_ptr = *tick_ptr + 1u;
         if ((flags & 16) && a == 0 && tick_ptr) *tick_ptr = tick_set;
     }
+    if ((flags & 35) == 35) {
+        // The next tick's nominal table, behind everything the caller waits for (the outputs above are on their way): lanes =
+        // timesteps, from the pose just predicted and the controls just shifted -- the values this kernel stored, taken from LDS.  A
+        // tick whose inputs are exactly these (no fresh pose, no mppi_set_nominal in between: the engine keeps track) launches the
+        // rollout variant that LOADS the table; any other computes it in its prologue as before.
+        __syncthreads();
+        const bool valid = tid < T;
+        const double un0 = !valid ? 0.0 : (tid + 1 < T ? uf[tid + 1] : P.shift_fill[a * 2 + 0]);
+        const double un1 = !valid ? 0.0 : (tid + 1 < T ? uf[T + tid + 1] : P.shift_fill[a * 2 + 1]);
+        const double gx = goal[a * 3 + 0], gy = goal[a * 3 + 1], gth = goal[a * 3 + 2];
+        if (T <= 64) {
+            if (tid < 64) nominal_table_lanes<1>(P, a, nx_sh[0], nx_sh[1], nx_sh[2], gx, gy, gth, un0, un1, tid, tab_sh, tc, base, pk);
+        } else {   // (T <= 256 <= blockDim.x: every thread takes part in the scans' barriers)
+            nominal_table_lanes<0>(P, a, nx_sh[0], nx_sh[1], nx_sh[2], gx, gy, gth, un0, un1, tid, tab_sh, tc, base, pk);
+        }
+    }
 }
 
 #ifndef MPPI_ROLLOUT_TU  // non-template kernels are emitted by the engine translation unit only
@@ -1772,10 +1901,11 @@ __global__ __launch_bounds__(1024) void finalize_kernel(DevParams P, const doubl
                                                       double* __restrict__ ufilt, double* __restrict__ state,
                                                       double* __restrict__ outv, uint32_t* tick_ptr, int flags,
                                                       uint32_t tick_set, double* host_out, uint32_t* host_seq, uint32_t seq,
-                                                      P2PWait wait) {
+                                                      P2PWait wait, const double* __restrict__ goal, double* __restrict__ tc,
+                                                      double* __restrict__ base, PkRow* __restrict__ pk) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     finalize_block(P, blockIdx.x, gathered, G, lay, Smat, unom, ufilt, state, outv, tick_ptr, flags, tick_set, host_out, host_seq,
-                   seq, smem_raw, wait);
+                   seq, smem_raw, wait, goal, tc, base, pk);
 }
 #endif
 

@@ -45,19 +45,13 @@ namespace mppi {
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u2 __attribute__((ext_vector_type(2)));
 
-struct __attribute__((aligned(16))) PkRow {
-    float d0, d1, lo0, hi0;   // hk (un_i - clip(un_i)); clip bounds of the deviation: hk (-+u_max - clip(un_i))
-    float lo1, hi1, A1, Cn;   // dW = dphi (A1 + Cn dphi): A1 = -2 rho sin phin, Cn = -rho cos phin
-    float Wn, Pn, w0, w1;     // rho (4 + 2 cos phin); hk (u0c + u1c); lam (un . Sig) -- the noise-cost weights
-    double c1n, s1n;          // nominal mid-step heading
-    double X2, Y2;            // 2 * scaled nominal position after the step (relative to the goal)
-};
-static_assert(sizeof(PkRow) == 80, "PkRow is read as five 16-byte LDS words");
+// (PkRow, the 80-byte per-step row of the nominal trajectory this kernel reads from LDS, is defined in mppi_kernels.hpp: the
+// finalize kernel writes the same rows for launches that load their table)
 
 struct RolloutPkArgs {
     DevParams P;
     hipStream_t stream;
-    int inline_nominal;   // 1: one wave (T <= 64), 2: four waves (T <= 256)
+    int inline_nominal;   // 1: one wave (T <= 64), 2: four waves (T <= 256); 0: no prologue -- the table is loaded (pkrows, tc)
     uint64_t seed;
     uint32_t tick;
     const uint32_t* tick_ptr;
@@ -65,6 +59,7 @@ struct RolloutPkArgs {
     double *tc, *base;
     float *dP, *stot, *epart;
     float al_guard;
+    const PkRow* pkrows;  // inline_nominal 0: the table the previous tick's finalize kernel left ([A][T])
     int waves;            // 4: the compiler's own allocation (no spills); 5: one more wave per SIMD at the price of a few spills
     int noise_pack;       // option "noise_packing": 0 three steps per Philox call (the default stream), 1 four, 2 hipRAND's normals, two (NoisePack, mppi_kernels.hpp)
     hipEvent_t ev_start, ev_stop;
@@ -97,7 +92,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
                                                         float* __restrict__ dP, float* __restrict__ Stot, uint64_t seed,
                                                         uint32_t tick_arg, const uint32_t* __restrict__ tick_ptr,
                                                         float* __restrict__ epart, const double* __restrict__ unom,
-                                                        double* __restrict__ base, float al_guard) {
+                                                        double* __restrict__ base, float al_guard, const PkRow* __restrict__ pkrows) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     PkRow* lt = reinterpret_cast<PkRow*>(smem_raw);  // [T]
     __shared__ double fin_sh[1];                      // the nominal trajectory's final heading (unwrapped)
@@ -186,7 +181,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
             for (int i = 0; i < SPD; ++i) { nz[j + i][0] = w0[i].x; nz[j + i][1] = w0[i].y; nz[j + i][2] = w1[i].x; nz[j + i][3] = w1[i].y; }
         }
     };
-    {
+    if constexpr (INLINE_NOM == 0) {
+        // the table from memory: the previous tick's finalize kernel computed it for this tick's inputs (nominal_table_lanes)
+        const PkRow* src = pkrows + (size_t)a * T;
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        for (int i = tid; i < T * 5; i += 256) reinterpret_cast<f4*>(lt)[i] = reinterpret_cast<const f4*>(src)[i];
+        if (tid == 0) fin_sh[0] = tc[(size_t)a * T * kTcW + 7];
+        if constexpr (PACK == 0) {   // the first chunk's noise depends on nothing the table holds: drawn while the loads are in flight
+            draw(0, U);
+            drawn0 = true;
+        }
+    } else {
         // the block runs the nominal rollout itself, lanes = timesteps (as rollout_kernel does), and derives the per-step
         // constants of the deviation form from it
         __shared__ double nom_sh[4];
@@ -197,20 +202,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
             NomExtra ex;
             nominal_lanes<(INLINE_NOM == 2 ? 4 : 1)>(P, state, goal, unom, a, tid, row, base_t, nom_sh, nullptr, &ex);
             if (tid < T) {
-                const double hk = 0.5 * P.kth * P.dt, phin = 0.5 * ex.h;
-                double sp, cp;
-                if (fabs(phin) <= 0.25) small_sincos<7>(phin, sp, cp);
-                else sincos(phin, &sp, &cp);
-                PkRow r;
-                r.d0 = (float)(hk * (row[0] - ex.u0c)); r.d1 = (float)(hk * (row[1] - ex.u1c));
-                r.lo0 = (float)(hk * (-P.u_max - ex.u0c)); r.hi0 = (float)(hk * (P.u_max - ex.u0c));
-                r.lo1 = (float)(hk * (-P.u_max - ex.u1c)); r.hi1 = (float)(hk * (P.u_max - ex.u1c));
-                r.A1 = (float)(-2.0 * sp * P.lean_rho); r.Cn = (float)(-cp * P.lean_rho);
-                r.Wn = (float)((4.0 + 2.0 * cp) * P.lean_rho); r.Pn = (float)(hk * (ex.u0c + ex.u1c));
-                r.w0 = (float)row[2]; r.w1 = (float)row[3];
-                r.c1n = ex.c1; r.s1n = ex.s1;
-                r.X2 = 2.0 * P.lean_f * (ex.X - gx); r.Y2 = 2.0 * P.lean_f * (ex.Y - gy);
-                lt[tid] = r;
+                lt[tid] = make_pkrow(P, row, ex, gx, gy);
                 if (tid == T - 1) fin_sh[0] = ex.th + ex.h;
                 if (blockIdx.x == 0) {  // for mppi_download_value: V = base + Stot - dP
                     base[(size_t)a * T + tid] = base_t;
@@ -232,6 +224,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
         }
     }
     __syncthreads();
+    int mk = 0;   // (timeline marks of a diagnostic build; dead code in the product)
+    probe.mark(P, mk++);
     // per-wave sums of eps (the E of the softmax floor term, control/src/mppi:193) for the chunk's steps x 2 wheels: the
     // lane's two samples are added first, one 16-value reduce-scatter serves 128 samples.  epart keeps its
     // [A][T][2][Ks/64] layout: the wave's total goes to the slot of its first 64 samples, 0 to the slot of the other 64
@@ -341,11 +335,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
             if (!drawn0) draw(0, U);   // (uniform)
             eps_sums(0, full_tag, std::false_type{});
             chunk(0, U, full_tag);
+            probe.mark(P, mk++);
         }
         for (int t0 = U; t0 < t_loop; t0 += U) {
             draw(t0, U);
             eps_sums(t0, full_tag, std::false_type{});
             chunk(t0, U, full_tag);
+            probe.mark(P, mk++);
         }
         if (ride) {
             const int t0 = T4 - U;
@@ -396,6 +392,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
         if (actA) Stot[(size_t)a * Ks + kA] = tot[0];
         if (actB) Stot[(size_t)a * Ks + kA + 1] = tot[1];
     }
+    probe.mark(P, mk++);
     probe.stop(P);
 }
 
@@ -406,14 +403,14 @@ hipError_t launch_rollout_pk(const RolloutPkArgs& a) {
     do {                                                                                                                      \
         if (a.ev_start)                                                                                                       \
             hipExtLaunchKernelGGL((rollout_pk_kernel<IN, W, PK>), grid, dim3(256), lds, a.stream, a.ev_start, a.ev_stop, 0, a.P, a.state, \
-                                  a.goal, a.tc, a.dP, a.stot, a.seed, a.tick, a.tick_ptr, a.epart, a.unom, a.base, a.al_guard); \
+                                  a.goal, a.tc, a.dP, a.stot, a.seed, a.tick, a.tick_ptr, a.epart, a.unom, a.base, a.al_guard, a.pkrows); \
         else                                                                                                                  \
             hipLaunchKernelGGL((rollout_pk_kernel<IN, W, PK>), grid, dim3(256), lds, a.stream, a.P, a.state, a.goal, a.tc, a.dP, a.stot, \
-                               a.seed, a.tick, a.tick_ptr, a.epart, a.unom, a.base, a.al_guard);                              \
+                               a.seed, a.tick, a.tick_ptr, a.epart, a.unom, a.base, a.al_guard, a.pkrows);                    \
     } while (0)
 #define MPPI_PK_GO(IN, W) do { if (a.noise_pack == 2) MPPI_PK_GO_(IN, W, 2); else if (a.noise_pack == 1) MPPI_PK_GO_(IN, W, 1); else MPPI_PK_GO_(IN, W, 0); } while (0)
-    if (a.waves == 5) { if (a.inline_nominal == 2) MPPI_PK_GO(2, 5); else MPPI_PK_GO(1, 5); }
-    else { if (a.inline_nominal == 2) MPPI_PK_GO(2, 4); else MPPI_PK_GO(1, 4); }
+    if (a.waves == 5) { if (a.inline_nominal == 2) MPPI_PK_GO(2, 5); else if (a.inline_nominal == 1) MPPI_PK_GO(1, 5); else MPPI_PK_GO(0, 5); }
+    else { if (a.inline_nominal == 2) MPPI_PK_GO(2, 4); else if (a.inline_nominal == 1) MPPI_PK_GO(1, 4); else MPPI_PK_GO(0, 4); }
 #undef MPPI_PK_GO
 #undef MPPI_PK_GO_
     return hipGetLastError();

@@ -217,6 +217,12 @@ class Engine(object):
         arrs = [None if v is None else _f64(v, (n,)) for v, n in ((q, 3), (r, 2), (p1, 3))]
         self._ck(self._lib.mppi_set_weights(self._h, *[_capi.dptr(a) for a in arrs]))
 
+    def set_weight_matrices(self, Q=None, R=None, P1=None):
+        """The full matrices Q [3][3], R [2][2], P1 [3][3] the reference multiplies (control/src/mppi:168, :181-184); None keeps
+        the current one.  Off-diagonal terms select the general-cost rollout."""
+        arrs = [None if v is None else _f64(v, (n, n)) for v, n in ((Q, 3), (R, 2), (P1, 3))]
+        self._ck(self._lib.mppi_set_weight_matrices(self._h, *[_capi.dptr(a) for a in arrs]))
+
     def set_sync_timeout(self, milliseconds):
         self._ck(self._lib.mppi_set_sync_timeout(self._h, int(milliseconds)))
 
@@ -423,6 +429,13 @@ class Engine(object):
         self._ck(self._lib.mppi_shader_clock(self._h, C.byref(mhz)))
         return mhz.value
 
+    def probe_timeline(self):
+        """(stamps [30], total): shader cycles of the last rollout launch's probe wave at its marks (diagnostic builds of the
+        library only -- make PROBE=1; the product build returns zeros)."""
+        marks, total = (C.c_uint64 * _capi.PROBE_MARKS)(), C.c_uint64()
+        self._ck(self._lib.mppi_probe_timeline(self._h, marks, C.byref(total)))
+        return [int(v) for v in marks], int(total.value)
+
     def info(self):
         b, r, u = C.c_size_t(), C.c_int32(), C.c_int32()
         self._ck(self._lib.mppi_engine_info(self._h, C.byref(b), C.byref(r), C.byref(u)))
@@ -516,8 +529,9 @@ class MPPI(object):
 
     # Q, R, P1 (control/src/mppi:69-73) are plain instance attributes in the reference, read on every call (:168, :183):
     # ``m.Q = ...`` or ``m.Q[0, 0] = ...`` must change the cost of the next rollout here too.  The attributes stay plain
-    # arrays; every call that rolls out hands their current diagonals to the engine first (mppi_set_weights) when they
-    # differ from what it has.  The kernels implement diagonal weights: anything else is refused by name.
+    # arrays; every call that rolls out hands their current values to the engine first when they differ from what it has:
+    # diagonal matrices by their diagonals (mppi_set_weights: the fast kernels), anything else whole (mppi_set_weight_matrices:
+    # the general-cost rollout carries the symmetric parts, which is all a quadratic form sees).
     def _sync_weights(self):
         # fast path (every tick of the node): the three attributes are still float64 arrays holding the bytes last validated and sent
         raw = self._weights_raw
@@ -527,18 +541,19 @@ class MPPI(object):
                     r.dtype == np.float64 and p1.dtype == np.float64 and q.tobytes() == raw[0] and r.tobytes() == raw[1] and
                     p1.tobytes() == raw[2]):
                 return
-        mats = []
+        mats, diagonal = [], True
         for name, n in (("Q", 3), ("R", 2), ("P1", 3)):
-            m = np.asarray(getattr(self, name), dtype=np.float64)
+            m = np.array(getattr(self, name), dtype=np.float64)
             if m.shape != (n, n):
                 raise ValueError("%s must be %d x %d (control/src/mppi:69-73)" % (name, n, n))
-            if np.count_nonzero(m - np.diag(np.diag(m))):
-                raise ValueError("%s has off-diagonal terms: libmppi_hip implements diagonal Q, R, P1 (the reference's own "
-                                 "are diagonal, control/src/mppi:69-73)" % name)
-            mats.append(np.diag(m).copy())
+            diagonal = diagonal and not np.count_nonzero(m - np.diag(np.diag(m)))
+            mats.append(m)
         key = tuple(map(bytes, (v.tobytes() for v in mats)))
         if key != self._weights_sent:
-            self._eng.set_weights(*mats)
+            if diagonal:
+                self._eng.set_weights(*[np.diag(m).copy() for m in mats])
+            else:
+                self._eng.set_weight_matrices(*mats)
             self._weights_sent = key
         self._weights_raw = tuple(np.asarray(getattr(self, name), dtype=np.float64).tobytes() for name in ("Q", "R", "P1"))
 

@@ -23,7 +23,8 @@ class OrcParams(C.Structure):
                 ("grid", C.c_void_p), ("grid_w", C.c_int), ("grid_h", C.c_int),
                 ("grid_res", C.c_double), ("grid_ox", C.c_double), ("grid_oy", C.c_double),
                 ("grid_weight", C.c_double), ("use_sig", C.c_int), ("sig", C.c_double * 4),
-                ("shift_fill", C.c_double * 2)]
+                ("shift_fill", C.c_double * 2),
+                ("use_full", C.c_int), ("Qf", C.c_double * 9), ("Rf", C.c_double * 4), ("P1f", C.c_double * 9)]
 
 
 def build(force=False):
@@ -79,6 +80,18 @@ def set_sig_matrix(params, sig):
     sig = np.asarray(sig, dtype=np.float64).reshape(2, 2)
     params.use_sig = 1
     params.sig[:] = [sig[0, 0], sig[0, 1], sig[1, 0], sig[1, 1]]
+    return params
+
+
+def set_weight_matrices(params, Q, R, P1):
+    """Q [3,3], R [2,2], P1 [3,3] as the reference's attributes (control/src/mppi:69-73), multiplied whole (:168, :181-184)."""
+    Q, R, P1 = (np.asarray(m, dtype=np.float64) for m in (Q, R, P1))
+    assert Q.shape == (3, 3) and R.shape == (2, 2) and P1.shape == (3, 3)
+    params.use_full = 1
+    params.Qf[:] = list(Q.ravel())
+    params.Rf[:] = list(R.ravel())
+    params.P1f[:] = list(P1.ravel())
+    params.q[:] = list(np.diag(Q)); params.r[:] = list(np.diag(R)); params.p1[:] = list(np.diag(P1))
     return params
 
 

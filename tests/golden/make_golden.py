@@ -428,6 +428,40 @@ def main():
     out["edge_meta"] = np.array(edge, dtype=np.int64)
     out["edge_state0"], out["edge_goal"] = np.array([0.02, -0.01, 0.1]), np.array([0.25, -0.4, -0.3])
 
+    # ---------------- N (round 5): Q, R, P1 are plain attributes the reference multiplies WHOLE -- (state - desired).T.dot(Q).dot(...),
+    # u.T.dot(R).dot(u) (:181-184), .dot(P1) (:168): matrices with off-diagonal terms.  A symmetric set, and a set that is not
+    # symmetric (a quadratic form sees the symmetric part only; the reference accepts either).
+    K, T, seed, nt = 48, 50, 61, 4
+    Qs = np.array([[1000.0, 150.0, 20.0], [150.0, 800.0, -30.0], [20.0, -30.0, 5.0]])
+    Rs = np.array([[1.0, 0.3], [0.3, 2.0]])
+    Ps = np.array([[900.0, -200.0, 50.0], [-200.0, 1100.0, 80.0], [50.0, 80.0, 600.0]])
+    Qa = Qs + np.array([[0.0, 40.0, -10.0], [-40.0, 0.0, 25.0], [10.0, -25.0, 0.0]])
+    Ra = Rs + np.array([[0.0, 0.2], [-0.2, 0.0]])
+    Pa = Ps + np.array([[0.0, -60.0, 15.0], [60.0, 0.0, -35.0], [-15.0, 35.0, 0.0]])
+    for tag, Qm, Rm, Pm in (("wfull_sym", Qs, Rs, Ps), ("wfull_asym", Qa, Ra, Pa)):
+        mp = ref.MPPI(horizon=T, samples=K)
+        mp.Q, mp.R, mp.P1 = Qm.copy(), Rm.copy(), Pm.copy()
+        u0 = nominal_warm(T)
+        state, goal = np.array([0.1, -0.05, 2.9]), np.array([0.4, -1.0, -2.8])
+        sig = np.array([[SIG, 0.0], [0.0, SIG]])
+        np.random.seed(seed)
+        V, eps = mp.get_cost2go(state, u0.copy(), goal, LAM, sig)
+        assert np.array_equal(np.array(eps), np.random.RandomState(seed).normal(0.0, SIG, (T, 2, K)))
+        out[tag + "_c2g_V"] = V.copy()
+        out[tag + "_c2g_unew"] = mp.update_action(u0.copy(), eps, V.copy(), sig, LAM)
+        mp.initialize()
+        np.random.seed(seed + 1)
+        st, states, us = state.copy(), [], []
+        for _ in range(nt):
+            st = mp.get_path(st, goal)
+            states.append(st.copy())
+            us.append(mp.uvec[-1].copy())
+        out[tag + "_seq_states"], out[tag + "_seq_u"] = np.array(states), np.array(us)
+        out[tag + "_seq_latest_uvec"] = mp.latest_uvec.copy()
+        out[tag + "_Q"], out[tag + "_R"], out[tag + "_P1"] = Qm, Rm, Pm
+    out["wfull_meta"] = np.array([K, T, seed, nt], dtype=np.int64)
+    out["wfull_state"], out["wfull_goal"], out["wfull_u0"] = state, goal, nominal_warm(T)
+
     np.savez_compressed(os.path.join(HERE, "mppi_golden.npz"), **out)
     with open(os.path.join(HERE, "mppi_kat.json"), "w") as f:
         json.dump(kat, f, indent=1, sort_keys=True)

@@ -11,10 +11,13 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    src = open(os.path.join(ROOT, "include", "mppi_hip.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(mppi_[a-z_0-9]+)\s*\(", src)))
+def _declared(headers=("mppi_hip.h", "mppi_hip_diag.h")):
+    names = set()
+    for h in headers:
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(mppi_[a-z_0-9]+)\s*\(", src))
+    return sorted(names)
 
 
 def test_header_symbols_all_exported_and_bound():
@@ -25,7 +28,7 @@ def test_header_symbols_all_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), "libmppi_hip.so does not export %s" % n
     assert sorted(_capi.SIGNATURES) == names  # the ctypes binding covers exactly the header
-    assert lib.mppi_abi_version() == _capi.ABI_VERSION == 4
+    assert lib.mppi_abi_version() == _capi.ABI_VERSION == 5
 
 
 def test_default_config_is_the_reference_node(kat):
@@ -268,6 +271,7 @@ def test_python_shell_fast_paths_still_see_every_change():
         sigma = lam = None
         def __init__(self): self.calls = []
         def set_weights(self, q, r, p1): self.calls.append(("weights", q.copy(), r.copy(), p1.copy()))
+        def set_weight_matrices(self, Q, R, P1): self.calls.append(("matrices", Q.copy(), R.copy(), P1.copy()))
         def set_shift_fill(self, f): self.calls.append(("fill", np.array(f)))
         def set_sig(self, sig, lam): pass
         def set_nominal(self, u): self.calls.append(("nominal",))
@@ -296,22 +300,27 @@ def test_python_shell_fast_paths_still_see_every_change():
     m.P1 = np.diag([1, 2, 3]).astype(np.int64)                       # another dtype
     m.get_path(m.start, m.goal)
     assert n("weights") == 4 and list(eng.calls[-1][3]) == [1.0, 2.0, 3.0]
-    m.Q = np.ones((3, 3))
+    m.Q = np.ones((3, 3))                                             # off-diagonal terms: the whole matrices go (control/src/mppi:181-184 multiplies them)
+    m.get_path(m.start, m.goal); m.get_path(m.start, m.goal)
+    assert n("matrices") == 1 and n("weights") == 4 and np.all(eng.calls[-1][1] == 1.0) and eng.calls[-1][3].shape == (3, 3)
+    m.Q = np.ones((2, 3))
     with pytest.raises(ValueError):
         m.get_path(m.start, m.goal)
-    m.Q = np.diag([1e3, 1e3, 0.0])
+    m.Q = np.diag([1e3, 1e3, 0.0])                                    # diagonal again: back to the diagonals' call
+    m.get_path(m.start, m.goal)
+    assert n("weights") == 5 and n("matrices") == 1
     m.uvec_init[:, 0] = [0.3, -0.2]                                   # in place: the shift fill of the next tick
     m.get_path(m.start, m.goal)
     assert n("fill") == 1 and list(eng.calls[-1][1]) == [0.3, -0.2]
     m.get_path(m.start, m.goal)
     assert n("fill") == 1
     # path / uvec: one row per get_path behind the initial one, plain arrays, assignable
-    assert m.path.shape == (9, 3) and m.uvec.shape == (9, 2) and len(m.fin_time) == 9
+    assert m.path.shape == (12, 3) and m.uvec.shape == (12, 2) and len(m.fin_time) == 12
     assert np.all(m.uvec[-1] == [0.5, -0.5]) and np.all(m.path[0] == 0.0)
     old = m.path
     for _ in range(200):                                              # across several doublings of the buffers
         m.get_path(m.start, m.goal)
-    assert m.path.shape == (209, 3) and np.array_equal(m.path[:9], old) and old.shape == (9, 3)
+    assert m.path.shape == (212, 3) and np.array_equal(m.path[:12], old) and old.shape == (12, 3)
     m.path = np.zeros((1, 3)); m.uvec = [[1.0, 2.0]]
     m.get_path(m.start, m.goal)
     assert m.path.shape == (2, 3) and m.uvec.shape == (2, 2) and np.all(m.uvec[0] == [1.0, 2.0])

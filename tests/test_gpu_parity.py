@@ -261,6 +261,71 @@ def test_general_weights_golden(golden, storage):
 
 
 @pytest.mark.parametrize("storage", ["f64", "f32"])
+@pytest.mark.parametrize("tag", ["wfull_sym", "wfull_asym"])
+def test_full_weight_matrices_golden(orc, golden, tag, storage):
+    """Q, R, P1 with off-diagonal terms, multiplied whole by the reference (control/src/mppi:168, :181-184), against the reference
+    itself (golden section N): through the C ABI's mppi_set_weight_matrices (the general-cost rollout; on the scan path the one
+    kernel) and through the drop-in class, whose attributes are assigned the way the golden script assigns the reference's."""
+    from motion_planning_amd import MPPI
+    Q, R, P1 = golden[tag + "_Q"], golden[tag + "_R"], golden[tag + "_P1"]
+    K, T, seed, nt = [int(x) for x in golden["wfull_meta"]]
+    eps = np.random.RandomState(seed).normal(0.0, SIG, (T, 2, K))
+    state, goal, u0 = golden["wfull_state"], golden["wfull_goal"], golden["wfull_u0"]
+    Vg = golden[tag + "_c2g_V"]
+    tv, tu = (1e-9 * np.abs(Vg).max(), 1e-9) if storage == "f64" else (3e-3, 1e-5)
+    with _engine(K, T, storage) as e:
+        e.set_weight_matrices(Q, R, P1)
+        e.set_nominal(u0)
+        e.upload_noise(eps)
+        e.rollout(state, goal, noise="injected")
+        V = e.download_value()[0]
+        u = e.update()[0]
+        assert np.abs(V - Vg).max() < tv
+        assert np.abs(u - golden[tag + "_c2g_unew"]).max() < tu
+        noise = np.random.RandomState(seed + 1).normal(0.0, SIG, (nt, T, 2, K))
+        e.reset()
+        st = state.copy()
+        for i in range(nt):
+            e.upload_noise(noise[i])
+            nxt, ua = e.tick(st, goal, noise="injected")
+            st = nxt[0]
+            assert np.abs(st - golden[tag + "_seq_states"][i]).max() < (1e-10 if storage == "f64" else 1e-8), i
+            assert np.abs(ua[0] - golden[tag + "_seq_u"][i]).max() < tu, i
+        assert np.abs(e.get_nominal() - golden[tag + "_seq_latest_uvec"]).max() < tu
+        # a device-noise tick with these weights replays on the oracle (the tick-path kernels, not only the injected-noise ones)
+        e.set_nominal(u0)
+        nxt, ua = e.tick(state, goal, noise="philox", seed=9, tick_id=3)
+        used = e.download_noise()[0]
+        p = orc.set_weight_matrices(orc.default_params(), Q, R, P1)
+        so, uo, _ = orc.get_path(state, goal, u0, used, LAM, SIG, params=p)
+        assert np.abs(nxt[0] - so).max() < (1e-10 if storage == "f64" else 1e-8) and np.abs(ua[0] - uo).max() < tu
+        # the diagonals' call makes the matrices diagonal again
+        e.set_weights(np.diag(Q).copy(), np.diag(R).copy(), np.diag(P1).copy())
+        e.set_nominal(u0)
+        e.upload_noise(eps)
+        e.rollout(state, goal, noise="injected")
+        pd = orc.default_params()
+        pd.q[:], pd.r[:], pd.p1[:] = np.diag(Q), np.diag(R), np.diag(P1)
+        Vd = orc.get_cost2go(state, u0, goal, LAM, SIG, _round_eps(eps, storage), params=pd)
+        assert np.abs(e.download_value()[0] - Vd).max() < tv
+    m = MPPI(horizon=T, samples=K, storage=storage)
+    m.Q, m.R = Q.copy(), R.copy()                       # assignment after construction, like make_golden.py
+    m.P1[...] = P1                                       # written in place into the default array
+    sig = np.array([[SIG, 0.0], [0.0, SIG]])
+    np.random.seed(seed)
+    V, eps_l = m.get_cost2go(state, u0.copy(), goal, LAM, sig)
+    assert np.abs(V - Vg).max() < tv
+    assert np.abs(m.update_action(u0.copy(), eps_l, V.copy(), sig, LAM) - golden[tag + "_c2g_unew"]).max() < tu
+    m.initialize()
+    np.random.seed(seed + 1)
+    st = state.copy()
+    for i in range(nt):
+        st = m.get_path(st, goal)
+        assert np.abs(st - golden[tag + "_seq_states"][i]).max() < (1e-10 if storage == "f64" else 1e-8), i
+        assert np.abs(m.uvec[-1] - golden[tag + "_seq_u"][i]).max() < tu, i
+
+
+@pytest.mark.parametrize("storage", ["f64", "f32"])
 def test_live_weights_through_the_class(golden, storage):
     """Golden section H THROUGH the drop-in class, the way the golden script itself does it (make_golden.py: `mp.Q = ...`
     after construction): Q, R, P1 are plain instance attributes in the reference, read on every call (control/src/mppi:69-73,

@@ -235,6 +235,31 @@ def test_general_weights_golden(orc, golden):
         assert np.abs(ua - golden["wts_seq_u"][i]).max() < 1e-9
 
 
+@pytest.mark.parametrize("tag", ["wfull_sym", "wfull_asym"])
+def test_full_weight_matrices_golden(orc, golden, tag):
+    """Q, R, P1 with OFF-DIAGONAL terms -- the reference multiplies the whole matrices (control/src/mppi:168, :181-184) --,
+    a symmetric set and one that is not (golden section N: the reference's MPPI instance with its attributes overwritten)."""
+    p = orc.set_weight_matrices(orc.default_params(), golden[tag + "_Q"], golden[tag + "_R"], golden[tag + "_P1"])
+    K, T, seed, nt = [int(x) for x in golden["wfull_meta"]]
+    eps = orc.reference_noise(seed, SIG, T, K)
+    state, goal, u0 = golden["wfull_state"], golden["wfull_goal"], golden["wfull_u0"]
+    V = orc.get_cost2go(state, u0, goal, LAM, SIG, eps, params=p)
+    Vg = golden[tag + "_c2g_V"]
+    assert np.abs(V - Vg).max() < 1e-12 * np.abs(Vg).max()
+    assert np.abs(orc.update_action(u0, eps, V, LAM, params=p) - golden[tag + "_c2g_unew"]).max() < 1e-9
+    noise = orc.reference_noise(seed + 1, SIG, T, K, n_ticks=nt)
+    st, lat = state.copy(), np.zeros((2, T))
+    for i in range(nt):
+        st, ua, lat = orc.get_path(st, goal, lat, noise[i], LAM, SIG, params=p)
+        assert np.abs(st - golden[tag + "_seq_states"][i]).max() < 1e-10
+        assert np.abs(ua - golden[tag + "_seq_u"][i]).max() < 1e-9
+    assert np.abs(lat - golden[tag + "_seq_latest_uvec"]).max() < 1e-9
+    # the off-diagonal terms matter: the diagonals alone give another V
+    pd = orc.default_params()
+    pd.q[:], pd.r[:], pd.p1[:] = np.diag(golden[tag + "_Q"]), np.diag(golden[tag + "_R"]), np.diag(golden[tag + "_P1"])
+    assert np.abs(orc.get_cost2go(state, u0, goal, LAM, SIG, eps, params=pd) - Vg).max() > 1.0
+
+
 def test_other_sigma_and_lambda_golden(orc, golden):
     """get_path with the sig / lam arguments the node never changes (control/src/mppi:88-89), golden section I."""
     K, T, seed, nt = [int(x) for x in golden["lamsig_seq_meta"]]
