@@ -476,6 +476,8 @@ struct mppi_engine {
         if (load_table && !table_taken) { use_table_set(tab ^ 1); table_taken = true; }
         a.inline_nominal = !inline_nominal() || load_table ? 0 : (cfg.horizon <= 64 ? 1 : 2);
         a.general = general_cost();
+        // under-filled launches (fewer than ~4 waves of this kernel per SIMD: blocks <= 1024) take the software-pipelined variant
+        a.pipe = low_occ_opt >= 0 ? low_occ_opt != 0 : (long)cfg.n_agents * ((k1 - k0 + 255) / 256) <= 1024;
         a.seed = seed; a.tick = tick; a.tick_ptr = tick_ptr;
         a.state = ro_state ? ro_state : d_state; a.goal = ro_goal ? ro_goal : d_goal;
         a.unom = ro_unom ? ro_unom : d_unom; a.tc = d_tc; a.base = d_base;

@@ -669,19 +669,25 @@ __device__ __forceinline__ void nominal_table_lanes(const DevParams& P, int a, d
 // HIPRAND_RNG_PSEUDO_PHILOX4_32_10 -- inlined so that (seed, tick, agent, global sample, t)
 // addresses the stream identically on any shard layout and on the CPU twin (oracle/).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+// rounds [R0, R1) of the ten, in place (k0, k1 = the call's key: the round keys are k + r * Weyl); philox4x32_10 is rounds [0, 10) --
+// the pipelined rollout (rollout_kernel PIPE) advances a call a few rounds at a time between the steps of the previous chunk
+template <int R0, int R1>
+__device__ __forceinline__ void philox_rounds(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;  // v_mad_u64_u32
+    for (int r = R0; r < R1; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];  // v_mad_u64_u32
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
         const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         // three-input xor in one instruction (v_bitop3_b32, truth table 0x96 -- a gfx950 addition)
-        const uint32_t n0 = __builtin_amdgcn_bitop3_b32(hi1, c1, k0, 0x96), n2 = __builtin_amdgcn_bitop3_b32(hi0, c3, k1, 0x96);
-        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        const uint32_t n0 = __builtin_amdgcn_bitop3_b32(hi1, c[1], k0 + (uint32_t)r * 0x9E3779B9u, 0x96);
+        const uint32_t n2 = __builtin_amdgcn_bitop3_b32(hi0, c[3], k1 + (uint32_t)r * 0xBB67AE85u, 0x96);
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
     }
+}
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+    philox_rounds<0, 10>(out, k0, k1);
 }
 
 // Two N(0, sigma^2) draws from two 21-bit uniforms: Box-Muller in fp32 with u1 = (a + 1/2) / 2^21 in
@@ -765,6 +771,14 @@ __device__ __forceinline__ void philox_normals(uint32_t gk, uint32_t draw, uint3
     }
 }
 
+// pair j (0..2) of a default-packing call's words o: what philox_normals<0> puts into e[2j], e[2j+1]
+template <int J>
+__device__ __forceinline__ void philox_pair(const uint32_t (&o)[4], float nscale, float& e0, float& e1) {
+    if (J == 0) box_muller(o[0] >> 11, (o[1] >> 9) & 0x7FFFFCu, nscale, e0, e1);
+    else if (J == 1) box_muller(o[2] >> 11, (o[3] >> 9) & 0x7FFFFCu, nscale, e0, e1);
+    else box_muller(((o[0] & 0x7FFu) << 10) | ((o[1] & 0x7FFu) >> 1), ((o[2] & 0x7FFu) << 12) | ((o[3] & 0x7FEu) << 1), nscale, e0, e1);
+}
+
 // the same stream addressed by (sample, t): only step t's pair of its draw's three (four)
 template <int PACK = 0>
 __device__ __forceinline__ void philox_normal_pair(uint32_t gk, uint32_t t, uint32_t tick, uint32_t a, uint32_t key0,
@@ -802,9 +816,14 @@ __device__ __forceinline__ void philox_normal_pair(uint32_t gk, uint32_t t, uint
 // grid = (ceil(K / 256), A), block = 256, LDS = the 40*T-byte per-step table.  Per lane and step: 2 eps + 1 dP element
 // through HBM, fully coalesced (consecutive lanes = consecutive k).
 // ---------------------------------------------------------------------------------------------
-template <typename S, int NTERM, bool PHILOX, bool STORE_EPS, int INLINE_NOM, int MODEL, bool GENERAL>
+//   PIPE   (PHILOX, noise not stored, the node's cost and model only) the variant for launches that leave a SIMD fewer than ~4 waves:
+//          nothing then hides a wave's own dependent chains -- Philox -> Box-Muller -> [reduce-scatter] -> six steps of fp64 dynamics,
+//          one behind the other in the default variant's schedule -- so the chunk is software-pipelined: while chunk c integrates, the
+//          two Philox calls of chunk c + 1 advance a few rounds behind every step and its Box-Muller pairs follow (the compiler's
+//          scheduler interleaves what the source interleaves); at most 4 waves per SIMD (128 registers: both chunks' noise live)
+template <typename S, int NTERM, bool PHILOX, bool STORE_EPS, int INLINE_NOM, int MODEL, bool GENERAL, bool PIPE = false>
 // (fp64 storage: 4 waves per SIMD -- at 5 the kernel spilled 22 registers around its 8-byte stores; 140.8 -> 136.1 us together with the row-buffer stores)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(S) == 8 ? 4 : 5, 8))) void rollout_kernel(DevParams P, const double* __restrict__ state,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE ? 2 : (sizeof(S) == 8 ? 4 : 5), PIPE ? 4 : 8))) void rollout_kernel(DevParams P, const double* __restrict__ state,
                                                      const double* __restrict__ goal,
                                                      double* __restrict__ tc, S* __restrict__ eps,
                                                      S* __restrict__ dP, S* __restrict__ Stot, uint64_t seed,
@@ -969,20 +988,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(S) =
     // theta is carried UNWRAPPED inside the loop: only cos/sin of it (carried separately as the heading
     // vector) enter the dynamics, and the reference's per-step wrap to (-pi, pi] (control/src/mppi:52-53)
     // is applied where theta itself is used -- the Q[2,2] stage term and the terminal cost.
-    auto integrate = [&](int t0, auto guard_tag, auto full_tag) {
-        constexpr bool GUARD = decltype(guard_tag)::value;  // tail chunk: steps beyond T are skipped
+    // one step t with the noise (n0, n1): the prefix BEFORE the step goes out, then explore + clip + model + cost
+    auto step = [&](int t, S n0, S n1, auto full_tag) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_tag)::value;    // every lane of the block has a sample: plain stores
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            const int t = t0 + j;
-            if (!GUARD || t < T) {
+        {
+            {
                 const double* tcp = lt + t * 5;
                 const double un0 = tcp[0], un1 = tcp[1], w0 = tcp[2], w1 = tcp[3], cb = tcp[4];
-                const double e0 = (double)cur[j][0], e1 = (double)cur[j][1];
+                const double e0 = (double)n0, e1 = (double)n1;
                 if (FULL || active) {
                     if (PHILOX && STORE_EPS) {
-                        eps_a[(size_t)(t * 2 + 0) * Ks] = cur[j][0];
-                        eps_a[(size_t)(t * 2 + 1) * Ks] = cur[j][1];
+                        eps_a[(size_t)(t * 2 + 0) * Ks] = n0;
+                        eps_a[(size_t)(t * 2 + 1) * Ks] = n1;
                     }
                     if (FULL) {
                         // row t of dP as its own buffer: the descriptor is scalar arithmetic (base + t * pitch on
@@ -1022,7 +1039,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(S) =
                     dc = fma(w0, e0, dc);
                     dc = fma(w1, e1, dc);
                     pre += dc;
-                    continue;
+                    return;
                 }
                 const double u0 = clampd(un0 + e0, P.u_max), u1 = clampd(un1 + e1, P.u_max);
                 if (MODEL == 1) {
@@ -1085,6 +1102,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(S) =
             }
         }
     };
+    auto integrate = [&](int t0, auto guard_tag, auto full_tag) __attribute__((always_inline)) {
+        constexpr bool GUARD = decltype(guard_tag)::value;  // tail chunk: steps beyond T are skipped
+#pragma unroll
+        for (int j = 0; j < U; ++j)
+            if (!GUARD || t0 + j < T) step(t0 + j, cur[j][0], cur[j][1], full_tag);
+    };
     // terminal cost (control/src/mppi:165-173), theta error not wrapped beyond rk4's own wrap; the nominal
     // terminal cost is already inside cb[T-1], and dP[T-1] is the prefix BEFORE the last step, so the
     // sample's terminal cost only enters the total
@@ -1102,6 +1125,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(S) =
     const bool ride = PHILOX && T4 >= U && (T - T4 == 1 || T - T4 == 2);  // (uniform)
     auto run = [&](auto full_tag) {
         const int t_loop = ride ? T4 - U : T4;
+        if constexpr (PIPE) {
+            // cur = the noise of the chunk about to integrate; behind step j of it the NEXT chunk's two Philox calls (counters d, d + 1
+            // of draws of three steps) advance -- rounds 0-2, 3-4, 5-7, 8-9 behind steps 0..3 -- and behind steps 4, 5 their three
+            // Box-Muller pairs each.  The chunk behind the last full one is drawn too (the ride / tail below starts from it; with
+            // neither, one wasted draw).  Draws wholly beyond T: their noise is never integrated, their sums never stored.
+            draw_chunk(0, cur, std::false_type{});
+            const float nscale = -1.3862943611198906f * (sigf * sigf);
+            const uint32_t ag = P.agent_offset + (uint32_t)a;
+            for (int t0 = 0; t0 < t_loop; t0 += U) {
+                uint32_t pa[4] = {ctr0, (uint32_t)((t0 + U) / kStepsPerDraw), tick, ag};
+                uint32_t pb[4] = {ctr0, (uint32_t)((t0 + U) / kStepsPerDraw) + 1u, tick, ag};
+                float na[6], nb[6];
+                eps_sums(t0, full_tag, std::false_type{});
+                step(t0 + 0, cur[0][0], cur[0][1], full_tag);
+                philox_rounds<0, 3>(pa, key0, key1); philox_rounds<0, 3>(pb, key0, key1);
+                step(t0 + 1, cur[1][0], cur[1][1], full_tag);
+                philox_rounds<3, 5>(pa, key0, key1); philox_rounds<3, 5>(pb, key0, key1);
+                step(t0 + 2, cur[2][0], cur[2][1], full_tag);
+                philox_rounds<5, 8>(pa, key0, key1); philox_rounds<5, 8>(pb, key0, key1);
+                step(t0 + 3, cur[3][0], cur[3][1], full_tag);
+                philox_rounds<8, 10>(pa, key0, key1); philox_rounds<8, 10>(pb, key0, key1);
+                step(t0 + 4, cur[4][0], cur[4][1], full_tag);
+                philox_pair<0>(pa, nscale, na[0], na[1]); philox_pair<1>(pa, nscale, na[2], na[3]); philox_pair<2>(pa, nscale, na[4], na[5]);
+                step(t0 + 5, cur[5][0], cur[5][1], full_tag);
+                philox_pair<0>(pb, nscale, nb[0], nb[1]); philox_pair<1>(pb, nscale, nb[2], nb[3]); philox_pair<2>(pb, nscale, nb[4], nb[5]);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    cur[i][0] = (S)na[2 * i]; cur[i][1] = (S)na[2 * i + 1];
+                    cur[3 + i][0] = (S)nb[2 * i]; cur[3 + i][1] = (S)nb[2 * i + 1];
+                }
+                probe.mark(P, mk++);
+            }
+        } else
         for (int t0 = 0; t0 < t_loop; t0 += U) {  // full chunks: straight-line code
             if (PHILOX) draw_chunk(t0, cur, std::false_type{});
             else load_chunk(t0 + U, nxt);  // prefetch: HBM latency hides under this chunk's math
@@ -1115,7 +1171,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(S) =
         }
         if (PHILOX && ride) {
             const int t0 = T4 - U;
-            draw_chunk(t0, cur, std::false_type{});
+            if (!PIPE) draw_chunk(t0, cur, std::false_type{});   // (PIPE: drawn behind the steps of the chunk before)
             {
                 float e[6];
                 philox_normals(ctr0, (uint32_t)(T4 / kStepsPerDraw), tick, P.agent_offset + (uint32_t)a, key0, key1, sigf, e);
@@ -1134,7 +1190,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(S) =
             }
             integrate(T4, std::true_type{}, full_tag);
         } else if (T4 < T) {  // ragged tail
-            if (PHILOX) draw_chunk(T4, cur, std::true_type{});
+            if (PHILOX && (!PIPE || T4 == 0)) draw_chunk(T4, cur, std::true_type{});   // (PIPE: drawn behind the steps of the chunk before)
             eps_sums(T4, full_tag, std::false_type{});
             integrate(T4, std::true_type{}, full_tag);
         }

@@ -15,7 +15,7 @@ from motion_planning_amd.mppi import Engine
 def run(opt, val, a):
     T, A = a.horizon, a.agents
     with Engine(a.samples, T, n_agents=A, storage=a.storage, tick_path=a.tick_path, co_shards=a.co_shards,
-                options={opt: int(val)}) as e:
+                options=dict(a.fixed_options, **{opt: int(val)})) as e:
         u0 = np.tile(np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)]), (A, 1, 1))
         goal = np.tile(np.array([[0.0, -1.0, 0.0]]), (A, 1))
         start = np.zeros((A, 3))
@@ -40,7 +40,7 @@ def run(opt, val, a):
             e.tick_async(seed=0, tick_id=2000001 + j)
         e.synchronize()
         dt = e.kernel_times()
-    return {"option": opt, "value": int(val), "K": a.samples, "T": T, "A": A, "tick_us": 1e6 * el / a.ticks,
+    return {"option": opt, "value": int(val), "fixed": a.fixed_options, "storage": a.storage, "K": a.samples, "T": T, "A": A, "tick_us": 1e6 * el / a.ticks,
             "bracketed_us": {k: 1e3 * v[0] / max(v[1], 1) for k, v in dt.items() if v[1]},
             "u_applied": [float(x) for x in np.asarray(ua).ravel()[:4]], "state": [float(x) for x in np.asarray(nxt).ravel()[:6]]}
 
@@ -57,7 +57,9 @@ if __name__ == "__main__":
     ap.add_argument("--co-shards", type=int, default=1)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--ticks", type=int, default=400)
+    ap.add_argument("--fixed", default="", help="name=value,...: options every run gets next to the one under test")
     a = ap.parse_args()
+    a.fixed_options = dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in a.fixed.split(",") if kv)
     for r in range(a.rounds):
         for v in a.values.split(","):
             print(json.dumps(dict(run(a.option, int(v), a), round=r, co_shards=a.co_shards)), flush=True)
