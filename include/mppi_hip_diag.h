@@ -36,12 +36,13 @@ extern "C" {
  *   "k_pieces"        0 (default: the engine's rule, below) | 1..16: a lane-per-sample tick that does not store its noise runs its
  *                     samples in that many pieces, rollout + update per piece, every piece's cost prefix in the SAME region of the
  *                     buffer -- sized so that what the rollout writes is still in the 256 MB Infinity Cache when the update reads it
- *                     (fp64 storage at config 4: 400 MB per tick as one piece, 133 MB as three).  AUTO: pieces of <= 144 MB for fp64
- *                     storage.  The tick's V then exists piece by piece only: mppi_download_value / mppi_update re-run the rollout
+ *                     (fp64 storage at config 4: 400 MB per tick as one piece, 133 MB as three).  AUTO: one piece -- measured, the
+ *                     update's read rate recovers (100 MB pieces: 4.3 TB/s against 4.0) but every piece pays its rollout's ramp again:
+ *                     config 4 in fp64 220 us as one piece, 218 as two, 234 as three (profiles/r5_ab_k_pieces.jsonl).  The tick's V then exists piece by piece only: mppi_download_value / mppi_update re-run the rollout
  *                     from the tick's input snapshot (as after a small-K tick).  1: never
- *   "table_hoist"     1 (default) | 0: the nominal trajectory's per-step table of a tick whose inputs are the previous tick's own
- *                     outputs is computed by that tick's finalize kernel instead of by every rollout workgroup's prologue
- *   "low_occ"         -1 (default: by launch size) | 0 | 1: the rollout variant for launches of fewer than ~4 waves per SIMD
+ *   "table_hoist"     -1 (default: by size) | 0 | 1: the nominal trajectory's per-step table of a tick whose inputs are the previous
+ *                     tick's own outputs is computed by that tick's finalize kernel instead of by every rollout workgroup's prologue
+ *                     (AUTO: handles of >= 786 432 sample-agents at T <= 64, where the prologue costs a launch 4-5 us)
  * and one that selects another noise STREAM (same generator, same counters, other use of its bits):
  *   "noise_packing"   0 (default): one Philox4x32-10 call serves three steps (2 x 21-bit uniforms per step: Box-Muller radius
  *                     <= 5.53 sigma, 2^21 directions); 1: four steps (word j of call t / 4 serves step t: its low 16 bits the radius

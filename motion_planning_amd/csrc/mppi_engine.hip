@@ -5,7 +5,10 @@
 // `latest_uvec` lives on the device between ticks exactly like the Python attribute does.
 #include <hip/hip_runtime.h>
 
+#include <errno.h>
+#include <signal.h>
 #include <time.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
@@ -127,10 +130,19 @@ struct mppi_engine {
     mppi::PkRow* pkb[2] = {nullptr, nullptr};   // [A][T] the deviation-form rows (rollout_pk.hpp) of the same tables
     int tab = 0;
     bool table_valid = false;   // set tab ^ 1 holds the table of (d_state, d_goal, d_unom) as they are now
-    bool hoist = true;          // option "table_hoist"
+    int hoist_opt = -1;         // option "table_hoist": -1 by size (hoist_on), 0, 1
+    // Where the table pays (same box, tick us without / with it, profiles/r5_ab_table_hoist.jsonl): the prologue it takes out of every
+    // rollout workgroup is worth 4-5 us of a launch that runs several rounds of workgroups (config 4 co-scheduled 136.7 -> 133.4,
+    // config 5 149.2 -> 146.7; config 4 on one engine 146.4 -> 146.0) and under 1 us of an under-filled one (the other workgroups'
+    // waves fill the SIMD while one wave runs the prologue), while the finalize kernel's one wave per agent takes 1.9 us for it at
+    // T = 50 and 5.7 at T = 100: 125 000 samples 39.7 -> 40.4, 250 000 54.6 -> 55.7, 500 000 84.4 -> 85.0, config 3 57.9 -> 62.2.
+    // AUTO: handles of >= 786 432 sample-agents with T <= 64 (a co-scheduled group decides for its shards).
+    bool hoist_on() const {
+        if (hoist_opt >= 0) return hoist_opt != 0;
+        return cfg.horizon <= 64 && (long)cfg.n_agents * cfg.samples >= 786432;
+    }
     int fin_threads_opt = 0;    // option "fin_threads"
     int k_pieces_opt = 0;       // option "k_pieces"
-    int low_occ_opt = -1;       // option "low_occ"
     int graph_tab = 0;
     bool table_taken = false;   // this tick's rollout launches already switched to the set they load
     void use_table_set(int t) { tab = t; d_tc = tcb[t]; d_base = baseb[t]; }
@@ -280,7 +292,7 @@ struct mppi_engine {
         for (auto* e : subs) delete e;
         subs.clear();
         if (p2p_internal) { p2p_release(); p2p_internal = false; }
-        co_agents = false; co_dirty = false;
+        co_agents = false; co_dirty = false; co_value_dirty = false;
     }
     bool p2p_internal = false;  // the mailboxes belong to the co-scheduled group, not to a caller's cross-GPU exchange
     std::string co_fallback = "";   // why this handle runs unsplit although co-scheduling was possible (mppi_co_note)
@@ -316,17 +328,20 @@ struct mppi_engine {
     // first pulls the sub's results into this engine's arrays (co_pull), and the next split tick pushes what changed (co_push_agents).
     bool co_agents = false;    // the group splits the agents, not the samples
     int co_a0 = 0;             // agents of this engine while a split tick is enqueued
-    bool co_dirty = false;     // the sub holds newer nominal controls / state / V of its agents than this engine's arrays
+    bool co_dirty = false;     // the sub holds newer nominal / filtered controls, state and outputs of its agents than this engine's arrays (a few KB: pulled by whatever is called next)
+    bool co_value_dirty = false;   // ... and a newer V (cost prefix, totals, table, eps sums: ~100 MB at config 5): pulled only by what reads V (co_pull_value)
     double* out_view_ext = nullptr;   // (a sub of an agent split) where its finalize drops the outputs: the handle's pinned rows
     uint32_t* seq_view_ext = nullptr;
     uint32_t seq_ext = 0;
     struct AgentView {   // this engine's view of its own agents while a split tick is enqueued
         mppi_engine* e; int A;
-        explicit AgentView(mppi_engine* e_) : e(e_), A(e_->cfg.n_agents) { e->cfg.n_agents = e->co_a0; e->P.A = e->co_a0; }
-        ~AgentView() { e->cfg.n_agents = A; e->P.A = A; }
+        explicit AgentView(mppi_engine* e_) : e(e_), A(e_->cfg.n_agents) { e->cfg.n_agents = e->co_a0; e->P.A = e->co_a0; e->in_agent_view = true; }
+        ~AgentView() { e->cfg.n_agents = A; e->P.A = A; e->in_agent_view = false; }
     };
+    bool in_agent_view = false;
     void co_push_agents();
     void co_pull();
+    void co_pull_value();
     void co_tick_agents(const double* state, const double* goal, uint64_t seed, uint32_t tick);
     bool co_pending = false;   // co_shards AUTO decided to split: the shards are built with the first fused device-noise tick
     int co_plan(bool& wanted, bool* by_agents = nullptr) const;
@@ -472,12 +487,10 @@ struct mppi_engine {
         a.model = cfg.model;
         // the table the previous tick's finalize kernel left for exactly these inputs: load it (no prologue); that set becomes the
         // current one (d_tc / d_base: what mppi_download_value adds to the stored offsets)
-        const bool load_table = hoist && table_valid && inline_nominal() && !ro_state && !ro_goal && !ro_unom && !capturing;
+        const bool load_table = hoist_on() && table_valid && inline_nominal() && !ro_state && !ro_goal && !ro_unom && !capturing;
         if (load_table && !table_taken) { use_table_set(tab ^ 1); table_taken = true; }
         a.inline_nominal = !inline_nominal() || load_table ? 0 : (cfg.horizon <= 64 ? 1 : 2);
         a.general = general_cost();
-        // under-filled launches (fewer than ~4 waves of this kernel per SIMD: blocks <= 1024) take the software-pipelined variant
-        a.pipe = low_occ_opt >= 0 ? low_occ_opt != 0 : (long)cfg.n_agents * ((k1 - k0 + 255) / 256) <= 1024;
         a.seed = seed; a.tick = tick; a.tick_ptr = tick_ptr;
         a.state = ro_state ? ro_state : d_state; a.goal = ro_goal ? ro_goal : d_goal;
         a.unom = ro_unom ? ro_unom : d_unom; a.tc = d_tc; a.base = d_base;
@@ -632,11 +645,25 @@ struct mppi_engine {
         hipLaunchKernelGGL(mppi::merge_kernel, dim3(cfg.horizon, cfg.n_agents), dim3(nch > 128 ? 256 : 64), 0, stream, P, d_part, nch, d_merged);
         HIPCHK(hipGetLastError());
     }
-    void check_noise_mode(int noise_mode) {
+    // Everything a tick / rollout can refuse for, checked BEFORE any state of the handle changes (inputs staged, lazy-noise bookkeeping,
+    // a co-scheduled group half way through its launches): a refused call leaves the handle exactly as it was.
+    // tick_path: the call is a tick (its device noise is not stored unless option store_eps says so); else mppi_rollout
+    void check_noise_mode(int noise_mode, bool tick_path = true) {
         if (noise_mode == MPPI_NOISE_INJECTED && !injected_ready)
             fail(MPPI_E_STATE, "MPPI_NOISE_INJECTED but no noise is resident (mppi_upload_noise, or a rollout that stored its noise)");
         if (noise_mode != MPPI_NOISE_INJECTED && noise_mode != MPPI_NOISE_PHILOX)
             fail(MPPI_E_INVALID, "unknown noise_mode %d", noise_mode);
+        if (noise_mode == MPPI_NOISE_PHILOX && noise_pack && small_nb == 0) {
+            // (mppi_rollout draws with the mixed kernel and re-draws the noise into d_eps: it never asks that kernel to store)
+            const bool store = tick_path && store_eps_always;
+            const int forced = force_pk;
+            force_pk = -1;
+            const bool ok = pick_pk(true, store, 0, cfg.samples);
+            force_pk = forced;
+            if (!ok)
+                fail(MPPI_E_INVALID, "noise_packing 1 / 2 is drawn by the mixed-precision rollout only: all samples of an fp32-storage engine, noise not stored "
+                                     "(option store_eps 0), the node's cost (Q = diag(q, q, 0), no obstacle grid), rk4 / diff drive, T <= 256 with sigma small enough for its series");
+        }
     }
     bool general_cost() const {
         // the lean rollout instantiations are written for the node's cost: Q = diag(q, q, 0), q > 0 (and sane: they scale
@@ -667,6 +694,7 @@ struct mppi_engine {
     static constexpr int kDirectTuples = 16;
     void run_pipeline(int noise_mode, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr, bool skip_small_merge = false) {
         check_noise_mode(noise_mode);
+        if (!in_agent_view) co_value_dirty = false;   // (V of EVERY agent is about to be this engine's own: nothing of a sub's is wanted any more)
         const bool ph = noise_mode == MPPI_NOISE_PHILOX;
         const bool store = !ph || store_eps_always;
         eps_lazy = ph && !store;
@@ -711,15 +739,11 @@ struct mppi_engine {
         if (!merge_skipped) launch_merge(NCH);
         noise_ready = true; value_ready = true; value_lazy = false; partials_ready = true; epart_ready = true;
     }
-    // How many pieces a lane-per-sample tick runs its samples in (option "k_pieces"; include/mppi_hip_diag.h).  AUTO: fp64 storage whose
-    // cost prefix does not fit the Infinity Cache next to everything else -- pieces of at most 144 MB.
+    // How many pieces a lane-per-sample tick runs its samples in (option "k_pieces"; include/mppi_hip_diag.h)
     int tick_pieces(bool ph, bool store) const {
         if (!ph || store || small_nb > 0 || NCH < 2 || noise_pack) return 1;
         int n = k_pieces_opt;
-        if (n == 0) {
-            const size_t bytes = (size_t)cfg.n_agents * cfg.horizon * P.Ks * esz();
-            n = f64() && bytes > ((size_t)208 << 20) ? (int)((bytes + ((size_t)144 << 20) - 1) / ((size_t)144 << 20)) : 1;
-        }
+        if (n == 0) n = 1;   // AUTO: one piece (measured: see include/mppi_hip_diag.h "k_pieces")
         return std::max(1, std::min(n, NCH));
     }
     // T <= 256: the nominal rollout runs inside every rollout block (lanes = timesteps)
@@ -732,7 +756,8 @@ struct mppi_engine {
         HIPCHK(hipGetLastError());
     }
     void run_rollout(int noise_mode, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
-        check_noise_mode(noise_mode);
+        check_noise_mode(noise_mode, /*tick_path=*/false);
+        co_value_dirty = false;   // (V of every agent is about to be this engine's own)
         const bool ph = noise_mode == MPPI_NOISE_PHILOX;
         // (the 16-bit packing is drawn by the mixed-precision kernel, which does not store its noise: the re-draw kernel leaves the same bits in d_eps)
         launch_rollout(stream, 0, cfg.samples, ph, !(ph && noise_pack), seed, tick, tick_ptr);
@@ -775,10 +800,14 @@ struct mppi_engine {
         }
         // 16 lanes per row for the tuple merge, one wave per filter coefficient (16 of them): T = 50 -> 1024 threads; at least 256
         int fin_threads = std::min(1024, std::max(256, ((2 * T * std::max(1, 1024 / (2 * T)) + 63) / 64) * 64));
+        // co-scheduled engines (shards, or the two halves of an agent split): a 1024-thread workgroup needs four free waves on EVERY SIMD
+        // of a CU at once and waits for the other engine's rollout waves to drain; 512 threads start in the gaps (config 5 on its two
+        // engines 134.5 -> 129.5 us per tick; one engine alone prefers 1024: 145.8 against 147.1, profiles/r5_ab_fin_threads.jsonl)
         if (fin_threads_opt) fin_threads = fin_threads_opt;
+        else if ((co_active() || is_co_sub) && fin_threads > 512) fin_threads = 512;
         // the next tick's nominal table on the way out (lane-per-sample ticks that run the plant step and the shift; a graph replay
         // keeps its prologue: its launches are frozen)
-        if ((flags & 3) == 3 && !(flags & 4) && hoist && inline_nominal() && small_nb == 0 && !capturing) flags |= 32;
+        if ((flags & 3) == 3 && !(flags & 4) && hoist_on() && inline_nominal() && small_nb == 0 && !capturing) flags |= 32;
         uint32_t tick_set = 0;
         if ((flags & 1) && !(flags & 4) && last_tick_eager) { flags |= 16; tick_set = last_tick_id + 1u; }
         // eager ticks also drop their outputs into the pinned host buffer (a graph replay cannot: its sequence number
@@ -821,6 +850,7 @@ struct mppi_engine {
     // anything that changes what a re-draw or re-run would produce must materialise them first, so that
     // mppi_download_noise / _value keep returning what the last rollout really used.
     void settle_lazy_state() {
+        if (co_value_dirty) co_pull_value();   // (an agent split: what is about to change must not change the meaning of the sub's V)
         if (value_lazy && have_state && have_goal) materialise_value();
         materialise_eps();
     }
@@ -1092,13 +1122,13 @@ void mppi_engine::co_build() {
             e->sync_timeout_ms = sync_timeout_ms;
             e->store_eps_always = store_eps_always; e->use_pk = use_pk; e->upd_skip_light = upd_skip_light; e->pk_waves = pk_waves;
             e->pk_min_set = pk_min_set; e->pk_min_samples = pk_min_samples; e->noise_pack = noise_pack;
-            e->fin_threads_opt = fin_threads_opt; e->k_pieces_opt = k_pieces_opt; e->hoist = hoist; e->low_occ_opt = low_occ_opt;
+            e->fin_threads_opt = fin_threads_opt; e->k_pieces_opt = k_pieces_opt; e->hoist_opt = hoist_on() ? 1 : 0;
             for (int i = 0; i < 7; ++i) e->w_off[i] = w_off[i];
             e->refresh_weights();
             e->out_view_ext = d_out_view + (size_t)co_a0 * 8;
             e->seq_view_ext = d_seq_view + co_a0;
             if (!ev_co) HIPCHK(hipEventCreateWithFlags(&ev_co, hipEventDisableTiming));
-            co_agents = true; co_synced = false; co_dirty = false;
+            co_agents = true; co_synced = false; co_dirty = false; co_value_dirty = false;
         } catch (const EngineError& er) {
             co_release();
             co_fallback = "co_shards AUTO (agents) fell back to one engine: " + er.msg;
@@ -1133,7 +1163,7 @@ void mppi_engine::co_build() {
             e->sync_timeout_ms = sync_timeout_ms;
             e->store_eps_always = store_eps_always; e->use_pk = use_pk; e->upd_skip_light = upd_skip_light; e->pk_waves = pk_waves;
             e->pk_min_set = pk_min_set; e->pk_min_samples = pk_min_samples; e->noise_pack = noise_pack;
-            e->fin_threads_opt = fin_threads_opt; e->k_pieces_opt = k_pieces_opt; e->hoist = hoist; e->low_occ_opt = low_occ_opt;
+            e->fin_threads_opt = fin_threads_opt; e->k_pieces_opt = k_pieces_opt; e->hoist_opt = hoist_on() ? 1 : 0;
             for (int i = 0; i < 7; ++i) e->w_off[i] = w_off[i];
             e->refresh_weights();
         }
@@ -1176,17 +1206,20 @@ void mppi_engine::co_push_agents() {
     co_synced = true;
 }
 
-// the sub's results of the last split tick(s) -> this engine's arrays: nominal and filtered controls, state, outputs, and the
-// tick's V (cost prefix, totals, nominal cost-to-go, per-step table, per-wave eps sums).  The noise is not copied: it is a
-// function of (seed, tick, GLOBAL agent, sample, t) and re-drawn here on demand.
+// The sub's results of the last split tick(s) -> this engine's arrays, in two parts (the V set of config 5 is ~100 MB
+// device-to-device; a caller that reads its nominal controls between ticks must not pay for it):
+//   co_pull        nominal and filtered controls, state, outputs -- a few KB, by every call but the split tick itself and the read-only
+//                  queries.  The sub still holds the same values afterwards: co_synced stays as it is (the calls that CHANGE this
+//                  engine's controls / state clear it themselves, and the next split tick hands those over).
+//   co_pull_value  the tick's V (cost prefix, totals, nominal cost-to-go, per-step table, per-wave eps sums) -- only by what reads V:
+//                  mppi_download_value, mppi_update, and whatever settles the lazy state before a parameter change.
+// The noise is never copied: it is a function of (seed, tick, GLOBAL agent, sample, t) and re-drawn here on demand.
 void mppi_engine::co_pull() {
     if (!co_dirty) return;
     co_dirty = false;
     invalidate_table();   // (the sub's agents' controls / poses arrive in this engine's arrays: its own table knows nothing of them)
-    co_synced = false;   // whoever called may change this engine's arrays: the next split tick hands them over again
     mppi_engine* e = subs[0];
-    const size_t A1 = e->cfg.n_agents, T_ = cfg.horizon, a0 = (size_t)co_a0, Ks = (size_t)P.Ks, NW = Ks >> 6;
-    const size_t es = f64() ? sizeof(double) : sizeof(float);
+    const size_t A1 = e->cfg.n_agents, T_ = cfg.horizon, a0 = (size_t)co_a0;
     HIPCHK(hipEventRecord(ev_co, e->stream));
     HIPCHK(hipStreamWaitEvent(stream, ev_co, 0));
     auto pull = [&](void* dst, const void* src, size_t per_agent_bytes) {
@@ -1196,15 +1229,29 @@ void mppi_engine::co_pull() {
     pull(d_ufilt, e->d_ufilt, 2 * T_ * sizeof(double));
     pull(d_state, e->d_state, 3 * sizeof(double));
     pull(d_out, e->d_out, 8 * sizeof(double));
+    // (the sub's stream must not run ahead of these copies: its next launches come after co_push_agents' event)
+    out_via_host = false;   // d_out is whole; the pinned rows are too, but a later non-split finalize rewrites only d_out's sequence
+    wait_stream("co-scheduled agents: results pulled");
+}
+void mppi_engine::co_pull_value() {
+    co_pull();
+    if (!co_value_dirty) return;
+    co_value_dirty = false;
+    mppi_engine* e = subs[0];
+    const size_t A1 = e->cfg.n_agents, T_ = cfg.horizon, a0 = (size_t)co_a0, Ks = (size_t)P.Ks, NW = Ks >> 6;
+    const size_t es = f64() ? sizeof(double) : sizeof(float);
+    HIPCHK(hipEventRecord(ev_co, e->stream));
+    HIPCHK(hipStreamWaitEvent(stream, ev_co, 0));
+    auto pull = [&](void* dst, const void* src, size_t per_agent_bytes) {
+        HIPCHK(hipMemcpyAsync(static_cast<char*>(dst) + a0 * per_agent_bytes, src, A1 * per_agent_bytes, hipMemcpyDeviceToDevice, stream));
+    };
     pull(d_dP, e->d_dP, T_ * Ks * es);
     pull(d_stot, e->d_stot, Ks * es);
     pull(d_base, e->d_base, T_ * sizeof(double));
     pull(d_tc, e->d_tc, T_ * mppi::kTcW * sizeof(double));
     pull(d_epart, e->d_epart, T_ * 2 * NW * es);
     if (!eps_lazy && injected_ready) pull(d_eps, e->d_eps, T_ * 2 * Ks * es);   // (option store_eps: the tick's noise is resident, not re-drawn on demand)
-    // (the sub's stream must not run ahead of these copies: its next launches come after co_push_agents' event)
-    out_via_host = false;   // d_out is whole; the pinned rows are too, but a later non-split finalize rewrites only d_out's sequence
-    wait_stream("co-scheduled agents: results pulled");
+    wait_stream("co-scheduled agents: V pulled");
 }
 
 // the fused device-noise tick of a handle whose agents are split over two engines
@@ -1223,7 +1270,7 @@ void mppi_engine::co_tick_agents(const double* state, const double* goal, uint64
     e->run_nominal();
     e->run_pipeline(MPPI_NOISE_PHILOX, seed, tick, nullptr, /*skip_small_merge=*/true);
     e->run_finalize(nullptr, 1, 1 | 2);
-    co_dirty = true;
+    co_dirty = true; co_value_dirty = true;
     co_last = false;
 }
 
@@ -1541,7 +1588,7 @@ int mppi_download_noise(mppi_engine* h, double* eps) {
 int mppi_rollout(mppi_engine* h, const double* state, const double* goal, int noise_mode, uint64_t seed, uint32_t tick_id) {
     API_BEGIN(h)
     h->co_synced = false;   // (the co-scheduled shards no longer hold this engine's nominal controls / state)
-    h->check_noise_mode(noise_mode);   // refuse before the inputs are staged: nothing half-set on failure
+    h->check_noise_mode(noise_mode, /*tick_path=*/false);   // refuse before the inputs are staged: nothing half-set on failure
     h->set_inputs(state, goal);
     h->run_nominal();
     h->run_rollout(noise_mode, seed, tick_id, nullptr);
@@ -1551,6 +1598,7 @@ int mppi_rollout(mppi_engine* h, const double* state, const double* goal, int no
 int mppi_download_value(mppi_engine* h, double* V) {
     API_BEGIN(h)
     if (!V) fail(MPPI_E_INVALID, "V is NULL");
+    h->co_pull_value();
     h->materialise_value();
     if (!h->value_ready) fail(MPPI_E_STATE, "no value function resident");
     const int A = h->cfg.n_agents, T = h->cfg.horizon, K = h->cfg.samples;
@@ -1568,6 +1616,7 @@ int mppi_download_value(mppi_engine* h, double* V) {
 int mppi_upload_value(mppi_engine* h, const double* V) {
     API_BEGIN(h)
     if (!V) fail(MPPI_E_INVALID, "V is NULL");
+    h->co_value_dirty = false;   // (every agent's V is replaced: nothing of the sub's is wanted any more)
     const int A = h->cfg.n_agents, T = h->cfg.horizon, K = h->cfg.samples;
     const size_t n = (size_t)A * T * K;
     h->ensure_tmp(n);
@@ -1586,6 +1635,7 @@ int mppi_upload_value(mppi_engine* h, const double* V) {
 
 int mppi_update(mppi_engine* h, double* uvec_out) {
     API_BEGIN(h)
+    h->co_pull_value();
     h->co_synced = false;   // (the co-scheduled shards no longer hold this engine's nominal controls / state)
     h->run_update();
     h->run_finalize(nullptr, 1, 0);
@@ -1723,13 +1773,17 @@ int mppi_p2p_rendezvous(mppi_engine* h, const char* prefix, int n_ranks, int ran
     if (!h) return MPPI_E_INVALID;
     if (!prefix || !*prefix) { h->err = "p2p rendezvous: empty path prefix"; return MPPI_E_INVALID; }
     unsigned char mine[MPPI_IPC_HANDLE_BYTES];
+    // this rank's file of an EARLIER run goes first: a fast peer must not find it while this rank is still creating its mailbox
+    if (rank >= 0) (void)std::remove((std::string(prefix) + "." + std::to_string(rank)).c_str());
     if (int rc = mppi_p2p_create(h, n_ranks, rank, mine)) return rc;
     API_BEGIN(h)
     const std::string base(prefix);
     auto name = [&](int r) { return base + "." + std::to_string(r); };
-    // file = {magic, n_ranks, rank, bytes of one mailbox} + the handle: a reader refuses a file that is not this group's
-    struct Head { char magic[8]; int32_t n_ranks, rank; uint64_t mbox_bytes; };
-    auto head_of = [&](int r) { Head hd{}; std::memcpy(hd.magic, "MPPIMBX1", 8); hd.n_ranks = n_ranks; hd.rank = r; hd.mbox_bytes = h->p2p_bytes; return hd; };
+    // file = {magic, n_ranks, rank, bytes of one mailbox, writer's pid} + the handle.  A reader refuses a file of another SHAPE (not
+    // this group's) and keeps waiting over a file whose writer is no longer alive (a stale file of an earlier run of the same
+    // shape -- the normal relaunch case: its handle would name a dead process's memory)
+    struct Head { char magic[8]; int32_t n_ranks, rank; uint64_t mbox_bytes; int64_t pid; };
+    auto head_of = [&](int r) { Head hd{}; std::memcpy(hd.magic, "MPPIMBX2", 8); hd.n_ranks = n_ranks; hd.rank = r; hd.mbox_bytes = h->p2p_bytes; hd.pid = (int64_t)getpid(); return hd; };
     {
         const std::string tmp = name(rank) + ".tmp";
         FILE* f = std::fopen(tmp.c_str(), "wb");
@@ -1749,8 +1803,10 @@ int mppi_p2p_rendezvous(mppi_engine* h, const char* prefix, int n_ranks, int ran
                 Head hd{};
                 const size_t got = std::fread(&hd, 1, sizeof(hd), f) + std::fread(all.data() + (size_t)r * MPPI_IPC_HANDLE_BYTES, 1, MPPI_IPC_HANDLE_BYTES, f);
                 std::fclose(f);
-                if (got == sizeof(hd) + MPPI_IPC_HANDLE_BYTES) {
-                    const Head want = head_of(r);
+                const bool writer_alive = hd.pid > 0 && (kill((pid_t)hd.pid, 0) == 0 || errno == EPERM);
+                if (got == sizeof(hd) + MPPI_IPC_HANDLE_BYTES && writer_alive) {
+                    Head want = head_of(r);
+                    want.pid = hd.pid;
                     if (std::memcmp(&hd, &want, sizeof(hd)) != 0)
                         fail(MPPI_E_INVALID, "p2p rendezvous: %s belongs to another group (ranks %d / rank %d / mailbox %llu bytes; this group: %d / %d / %llu): "
                              "a stale file of an earlier run, or engines of different shapes", name(r).c_str(), hd.n_ranks, hd.rank,
@@ -1901,17 +1957,34 @@ static int co_build_now(mppi_engine* h) {
 // the fused tick of a handle that carries co-scheduled shards (device noise; injected noise lives in this engine's own buffer)
 static int tick_co(mppi_engine* h, const double* state, const double* goal, uint64_t seed, uint32_t tick_id) {
     API_BEGIN_FAST(h)
+    h->check_noise_mode(MPPI_NOISE_PHILOX);   // a plain configuration refusal must not cost the handle its group (the catch below dissolves it)
     try {
         h->co_tick(state, goal, seed, tick_id);
     } catch (...) {
         // a throw between the shards' publishes / finalizes leaves their mailbox epochs and nominal controls out of step:
         // dissolve the group -- the one engine serves every later call (bounded waits: a dead device cannot hang this)
+        bool lost = false;
         try {
             try { h->wait_stream("co-scheduled tick unwinding"); } catch (...) {}
+            // an agent split: the sub may hold the only current controls / poses of its agents -- fetch them before it goes
+            if (h->co_agents && h->co_dirty) {
+                try { h->subs[0]->wait_stream("co-scheduled tick unwinding"); h->co_pull(); }
+                catch (...) {
+                    // they are gone: those agents start over from zero controls, and the caller must pass their poses again
+                    lost = true;
+                    const size_t T_ = h->cfg.horizon, a0 = (size_t)h->co_a0, A1 = (size_t)h->cfg.n_agents - a0;
+                    (void)hipMemsetAsync(h->d_unom + a0 * 2 * T_, 0, A1 * 2 * T_ * sizeof(double), h->stream);
+                    h->have_state = false;
+                }
+            }
+            h->out_via_host = false;   // (a deleted sub will never raise its agents' sequence words)
             h->co_release();
         } catch (...) {}
         h->co_synced = false; h->co_last = false;
-        h->co_fallback = "a co-scheduled tick failed: the group was dissolved";
+        h->invalidate_table();
+        h->co_fallback = lost ? "a co-scheduled tick failed and the second engine's results could not be fetched: the group was dissolved, the agents it "
+                                "carried were reset (zero nominal controls; pass every agent's state with the next call)"
+                              : "a co-scheduled tick failed: the group was dissolved";
         throw;
     }
     API_END(h)
@@ -1942,6 +2015,7 @@ int mppi_tick_graph(mppi_engine* h, uint64_t seed) {
     h->co_synced = false;   // (the co-scheduled shards no longer hold this engine's nominal controls / state)
     if (!h->have_state || !h->have_goal) fail(MPPI_E_STATE, "tick_graph needs a resident state and goal (run one mppi_tick first)");
     if (h->stream == nullptr) fail(MPPI_E_STATE, "graph capture is not possible on the null stream");
+    h->check_noise_mode(MPPI_NOISE_PHILOX);
     if (h->graph_exec && h->graph_seed != seed) h->destroy_graph();
     if (!h->graph_exec) {
         const uint32_t saved = h->time_mask;
@@ -1983,7 +2057,7 @@ int mppi_set_option(mppi_engine* h, const char* key, int64_t value) {
     if (!key) fail(MPPI_E_INVALID, "option key is NULL");
     const std::string k(key);
     for (auto* sub__ : h->subs)
-        if (k != "co_cut_pct") if (int rc__ = mppi_set_option(sub__, key, value)) fail(rc__, "co-scheduled shard: %s", sub__->err.c_str());
+        if (k != "co_cut_pct" && k != "table_hoist") if (int rc__ = mppi_set_option(sub__, key, value)) fail(rc__, "co-scheduled shard: %s", sub__->err.c_str());
     if (k == "store_eps") { h->settle_lazy_state(); h->store_eps_always = value != 0; h->destroy_graph(); }
     else if (k == "rollout_pk") { h->settle_lazy_state(); h->use_pk = value != 0; h->destroy_graph(); }
     else if (k == "upd_skip") h->upd_skip_light = value != 0;
@@ -2001,10 +2075,10 @@ int mppi_set_option(mppi_engine* h, const char* key, int64_t value) {
         if (value < 0 || value > 16) fail(MPPI_E_INVALID, "k_pieces: 0 (the engine's rule) or 1..16");
         h->settle_lazy_state(); h->k_pieces_opt = (int)value; h->destroy_graph();
     }
-    else if (k == "table_hoist") { h->hoist = value != 0; h->invalidate_table(); }
-    else if (k == "low_occ") {
-        if (value < -1 || value > 1) fail(MPPI_E_INVALID, "low_occ: -1 (by launch size), 0 or 1");
-        h->low_occ_opt = (int)value; h->destroy_graph();
+    else if (k == "table_hoist") {
+        if (value < -1 || value > 1) fail(MPPI_E_INVALID, "table_hoist: -1 (by size), 0 or 1");
+        if (!h->is_co_sub) { h->hoist_opt = (int)value; for (auto* e : h->subs) e->hoist_opt = h->hoist_on() ? 1 : 0; }
+        h->invalidate_table();
     }
     else if (k == "pk_waves") { if (value != 4 && value != 5) fail(MPPI_E_INVALID, "pk_waves: 4 or 5"); h->pk_waves = (int)value; }
     else if (k == "pk_min_samples") { h->settle_lazy_state(); h->pk_min_set = value >= 0; h->pk_min_samples = value >= 0 ? (long)value : 400000; h->destroy_graph(); }
@@ -2025,7 +2099,7 @@ int mppi_set_option(mppi_engine* h, const char* key, int64_t value) {
                 e->store_eps_always = h->store_eps_always; e->use_pk = h->use_pk; e->upd_skip_light = h->upd_skip_light; e->pk_waves = h->pk_waves;
                 e->pk_min_set = h->pk_min_set; e->pk_min_samples = h->pk_min_samples; e->sync_timeout_ms = h->sync_timeout_ms;
                 e->noise_pack = h->noise_pack;
-                e->fin_threads_opt = h->fin_threads_opt; e->k_pieces_opt = h->k_pieces_opt; e->hoist = h->hoist; e->low_occ_opt = h->low_occ_opt;
+                e->fin_threads_opt = h->fin_threads_opt; e->k_pieces_opt = h->k_pieces_opt; e->hoist_opt = h->hoist_on() ? 1 : 0;
             }
         }
     }
@@ -2044,8 +2118,7 @@ int mppi_get_option(mppi_engine* h, const char* key, int64_t* value) {
     else if (k == "pk_waves") *value = h->pk_waves;
     else if (k == "fin_threads") *value = h->fin_threads_opt;
     else if (k == "k_pieces") *value = h->k_pieces_opt;
-    else if (k == "table_hoist") *value = h->hoist;
-    else if (k == "low_occ") *value = h->low_occ_opt;
+    else if (k == "table_hoist") *value = h->hoist_opt;
     else if (k == "pk_min_samples") *value = h->pk_min_set ? h->pk_min_samples : -1;
     else if (k == "co_cut_pct") *value = h->co_cut_pct;
     else fail(MPPI_E_INVALID, "unknown option '%s'", key);

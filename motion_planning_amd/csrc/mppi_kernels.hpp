@@ -669,8 +669,7 @@ __device__ __forceinline__ void nominal_table_lanes(const DevParams& P, int a, d
 // HIPRAND_RNG_PSEUDO_PHILOX4_32_10 -- inlined so that (seed, tick, agent, global sample, t)
 // addresses the stream identically on any shard layout and on the CPU twin (oracle/).
 // ---------------------------------------------------------------------------------------------
-// rounds [R0, R1) of the ten, in place (k0, k1 = the call's key: the round keys are k + r * Weyl); philox4x32_10 is rounds [0, 10) --
-// the pipelined rollout (rollout_kernel PIPE) advances a call a few rounds at a time between the steps of the previous chunk
+// rounds [R0, R1) of the ten, in place (k0, k1 = the call's key: the round keys are k + r * Weyl); philox4x32_10 is rounds [0, 10)
 template <int R0, int R1>
 __device__ __forceinline__ void philox_rounds(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
 #pragma unroll
@@ -771,14 +770,6 @@ __device__ __forceinline__ void philox_normals(uint32_t gk, uint32_t draw, uint3
     }
 }
 
-// pair j (0..2) of a default-packing call's words o: what philox_normals<0> puts into e[2j], e[2j+1]
-template <int J>
-__device__ __forceinline__ void philox_pair(const uint32_t (&o)[4], float nscale, float& e0, float& e1) {
-    if (J == 0) box_muller(o[0] >> 11, (o[1] >> 9) & 0x7FFFFCu, nscale, e0, e1);
-    else if (J == 1) box_muller(o[2] >> 11, (o[3] >> 9) & 0x7FFFFCu, nscale, e0, e1);
-    else box_muller(((o[0] & 0x7FFu) << 10) | ((o[1] & 0x7FFu) >> 1), ((o[2] & 0x7FFu) << 12) | ((o[3] & 0x7FEu) << 1), nscale, e0, e1);
-}
-
 // the same stream addressed by (sample, t): only step t's pair of its draw's three (four)
 template <int PACK = 0>
 __device__ __forceinline__ void philox_normal_pair(uint32_t gk, uint32_t t, uint32_t tick, uint32_t a, uint32_t key0,
@@ -816,14 +807,9 @@ __device__ __forceinline__ void philox_normal_pair(uint32_t gk, uint32_t t, uint
 // grid = (ceil(K / 256), A), block = 256, LDS = the 40*T-byte per-step table.  Per lane and step: 2 eps + 1 dP element
 // through HBM, fully coalesced (consecutive lanes = consecutive k).
 // ---------------------------------------------------------------------------------------------
-//   PIPE   (PHILOX, noise not stored, the node's cost and model only) the variant for launches that leave a SIMD fewer than ~4 waves:
-//          nothing then hides a wave's own dependent chains -- Philox -> Box-Muller -> [reduce-scatter] -> six steps of fp64 dynamics,
-//          one behind the other in the default variant's schedule -- so the chunk is software-pipelined: while chunk c integrates, the
-//          two Philox calls of chunk c + 1 advance a few rounds behind every step and its Box-Muller pairs follow (the compiler's
-//          scheduler interleaves what the source interleaves); at most 4 waves per SIMD (128 registers: both chunks' noise live)
-template <typename S, int NTERM, bool PHILOX, bool STORE_EPS, int INLINE_NOM, int MODEL, bool GENERAL, bool PIPE = false>
+template <typename S, int NTERM, bool PHILOX, bool STORE_EPS, int INLINE_NOM, int MODEL, bool GENERAL>
 // (fp64 storage: 4 waves per SIMD -- at 5 the kernel spilled 22 registers around its 8-byte stores; 140.8 -> 136.1 us together with the row-buffer stores)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE ? 2 : (sizeof(S) == 8 ? 4 : 5), PIPE ? 4 : 8))) void rollout_kernel(DevParams P, const double* __restrict__ state,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(S) == 8 ? 4 : 5, 8))) void rollout_kernel(DevParams P, const double* __restrict__ state,
                                                      const double* __restrict__ goal,
                                                      double* __restrict__ tc, S* __restrict__ eps,
                                                      S* __restrict__ dP, S* __restrict__ Stot, uint64_t seed,
@@ -1125,39 +1111,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE ? 2 : 
     const bool ride = PHILOX && T4 >= U && (T - T4 == 1 || T - T4 == 2);  // (uniform)
     auto run = [&](auto full_tag) {
         const int t_loop = ride ? T4 - U : T4;
-        if constexpr (PIPE) {
-            // cur = the noise of the chunk about to integrate; behind step j of it the NEXT chunk's two Philox calls (counters d, d + 1
-            // of draws of three steps) advance -- rounds 0-2, 3-4, 5-7, 8-9 behind steps 0..3 -- and behind steps 4, 5 their three
-            // Box-Muller pairs each.  The chunk behind the last full one is drawn too (the ride / tail below starts from it; with
-            // neither, one wasted draw).  Draws wholly beyond T: their noise is never integrated, their sums never stored.
-            draw_chunk(0, cur, std::false_type{});
-            const float nscale = -1.3862943611198906f * (sigf * sigf);
-            const uint32_t ag = P.agent_offset + (uint32_t)a;
-            for (int t0 = 0; t0 < t_loop; t0 += U) {
-                uint32_t pa[4] = {ctr0, (uint32_t)((t0 + U) / kStepsPerDraw), tick, ag};
-                uint32_t pb[4] = {ctr0, (uint32_t)((t0 + U) / kStepsPerDraw) + 1u, tick, ag};
-                float na[6], nb[6];
-                eps_sums(t0, full_tag, std::false_type{});
-                step(t0 + 0, cur[0][0], cur[0][1], full_tag);
-                philox_rounds<0, 3>(pa, key0, key1); philox_rounds<0, 3>(pb, key0, key1);
-                step(t0 + 1, cur[1][0], cur[1][1], full_tag);
-                philox_rounds<3, 5>(pa, key0, key1); philox_rounds<3, 5>(pb, key0, key1);
-                step(t0 + 2, cur[2][0], cur[2][1], full_tag);
-                philox_rounds<5, 8>(pa, key0, key1); philox_rounds<5, 8>(pb, key0, key1);
-                step(t0 + 3, cur[3][0], cur[3][1], full_tag);
-                philox_rounds<8, 10>(pa, key0, key1); philox_rounds<8, 10>(pb, key0, key1);
-                step(t0 + 4, cur[4][0], cur[4][1], full_tag);
-                philox_pair<0>(pa, nscale, na[0], na[1]); philox_pair<1>(pa, nscale, na[2], na[3]); philox_pair<2>(pa, nscale, na[4], na[5]);
-                step(t0 + 5, cur[5][0], cur[5][1], full_tag);
-                philox_pair<0>(pb, nscale, nb[0], nb[1]); philox_pair<1>(pb, nscale, nb[2], nb[3]); philox_pair<2>(pb, nscale, nb[4], nb[5]);
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    cur[i][0] = (S)na[2 * i]; cur[i][1] = (S)na[2 * i + 1];
-                    cur[3 + i][0] = (S)nb[2 * i]; cur[3 + i][1] = (S)nb[2 * i + 1];
-                }
-                probe.mark(P, mk++);
-            }
-        } else
         for (int t0 = 0; t0 < t_loop; t0 += U) {  // full chunks: straight-line code
             if (PHILOX) draw_chunk(t0, cur, std::false_type{});
             else load_chunk(t0 + U, nxt);  // prefetch: HBM latency hides under this chunk's math
@@ -1171,7 +1124,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE ? 2 : 
         }
         if (PHILOX && ride) {
             const int t0 = T4 - U;
-            if (!PIPE) draw_chunk(t0, cur, std::false_type{});   // (PIPE: drawn behind the steps of the chunk before)
+            draw_chunk(t0, cur, std::false_type{});
             {
                 float e[6];
                 philox_normals(ctr0, (uint32_t)(T4 / kStepsPerDraw), tick, P.agent_offset + (uint32_t)a, key0, key1, sigf, e);
@@ -1190,7 +1143,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE ? 2 : 
             }
             integrate(T4, std::true_type{}, full_tag);
         } else if (T4 < T) {  // ragged tail
-            if (PHILOX && (!PIPE || T4 == 0)) draw_chunk(T4, cur, std::true_type{});   // (PIPE: drawn behind the steps of the chunk before)
+            if (PHILOX) draw_chunk(T4, cur, std::true_type{});
             eps_sums(T4, full_tag, std::false_type{});
             integrate(T4, std::true_type{}, full_tag);
         }

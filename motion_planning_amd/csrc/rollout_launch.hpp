@@ -19,7 +19,6 @@ struct RolloutArgs {
     int inline_nominal;      // 0: table from nominal_kernel, 1: one wave (T <= 64), 2: four waves (T <= 256)
     int model;               // MPPI_MODEL_*
     bool general;            // Q[2,2] != 0 or an obstacle grid is set
-    bool pipe;               // the software-pipelined variant for under-filled launches (device noise, not stored, node's cost / model, series rotation)
     uint64_t seed;
     uint32_t tick;
     const uint32_t* tick_ptr;
@@ -38,9 +37,9 @@ hipError_t launch_rollout_typed(const RolloutArgs& a);
 
 #ifdef MPPI_ROLLOUT_TU
 // ---- body, compiled only inside the rollout_*.hip translation units ---------------------------------
-template <typename S, int NT, bool PH, bool SE, int IN, int MODEL, bool GEN, bool PIPE = false>
+template <typename S, int NT, bool PH, bool SE, int IN, int MODEL, bool GEN>
 static hipError_t rollout_go(const RolloutArgs& a) {
-    auto kern = rollout_kernel<S, NT, PH, SE, IN, MODEL, GEN, PIPE>;
+    auto kern = rollout_kernel<S, NT, PH, SE, IN, MODEL, GEN>;
     dim3 grid((a.k1 - a.k0 + 255) / 256, a.P.A);
     const unsigned lds = (unsigned)((size_t)a.P.T * 5 * sizeof(double));
     if (a.ev_start)
@@ -56,8 +55,6 @@ static hipError_t rollout_go(const RolloutArgs& a) {
 template <typename S, int NT, bool PH, bool SE, int IN, int MODEL>
 static hipError_t rollout_gen(const RolloutArgs& a) {
     // the node's cost (Q[2,2] = 0, no obstacle grid) runs the branch-free instantiation
-    if constexpr (PH && !SE && MODEL == 0 && NT != 0)
-        if (a.pipe && !a.general) return rollout_go<S, NT, PH, SE, IN, MODEL, false, true>(a);
     return a.general ? rollout_go<S, NT, PH, SE, IN, MODEL, true>(a) : rollout_go<S, NT, PH, SE, IN, MODEL, false>(a);
 }
 template <typename S, int NT, bool PH, bool SE>

@@ -363,8 +363,14 @@ def test_live_weights_through_the_class(golden, storage):
     np.random.seed(3)
     Vd2, _ = m2.get_cost2go(state, u0.copy(), goal, LAM, sig)
     assert np.array_equal(Vd, Vd2)
+    # off-diagonal terms are live too (the reference multiplies the whole matrices, :181-184; test_full_weight_matrices_golden
+    # pins them to the reference): the cost changes, and a matrix of the wrong shape is still refused by name
     m.Q = np.array([[1e3, 5.0, 0.0], [5.0, 1e3, 0.0], [0.0, 0.0, 0.0]])
-    with pytest.raises(ValueError, match="off-diagonal"):
+    np.random.seed(3)
+    Vo, _ = m.get_cost2go(state, u0.copy(), goal, LAM, sig)
+    assert np.abs(Vo - Vd).max() > 1e-3
+    m.Q = np.ones((2, 3))
+    with pytest.raises(ValueError, match="3 x 3"):
         m.get_path(state, goal)
 
 
