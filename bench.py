@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.
 CLOCK_PEAK_HZ = 2.4e9  # max shader clock, same guide
 N_SIMD = 1024          # 256 CUs x 4 SIMDs
 BYTES_PER_STEP_PER_KERNEL = 12  # eps 2 x fp32 + V 1 x fp32, written once (rollout) / read once (update): SURVEY 8(d)
-PROFILE_ROUND = "r4"
+PROFILE_ROUND = "r5"
 HBM_ACHIEVABLE_GBS = 6300.0  # what a streaming read reaches on this part (MI355X_MICROARCH.md, HBM section)
 
 WORKLOADS = {
@@ -122,6 +122,64 @@ def cpu_baseline(T, goal, budget_s=14.0):
             "sample": "oracle get_path ticks (fp64, injected noise, OpenMP over K), K=%d T=%d, same goal/nominal as the "
                       "GPU workload; noise generation excluded" % (K_cpu, T),
             "baseline_md_inputs": md}
+
+
+def compact_line(line, full_path):
+    """The printed line: the contract's keys; `roofline` and `cpu_baseline` flattened to scalars -- every figure a reader needs to redo the
+    arithmetic is a top-level member of its object:
+      roofline.frac                  = VALU issue cycles of the dominant kernel's launch / (avg_launch_us x clock_mhz_under_load)   [the roof it is ON]
+      roofline.frac_at_peak_clock    = the same at the 2.4 GHz peak clock
+      roofline.hbm_rollout_frac      = hbm_rollout_bytes (PMC counters, = `traffic`) / avg_launch_us / 8 TB/s
+      roofline.hbm_update_frac       = hbm_update_bytes / hbm_update_us / 8 TB/s   (hbm_update_frac_of_achievable: against 6.3 TB/s)
+      roofline.accounting_8d_frac    = SURVEY 8(d): 12 B x state-steps of the launch / avg_launch_us / 8 TB/s (an accounting figure: eps is never stored)
+      roofline.tick_accounting_8d_frac = 24 B x state-steps of the tick / tick time / 8 TB/s (can exceed 1 for the same reason)
+      roofline.tick_floor_us, tick_frac = max(rollout issue time, update bytes / 6.3 TB/s) + measured merge + finalize; over the tick
+    plus the one-engine and all-fp64 legs as scalars.  The full nested record is in `full_record`."""
+    roof, cpu = line.get("roofline") or {}, line.get("cpu_baseline")
+    hbm = roof.get("hbm") or {}
+    hr, hu = hbm.get("rollout") or {}, hbm.get("update") or {}
+    acc, valu = roof.get("accounting_8d") or {}, roof.get("valu") or {}
+    tl = (roof.get("tick_level") or {})
+    one, f64 = line.get("one_engine") or {}, line.get("f64_storage") or {}
+    r = {"kernel": roof.get("kernel"), "bound": roof.get("bound"), "achieved": roof.get("achieved"), "peak": roof.get("peak"), "unit": roof.get("unit"),
+         "frac": roof.get("frac"), "traffic": roof.get("traffic"), "frac_at_peak_clock": roof.get("frac_at_peak_clock"),
+         "avg_launch_us": roof.get("avg_launch_us"), "launches_timed": roof.get("launches_timed"), "samples_per_launch": roof.get("samples_per_launch"),
+         "clock_mhz_under_load": roof.get("clock_mhz_under_load"), "min_launch_us": roof.get("min_launch_us"),
+         "valu_per_step": valu.get("valu_per_step"), "issue_cycles_per_step": valu.get("issue_cycles_per_step"),
+         "hbm_peak_gbs": HBM_PEAK_GBS, "hbm_achievable_gbs": HBM_ACHIEVABLE_GBS,
+         "hbm_rollout_bytes": hr.get("counter_bytes"), "hbm_rollout_gbs": hr.get("achieved"), "hbm_rollout_frac": hr.get("frac"),
+         "hbm_update_bytes": hu.get("counter_bytes"), "hbm_update_us": hu.get("avg_launch_us"), "hbm_update_gbs": hu.get("achieved"),
+         "hbm_update_frac": hu.get("frac"), "hbm_update_frac_of_achievable": hu.get("frac_of_achievable"),
+         "accounting_8d_bytes": acc.get("algorithmic_bytes_per_launch"), "accounting_8d_gbs": acc.get("achieved"), "accounting_8d_frac": acc.get("frac"),
+         "tick_accounting_8d_bytes": (tl.get("accounting_8d") or {}).get("algorithmic_bytes"), "tick_accounting_8d_frac": (tl.get("accounting_8d") or {}).get("frac"),
+         "tick_valu_frac": tl.get("valu_frac"), "tick_floor_us": roof.get("tick_floor_us"), "tick_frac": roof.get("tick_frac"),
+         "measured_in": "one_engine leg (co_shards = 1) of this command" if roof.get("measured_in") else "the timed region of this command",
+         "one_engine_ms": one.get("ms_per_step"), "one_engine_rollout_us": one.get("rollout_us"),
+         "f64_ms": f64.get("ms_per_step"), "f64_rollout_us": f64.get("rollout_us"), "f64_update_us": f64.get("update_us")}
+    co = roof.get("co_scheduled_launch") or {}
+    if co:
+        r.update({"co_launch_samples": co.get("samples_per_launch"), "co_launch_us": co.get("avg_launch_us"), "co_launches": co.get("concurrent_launches")})
+    c = None
+    if cpu:
+        c = {k: cpu.get(k) for k in ("value", "unit", "cores", "kind", "usable_cores")}
+        c["sample"] = (cpu.get("sample") or "")[:200]
+        for thr, v in (cpu.get("by_threads") or {}).items():
+            c["threads_%s_value" % thr] = v
+    cfg = {k: line["config"].get(k) for k in ("workload", "agents", "samples_total", "horizon", "samples_per_gpu", "state_steps_per_tick", "storage", "noise",
+                                              "parallelism", "graph", "tick_kernels", "co_shards", "co_samples")}
+    sync, tick = line.get("sync_tick_us") or {}, line.get("tick_us") or {}
+    out = {k: line.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                                    "dtype", "data")}
+    out.update({"config": cfg, "roofline": r, "cpu_baseline": c,
+                "tick_us_median": tick.get("median"), "tick_us_p99": tick.get("p99"),
+                # the node's own call: fresh state in, blocking, controls out (mppi_tick) -- what Controller.pos_cb pays per odometry message
+                "sync_tick_us_median": sync.get("median"), "sync_tick_us_p99": sync.get("p99"),
+                "kernels_us": {k: (round(v, 2) if v else v) for k, v in (line.get("kernels_us") or {}).items()},
+                "exchange_us": line.get("exchange_us"), "value_parked_at_goal": line.get("value_parked_at_goal"),
+                "one_engine_ms": one.get("ms_per_step"), "f64_ms": f64.get("ms_per_step"),
+                "final_state": line.get("final_state"), "final_u": line.get("final_u"),
+                "dtype_detail": (line.get("dtype_detail") or "")[:160], "full_record": full_path})
+    return out
 
 
 class HipEvents(object):
@@ -217,6 +275,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the tick as one hipGraph (N=1 only)")
     ap.add_argument("--no-co-line", action="store_true", help="(kept for old command lines; the co-scheduled tick is the headline handle's own now)")
     ap.add_argument("--co-shards", type=int, default=None, help="mppi_config.co_shards of the measured engine (default: the engine's own rule)")
+    ap.add_argument("--full-out", default="", help="where the full nested record goes (default: gpurun_out/ on a gpurun box, else profiles/)")
     ap.add_argument("--all-ranks-on-gpu0", action="store_true",
                     help="TEST ONLY: every rank drives cuda:0 and the process group is gloo (RCCL refuses two ranks on one "
                          "device) -- runs the N > 1 code path of this script on a one-GPU box; use with --exchange p2p")
@@ -598,11 +657,11 @@ def main():
 
     if rank == 0:
         lanes = info.get("tick_kernels", "lanes") == "lanes"
-        mixes = load_profile(PROFILE_ROUND + "_valu_mix.json") or load_profile("r3_valu_mix.json") or {}
+        mixes = load_profile(PROFILE_ROUND + "_valu_mix.json") or load_profile("r4_valu_mix.json") or {}
 
         pmc_name = PROFILE_ROUND + "_pmc_summary_bench_c4.json"
         pm = load_profile(pmc_name)
-        for older in ("r3", "r1"):
+        for older in ("r4", "r3", "r1"):
             if pm is None:
                 pmc_name = older + "_pmc_summary_bench_c4.json"
                 pm = load_profile(pmc_name)
@@ -788,7 +847,22 @@ def main():
         # the other regime of the closed loop at the top level too: the robot parked at its goal
         if "parked_at_goal" in extra:
             line["value_parked_at_goal"] = extra["parked_at_goal"]["value"]
-        print(json.dumps(line))
+        # The full record goes to a side file; the line that is PRINTED is the contract's keys plus FLAT `roofline` / `cpu_baseline`
+        # objects (scalars only: a record that keeps top-level scalars loses nothing) and stays under 4 KB.
+        full_path = args.full_out
+        if not full_path:
+            base = os.environ.get("GRAFT_REPO_ROOT") or ROOT
+            out_dir = os.path.join(base, "gpurun_out") if os.environ.get("GRAFT_REPO_ROOT") else os.path.join(base, "profiles")
+            full_path = os.path.join(out_dir, "bench_full_%s%s.json" % (args.workload, "" if args.storage == "f32" else "_" + args.storage))
+        try:
+            os.makedirs(os.path.dirname(full_path), exist_ok=True)
+            json.dump(line, open(full_path, "w"))
+        except OSError:
+            full_path = None
+        out = compact_line(line, full_path)
+        text = json.dumps(out)
+        assert len(text) <= 4096, len(text)
+        print(text)
     if in_group:
         dist.destroy_process_group()
 

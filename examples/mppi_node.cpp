@@ -13,9 +13,15 @@
 //   --handles G   ONE process drives G engines (device g where the node has that many, device 0 otherwise), samples split
 //                 G ways, mailboxes connected by pointer (mppi_p2p_connect local_ptrs; peer access across devices is enabled
 //                 by the library): mppi_tick_begin on all -> mppi_p2p_publish on all -> mppi_tick_finish_p2p on all;
-//   --procs G     G processes (forked before anything touches the GPU), one engine each, the IPC handles exchanged through
-//                 files in a fresh temporary directory (mppi_p2p_rendezvous); every rank runs the same node shell on the same
-//                 plant, rank 0 prints.
+//   --procs G     G processes (forked before anything touches the GPU), one engine each (device rank where the node has that many
+//                 GPUs), the IPC handles exchanged through files in a fresh temporary directory (mppi_p2p_rendezvous); every rank
+//                 runs the same node shell on the same plant, rank 0 prints.
+//   --exchange auto|p2p|rccl   (with --procs) how the [A][T][8] tuples cross ranks: p2p = the engine's own mailboxes; rccl = ONE
+//                 ncclAllGather per tick between mppi_tick_begin and mppi_tick_finish (include/mppi_hip.h: the caller's own
+//                 exchange; librccl linked directly, the unique id passed through a file of the same directory); auto = p2p when
+//                 EVERY rank's rendezvous and mailbox self-test pass, else rccl -- the ranks agree through status files, and rank
+//                 0 says on stderr which exchange runs and why ("exchange: ...").  --force-p2p-fail makes this rank report a failed
+//                 p2p set-up (tests of the fallback).  --procs 1 --exchange rccl runs the whole sharded call sequence in a world of one.
 // Either way the twists equal the one-handle node's to the split-invariance bound of the tuple merge (sample ids are global).
 //
 // Output: one line per odometry callback,
@@ -34,6 +40,12 @@
 #include <sys/mman.h>
 #include <sys/wait.h>
 #include <unistd.h>
+
+#include <chrono>
+#include <thread>
+
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
 
 #include "mppi_hip.h"
 
@@ -87,9 +99,11 @@ class Controller {
 public:
     // handles > 1: this process drives that many engines, the samples split between them.  n_ranks > 1: this process is rank
     // `rank` of a group of processes, one engine each, IPC handles exchanged through files under `rendezvous`.
+    // exchange: 0 auto, 1 p2p, 2 rccl (ranks that are processes only)
     Controller(const mppi_config& cfg, std::vector<std::pair<double, double>> waypoints, double thresh, uint64_t seed, int handles = 1,
-               int n_ranks = 1, int rank = 0, const std::string& rendezvous = "")
-        : cfg_(cfg), waypoints_(std::move(waypoints)), thresh_(thresh), seed_(seed) {
+               int n_ranks = 1, int rank = 0, const std::string& rendezvous = "", int exchange = 0, bool force_p2p_fail = false)
+        : cfg_(cfg), waypoints_(std::move(waypoints)), thresh_(thresh), seed_(seed), n_ranks_(n_ranks), rank_(rank) {
+        const bool world_of_one = n_ranks == 1 && handles == 1 && exchange == 2;   // the sharded call sequence with one rank
         const int G = n_ranks > 1 ? n_ranks : handles;
         const int first = n_ranks > 1 ? rank : 0, count = n_ranks > 1 ? 1 : handles;
         for (int g = first; g < first + count; ++g) {
@@ -99,9 +113,9 @@ public:
             c.sample_offset = cfg_.sample_offset + (uint32_t)(g * base + (g < rem ? g : rem));
             c.co_shards = G > 1 ? 1 : cfg_.co_shards;
             mppi_engine* e = nullptr;
-            if (handles > 1) c.device = cfg_.device + g;                           // one GPU per handle where the node has them ...
+            if (handles > 1 || n_ranks > 1) c.device = cfg_.device + g;            // one GPU per handle / rank where the node has them ...
             int rc = mppi_create(&c, &e);
-            if (rc == MPPI_E_INVALID && handles > 1 && c.device != cfg_.device) {  // ... all on the one device otherwise
+            if (rc == MPPI_E_INVALID && c.device != cfg_.device) {                 // ... all on the one device otherwise
                 c.device = cfg_.device;
                 rc = mppi_create(&c, &e);
             }
@@ -110,10 +124,23 @@ public:
                 std::exit(2);
             }
             engs_.push_back(e);
+            dev_of_engine_ = c.device;
         }
         eng_ = eng_err_ = engs_[0];
-        if (n_ranks > 1) {
-            MPPI_CALL(mppi_p2p_rendezvous(eng_, rendezvous.c_str(), n_ranks, rank, 60000));
+        if (n_ranks > 1 || world_of_one) {
+            // p2p unless told otherwise; every rank must take the SAME exchange: each leaves its verdict in a status file and reads the others'
+            std::string why = exchange == 2 ? "asked for by name" : "";
+            bool p2p_ok = exchange != 2;
+            if (p2p_ok) {
+                int rc = force_p2p_fail ? MPPI_E_INTERNAL : mppi_p2p_rendezvous(eng_, rendezvous.c_str(), n_ranks, rank, 20000);
+                if (rc == 0) rc = mppi_p2p_selftest(eng_, 2);
+                if (rc != 0) { p2p_ok = false; why = force_p2p_fail ? "p2p set-up failure forced (--force-p2p-fail)" : std::string("p2p set-up failed: ") + mppi_last_error(eng_); }
+                if (n_ranks > 1 && !agree(rendezvous, p2p_ok)) { p2p_ok = false; if (why.empty()) why = "another rank's p2p set-up failed"; }
+                if (!p2p_ok && exchange == 1) { std::fprintf(stderr, "exchange: p2p asked for by name, and %s\n", why.c_str()); std::exit(2); }
+                if (!p2p_ok) (void)mppi_p2p_destroy(eng_);
+            }
+            if (!p2p_ok) rccl_init(rendezvous, why);
+            if (rank == 0) std::fprintf(stderr, "exchange: %s%s%s\n", p2p_ok ? "p2p" : "rccl", why.empty() ? "" : " -- ", why.c_str());
         } else if (handles > 1) {
             std::vector<void*> ptrs(handles, nullptr);
             for (int g = 0; g < handles; ++g) {
@@ -127,11 +154,13 @@ public:
             }
             eng_err_ = eng_;
         }
-        sharded_ = G > 1;
+        sharded_ = G > 1 || world_of_one;
         parallel_park_ = waypoints_.empty();  // :305-309
     }
     ~Controller() {
         for (mppi_engine* e : engs_) mppi_synchronize(e);   // nobody unmaps a mailbox a peer's kernel may still be writing to
+        if (comm_) ncclCommDestroy(comm_);
+        if (gathered_) (void)hipFree(gathered_);
         for (mppi_engine* e : engs_) mppi_destroy(e);
     }
 
@@ -149,8 +178,19 @@ public:
                 // K sharded: every engine rolls its samples out and reduces them to one tuple per timestep; ALL publishes are enqueued
                 // before any finalize that waits for them (one thread drives the engines of this process, include/mppi_hip.h)
                 for (mppi_engine* e : engs_) { eng_err_ = e; MPPI_CALL(mppi_tick_begin(e, s, g, MPPI_NOISE_PHILOX, seed_, tick_)); }
-                for (mppi_engine* e : engs_) { eng_err_ = e; MPPI_CALL(mppi_p2p_publish(e)); }
-                for (mppi_engine* e : engs_) { eng_err_ = e; MPPI_CALL(mppi_tick_finish_p2p(e)); }
+                if (comm_) {
+                    // the caller's own exchange (include/mppi_hip.h, mppi_tick_begin ... mppi_tick_finish): ONE all-gather of this rank's
+                    // [A][T][8] tuples on the engine's stream, every rank then merges the same n_ranks blocks
+                    void* part = nullptr; size_t bytes = 0; void* st = nullptr;
+                    MPPI_CALL(mppi_partials_ptr(eng_, &part, &bytes));
+                    MPPI_CALL(mppi_get_stream(eng_, &st));
+                    const ncclResult_t nr = ncclAllGather(part, gathered_, bytes / sizeof(double), ncclDouble, comm_, static_cast<hipStream_t>(st));
+                    if (nr != ncclSuccess) { std::fprintf(stderr, "ncclAllGather: %s\n", ncclGetErrorString(nr)); std::exit(2); }
+                    MPPI_CALL(mppi_tick_finish(eng_, gathered_, n_ranks_));
+                } else {
+                    for (mppi_engine* e : engs_) { eng_err_ = e; MPPI_CALL(mppi_p2p_publish(e)); }
+                    for (mppi_engine* e : engs_) { eng_err_ = e; MPPI_CALL(mppi_tick_finish_p2p(e)); }
+                }
                 eng_err_ = eng_;
                 MPPI_CALL(mppi_get_outputs(eng_, nxt, u_last_));
                 for (size_t i = 1; i < engs_.size(); ++i) {   // every engine finishes every tick identically (the merge is one formula on the same tuples)
@@ -194,6 +234,56 @@ public:
     const mppi_config& cfg() const { return cfg_; }
 
 private:
+    // every rank writes "<prefix>.ok.<rank>" = its verdict and reads the others': true when ALL said yes (a rank that never answers counts as no)
+    bool agree(const std::string& prefix, bool mine) {
+        auto name = [&](int r) { return prefix + ".ok." + std::to_string(r); };
+        if (FILE* f = std::fopen((name(rank_) + ".tmp").c_str(), "w")) { std::fputc(mine ? '1' : '0', f); std::fclose(f); std::rename((name(rank_) + ".tmp").c_str(), name(rank_).c_str()); }
+        bool all = mine;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int r = 0; r < n_ranks_; ++r) {
+            if (r == rank_) continue;
+            for (;;) {
+                if (FILE* f = std::fopen(name(r).c_str(), "r")) { const int c = std::fgetc(f); std::fclose(f); if (c == '0' || c == '1') { all = all && c == '1'; break; } }
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) { all = false; break; }
+                std::this_thread::sleep_for(std::chrono::milliseconds(2));
+            }
+        }
+        return all;
+    }
+    // RCCL communicator of the ranks: rank 0's unique id travels through "<prefix>.ncclid"
+    void rccl_init(const std::string& prefix, const std::string& why) {
+        ncclUniqueId id;
+        const std::string path = prefix + ".ncclid";
+        if (rank_ == 0) {
+            ncclResult_t r = ncclGetUniqueId(&id);
+            if (r != ncclSuccess) { std::fprintf(stderr, "exchange: rccl unavailable (%s); p2p: %s\n", ncclGetErrorString(r), why.c_str()); std::exit(2); }
+            if (n_ranks_ > 1) {
+                FILE* f = std::fopen((path + ".tmp").c_str(), "wb");
+                if (!f || std::fwrite(&id, sizeof(id), 1, f) != 1 || std::fclose(f) != 0 || std::rename((path + ".tmp").c_str(), path.c_str()) != 0) {
+                    std::fprintf(stderr, "exchange: cannot publish the RCCL id at %s\n", path.c_str()); std::exit(2);
+                }
+            }
+        } else {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (;;) {
+                if (FILE* f = std::fopen(path.c_str(), "rb")) { const size_t got = std::fread(&id, sizeof(id), 1, f); std::fclose(f); if (got == 1) break; }
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) { std::fprintf(stderr, "exchange: rank 0's RCCL id did not appear\n"); std::exit(2); }
+                std::this_thread::sleep_for(std::chrono::milliseconds(2));
+            }
+        }
+        // the communicator lives on the device this rank's engine was created on (the engine restores the caller's device after every call)
+        (void)hipSetDevice(dev_of_engine_);
+        ncclResult_t r = ncclCommInitRank(&comm_, n_ranks_, id, rank_);
+        if (r != ncclSuccess) {
+            // (two ranks on ONE GPU is the case a one-GPU test box produces: RCCL refuses it by design)
+            std::fprintf(stderr, "exchange: rccl communicator of %d ranks failed: %s (%s); p2p: %s\n", n_ranks_, ncclGetErrorString(r), ncclGetLastError(nullptr), why.c_str());
+            std::exit(5);
+        }
+        void* part = nullptr; size_t bytes = 0;
+        MPPI_CALL(mppi_partials_ptr(eng_, &part, &bytes));
+        if (hipMalloc(&gathered_, bytes * (size_t)n_ranks_) != hipSuccess) { std::fprintf(stderr, "exchange: hipMalloc of the gather buffer failed\n"); std::exit(2); }
+    }
+
     void initialize() {  // MPPI.initialize, :79-83
         for (mppi_engine* e : engs_) { eng_err_ = e; MPPI_CALL(mppi_reset(e, -1)); }
         eng_err_ = eng_;
@@ -205,6 +295,9 @@ private:
     }
 
     mppi_config cfg_;
+    ncclComm_t comm_ = nullptr;        // non-null: the tuples cross ranks by ncclAllGather (else the engine's p2p mailboxes)
+    void* gathered_ = nullptr;         // [n_ranks][A][T][8] float64 on this rank's device
+    int dev_of_engine_ = 0;
     mppi_engine* eng_ = nullptr;       // engine 0: where the outputs are read
     mppi_engine* eng_err_ = nullptr;   // the engine of the call in flight (error messages)
     std::vector<mppi_engine*> engs_;
@@ -212,6 +305,7 @@ private:
     std::vector<std::pair<double, double>> waypoints_;
     double thresh_;
     uint64_t seed_;
+    int n_ranks_ = 1, rank_ = 0;
     uint32_t tick_ = 0;
     bool parallel_park_ = true, init_ = true, done_ = false;
     size_t idx_ = 0;
@@ -225,7 +319,8 @@ int main(int argc, char** argv) {
     mppi_config cfg;
     mppi_default_config(&cfg);
     std::string task = "park";
-    int callbacks = 40, handles = 1, procs = 1;
+    int callbacks = 40, handles = 1, procs = 1, exchange = 0;
+    bool force_p2p_fail = false;
     double thresh = 0.05;
     uint64_t seed = 0;
     for (int i = 1; i < argc; ++i) {
@@ -244,12 +339,14 @@ int main(int argc, char** argv) {
         else if (const char* v = val("--device")) cfg.device = std::atoi(v);
         else if (const char* v = val("--handles")) handles = std::atoi(v);
         else if (const char* v = val("--procs")) procs = std::atoi(v);
+        else if (const char* v = val("--exchange")) exchange = std::strcmp(v, "p2p") == 0 ? 1 : std::strcmp(v, "rccl") == 0 ? 2 : 0;
+        else if (std::strcmp(argv[i], "--force-p2p-fail") == 0) force_p2p_fail = true;
         else if (const char* v = val("--tick-path"))
             cfg.tick_path = std::strcmp(v, "lanes") == 0 ? MPPI_TICK_LANES : std::strcmp(v, "scan") == 0 ? MPPI_TICK_SCAN : MPPI_TICK_AUTO;
         else {
             std::fprintf(stderr, "usage: mppi_node [--task park|pentagon] [--samples K] [--horizon T] [--callbacks N]\n"
                                  "                 [--thresh m] [--seed s] [--storage f32|f64] [--device d]\n"
-                                 "                 [--tick-path auto|lanes|scan] [--handles G | --procs G]\n");
+                                 "                 [--tick-path auto|lanes|scan] [--handles G | --procs G [--exchange auto|p2p|rccl] [--force-p2p-fail]]\n");
             return 1;
         }
     }
@@ -262,7 +359,8 @@ int main(int argc, char** argv) {
     int rank = 0;
     std::string rendezvous;
     std::vector<pid_t> children;
-    if (procs > 1) {
+    if (exchange == 2 && handles > 1) { std::fprintf(stderr, "--exchange rccl serves ranks that are processes (--procs)\n"); return 1; }
+    if (procs > 1 || exchange == 2) {
         char dir[] = "/tmp/mppi_node_XXXXXX";
         if (!mkdtemp(dir)) { std::perror("mkdtemp"); return 1; }
         rendezvous = std::string(dir) + "/mbox";
@@ -293,7 +391,7 @@ int main(int argc, char** argv) {
     const bool trace = progress != nullptr;
     if (trace) *progress = -1;
     {
-    Controller node(cfg, wp, thresh, seed, handles, procs, rank, rendezvous);
+    Controller node(cfg, wp, thresh, seed, handles, procs, rank, rendezvous, exchange, force_p2p_fail);
     if (trace) *progress = -2;
     Pose plant{0.0, 0.0, 0.0};
     for (int i = 0; i < callbacks; ++i) {
@@ -314,8 +412,9 @@ int main(int argc, char** argv) {
         int st = 0;
         if (waitpid(pid, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) status = 4;
     }
-    if (procs > 1 && rank == 0) {
-        for (int r = 0; r < procs; ++r) std::remove((rendezvous + "." + std::to_string(r)).c_str());
+    if (!rendezvous.empty() && rank == 0) {
+        for (int r = 0; r < procs; ++r) { std::remove((rendezvous + "." + std::to_string(r)).c_str()); std::remove((rendezvous + ".ok." + std::to_string(r)).c_str()); }
+        std::remove((rendezvous + ".ncclid").c_str());
         rmdir(rendezvous.substr(0, rendezvous.rfind('/')).c_str());
     }
     return status;

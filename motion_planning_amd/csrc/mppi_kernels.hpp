@@ -40,6 +40,12 @@
 namespace mppi {
 
 constexpr int kTupleW = 8;  // {min, D, N0, N1, E0, E1, count, pad}
+// cache-policy bits of the rollout kernels' cost-prefix stores (the aux operand of raw_buffer_store on gfx950: 1 = sc0, 2 = nt,
+// 16 = sc1).  A measurement build overrides it (make VARIANT=... EXTRA=-DMPPI_DP_STORE_AUX=...; tools/ab_lib.py).
+#ifndef MPPI_DP_STORE_AUX
+#define MPPI_DP_STORE_AUX 0
+#endif
+constexpr int kDpStoreAux = MPPI_DP_STORE_AUX;
 constexpr int kTcW = 8;     // {un0, un1, w0, w1, cb, 0, 0, 0}
 
 struct DevParams {
@@ -550,6 +556,10 @@ template <int NWAVES>
 __device__ __forceinline__ void nominal_lanes_v(const DevParams& P, double sx, double sy, double sth, double gx, double gy, double gth,
                                                 double un0_in, double un1_in, int t, double (&row)[5], double& base_t, double* sh,
                                                 double* head0 = nullptr, NomExtra* ex = nullptr) {
+    // No contraction the source does not spell out: this function is inlined into kernels of different shapes (every rollout kernel's
+    // prologue, the finalize kernel's table for the next tick) and all of them must produce the SAME table bit for bit -- a handle
+    // whose engines take the table from different places still equals the one engine exactly (tests: agent split, co-scheduled shards)
+#pragma clang fp contract(off)
     const int T = P.T;
     double tot_;
     const bool valid = t < T;
@@ -622,6 +632,7 @@ struct __attribute__((aligned(16))) PkRow {
 };
 static_assert(sizeof(PkRow) == 80, "PkRow is read as five 16-byte LDS words");
 __device__ __forceinline__ PkRow make_pkrow(const DevParams& P, const double (&row)[5], const NomExtra& ex, double gx, double gy) {
+#pragma clang fp contract(off)   // (as nominal_lanes_v: the same row whichever kernel derives it)
     const double hk = 0.5 * P.kth * P.dt, phin = 0.5 * ex.h;
     double sp, cp;
     if (fabs(phin) <= 0.25) small_sincos<7>(phin, sp, cp);
@@ -994,10 +1005,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(S) =
                         const __amdgpu_buffer_rsrc_t row = __builtin_amdgcn_make_buffer_rsrc(
                             dP_a + (size_t)t * Ks, 0, (int)(Ks * sizeof(S)), 0x00020000);
                         if (sizeof(S) == 4) {
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)pre), row, (unsigned)k * 4u, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)pre), row, (unsigned)k * 4u, 0, kDpStoreAux);
                         } else {
                             typedef unsigned u2v __attribute__((ext_vector_type(2)));
-                            __builtin_amdgcn_raw_buffer_store_b64(u2v{(unsigned)__double2loint(pre), (unsigned)__double2hiint(pre)}, row, (unsigned)k * 8u, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b64(u2v{(unsigned)__double2loint(pre), (unsigned)__double2hiint(pre)}, row, (unsigned)k * 8u, 0, kDpStoreAux);
                         }
                     } else {
                         dp[(size_t)t * Ks] = (S)pre;

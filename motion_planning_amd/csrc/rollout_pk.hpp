@@ -257,10 +257,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
             const __amdgpu_buffer_rsrc_t row = __builtin_amdgcn_make_buffer_rsrc(dP_a + (size_t)t * Ks, 0, (int)(Ks * sizeof(float)), 0x00020000);
             const float pa = (float)pre[0] + ncs.x, pb = (float)pre[1] + ncs.y;
             if (FULL) {
-                __builtin_amdgcn_raw_buffer_store_b64(u2{__float_as_uint(pa), __float_as_uint(pb)}, row, (unsigned)kA * 4u, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(u2{__float_as_uint(pa), __float_as_uint(pb)}, row, (unsigned)kA * 4u, 0, kDpStoreAux);
             } else {
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pa), row, actA ? (unsigned)kA * 4u : 0xFFFFFFFFu, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pb), row, actB ? (unsigned)kA * 4u + 4u : 0xFFFFFFFFu, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pa), row, actA ? (unsigned)kA * 4u : 0xFFFFFFFFu, 0, kDpStoreAux);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pb), row, actB ? (unsigned)kA * 4u + 4u : 0xFFFFFFFFu, 0, kDpStoreAux);
             }
         }
         // EXPLORE + CLIP (control/src/mppi:147-152) as deviations from the clipped nominal

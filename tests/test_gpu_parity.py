@@ -1628,3 +1628,46 @@ def test_cpp_node_sharded_without_python(tmp_path, tick_path, mode, G):
     assert np.abs(a[:, 7:11] - b[:, 7:11]).max() < 1e-9, np.abs(a[:, 7:11] - b[:, 7:11]).max()   # wheel speeds and twists
     assert np.array_equal(a[:, 11:], b[:, 11:]) and np.any(a[:, 7:9] != 0.0)
 
+
+@pytest.mark.gpu
+def test_cpp_node_rccl_exchange_and_fallback(tmp_path, tick_path):
+    """north_star names an RCCL collective for the cross-GPU step (one all-gather of the [A][T][8] tuples per tick).  The
+    compiled node links librccl itself: --exchange rccl puts ONE ncclAllGather between mppi_tick_begin and mppi_tick_finish
+    (include/mppi_hip.h: the caller's own exchange).  (a) a world of one rank runs that whole call sequence on this box and publishes
+    the plain node's twists; (b) --procs 2 with the ranks' p2p set-up forced to fail falls back to RCCL BY AGREEMENT of the ranks and
+    says why on stderr -- on a one-GPU box RCCL then refuses two ranks on one device (its design), which the node reports with both
+    reasons; on a node with two GPUs the fallback runs and the twists match; (c) without the forced failure auto picks p2p."""
+    import os
+    import subprocess
+    if tick_path == "scan":
+        pytest.skip("the node names its tick path")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "mppi_node")
+    subprocess.run(["make", "-B", "-C", os.path.join(root, "examples"), "OUT=" + exe], check=True, capture_output=True)
+    K, T, n_cb = 48000, 50, 10
+    common = [exe, "--task", "pentagon", "--samples", str(K), "--horizon", str(T), "--callbacks", str(n_cb), "--thresh", "0.97", "--seed", "9",
+              "--tick-path", "lanes"]
+    env = dict(os.environ, MPPI_SYNC_TIMEOUT_MS="8000", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    rows = lambda r: np.array([[float(x) for x in ln.split()] for ln in r.stdout.strip().splitlines()])
+    one = subprocess.run(common, capture_output=True, text=True, timeout=60, env=env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    a = rows(one)
+    w1 = subprocess.run(common + ["--procs", "1", "--exchange", "rccl"], capture_output=True, text=True, timeout=120, env=env)
+    assert w1.returncode == 0, w1.stderr[-2000:]
+    assert "exchange: rccl -- asked for by name" in w1.stderr
+    b = rows(w1)
+    assert a.shape == b.shape == (n_cb, 14) and np.any(a[:, 7:9] != 0.0)
+    assert np.abs(a[:, 1:7] - b[:, 1:7]).max() < 1e-12 and np.abs(a[:, 7:11] - b[:, 7:11]).max() < 1e-9
+    fb = subprocess.run(common + ["--procs", "2", "--force-p2p-fail"], capture_output=True, text=True, timeout=120, env=env)
+    if fb.returncode == 0:      # two GPUs: the fallback ran
+        assert "exchange: rccl -- p2p set-up failure forced" in fb.stderr
+        c = rows(fb)
+        assert np.abs(a[:, 1:7] - c[:, 1:7]).max() < 1e-12 and np.abs(a[:, 7:11] - c[:, 7:11]).max() < 1e-9
+    else:                       # one GPU: RCCL refuses two ranks on one device -- reported with both reasons, no hang
+        assert fb.returncode in (4, 5), (fb.returncode, fb.stderr[-2000:])
+        assert "rccl communicator of 2 ranks failed" in fb.stderr and "p2p set-up failure forced" in fb.stderr
+    auto = subprocess.run(common + ["--procs", "2"], capture_output=True, text=True, timeout=120, env=env)
+    assert auto.returncode == 0 and "exchange: p2p" in auto.stderr, auto.stderr[-2000:]
+    d = rows(auto)
+    assert np.abs(a[:, 7:11] - d[:, 7:11]).max() < 1e-9
+

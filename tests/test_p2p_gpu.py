@@ -316,11 +316,29 @@ def test_rendezvous_refuses_stale_and_missing_files(tmp_path):
         with pytest.raises(MppiError) as err:
             e.p2p_rendezvous(prefix, 2, 0, timeout_ms=300)
         assert err.value.code == -5                                   # too short to be a complete file: treated as not there yet
-        with open(prefix + ".1", "wb") as f:                         # complete, but of a group of three
-            f.write(b"MPPIMBX1" + (3).to_bytes(4, "little") + (1).to_bytes(4, "little") + (0).to_bytes(8, "little") + b"\0" * 64)
+        import os
+        head = lambda n, r, pid: b"MPPIMBX2" + n.to_bytes(4, "little") + r.to_bytes(4, "little") + (0).to_bytes(8, "little") + pid.to_bytes(8, "little")
+        with open(prefix + ".1", "wb") as f:                         # complete, written by a live process, but of a group of three
+            f.write(head(3, 1, os.getpid()) + b"\0" * 64)
         with pytest.raises(MppiError) as err:
             e.p2p_rendezvous(prefix, 2, 0, timeout_ms=300)
         assert err.value.code == -1 and "another group" in str(err.value)
+        # a file of the right shape whose writer is gone (the leftover of an earlier run of the same job -- the normal relaunch
+        # case): its handle names a dead process's memory.  It is not taken: the rank keeps waiting for a live writer
+        import subprocess, sys
+        dead = subprocess.Popen([sys.executable, "-c", "pass"]); dead.wait()
+        with open(prefix + ".1", "wb") as f:
+            f.write(head(2, 1, dead.pid) + b"\0" * 64)
+        with pytest.raises(MppiError) as err:
+            e.p2p_rendezvous(prefix, 2, 0, timeout_ms=300)
+        assert err.value.code == -5 and "did not appear" in str(err.value)
+        # ... and this rank's own leftover is removed on entry (a fast peer must not read it before the new one is in place)
+        with open(prefix + ".0", "wb") as f:
+            f.write(b"stale")
+        with pytest.raises(MppiError):
+            e.p2p_rendezvous(prefix, 2, 0, timeout_ms=100)
+        assert open(prefix + ".0", "rb").read()[:8] == b"MPPIMBX2"
+        os.remove(prefix + ".1")
         nxt, ua = e.tick([0, 0, 0], [0, -1, 0], noise="philox", seed=1, tick_id=0)   # the handle still ticks (unconnected mailbox: plain tick)
         assert np.isfinite(ua).all()
 
