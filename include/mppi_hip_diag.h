@@ -32,6 +32,11 @@ extern "C" {
  *   "upd_skip"        0: the update forms exp() for every sample (default 1: wave-vectors without a weight above the cut are skipped)
  *   "store_eps"       1: the tick path stores its noise like mppi_rollout does
  *   "co_cut_pct"      share of shard 0 of a two-shard co-scheduled handle in per cent (default 58); re-cuts the group
+ *   "lanes_zero_copy" 1 (default) | 0: a fused lane-per-sample tick with fresh inputs lets its rollout read them from the pinned slot
+ *                     (0: one small fetch launch in front of it, as mppi_rollout / mppi_tick_begin do)
+ *   "upd_nv"          0 (default: by size) | 8 | 16: 16-byte vectors per lane of the update kernel = its chunk length (8: 8192 samples in
+ *                     fp32 storage; 16: twice that -- AUTO takes it where it brings a row to <= 16 chunk tuples, which the finalize kernel
+ *                     merges itself: no merge launch for 131 073 ... 262 144 samples).  Before the co-scheduled shards are built
  *   "fin_threads"     0 (default: the engine's rule) | 256 | 512 | 1024: threads of the finalize kernel's one block per agent
  *   "k_pieces"        0 (default: the engine's rule, below) | 1..16: a lane-per-sample tick that does not store its noise runs its
  *                     samples in that many pieces, rollout + update per piece, every piece's cost prefix in the SAME region of the

@@ -93,6 +93,8 @@ struct mppi_engine {
     // launch geometry
     int roll_bs = 256, roll_blocks = 0, nterm = 4;
     int NCH = 1, CH = 1024;
+    int upd_nv = mppi::kUpdNV;   // the update kernel's vectors per lane (8 | 16: mppi::UpdCfg)
+    int upd_nv_opt = 0;          // option "upd_nv": 0 by size, 8, 16
     // small-K tick: ONE scan_tick_kernel (lanes = timesteps) instead of rollout + update
     int small_nb = 0, small_spw = 1, small_nw = 1;  // blocks (0 = path not used), samples per unit, waves per unit
     double* d_prev = nullptr;                        // pre-tick {unom [A][2][T], state [A][3], goal [A][3]}
@@ -430,10 +432,16 @@ struct mppi_engine {
     // zero_copy: the caller's state / goal are written into a pinned, device-mapped ring slot and the tick's first
     // kernel (scan_tick_kernel) reads them from there over PCIe -- no H2D copy in front of a latency-bound tick
     // (two copies were 14 of the 47 us of a K = 10 tick); that kernel refreshes d_state / d_goal for the later ones.
+    // zero_copy on the LANE kernels (the fused tick only: a finalize kernel follows): the rollout's workgroups read the pose / goal
+    // straight from the pinned slot too (a few hundred to a few thousand 64-byte reads over PCIe, all in flight at once) and workgroup
+    // 0 leaves them in the pre-tick snapshot, where the finalize kernel finds this tick's pose (and refreshes the device-resident
+    // goal) -- no fetch launch in front of a blocking tick (its life + the launch boundary: ~3.5 us of the node's call).
+    bool lanes_fresh_state = false, lanes_fresh_goal = false;   // this tick's pose / goal live in the snapshot (d_prev), not in d_state / d_goal yet
     void set_inputs(const double* state, const double* goal, bool zero_copy = false) {
         const size_t n = (size_t)cfg.n_agents * 3;
         if (state || goal) invalidate_table();   // a fresh pose / goal: not what the last finalize kernel prepared the table for
         in_state = d_state; in_goal = d_goal; in_slot = -1;
+        lanes_fresh_state = lanes_fresh_goal = false;
         if (zero_copy && (state || goal)) {
             release_unclaimed_slot();
             const int slot = ring_pos;
@@ -444,6 +452,7 @@ struct mppi_engine {
             if (state) { std::memcpy(h, state, n * sizeof(double)); in_state = dv; have_state = true; }
             if (goal) { std::memcpy(h + n, goal, n * sizeof(double)); in_goal = dv + n; have_goal = true; }
             in_slot = slot;
+            if (small_nb == 0) { lanes_fresh_state = state != nullptr; lanes_fresh_goal = goal != nullptr; }
         } else if (state || goal) {
             // lane-per-sample tick: the inputs go into a pinned slot as well, and ONE small kernel moves them to d_state /
             // d_goal (two H2D copies cost ~10 us more in front of a blocking tick)
@@ -461,6 +470,12 @@ struct mppi_engine {
             slot_unclaimed = slot;   // free once that kernel has run: tied to this tick's finalize, or to an event
         }
         if (!have_state || !have_goal) fail(MPPI_E_STATE, "state/goal passed as NULL before ever being set");
+    }
+    // the lane kernels take fresh inputs from the pinned slot when the nominal trajectory is computed inside the rollout (no
+    // nominal_kernel reading d_state in front of it) and the launch is not so big that thousands of workgroups would queue on PCIe
+    bool lanes_zero_copy = true;   // option "lanes_zero_copy" (0: the fetch launch in front of the rollout, as every other call takes it)
+    bool lanes_zero_copy_ok() const {
+        return lanes_zero_copy && small_nb == 0 && inline_nominal() && (long)cfg.n_agents * roll_blocks <= 4096 && !capturing;
     }
     void inputs_consumed() {  // the kernel that reads the pinned slot has been enqueued: the slot is free once it has run
         if (in_slot >= 0) { slot_unclaimed = in_slot; in_slot = -1; }
@@ -492,7 +507,7 @@ struct mppi_engine {
         a.inline_nominal = !inline_nominal() || load_table ? 0 : (cfg.horizon <= 64 ? 1 : 2);
         a.general = general_cost();
         a.seed = seed; a.tick = tick; a.tick_ptr = tick_ptr;
-        a.state = ro_state ? ro_state : d_state; a.goal = ro_goal ? ro_goal : d_goal;
+        a.state = ro_state ? ro_state : (in_state ? in_state : d_state); a.goal = ro_goal ? ro_goal : (in_goal ? in_goal : d_goal);
         a.unom = ro_unom ? ro_unom : d_unom; a.tc = d_tc; a.base = d_base;
         a.eps = d_eps; a.dP = static_cast<char*>(d_dP) - (size_t)dp_shift * esz(); a.stot = d_stot; a.epart = d_epart;
         hipError_t e;
@@ -619,6 +634,16 @@ struct mppi_engine {
         HIPCHK(hipGetLastError());
         epart_ready = true;
     }
+    // chunk length of the update kernel: twice the streaming shape's where that is what takes a row to <= kDirectTuples chunk tuples
+    // (no merge launch in the fused tick); d_part is sized for the SHORT chunks, so the choice can change with the option
+    void pick_update_shape() {
+        const int ch8 = f64() ? mppi::UpdCfg<double, 8>::CH : mppi::UpdCfg<float, 8>::CH;
+        const int n8 = (cfg.samples + ch8 - 1) / ch8, n16 = (cfg.samples + 2 * ch8 - 1) / (2 * ch8);
+        upd_nv = upd_nv_opt ? upd_nv_opt : ((n8 > kDirectTuples && n16 <= kDirectTuples) ? 16 : 8);
+        if (noise_pack) upd_nv = 8;   // (the other noise packings' re-draws are built into the streaming shape only)
+        CH = ch8 * (upd_nv / 8);
+        NCH = (cfg.samples + CH - 1) / CH;
+    }
     void launch_update(hipStream_t st, int ch0, int nch, const uint32_t* tick_ptr = nullptr, int dp_shift = 0) {
         ensure_epart(st);
         const char* dP_at = static_cast<const char*>(d_dP) - (size_t)dp_shift * esz();
@@ -632,10 +657,19 @@ struct mppi_engine {
     hipLaunchKernelGGL((mppi::update_kernel<float, true, PK>), grid, dim3(256), 0, st, P, static_cast<const float*>(d_eps), \
                        reinterpret_cast<const float*>(dP_at), static_cast<const float*>(d_stot), d_part, NCH, ch0, nch,           \
                        static_cast<const float*>(d_epart), lazy_seed, lazy_tick, tick_ptr, upd_skip_light)
+#define LAUNCH_UPD16(TYPE, REGEN)                                                                                  \
+    hipLaunchKernelGGL((mppi::update_kernel<TYPE, REGEN, 0, 16>), grid, dim3(256), 0, st, P, static_cast<const TYPE*>(d_eps), \
+                       reinterpret_cast<const TYPE*>(dP_at), static_cast<const TYPE*>(d_stot), d_part, NCH, ch0, nch,    \
+                       static_cast<const TYPE*>(d_epart), lazy_seed, lazy_tick, tick_ptr, upd_skip_light)
+        if (upd_nv == 16) {
+            if (f64()) { if (eps_lazy) LAUNCH_UPD16(double, true); else LAUNCH_UPD16(double, false); }
+            else { if (eps_lazy) LAUNCH_UPD16(float, true); else LAUNCH_UPD16(float, false); }
+        } else
         if (f64()) { if (eps_lazy) LAUNCH_UPD(double, true); else LAUNCH_UPD(double, false); }
         else if (eps_lazy && noise_pack == 1) LAUNCH_UPD_PACK(1);
         else if (eps_lazy && noise_pack == 2) LAUNCH_UPD_PACK(2);
         else { if (eps_lazy) LAUNCH_UPD(float, true); else LAUNCH_UPD(float, false); }
+#undef LAUNCH_UPD16
 #undef LAUNCH_UPD_PACK
 #undef LAUNCH_UPD
         HIPCHK(hipGetLastError());
@@ -730,11 +764,18 @@ struct mppi_engine {
                 }
             } catch (...) { P.snap = snap_was; throw; }
             P.snap = snap_was;
+            if (in_slot >= 0) inputs_consumed();
             if (!merge_skipped) launch_merge(NCH);
             noise_ready = true; value_ready = false; value_lazy = true; partials_ready = true; epart_ready = true;
             return;
         }
-        launch_rollout(stream, 0, cfg.samples, ph, store, seed, tick, tick_ptr);
+        {
+            double* const snap_was = P.snap;
+            if (lanes_fresh_state || lanes_fresh_goal) P.snap = d_prev;   // (workgroup 0 keeps the inputs it read from the pinned slot)
+            try { launch_rollout(stream, 0, cfg.samples, ph, store, seed, tick, tick_ptr); } catch (...) { P.snap = snap_was; throw; }
+            P.snap = snap_was;
+            if (in_slot >= 0) inputs_consumed();
+        }
         launch_update(stream, 0, NCH, tick_ptr);
         if (!merge_skipped) launch_merge(NCH);
         noise_ready = true; value_ready = true; value_lazy = false; partials_ready = true; epart_ready = true;
@@ -822,7 +863,10 @@ struct mppi_engine {
         hipLaunchKernelGGL(mppi::finalize_kernel, dim3(cfg.n_agents), dim3(fin_threads), lds,
                            stream, P, gathered, G, lay, d_S, d_unom, d_ufilt, d_state, d_out, d_tick, flags, tick_set,
                            ext ? out_view_ext : (host_out ? d_out_view : nullptr), ext ? seq_view_ext : d_seq_view, ext ? seq_ext : out_seq, wait,
-                           (const double*)d_goal, tcb[tab ^ 1], baseb[tab ^ 1], pkb[tab ^ 1]);
+                           lanes_fresh_goal ? (const double*)(d_prev + (size_t)cfg.n_agents * 2 * cfg.horizon + (size_t)cfg.n_agents * 3) : (const double*)d_goal,
+                           tcb[tab ^ 1], baseb[tab ^ 1], pkb[tab ^ 1],
+                           lanes_fresh_state ? (const double*)(d_prev + (size_t)cfg.n_agents * 2 * cfg.horizon) : (const double*)nullptr, d_goal);
+        lanes_fresh_state = lanes_fresh_goal = false;
         if (flags & 1) out_via_host = host_out;
         HIPCHK(hipGetLastError());
         partials_ready = false;
@@ -918,8 +962,7 @@ struct mppi_engine {
         nterm = phi_max <= 0.03 ? 4 : (phi_max <= 0.25 ? 7 : 0);
 
         // update geometry: each block keeps one chunk of a row in registers
-        CH = f64() ? mppi::UpdCfg<double>::CH : mppi::UpdCfg<float>::CH;
-        NCH = (K + CH - 1) / CH;
+        pick_update_shape();
         const size_t Ks = (size_t)P.Ks;
         {
             void* p = nullptr;
@@ -963,7 +1006,10 @@ struct mppi_engine {
                 small_nb = small_nw == 1 ? (units + 3) / 4 : units;
             }
         }
-        d_part = dev_alloc<double>((size_t)A * T * std::max(NCH, small_nb) * mppi::kTupleW, hbm_bytes);
+        {
+            const int ch8 = f64() ? mppi::UpdCfg<double, 8>::CH : mppi::UpdCfg<float, 8>::CH;
+            d_part = dev_alloc<double>((size_t)A * T * std::max((K + ch8 - 1) / ch8, small_nb) * mppi::kTupleW, hbm_bytes);
+        }
         d_prev = dev_alloc<double>((size_t)A * (2 * T + 6), hbm_bytes);
         d_merged = dev_alloc<double>((size_t)A * T * mppi::kTupleW, hbm_bytes);
         d_S = dev_alloc<double>((size_t)4 * (T - 1) + 4, hbm_bytes);   // the Savitzky-Golay operator's orthonormal basis [4][T-1] (+ its four values at the even window's half-integer position)
@@ -1123,6 +1169,7 @@ void mppi_engine::co_build() {
             e->store_eps_always = store_eps_always; e->use_pk = use_pk; e->upd_skip_light = upd_skip_light; e->pk_waves = pk_waves;
             e->pk_min_set = pk_min_set; e->pk_min_samples = pk_min_samples; e->noise_pack = noise_pack;
             e->fin_threads_opt = fin_threads_opt; e->k_pieces_opt = k_pieces_opt; e->hoist_opt = hoist_on() ? 1 : 0;
+            if (upd_nv_opt) { e->upd_nv_opt = upd_nv_opt; e->pick_update_shape(); }
             for (int i = 0; i < 7; ++i) e->w_off[i] = w_off[i];
             e->refresh_weights();
             e->out_view_ext = d_out_view + (size_t)co_a0 * 8;
@@ -1164,6 +1211,7 @@ void mppi_engine::co_build() {
             e->store_eps_always = store_eps_always; e->use_pk = use_pk; e->upd_skip_light = upd_skip_light; e->pk_waves = pk_waves;
             e->pk_min_set = pk_min_set; e->pk_min_samples = pk_min_samples; e->noise_pack = noise_pack;
             e->fin_threads_opt = fin_threads_opt; e->k_pieces_opt = k_pieces_opt; e->hoist_opt = hoist_on() ? 1 : 0;
+            if (upd_nv_opt) { e->upd_nv_opt = upd_nv_opt; e->pick_update_shape(); }
             for (int i = 0; i < 7; ++i) e->w_off[i] = w_off[i];
             e->refresh_weights();
         }
@@ -1941,7 +1989,7 @@ static int tick_begin_fused(mppi_engine* h, const double* state, const double* g
     API_BEGIN(h)
     h->co_synced = false;   // (the co-scheduled shards no longer hold this engine's nominal controls / state)
     h->check_noise_mode(noise_mode);   // refuse before the inputs are staged: nothing half-set on failure
-    h->set_inputs(state, goal, /*zero_copy=*/h->small_nb > 0);
+    h->set_inputs(state, goal, /*zero_copy=*/h->small_nb > 0 || h->lanes_zero_copy_ok());
     h->run_nominal();
     h->run_pipeline(noise_mode, seed, tick_id, nullptr, /*skip_small_merge=*/true);
     API_END(h)
@@ -2065,7 +2113,7 @@ int mppi_set_option(mppi_engine* h, const char* key, int64_t value) {
         if (value < 0 || value > 2) fail(MPPI_E_INVALID, "noise_packing: 0 (three steps per Philox call, the default stream), 1 (four) or 2 (hipRAND's normals: two)");
         if (value && (h->f64() || h->small_nb > 0 || !h->inline_nominal()))
             fail(MPPI_E_INVALID, "noise_packing 1 / 2 is drawn by the mixed-precision rollout only: fp32 storage, the lane kernels (tick_path lanes), rk4 / diff drive, T <= 256");
-        h->settle_lazy_state(); h->noise_pack = (int)value; h->destroy_graph();
+        h->settle_lazy_state(); h->wait_stream(__func__); h->noise_pack = (int)value; h->pick_update_shape(); h->partials_ready = false; h->destroy_graph();
     }
     else if (k == "fin_threads") {
         if (value != 0 && value != 256 && value != 512 && value != 1024) fail(MPPI_E_INVALID, "fin_threads: 0 (the engine's rule), 256, 512 or 1024");
@@ -2079,6 +2127,13 @@ int mppi_set_option(mppi_engine* h, const char* key, int64_t value) {
         if (value < -1 || value > 1) fail(MPPI_E_INVALID, "table_hoist: -1 (by size), 0 or 1");
         if (!h->is_co_sub) { h->hoist_opt = (int)value; for (auto* e : h->subs) e->hoist_opt = h->hoist_on() ? 1 : 0; }
         h->invalidate_table();
+    }
+    else if (k == "lanes_zero_copy") h->lanes_zero_copy = value != 0;
+    else if (k == "upd_nv") {
+        if (value != 0 && value != 8 && value != 16) fail(MPPI_E_INVALID, "upd_nv: 0 (by size), 8 or 16");
+        if (h->co_active()) fail(MPPI_E_STATE, "upd_nv: set it before the handle builds its co-scheduled shards (their cuts follow the chunk length)");
+        if (value == 16 && h->noise_pack) fail(MPPI_E_INVALID, "upd_nv 16 is built for the default noise stream");
+        h->settle_lazy_state(); h->wait_stream(__func__); h->upd_nv_opt = (int)value; h->pick_update_shape(); h->partials_ready = false; h->destroy_graph();
     }
     else if (k == "pk_waves") { if (value != 4 && value != 5) fail(MPPI_E_INVALID, "pk_waves: 4 or 5"); h->pk_waves = (int)value; }
     else if (k == "pk_min_samples") { h->settle_lazy_state(); h->pk_min_set = value >= 0; h->pk_min_samples = value >= 0 ? (long)value : 400000; h->destroy_graph(); }
@@ -2116,6 +2171,8 @@ int mppi_get_option(mppi_engine* h, const char* key, int64_t* value) {
     else if (k == "upd_skip") *value = h->upd_skip_light;
     else if (k == "noise_packing") *value = h->noise_pack;
     else if (k == "pk_waves") *value = h->pk_waves;
+    else if (k == "upd_nv") *value = h->upd_nv;
+    else if (k == "lanes_zero_copy") *value = h->lanes_zero_copy;
     else if (k == "fin_threads") *value = h->fin_threads_opt;
     else if (k == "k_pieces") *value = h->k_pieces_opt;
     else if (k == "table_hoist") *value = h->hoist_opt;

@@ -40,10 +40,14 @@
 namespace mppi {
 
 constexpr int kTupleW = 8;  // {min, D, N0, N1, E0, E1, count, pad}
-// cache-policy bits of the rollout kernels' cost-prefix stores (the aux operand of raw_buffer_store on gfx950: 1 = sc0, 2 = nt,
-// 16 = sc1).  A measurement build overrides it (make VARIANT=... EXTRA=-DMPPI_DP_STORE_AUX=...; tools/ab_lib.py).
+// Cache-policy bits of what the rollout kernels store (the aux operand of raw_buffer_store on gfx950: 1 = sc0, 2 = nt, 16 = sc1).
+// sc1 = write through, no line kept in the XCD's L2: a launch that leaves its cost prefix DIRTY in the write-back L2 pays for the
+// write-back when it ends -- 4-5 us of an under-filled launch (25 MB dirty at 125 000 samples: rollout 24.0 -> 19.4 us, tick 39.7 ->
+// 34.9; config 3 57.7 -> 53.9), nothing of a launch whose rows leave the L2 on their own (config 4 144.7 / 145.1, config 5 128.2 /
+// 128.0); `nt` keeps the rollout's gain and slows the update that reads the rows back (profiles/r5_ab_store_policy.jsonl).
+// A measurement build overrides it (make VARIANT=plain EXTRA=-DMPPI_DP_STORE_AUX=0; tools/ab_lib.py).
 #ifndef MPPI_DP_STORE_AUX
-#define MPPI_DP_STORE_AUX 0
+#define MPPI_DP_STORE_AUX 16
 #endif
 constexpr int kDpStoreAux = MPPI_DP_STORE_AUX;
 constexpr int kTcW = 8;     // {un0, un1, w0, w1, cb, 0, 0, 0}
@@ -976,7 +980,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(S) =
                 // num_records is dropped by the hardware, so the chunk stays one basic block and the
                 // scheduler may interleave the noise chains with the fp64 dynamics that follow
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(tot), ep_rsrc,
-                                                      mine ? (unsigned)(at * 4) : 0xFFFFFFFFu, 0, 0);
+                                                      mine ? (unsigned)(at * 4) : 0xFFFFFFFFu, 0, kDpStoreAux);
             } else if (mine) {
                 epart[at] = (S)tot;
             }
@@ -1163,7 +1167,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(S) =
     else run(std::false_type{});
     terminal();
     // value_fcn = reverse cumulative sum over t (control/src/mppi:175) = total - exclusive prefix
-    if (active) Stot[(size_t)a * Ks + k] = (S)pre;
+    if (active) {
+        if (kDpStoreAux & 16) __hip_atomic_store(Stot + (size_t)a * Ks + k, (S)pre, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (an sc1 store, like the rows)
+        else Stot[(size_t)a * Ks + k] = (S)pre;
+    }
     probe.mark(P, mk++);
     probe.stop(P);
 }
@@ -1186,10 +1193,13 @@ __device__ __forceinline__ double uniform_value(double v) {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
-constexpr int kUpdNV = 8;  // 16-byte vectors per lane: chunk = 256 * kUpdNV * (16 / sizeof(S)) samples
-template <typename S> struct UpdCfg { static constexpr int VEC = 16 / (int)sizeof(S); static constexpr int CH = 256 * kUpdNV * VEC; };
+// NV 16-byte vectors per lane: chunk = 256 * NV * (16 / sizeof(S)) samples.  8: the streaming shape (54 / 64 VGPRs, eight workgroups per
+// CU).  16: chunks twice as long for the sizes where that brings a row down to <= 16 chunk tuples -- the finalize kernel then merges
+// them itself and the tick has no merge launch (131 073 ... 262 144 samples in fp32 storage: an N = 4 rank's share of config 4)
+constexpr int kUpdNV = 8;
+template <typename S, int NV = kUpdNV> struct UpdCfg { static constexpr int VEC = 16 / (int)sizeof(S); static constexpr int CH = 256 * NV * VEC; };
 
-template <typename S, bool REGEN, int PACK = 0>
+template <typename S, bool REGEN, int PACK = 0, int NV = kUpdNV>
 // (fp64 storage: 64 VGPRs, eight blocks per CU -- since the eps sums are read behind the loops and the block minimum sits in scalar
 // registers; 70 before, and FORCING 64 then spilled five registers and measured slower on the same box, update 110-117 us against
 // 95-103.  Without spills the eighth block changes nothing: 99-100 us for its 400 MB either way.)
@@ -1199,7 +1209,7 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
                                                     const S* __restrict__ epart, uint64_t seed, uint32_t tick_arg,
                                                     const uint32_t* __restrict__ tick_ptr, int skip_light) {
     using R = S;
-    constexpr int VEC = UpdCfg<S>::VEC, CH = UpdCfg<S>::CH;
+    constexpr int VEC = UpdCfg<S, NV>::VEC, CH = UpdCfg<S, NV>::CH;
     typedef S vec_t __attribute__((ext_vector_type(VEC)));
     // XCD-aware block -> (t, chunk) map.  Workgroups go to the 8 XCDs round-robin by linear id, and
     // each XCD has its own L2: id = xcd + 8 * (t + T * group) puts all T blocks that share chunk
@@ -1230,10 +1240,10 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
     __shared__ R red[4][6];
 
     // pass 1: the chunk into registers, lane minimum
-    S v[kUpdNV][VEC];
+    S v[NV][VEC];
     R m = (R)INFINITY;
 #pragma unroll
-    for (int j = 0; j < kUpdNV; ++j) {
+    for (int j = 0; j < NV; ++j) {
         const int k = k_begin + (j * 256 + tid) * VEC;
         if (k + VEC <= k_end) {  // rows are 256-byte aligned and k % VEC == 0: 16-byte aligned loads
             const vec_t pv = *reinterpret_cast<const vec_t*>(v_row + k);
@@ -1276,7 +1286,7 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
     // block's vectors are dealt to the waves in 1-KB pieces, so the four queues fill evenly.)  A wave whose queue overflows
     // (sigma = 0, a flat cost: every sample carries weight) walks its own values again from L2 and re-draws each candidate
     // in place.
-    constexpr int kQueue = sizeof(S) == 8 ? 1024 : 2048;
+    constexpr int kQueue = (sizeof(S) == 8 ? 1024 : 2048) * (NV / kUpdNV);   // (per sample of the chunk as before)
     constexpr int kQW = kQueue / 4;   // per wave
     __shared__ uint32_t q_k[REGEN ? kQueue : 1];
     __shared__ R q_e[REGEN ? kQueue : 1];
@@ -1290,7 +1300,7 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
         Na1 = fma((double)e, (double)(S)f1, Na1);
     };
 #pragma unroll
-    for (int j = 0; j < kUpdNV; ++j) {
+    for (int j = 0; j < NV; ++j) {
         const int k = k_begin + (j * 256 + tid) * VEC;
         R xs[VEC], es[VEC];
 #pragma unroll
@@ -1334,7 +1344,7 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
             for (int q = lane; q < n_w; q += 64) redraw(q_k[wid * kQW + q], q_e[wid * kQW + q]);
         } else {  // (rare) every candidate of the lane's own values, in place
 #pragma unroll 1
-            for (int idx = 0; idx < kUpdNV * VEC; ++idx) {
+            for (int idx = 0; idx < NV * VEC; ++idx) {
                 const int k = k_begin + ((idx / VEC) * 256 + tid) * VEC + idx % VEC;
                 if (k < k_end) {
                     const R x = (M - (s_row[k] - v_row[k])) * scale;
@@ -1747,7 +1757,12 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
                                                double* outv, uint32_t* tick_ptr, int flags, uint32_t tick_set,
                                                double* host_out, uint32_t* host_seq, uint32_t seq, char* smem_raw,
                                                P2PWait wait, const double* __restrict__ goal = nullptr, double* __restrict__ tc = nullptr,
-                                               double* __restrict__ base = nullptr, PkRow* __restrict__ pk = nullptr) {
+                                               double* __restrict__ base = nullptr, PkRow* __restrict__ pk = nullptr,
+                                               const double* state_src = nullptr, double* goal_keep = nullptr) {
+    // state_src: where this tick's pose is read from when it is not `state` yet -- a tick whose rollout read its inputs straight from
+    // the caller's pinned slot left them in the pre-tick snapshot (snapshot_inputs); `state` (device-resident) receives the pose the
+    // plant step predicts either way.  goal_keep: the device-resident goal, refreshed from `goal` (the snapshot's) on the same occasion.
+    if (state_src == nullptr) state_src = state;
     if (wait.flags) {  // peer-to-peer exchange: `gathered` is this rank's mailbox; wait until every peer's tuples are in
         if (!p2p_wait_block(wait)) {  // a peer never delivered: poison the outputs (mppi_get_outputs reports MPPI_E_TIMEOUT), touch nothing else
             if (threadIdx.x == 0) {
@@ -1846,12 +1861,14 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
     // perform_action (:210-213): the three distinct stage angles of rk4 evaluated by three lanes
     // (euler + unicycle only needs the first)
     const double sum = uf[0] + uf[T], om = (P.model == 1) ? uf[T] : P.kth * (uf[T] - uf[0]);
-    const double th0 = state[a * 3 + 2], k_th = P.dt * om;
+    const double th0 = state_src[a * 3 + 2], k_th = P.dt * om;
     if ((flags & 1) && tid < 3) {
         const double ang = (tid == 0) ? th0 : (tid == 1 ? th0 + k_th / 2 : th0 + k_th);
         trig[tid][0] = cos(ang);
         trig[tid][1] = sin(ang);
     }
+    if (goal_keep != nullptr && goal_keep != goal && tid < 3) goal_keep[a * 3 + tid] = goal[a * 3 + tid];
+    if (!(flags & 1) && state_src != state && tid < 3) state[a * 3 + tid] = state_src[a * 3 + tid];
     for (int j = tid; j < T; j += blockDim.x) {
         ufilt[((size_t)a * 2 + 0) * T + j] = uf[j];
         ufilt[((size_t)a * 2 + 1) * T + j] = uf[T + j];
@@ -1866,7 +1883,7 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
     __syncthreads();
     if (tid == 0) {
         if (flags & 1) {  // same operation order as rk4 (:39-54) with dd_dynamics (:23-30)
-            const double x0[3] = {state[a * 3 + 0], state[a * 3 + 1], th0};
+            const double x0[3] = {state_src[a * 3 + 0], state_src[a * 3 + 1], th0};
             double k1[3], k2[3], k3[3], k4[3], xn[3];
             if (P.model == 1) {  // euler (:57-58) over unicycle_dynamics (:33-36)
                 xn[0] = x0[0] + P.dt * (trig[0][0] * uf[0]);
@@ -1922,10 +1939,11 @@ __global__ __launch_bounds__(1024) void finalize_kernel(DevParams P, const doubl
                                                       double* __restrict__ outv, uint32_t* tick_ptr, int flags,
                                                       uint32_t tick_set, double* host_out, uint32_t* host_seq, uint32_t seq,
                                                       P2PWait wait, const double* __restrict__ goal, double* __restrict__ tc,
-                                                      double* __restrict__ base, PkRow* __restrict__ pk) {
+                                                      double* __restrict__ base, PkRow* __restrict__ pk, const double* state_src,
+                                                      double* goal_keep) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     finalize_block(P, blockIdx.x, gathered, G, lay, Smat, unom, ufilt, state, outv, tick_ptr, flags, tick_set, host_out, host_seq,
-                   seq, smem_raw, wait, goal, tc, base, pk);
+                   seq, smem_raw, wait, goal, tc, base, pk, state_src, goal_keep);
 }
 #endif
 

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
         const size_t slot = (size_t)(kwave >> 6) + half;
         const bool mine = lane < 32 && idx < (EXTRA ? 16 : 2 * U) && te < T && slot < NW;
         const size_t at = (((size_t)a * T + te) * 2 + (idx & 1)) * NW + slot;
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(half ? 0.f : tot), ep_rsrc, mine ? (unsigned)(at * 4) : 0xFFFFFFFFu, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(half ? 0.f : tot), ep_rsrc, mine ? (unsigned)(at * 4) : 0xFFFFFFFFu, 0, kDpStoreAux);
     };
     auto step = [&](int t, f2 n0, f2 n1, auto full_tag, bool robust) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_tag)::value;
@@ -386,7 +386,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
         tot[i] = (float)(pre[i] + term + (double)(i ? ncs.y : ncs.x));
     }
     // value_fcn = reverse cumulative sum over t (control/src/mppi:175) = total - exclusive prefix
-    if (block_full) {
+    if (kDpStoreAux & 16) {   // (sc1 stores, like the rows: nothing of this launch stays dirty in the L2)
+        if (block_full) {
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(Stot + (size_t)a * Ks + kA),
+                               ((unsigned long long)__float_as_uint(tot[1]) << 32) | __float_as_uint(tot[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (actA) __hip_atomic_store(Stot + (size_t)a * Ks + kA, tot[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (actB) __hip_atomic_store(Stot + (size_t)a * Ks + kA + 1, tot[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else if (block_full) {
         *reinterpret_cast<f2*>(Stot + (size_t)a * Ks + kA) = f2{tot[0], tot[1]};
     } else {
         if (actA) Stot[(size_t)a * Ks + kA] = tot[0];

@@ -1648,7 +1648,8 @@ def test_cpp_node_rccl_exchange_and_fallback(tmp_path, tick_path):
     common = [exe, "--task", "pentagon", "--samples", str(K), "--horizon", str(T), "--callbacks", str(n_cb), "--thresh", "0.97", "--seed", "9",
               "--tick-path", "lanes"]
     env = dict(os.environ, MPPI_SYNC_TIMEOUT_MS="8000", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    rows = lambda r: np.array([[float(x) for x in ln.split()] for ln in r.stdout.strip().splitlines()])
+    # (librccl prints its version banner on stdout when the first communicator is made: the node's rows start with the callback's index)
+    rows = lambda r: np.array([[float(x) for x in ln.split()] for ln in r.stdout.strip().splitlines() if ln[:1].isdigit()])
     one = subprocess.run(common, capture_output=True, text=True, timeout=60, env=env)
     assert one.returncode == 0, one.stderr[-2000:]
     a = rows(one)
