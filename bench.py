@@ -176,6 +176,10 @@ def compact_line(line, full_path):
                 "sync_tick_us_median": sync.get("median"), "sync_tick_us_p99": sync.get("p99"),
                 "kernels_us": {k: (round(v, 2) if v else v) for k, v in (line.get("kernels_us") or {}).items()},
                 "exchange_us": line.get("exchange_us"), "value_parked_at_goal": line.get("value_parked_at_goal"),
+                # N > 1: what every rank ran (its share, its big kernels, the exchange it came up on)
+                "per_rank": [{"rank": r.get("rank"), "samples": r.get("samples"), "rollout_us": (r.get("kernels_us") or {}).get("rollout"),
+                              "update_us": (r.get("kernels_us") or {}).get("update"), "exchange_us": r.get("exchange_us"),
+                              "exchange_ran": (r.get("exchange") or {}).get("ran")} for r in (line.get("per_rank") or [])] or None,
                 "one_engine_ms": one.get("ms_per_step"), "f64_ms": f64.get("ms_per_step"),
                 "final_state": line.get("final_state"), "final_u": line.get("final_u"),
                 "dtype_detail": (line.get("dtype_detail") or "")[:160], "full_record": full_path})

@@ -1620,6 +1620,7 @@ int mppi_download_noise(mppi_engine* h, double* eps) {
     API_BEGIN(h)
     if (!eps) fail(MPPI_E_INVALID, "eps is NULL");
     if (!h->noise_ready) fail(MPPI_E_STATE, "no noise resident");
+    if (!h->eps_lazy) h->co_pull_value();   // (an agent split whose ticks STORED their noise, option store_eps: the second engine's rows are pulled with its V)
     h->materialise_eps();
     const int A = h->cfg.n_agents, T = h->cfg.horizon, K = h->cfg.samples;
     const size_t n = (size_t)A * T * 2 * K;

@@ -50,6 +50,15 @@ constexpr int kTupleW = 8;  // {min, D, N0, N1, E0, E1, count, pad}
 #define MPPI_DP_STORE_AUX 16
 #endif
 constexpr int kDpStoreAux = MPPI_DP_STORE_AUX;
+// ... of the 8-byte rows of fp64 storage (400 MB per tick at config 4: more than the 256 MB Infinity Cache holds), and whether the
+// update kernel reads its rows with non-temporal loads -- measurement switches of the same kind
+#ifndef MPPI_DP_STORE_AUX_F64
+#define MPPI_DP_STORE_AUX_F64 MPPI_DP_STORE_AUX
+#endif
+#ifndef MPPI_UPD_LOAD_NT
+#define MPPI_UPD_LOAD_NT 0
+#endif
+constexpr int kDpStoreAuxF64 = MPPI_DP_STORE_AUX_F64;
 constexpr int kTcW = 8;     // {un0, un1, w0, w1, cb, 0, 0, 0}
 
 struct DevParams {
@@ -1012,7 +1021,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(S) =
                             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)pre), row, (unsigned)k * 4u, 0, kDpStoreAux);
                         } else {
                             typedef unsigned u2v __attribute__((ext_vector_type(2)));
-                            __builtin_amdgcn_raw_buffer_store_b64(u2v{(unsigned)__double2loint(pre), (unsigned)__double2hiint(pre)}, row, (unsigned)k * 8u, 0, kDpStoreAux);
+                            __builtin_amdgcn_raw_buffer_store_b64(u2v{(unsigned)__double2loint(pre), (unsigned)__double2hiint(pre)}, row, (unsigned)k * 8u, 0, kDpStoreAuxF64);
                         }
                     } else {
                         dp[(size_t)t * Ks] = (S)pre;
@@ -1246,7 +1255,7 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
     for (int j = 0; j < NV; ++j) {
         const int k = k_begin + (j * 256 + tid) * VEC;
         if (k + VEC <= k_end) {  // rows are 256-byte aligned and k % VEC == 0: 16-byte aligned loads
-            const vec_t pv = *reinterpret_cast<const vec_t*>(v_row + k);
+            const vec_t pv = MPPI_UPD_LOAD_NT ? __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(v_row + k)) : *reinterpret_cast<const vec_t*>(v_row + k);
             const vec_t sv = *reinterpret_cast<const vec_t*>(s_row + k);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) v[j][i] = sv[i] - pv[i];

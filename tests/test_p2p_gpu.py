@@ -435,8 +435,15 @@ def test_bench_with_all_ranks_on_the_one_gpu(exchange, n):
     out = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
                "--master-port", str(port)] + common + ["--gpus", str(n), "--all-ranks-on-gpu0"] + (["--exchange", exchange] if exchange != "auto" else []))
     assert out.returncode == 0, out.stderr[-3000:]
-    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    printed = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    short = json.loads(printed)
     ran = "p2p" if exchange == "auto" else exchange
+    # the printed line: under 4 KB, the contract's keys, which exchange every rank came up on; the full nested record in a side file
+    assert len(printed) <= 4096 and short["n_gpus"] == n and short["config"]["parallelism"] == "K-sharded x%d, exchange: %s" % (n, ran)
+    assert [r["rank"] for r in short["per_rank"]] == list(range(n)) and all(r["exchange_ran"] == ran and r["rollout_us"] > 0 for r in short["per_rank"])
+    assert all(not isinstance(v, (dict, list)) for v in short["roofline"].values())
+    line = json.load(open(short["full_record"]))
+    assert line["value"] == short["value"] and line["ms_per_step"] == short["ms_per_step"]
     assert line["n_gpus"] == n and line["config"]["samples_total"] == total and line["config"]["samples_per_gpu"] == 25000
     assert line["config"]["parallelism"] == "K-sharded x%d, exchange: %s" % (n, ran) and line["scaling"] == "strong"
     assert [r["rank"] for r in line["per_rank"]] == list(range(n)) and all(r["samples"] == 25000 for r in line["per_rank"])
