@@ -55,8 +55,12 @@ constexpr int kDpStoreAux = MPPI_DP_STORE_AUX;
 #ifndef MPPI_DP_STORE_AUX_F64
 #define MPPI_DP_STORE_AUX_F64 MPPI_DP_STORE_AUX
 #endif
+// (-1: by storage type -- non-temporal for the 8-byte rows: the update of fp64 storage reads 400 MB per tick at config 4 next to a
+// per-sample total it re-reads for every row; with rows that do not stay in the L2 behind them, that total does: update 90.7 -> 80.0 us,
+// tick 213 -> 200 (same box; 4-byte rows: 144.3 / 145.0 on one engine, 135.2 -> 139.1 co-scheduled -- they keep plain loads;
+// profiles/r5_ab_f64_memory_policy.jsonl))
 #ifndef MPPI_UPD_LOAD_NT
-#define MPPI_UPD_LOAD_NT 0
+#define MPPI_UPD_LOAD_NT -1
 #endif
 constexpr int kDpStoreAuxF64 = MPPI_DP_STORE_AUX_F64;
 constexpr int kTcW = 8;     // {un0, un1, w0, w1, cb, 0, 0, 0}
@@ -1255,7 +1259,8 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
     for (int j = 0; j < NV; ++j) {
         const int k = k_begin + (j * 256 + tid) * VEC;
         if (k + VEC <= k_end) {  // rows are 256-byte aligned and k % VEC == 0: 16-byte aligned loads
-            const vec_t pv = MPPI_UPD_LOAD_NT ? __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(v_row + k)) : *reinterpret_cast<const vec_t*>(v_row + k);
+            constexpr bool kNtRows = MPPI_UPD_LOAD_NT < 0 ? sizeof(S) == 8 : MPPI_UPD_LOAD_NT != 0;
+            const vec_t pv = kNtRows ? __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(v_row + k)) : *reinterpret_cast<const vec_t*>(v_row + k);
             const vec_t sv = *reinterpret_cast<const vec_t*>(s_row + k);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) v[j][i] = sv[i] - pv[i];
