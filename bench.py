@@ -531,24 +531,28 @@ def main():
         eng.close()
         t64, e64 = sharded.make_hip_ticker(K_total, T, n_agents=1, storage="f64", local_rank=local_rank)
         e64.set_nominal(nominal_warm(T))
+        # the headline's own protocol: its own engine, a warm-up by count AND wall time, the controller put back at the
+        # start (a time-based warm-up parks the robot at its goal: another workload), then --steps timed ticks of the same tick ids
         t64.tick_async(np.zeros((1, 3)), np.array([goal]), "philox", 0, 0)
         t_w, i = time.perf_counter(), 1
-        while time.perf_counter() - t_w < 0.3 or i < 20:
+        while time.perf_counter() - t_w < args.min_warmup_s or i < args.warmup:
             t64.tick_async(None, None, "philox", 0, i)
             i += 1
             if i % 16 == 0:
-                torch.cuda.synchronize()
+                e64.synchronize()
+        e64.set_nominal(nominal_warm(T))
+        t64.tick_async(np.zeros((1, 3)), np.array([goal]), "philox", 0, 1_000_000)
         e64.kernel_timing(("rollout", "update"), period=4)
-        torch.cuda.synchronize()
         e64.synchronize()
-        n64 = 100
+        n64 = args.steps
         t0 = time.perf_counter()
         for j in range(n64):
-            t64.tick_async(None, None, "philox", 0, i + j)
+            t64.tick_async(None, None, "philox", 0, 1_000_001 + j)
         e64.synchronize()
         el64 = time.perf_counter() - t0
         k64 = e64.kernel_times()
         f64_line = {"storage": "f64", "dtype": "f64", "ms_per_step": 1e3 * el64 / n64, "value": K_total / (el64 / n64), "steps": n64,
+                    "protocol": "as the headline: own engine, warm-up, controller back at the start, --steps timed ticks",
                     "rollout_us": k64["rollout"][0] * 1e3 / max(k64["rollout"][1], 1),
                     "update_us": k64["update"][0] * 1e3 / max(k64["update"][1], 1),
                     "note": "eps / V stored as fp64, softmax in fp64 (exp2 in fp64): the reference's own precision end to end"}

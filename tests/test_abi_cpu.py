@@ -131,6 +131,33 @@ def test_create_fails_loudly_without_gpu():
     assert ei.value.code == -2 and "HIP" in str(ei.value) or "device" in str(ei.value)
 
 
+def test_config_struct_size_is_checked_before_anything_else():
+    """mppi_config.struct_size (ABI 5): the caller's sizeof(mppi_config).  mppi_default_config fills it in; mppi_create copies
+    exactly that many bytes over its own defaults (a caller built against an older, shorter struct keeps working when fields are
+    appended) and refuses sizes it does not know BEFORE touching a device -- so this runs without a GPU.  The measurement surface
+    lives in its own header, which compiles as C next to the product header."""
+    import ctypes as C
+    import subprocess
+    import tempfile
+    from motion_planning_amd import _capi
+    lib = _capi.load()
+    cfg = _capi.default_config()
+    assert cfg.struct_size == C.sizeof(_capi.MppiConfig) == 168 and _capi.MppiConfig.struct_size.offset == 0
+    h = C.c_void_p()
+    for bad in (0, 167, C.sizeof(_capi.MppiConfig) + 8):
+        cfg.struct_size = bad
+        assert lib.mppi_create(C.byref(cfg), C.byref(h)) == -1 and h.value is None
+        assert b"struct_size" in lib.mppi_last_error(None)
+    with tempfile.TemporaryDirectory() as d:     # both headers are plain C; the product header does not need the diagnostic one
+        src = os.path.join(d, "h.c")
+        open(src, "w").write('#include "mppi_hip_diag.h"\nint main(void){ return MPPI_CONFIG_SIZE_V5 == sizeof(mppi_config) && MPPI_PROBE_MARKS == 30 ? 0 : 1; }\n')
+        exe = os.path.join(d, "h")
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+        assert subprocess.call([exe]) == 0
+    prod = open(os.path.join(ROOT, "include", "mppi_hip.h")).read()
+    assert "mppi_kernel_timing" not in prod and "mppi_set_option(" not in prod and "mppi_hip_diag.h" in prod
+
+
 def test_null_handle_is_an_error_not_a_crash():
     from motion_planning_amd import _capi
     lib = _capi.load()

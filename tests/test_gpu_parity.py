@@ -1672,3 +1672,51 @@ def test_cpp_node_rccl_exchange_and_fallback(tmp_path, tick_path):
     d = rows(auto)
     assert np.abs(a[:, 7:11] - d[:, 7:11]).max() < 1e-9
 
+
+@pytest.mark.parametrize("K,T,A", [(20000, 50, 1), (140000, 50, 1), (9000, 100, 2)])
+def test_round5_schedule_options_do_not_change_results(K, T, A, tick_path):
+    """How a tick is SCHEDULED must not change what it computes: the next tick's nominal table from the finalize kernel
+    (`table_hoist`: the same no-contraction code in every kernel that derives it), the finalize workgroup's size, the samples in
+    Infinity-Cache-sized pieces, fresh inputs read from the pinned slot -- each against the plain schedule over a closed loop that
+    mixes resident ticks, ticks with a fresh pose / goal, a changed nominal and downloads, BIT FOR BIT; the update kernel's longer
+    chunks regroup the samples of a row (the merge is exact, the fp32 chunk sums are not): 1e-10, the split-invariance bound."""
+    from motion_planning_amd.mppi import Engine
+    if tick_path == "scan":
+        pytest.skip("the engines below name their tick path")
+    u0 = np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
+    rng = np.random.RandomState(4)
+    st0, goals = rng.uniform(-0.2, 0.2, (A, 3)), rng.uniform(-1.0, 1.0, (A, 3))
+
+    def run(opts):
+        out = []
+        with Engine(K, T, n_agents=A, storage="f32", tick_path="lanes", co_shards=1, options=opts) as e:
+            for a in range(A):
+                e.set_nominal(u0 * (1.0 - 0.2 * a), agent=a)
+            nxt, ua = e.tick(st0, goals, seed=3, tick_id=0); out.append(np.hstack([nxt, ua]))
+            for i in range(3):                                   # resident ticks: the hoisted table's case
+                nxt, ua = e.tick(seed=3, tick_id=1 + i); out.append(np.hstack([nxt, ua]))
+            nxt, ua = e.tick(nxt + 0.01, None, seed=3, tick_id=5); out.append(np.hstack([nxt, ua]))     # a fresh pose only
+            nxt, ua = e.tick(None, goals * 0.9, seed=3, tick_id=6); out.append(np.hstack([nxt, ua]))    # a fresh goal only
+            e.set_nominal(u0 * 0.5, agent=A - 1)                 # the table of the last finalize is stale now
+            nxt, ua = e.tick(seed=3, tick_id=7); out.append(np.hstack([nxt, ua]))
+            out.append(e.download_value()[A - 1, ::7, ::997])    # V of the last tick (pieces: re-run from the snapshot)
+            nxt, ua = e.tick(seed=3, tick_id=8); out.append(np.hstack([nxt, ua]))
+            out.append(np.stack([e.get_nominal(a) for a in range(A)]).reshape(A, -1))
+            kind = e.info()["rollout_kernel"]
+        return out, kind
+    plain = {"table_hoist": 0, "lanes_zero_copy": 0, "upd_nv": 8, "k_pieces": 1, "fin_threads": 1024}
+    ref, kind = run(plain)
+    assert kind == "fp64"
+    for name, val in (("table_hoist", 1), ("lanes_zero_copy", 1), ("fin_threads", 256), ("fin_threads", 512), ("k_pieces", 2), ("k_pieces", 3)):
+        if name == "k_pieces" and K < 3 * 8192:
+            continue
+        got, _ = run(dict(plain, **{name: val}))
+        for i, (x, y) in enumerate(zip(ref, got)):
+            assert np.array_equal(x, y), (name, val, i, float(np.abs(x - y).max()))
+    got, _ = run(dict(plain, upd_nv=16))
+    for i, (x, y) in enumerate(zip(ref, got)):
+        assert np.abs(x - y).max() < 1e-10 * max(1.0, np.abs(x).max()), ("upd_nv", i, float(np.abs(x - y).max()))
+    got, _ = run({})                                             # the defaults, whatever they pick at this size
+    for i, (x, y) in enumerate(zip(ref, got)):
+        assert np.abs(x - y).max() < 1e-10 * max(1.0, np.abs(x).max()), ("defaults", i)
+

@@ -23,20 +23,25 @@ cp $O/stats_co/*/*kernel_stats.csv $O/kernel_stats_co_headline.csv 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c5 -- python $R/bench.py --workload c5 --no-cpu-baseline > $O/stats_c5.log 2>&1
 cp $O/stats_c5/*/*kernel_stats.csv $O/kernel_stats_c5_agents_split.csv 2>/dev/null
 timeout 300 python $R/bench.py --workload c5 --co-shards 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_c5_one_engine.json
-timeout 200 python $R/tools/ab_option.py --option noise_packing --values 0,1,2 --rounds 2 > $O/ab_noise_packing_one_engine.jsonl 2>/dev/null
-timeout 200 python $R/tools/ab_option.py --option noise_packing --values 0,1,2 --rounds 2 --co-shards 0 > $O/ab_noise_packing_co_scheduled.jsonl 2>/dev/null
 timeout 300 python $R/bench.py --co-shards 1 --no-cpu-baseline --no-f64-line 2>/dev/null | tail -1 > $O/bench_c4_one_engine.json
 cd $R
 timeout 900 bash tools/pmc.sh final/pmc --co-shards 1 > $O/pmc.log 2>&1; tail -4 $O/pmc.log
 for w in c2 c3 c5; do timeout 300 python bench.py --workload $w --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_$w.json; done
 for k in 500000 250000 125000; do timeout 200 python bench.py --samples $k --co-shards 1 --no-cpu-baseline --no-f64-line --steps 100 2>/dev/null | tail -1 > $O/bench_shard_$k.json; done
 python tools/ab_rollout.py --rounds 2 > $O/ab_rollout_c4.jsonl 2>/dev/null
+timeout 60 ./tools/depbench > $O/depbench.txt 2>&1
+timeout 120 ./tools/rampbench > $O/rampbench.txt 2>&1
+timeout 200 python tools/probe_timeline.py --samples 125000,250000,1000000 > $O/probe_timeline.jsonl 2>/dev/null
+timeout 120 python tools/probe_timeline.py --samples 100000 --horizon 100 >> $O/probe_timeline.jsonl 2>/dev/null
+timeout 300 python tools/ab_lib.py --libs default,plain --rounds 2 --samples 125000 > $O/ab_store_policy_final.jsonl 2>/dev/null
+cp $R/gpurun_out/bench_full_*.json $O/ 2>/dev/null
 g++ -O2 -std=c++17 -Iinclude tools/node_tail.cpp -o tools/node_tail -Lmotion_planning_amd/lib -lmppi_hip -Wl,-rpath,$R/motion_planning_amd/lib && ( ./tools/node_tail 10 100 5000 0; ./tools/node_tail 10 100 3000 500; ./tools/node_tail 1000 50 3000 0; ./tools/node_tail 10000 50 3000 0 ) > $O/node_tail.txt 2>&1
 timeout 120 python tools/node_latency.py > $O/node_latency.txt 2>&1
 timeout 60 ./tools/ubench > $O/ubench.txt 2>&1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/bwbench.hip -o tools/bwbench 2>/dev/null && timeout 120 ./tools/bwbench > $O/bwbench.txt 2>&1
 timeout 200 python bench.py --storage f64 --no-cpu-baseline --steps 100 2>/dev/null | tail -1 > $O/bench_c4_f64.json
-[ -n "$SKIP_HANG_HUNT" ] || timeout 300 bash tools/hang_hunt.sh 600 4 gpurun_out/final/hang 2>&1 | tail -5
+timeout 200 python bench.py --samples 125000 --storage f64 --co-shards 1 --no-cpu-baseline --no-f64-line --steps 100 2>/dev/null | tail -1 > $O/bench_shard_125000_f64.json
+[ -z "$RUN_HANG_HUNT" ] || timeout 300 bash tools/hang_hunt.sh 600 4 gpurun_out/final/hang 2>&1 | tail -5
 python3 - <<PY
 import csv, glob, json, collections
 rows = collections.defaultdict(list)
