@@ -183,6 +183,16 @@ def compact_line(line, full_path):
                 "one_engine_ms": one.get("ms_per_step"), "f64_ms": f64.get("ms_per_step"),
                 "final_state": line.get("final_state"), "final_u": line.get("final_u"),
                 "dtype_detail": (line.get("dtype_detail") or "")[:160], "full_record": full_path})
+
+    def trim(v, keep=False):   # seven significant digits are plenty for a record (`value`, `ms_per_step` and the final state stay as they are)
+        if isinstance(v, float) and not keep:
+            return float("%.7g" % v)
+        if isinstance(v, dict):
+            return {k: trim(x, keep or k in ("value", "ms_per_step", "final_state", "final_u")) for k, x in v.items()}
+        if isinstance(v, list):
+            return [trim(x, keep) for x in v]
+        return v
+    out = {k: trim(v, k in ("value", "ms_per_step", "final_state", "final_u")) for k, v in out.items()}
     return out
 
 
@@ -869,7 +879,11 @@ def main():
             full_path = None
         out = compact_line(line, full_path)
         text = json.dumps(out)
-        assert len(text) <= 4096, len(text)
+        for drop in ("dtype_detail", "final_state", "final_u", "kernels_us", "per_rank"):   # (never needed so far: 3.1 KB at N = 1, 3.6 KB at N = 8)
+            if len(text) <= 4096:
+                break
+            out.pop(drop, None)
+            text = json.dumps(out)
         print(text)
     if in_group:
         dist.destroy_process_group()

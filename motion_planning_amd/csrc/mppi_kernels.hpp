@@ -1802,12 +1802,26 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
     const int nb = T - 1;  // basis length = the filter window
     if (staged)
         for (int i = tid; i < 4 * nb + 4; i += blockDim.x) Sl[i] = Smat[i];
+#ifdef MPPI_FIN_PREFETCH
+    // (measurement build: everything this kernel reads from global memory besides the tuples is fetched NOW -- the nominal controls of
+    // the row this thread will apply in the first pass, the pose -- so that no load sits behind the merge or behind a barrier)
+    const int pre_t = (G > 1 && G <= 16) ? (tid >> 4) : tid;
+    const bool pre_ok = pre_t < T && ((G > 1 && G <= 16) ? (tid & 15) == 0 : true);
+    const double pre_u0 = pre_ok ? unom[((size_t)a * 2 + 0) * T + pre_t] : 0.0, pre_u1 = pre_ok ? unom[((size_t)a * 2 + 1) * T + pre_t] : 0.0;
+    const double pre_x = state_src[a * 3 + 0], pre_y = state_src[a * 3 + 1], pre_th = state_src[a * 3 + 2];
+#endif
     // omg = exp(-V/lam) + 1e-8, normalised; uvec += eps . omg   (control/src/mppi:193-196), then clip (:198-199)
     auto apply = [&](int t, double d, double n0, double n1, double e0, double e1, double cnt) {
         const double den = d + P.floor_w * cnt;
         const double du0 = (n0 + P.floor_w * e0) / den, du1 = (n1 + P.floor_w * e1) / den;
+#ifdef MPPI_FIN_PREFETCH
+        const bool hit = t == pre_t;
+        un[t] = clampd((hit ? pre_u0 : unom[((size_t)a * 2 + 0) * T + t]) + du0, P.u_max);
+        un[T + t] = clampd((hit ? pre_u1 : unom[((size_t)a * 2 + 1) * T + t]) + du1, P.u_max);
+#else
         un[t] = clampd(unom[((size_t)a * 2 + 0) * T + t] + du0, P.u_max);
         un[T + t] = clampd(unom[((size_t)a * 2 + 1) * T + t] + du1, P.u_max);
+#endif
     };
     if (G > 1 && G <= 16) {
         // several tuples per row (shards after an exchange, or a handful of chunk / scan-block tuples): 16 lanes per row
@@ -1875,7 +1889,11 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
     // perform_action (:210-213): the three distinct stage angles of rk4 evaluated by three lanes
     // (euler + unicycle only needs the first)
     const double sum = uf[0] + uf[T], om = (P.model == 1) ? uf[T] : P.kth * (uf[T] - uf[0]);
+#ifdef MPPI_FIN_PREFETCH
+    const double th0 = pre_th, k_th = P.dt * om;
+#else
     const double th0 = state_src[a * 3 + 2], k_th = P.dt * om;
+#endif
     if ((flags & 1) && tid < 3) {
         const double ang = (tid == 0) ? th0 : (tid == 1 ? th0 + k_th / 2 : th0 + k_th);
         trig[tid][0] = cos(ang);
@@ -1897,7 +1915,11 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
     __syncthreads();
     if (tid == 0) {
         if (flags & 1) {  // same operation order as rk4 (:39-54) with dd_dynamics (:23-30)
+#ifdef MPPI_FIN_PREFETCH
+            const double x0[3] = {pre_x, pre_y, th0};
+#else
             const double x0[3] = {state_src[a * 3 + 0], state_src[a * 3 + 1], th0};
+#endif
             double k1[3], k2[3], k3[3], k4[3], xn[3];
             if (P.model == 1) {  // euler (:57-58) over unicycle_dynamics (:33-36)
                 xn[0] = x0[0] + P.dt * (trig[0][0] * uf[0]);
