@@ -871,7 +871,10 @@ def main():
         if not full_path:
             base = os.environ.get("GRAFT_REPO_ROOT") or ROOT
             out_dir = os.path.join(base, "gpurun_out") if os.environ.get("GRAFT_REPO_ROOT") else os.path.join(base, "profiles")
-            full_path = os.path.join(out_dir, "bench_full_%s%s.json" % (args.workload, "" if args.storage == "f32" else "_" + args.storage))
+            tag = args.workload + ("_K%d" % args.samples if args.samples else "") + ("_T%d" % args.horizon if args.horizon else "") + \
+                ("" if args.storage == "f32" else "_" + args.storage) + ("" if args.co_shards is None else "_co%d" % args.co_shards) + \
+                ("" if args.gpus == 1 else "_n%d" % args.gpus)
+            full_path = os.path.join(out_dir, "bench_full_%s.json" % tag)
         try:
             os.makedirs(os.path.dirname(full_path), exist_ok=True)
             json.dump(line, open(full_path, "w"))

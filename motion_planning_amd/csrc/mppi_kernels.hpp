@@ -109,6 +109,28 @@ __device__ __forceinline__ void snapshot_inputs(const DevParams& P, const double
     }
 }
 constexpr int kProbeMarks = 30;   // stamps of a diagnostic build's timeline (ClockProbe::mark)
+// the finalize kernel's timeline in a diagnostic build: thread 0 of agent 0's workgroup stamps clk[2 + 16 + i]
+struct FinProbe {
+#ifdef MPPI_PROBE_TIMELINE
+    unsigned long long c0; bool on; unsigned long long* out;
+    __device__ __forceinline__ FinProbe(const DevParams& P, int a) : c0(clock64()), on(P.clk != nullptr && a == 0 && threadIdx.x == 0), out(P.clk) {}
+    __device__ __forceinline__ void mark(int i) { if (on && 16 + i < kProbeMarks) out[2 + 16 + i] = clock64() - c0; }
+#else
+    __device__ __forceinline__ FinProbe(const DevParams&, int) {}
+    __device__ __forceinline__ void mark(int) {}
+#endif
+};
+// the update kernel's: thread 0 of the launch's middle workgroup stamps clk[2 + 24 + i]
+struct UpdProbe {
+#ifdef MPPI_PROBE_TIMELINE
+    unsigned long long c0; bool on; unsigned long long* out;
+    __device__ __forceinline__ UpdProbe(const DevParams& P, bool mid) : c0(clock64()), on(P.clk != nullptr && mid && threadIdx.x == 0), out(P.clk) {}
+    __device__ __forceinline__ void mark(int i) { if (on && 24 + i < kProbeMarks) out[2 + 24 + i] = clock64() - c0; }
+#else
+    __device__ __forceinline__ UpdProbe(const DevParams&, bool) {}
+    __device__ __forceinline__ void mark(int) {}
+#endif
+};
 struct ClockProbe {
     unsigned long long c0 = 0, w0 = 0;
     bool on;
@@ -1234,6 +1256,7 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
     const int id = blockIdx.x + (int)gridDim.x * blockIdx.y;  // grid = (8 * T, ceil(A * chunks / 8))
     const int xcd = id & 7, q = id >> 3, t = q % T_, grp = q / T_;
     const int col = grp * 8 + xcd;
+    UpdProbe uprobe(P, id == (int)(gridDim.x * gridDim.y) / 2);   // (diagnostic builds only)
     if (col >= P.A * n_local) return;
     const int a = col / n_local, local = col % n_local;
     const int ch = ch_first + n_local - 1 - local;
@@ -1271,9 +1294,11 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
 #pragma unroll
         for (int i = 0; i < VEC; ++i) m = fmin(m, v[j][i]);
     }
+    uprobe.mark(0);   // the chunk is in registers (every load waited for)
     m = wave_min(m);
     if (lane == 0) red[wid][0] = m;
     __syncthreads();
+    uprobe.mark(1);
     // (the block minimum is uniform: kept in scalar registers -- in the fp64 mode the two vector registers it would hold are what
     // stands between seven and eight blocks per CU)
     const R M = uniform_value(fmin(fmin(red[0][0], red[1][0]), fmin(red[2][0], red[3][0])));
@@ -1348,6 +1373,7 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
                 }
         }
     }
+    uprobe.mark(2);   // weights formed
     if (REGEN) {
         // the wave reads back what its own lanes queued: LDS operations of one wave complete in order, the fence keeps the compiler from
         // moving the reads up
@@ -1379,6 +1405,7 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
         const int w_begin = k_begin >> 6, w_end = (k_end + 63) >> 6;
         for (int w = w_begin + tid; w < w_end; w += 256) { E0 += ep[w]; E1 += ep[NW + w]; }
     }
+    uprobe.mark(3);   // re-draws done, eps sums read
     __shared__ double redN[4][2];
     const double N0d = wave_sum((double)N0 + Na0), N1d = wave_sum((double)N1 + Na1);
     D = wave_sum(D); E0 = wave_sum(E0); E1 = wave_sum(E1);
@@ -1391,6 +1418,7 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
     } else if (tid == 5) {
         o[0] = (double)M; o[6] = (double)(k_end - k_begin); o[7] = 0.0;
     }
+    uprobe.mark(4);
 }
 
 // per-wave sums of eps for noise that did not come out of a rollout (mppi_upload_noise followed
@@ -1777,6 +1805,7 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
     // the caller's pinned slot left them in the pre-tick snapshot (snapshot_inputs); `state` (device-resident) receives the pose the
     // plant step predicts either way.  goal_keep: the device-resident goal, refreshed from `goal` (the snapshot's) on the same occasion.
     if (state_src == nullptr) state_src = state;
+    FinProbe fprobe(P, a);   // (diagnostic builds: stamps 16 ... of the probe buffer; nothing in the product)
     if (wait.flags) {  // peer-to-peer exchange: `gathered` is this rank's mailbox; wait until every peer's tuples are in
         if (!p2p_wait_block(wait)) {  // a peer never delivered: poison the outputs (mppi_get_outputs reports MPPI_E_TIMEOUT), touch nothing else
             if (threadIdx.x == 0) {
@@ -1802,27 +1831,14 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
     const int nb = T - 1;  // basis length = the filter window
     if (staged)
         for (int i = tid; i < 4 * nb + 4; i += blockDim.x) Sl[i] = Smat[i];
-#ifdef MPPI_FIN_PREFETCH
-    // (measurement build: everything this kernel reads from global memory besides the tuples is fetched NOW -- the nominal controls of
-    // the row this thread will apply in the first pass, the pose -- so that no load sits behind the merge or behind a barrier)
-    const int pre_t = (G > 1 && G <= 16) ? (tid >> 4) : tid;
-    const bool pre_ok = pre_t < T && ((G > 1 && G <= 16) ? (tid & 15) == 0 : true);
-    const double pre_u0 = pre_ok ? unom[((size_t)a * 2 + 0) * T + pre_t] : 0.0, pre_u1 = pre_ok ? unom[((size_t)a * 2 + 1) * T + pre_t] : 0.0;
-    const double pre_x = state_src[a * 3 + 0], pre_y = state_src[a * 3 + 1], pre_th = state_src[a * 3 + 2];
-#endif
     // omg = exp(-V/lam) + 1e-8, normalised; uvec += eps . omg   (control/src/mppi:193-196), then clip (:198-199)
     auto apply = [&](int t, double d, double n0, double n1, double e0, double e1, double cnt) {
         const double den = d + P.floor_w * cnt;
         const double du0 = (n0 + P.floor_w * e0) / den, du1 = (n1 + P.floor_w * e1) / den;
-#ifdef MPPI_FIN_PREFETCH
-        const bool hit = t == pre_t;
-        un[t] = clampd((hit ? pre_u0 : unom[((size_t)a * 2 + 0) * T + t]) + du0, P.u_max);
-        un[T + t] = clampd((hit ? pre_u1 : unom[((size_t)a * 2 + 1) * T + t]) + du1, P.u_max);
-#else
         un[t] = clampd(unom[((size_t)a * 2 + 0) * T + t] + du0, P.u_max);
         un[T + t] = clampd(unom[((size_t)a * 2 + 1) * T + t] + du1, P.u_max);
-#endif
     };
+    fprobe.mark(0);   // behind the p2p wait and the issue of the basis loads
     if (G > 1 && G <= 16) {
         // several tuples per row (shards after an exchange, or a handful of chunk / scan-block tuples): 16 lanes per row
         const int rows_per_pass = (int)blockDim.x >> 4, r = tid >> 4, g = tid & 15;
@@ -1852,7 +1868,9 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
             apply(t, d, n0, n1, e0, e1, cnt);
         }
     }
+    fprobe.mark(1);   // tuples merged, controls updated (this thread's share)
     __syncthreads();
+    fprobe.mark(2);
     {   // savgol_filter (:202) as u @ S, clip (:205-206).  With window T-1 the operator has rank 8 (savgol.hpp):
         //   (u @ S)[j] = sum_d p_d(e_j) c_d[shift_j],   c_d[s] = sum_i p_d(i) u[i + s]
         // so per wheel eight dot products against the orthonormal basis -- one wave each, sixteen in all -- and four
@@ -1870,6 +1888,7 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
             if (lane == 0) coef[w][sh][d] = acc;
         }
         __syncthreads();
+        fprobe.mark(3);   // the sixteen filter coefficients
         // position inside its window (left window starts at 0, right at 1).  Odd window: the left one up to its centre.  Even
         // window (odd horizon, scipy >= 1.x semantics, savgol.hpp): the left one for j < nb/2, and the one interior sample
         // j = nb/2 is the RIGHT window's cubic at the half-integer position nb/2 - 1/2 -- the basis' four extra values
@@ -1886,14 +1905,11 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
         }
     }
     __syncthreads();
+    fprobe.mark(4);   // filtered controls
     // perform_action (:210-213): the three distinct stage angles of rk4 evaluated by three lanes
     // (euler + unicycle only needs the first)
     const double sum = uf[0] + uf[T], om = (P.model == 1) ? uf[T] : P.kth * (uf[T] - uf[0]);
-#ifdef MPPI_FIN_PREFETCH
-    const double th0 = pre_th, k_th = P.dt * om;
-#else
     const double th0 = state_src[a * 3 + 2], k_th = P.dt * om;
-#endif
     if ((flags & 1) && tid < 3) {
         const double ang = (tid == 0) ? th0 : (tid == 1 ? th0 + k_th / 2 : th0 + k_th);
         trig[tid][0] = cos(ang);
@@ -1913,13 +1929,10 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
         }
     }
     __syncthreads();
+    fprobe.mark(5);   // stage angles' cos / sin, controls written
     if (tid == 0) {
         if (flags & 1) {  // same operation order as rk4 (:39-54) with dd_dynamics (:23-30)
-#ifdef MPPI_FIN_PREFETCH
-            const double x0[3] = {pre_x, pre_y, th0};
-#else
             const double x0[3] = {state_src[a * 3 + 0], state_src[a * 3 + 1], th0};
-#endif
             double k1[3], k2[3], k3[3], k4[3], xn[3];
             if (P.model == 1) {  // euler (:57-58) over unicycle_dynamics (:33-36)
                 xn[0] = x0[0] + P.dt * (trig[0][0] * uf[0]);
@@ -1949,6 +1962,7 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
         }
         if ((flags & 4) && a == 0 && tick_ptr) *tick_ptr = *tick_ptr + 1u;
         if ((flags & 16) && a == 0 && tick_ptr) *tick_ptr = tick_set;
+        fprobe.mark(6);   // plant step, outputs on their way
     }
     if ((flags & 35) == 35) {
         // The next tick's nominal table, behind everything the caller waits for (the outputs above are on their way): lanes =

@@ -287,6 +287,49 @@ def test_committed_round4_bench_line_says_what_bounds_the_kernels():
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0
 
 
+def test_committed_round5_bench_line_is_flat_and_reproducible_from_itself():
+    """profiles/r5_bench_c4.json = the line bench.py PRINTED on the GPU box with the round's final build: under
+    4 KB, `roofline` and `cpu_baseline` hold scalars only, and every fraction can be recomputed from the scalars next to it -- the VALU
+    roof the rollout is on, the HBM fractions of rollout and update from counter bytes over live durations, SURVEY 8(d)'s accounting
+    figure per kernel and per tick (which exceeds 1: eps is never stored), the tick's floor; the one-engine and all-fp64 legs and the
+    node's blocking call are first-class scalars.  The full nested record is the side file next to it."""
+    import json
+    path = os.path.join(ROOT, "profiles", "r5_bench_c4.json")
+    if not os.path.exists(path):
+        pytest.skip("the round's bench line is committed with the final profile refresh")
+    text = open(path).read().strip()
+    line = json.loads(text)
+    assert len(text) <= 4096
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["vs_baseline"] is None and line["unit"] == "rollouts/s" and line["dtype"] == "f32"
+    assert "K=1000000 T=50" in line["config"]["workload"] and "model" not in line["config"]
+    assert abs(line["value"] - line["config"]["samples_total"] / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+    roof, cpu = line["roofline"], line["cpu_baseline"]
+    assert all(not isinstance(v, (dict, list)) for v in roof.values()) and all(not isinstance(v, (dict, list)) for v in cpu.values())
+    steps = line["config"]["state_steps_per_tick"]
+    launch_s, tick_s = roof["avg_launch_us"] * 1e-6, line["ms_per_step"] * 1e-3
+    rel = lambda a, b: abs(a - b) <= 2e-6 * abs(b)
+    assert roof["bound"] == "valu-issue" and roof["kernel"] == "rollout_pk_kernel"
+    t_min = roof["issue_cycles_per_step"] * (steps / 64.0) / 1024 / (roof["clock_mhz_under_load"] * 1e6)       # the roof it is ON
+    assert rel(roof["frac"], t_min / launch_s) and rel(roof["min_launch_us"], 1e6 * t_min) and rel(roof["frac"], roof["achieved"] / roof["peak"])
+    assert rel(roof["frac_at_peak_clock"], roof["issue_cycles_per_step"] * (steps / 64.0) / 1024 / 2.4e9 / launch_s) and 0.5 < roof["frac_at_peak_clock"] < 1.0
+    assert roof["traffic"] == roof["hbm_rollout_bytes"] and rel(roof["hbm_rollout_frac"], roof["hbm_rollout_bytes"] / launch_s / 8e12)
+    assert rel(roof["hbm_update_frac"], roof["hbm_update_bytes"] / (roof["hbm_update_us"] * 1e-6) / 8e12)
+    assert rel(roof["hbm_update_frac_of_achievable"], roof["hbm_update_frac"] * 8000.0 / 6300.0)
+    assert 0.15 < roof["hbm_rollout_frac"] < 0.4 and 0.5 < roof["hbm_update_frac"] < 0.8
+    assert roof["accounting_8d_bytes"] == 12 * steps and rel(roof["accounting_8d_frac"], 12 * steps / launch_s / 8e12)    # SURVEY 8(d), per kernel
+    assert roof["tick_accounting_8d_bytes"] == 24 * steps and rel(roof["tick_accounting_8d_frac"], 24 * steps / tick_s / 8e12) and roof["tick_accounting_8d_frac"] > 0.9
+    assert 0.4 < roof["tick_frac"] < 1.0 and roof["tick_floor_us"] > roof["min_launch_us"]
+    assert roof["one_engine_ms"] == line["one_engine_ms"] >= line["ms_per_step"] * 0.95 and roof["f64_ms"] == line["f64_ms"] > line["ms_per_step"]
+    assert line["sync_tick_us_median"] > 1e3 * line["ms_per_step"] and line["sync_tick_us_p99"] >= line["sync_tick_us_median"]
+    assert cpu["kind"] == "port" and cpu["cores"] >= 1 and abs(cpu["value"] - max(v for k, v in cpu.items() if k.startswith("threads_"))) <= 1e-6 * cpu["value"] and "threads_1_value" in cpu
+    full = json.load(open(os.path.join(ROOT, "profiles", "r5_bench_c4_full_record.json")))    # the side file of the same run
+    assert full["value"] == line["value"] and full["one_engine"]["self_check"]["max_abs_diff_u"] <= 1e-10
+    assert "protocol" in full["f64_storage"] and full["f64_storage"]["steps"] == line["steps"]
+
+
 def test_python_shell_fast_paths_still_see_every_change():
     """The reference reads Q, R, P1 and uvec_init[:, 0] on every get_path (control/src/mppi:69-73, :101) and grows path / uvec by
     np.concatenate (:97-98).  The shell keeps those semantics on fast paths (a byte comparison of the attributes, buffers that

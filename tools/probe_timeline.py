@@ -31,10 +31,14 @@ def run(K, T, storage, opts, ticks=40):
         e.synchronize()
         kt = e.kernel_times()
         kind = e.info()["rollout_kernel"]
-    m = [x for x in marks if x]
+    fin = [x for x in marks[16:24] if x]
+    upd = [x for x in marks[24:] if x]
+    m = [x for x in marks[:16] if x]
     deltas = [m[0]] + [m[i] - m[i - 1] for i in range(1, len(m))]
     return {"K": K, "T": T, "storage": storage, "options": opts, "kernel": kind, "clock_mhz": mhz, "wave_total_cycles": total,
-            "wave_total_us": total / mhz if mhz else None, "stamps": m, "deltas_cycles": deltas,
+            "wave_total_us": total / mhz if mhz else None, "stamps": m, "deltas_cycles": deltas, "finalize_stamps_cycles": fin, "update_stamps_cycles": upd,
+            "update_what": "cycles since the middle update workgroup's first instruction: [chunk loaded, block minimum, weights, re-draws + eps sums, tuple stored]",
+            "finalize_what": "cycles since the finalize workgroup's first instruction: [basis loads issued, tuples merged + controls updated, barrier, filter coefficients, filtered controls, stage angles + controls written, plant step + outputs]",
             "what": "deltas: [0] wave start -> behind the prologue's barrier; [1..] each chunk of six steps (the last entries: ride / tail chunk + terminal)",
             "bracketed_us": {k: 1e3 * v[0] / max(v[1], 1) for k, v in kt.items() if v[1]}}
 

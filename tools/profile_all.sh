@@ -6,7 +6,7 @@ set -x
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final; mkdir -p $O
 cd $R
 ( time timeout 1500 python -m pytest tests -m gpu -q 2>&1 ) > $O/gpu_tests.log 2>&1; tail -4 $O/gpu_tests.log
-timeout 400 python bench.py 2>$O/bench_c4.err | tail -1 > $O/bench_c4.json
+timeout 400 python bench.py 2>$O/bench_c4.err | tail -1 > $O/bench_c4.json; cp $R/gpurun_out/bench_full_c4.json $O/bench_c4_full_record.json
 timeout 300 python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_c4_driver_flags.json
 cd /tmp && export TMPDIR=/tmp
 # kernel stats: three runs with ONE engine (every rollout launch covers all 10^6 samples: its average is the duration the SURVEY 8(d)
