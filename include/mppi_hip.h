@@ -83,7 +83,7 @@ extern "C" {
  *   SCAN   one wave (T <= 64) or block (T <= 256) per sample, lanes = timesteps, the trajectory as prefix
  *          scans, rollout + cost-to-go + softmax partials in ONE kernel: the latency path for small K
  *          (diff-drive rk4 model only; falls back to LANES where it does not apply);
- *   AUTO   SCAN while n_agents * samples <= 16384 (T <= 64) or 6144 (T <= 256) -- the measured
+ *   AUTO   SCAN while n_agents * samples <= 14336 (T <= 64) or 5120 (T <= 256) -- the measured
  *          crossovers --, else LANES.
  * Both give the same results to rounding. */
 #define MPPI_TICK_AUTO 0

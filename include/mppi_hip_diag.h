@@ -71,6 +71,9 @@ int mppi_get_option(mppi_engine *h, const char *key, int64_t *value);
  * duration (ms) and the number of launches since timing was (re)enabled.  The rollout kernel's
  * events ride on its own launch (dispatch begin / end timestamps, no marker packets in the
  * stream); the small kernels are bracketed by recorded events.
+ * On a handle that runs co-scheduled engines (mppi_co_info) the times are those of the handle's OWN engine:
+ * shard 0's samples (mppi_co_info's samples[0]), or, on an agent split, the first ceil(n_agents / 2) agents -- scale
+ * by what that engine covers, as bench.py does, before comparing with an unsplit handle.
  */
 int mppi_kernel_timing(mppi_engine *h, uint32_t mask);
 /* Bracket only every `period`-th launch of each selected kernel (default 1 = every launch):

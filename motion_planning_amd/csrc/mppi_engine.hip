@@ -992,8 +992,11 @@ struct mppi_engine {
             // Round 2 (back to back | blocking call, which only the scan path serves zero-copy), T = 50: K = 8000 24.7 vs 28.4 | 48 vs 61,
             // 12000 27.5 vs 29.7 | 51 vs 62, 16000 31.8 vs 30.3 | 56 vs 62, 24000 36.4 vs 31.5 | 61 vs 67; T = 100: 4000 34.9 vs 38.1 | 59 vs 75,
             // 6000 40.5 vs 39.8 | 65 vs 72, 10000 55.5 vs 44.0 | 79 vs 76  ->  16384 / 6144
+            // Round 5 (the lane rollout's rows stored write-through, its fresh inputs zero-copy as well: profiles/r5_ab_tick_path_small_k.jsonl,
+            // r5_blocking_tick_scan_vs_lanes.txt), T = 50: 12000 26.2 vs 26.8 | 34.7 vs 38.2, 14000 27.9 vs 26.8 | 36.5 vs 37.8, 16000 30.5 vs 27.1 |
+            // 39.1 vs 38.4; T = 100: 4000 32.0 vs 35.0 | 40.3 vs 43.2, 5000 35.0 vs 35.2 | 43.2 vs 43.3, 6000 38.1 vs 35.5 | 46.1 vs 43.8  ->  14336 / 5120
             const bool applies = T <= 256 && cfg.model == MPPI_MODEL_DIFFDRIVE_RK4;
-            const bool want = cfg.tick_path == MPPI_TICK_SCAN || (cfg.tick_path == MPPI_TICK_AUTO && (long)A * K <= (T <= 64 ? 16384 : 6144));
+            const bool want = cfg.tick_path == MPPI_TICK_SCAN || (cfg.tick_path == MPPI_TICK_AUTO && (long)A * K <= (T <= 64 ? 14336 : 5120));
             if (applies && want) {
                 small_nw = T <= 64 ? 1 : 4;
                 // units the chip keeps resident at once (152 VGPRs: 3 waves per SIMD x 1024 SIMDs): the kernel is

@@ -87,7 +87,7 @@ _MODELS = {"rk4": _capi.MPPI_MODEL_DIFFDRIVE_RK4, "euler": _capi.MPPI_MODEL_UNIC
            _capi.MPPI_MODEL_UNICYCLE_EULER: _capi.MPPI_MODEL_UNICYCLE_EULER}
 
 # which kernels a tick runs (include/mppi_hip.h MPPI_TICK_*): "lanes" = lane per sample (throughput),
-# "scan" = lanes are timesteps, one kernel (small-K latency), "auto" = scan while A * K <= 16384 (T <= 64) / 6144 (T <= 256)
+# "scan" = lanes are timesteps, one kernel (small-K latency), "auto" = scan while A * K <= 14336 (T <= 64) / 5120 (T <= 256)
 _TICK_PATHS = {"auto": _capi.MPPI_TICK_AUTO, "lanes": _capi.MPPI_TICK_LANES, "scan": _capi.MPPI_TICK_SCAN}
 _STORAGE = {"f32": MPPI_STORE_F32, "f64": MPPI_STORE_F64, MPPI_STORE_F32: MPPI_STORE_F32,
             MPPI_STORE_F64: MPPI_STORE_F64}
