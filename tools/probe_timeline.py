@@ -11,7 +11,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from motion_planning_amd import _capi
-_capi.LIB_PATH = os.path.join(ROOT, "motion_planning_amd", "lib", "libmppi_hip_probe.so")
+_LIB = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--lib=")]   # another diagnostic build: --lib=NAME -> lib/libmppi_hip_NAME.so
+_capi.LIB_PATH = os.path.join(ROOT, "motion_planning_amd", "lib", "libmppi_hip_%s.so" % (_LIB[0] if _LIB else "probe"))
 from motion_planning_amd.mppi import Engine
 
 
@@ -48,6 +49,7 @@ if __name__ == "__main__":
     ap.add_argument("--samples", default="125000")
     ap.add_argument("--horizon", type=int, default=50)
     ap.add_argument("--storage", default="f32")
+    ap.add_argument("--lib", default="probe", help="lib/libmppi_hip_<lib>.so (a build with -DMPPI_PROBE_TIMELINE)")
     ap.add_argument("--options", default="", help="name=value,... ; several sets separated by '/'")
     a = ap.parse_args()
     sets = [dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in s.split(",") if kv) for s in (a.options.split("/") if a.options else [""])]
