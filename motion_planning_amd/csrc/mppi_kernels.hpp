@@ -1992,20 +1992,8 @@ __global__ __launch_bounds__(1024) void finalize_kernel(DevParams P, const doubl
                                                       double* __restrict__ base, PkRow* __restrict__ pk, const double* state_src,
                                                       double* goal_keep) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-#ifdef MPPI_FIN_TWICE
-    // (timing experiment, never the product: the block runs twice, the second time with its instructions in the cache; the stamps a
-    // diagnostic build reads back are the second pass's.  Its outputs are not a tick's: state and counter advance twice.)
-    const int reps = P.T > 0 ? 2 : 1;
-#pragma clang loop unroll(disable)
-    for (int rep = 0; rep < reps; ++rep) {
-        finalize_block(P, blockIdx.x, gathered, G, lay, Smat, unom, ufilt, state, outv, tick_ptr, flags, tick_set, host_out, host_seq,
-                       seq, smem_raw, wait, goal, tc, base, pk, state_src, goal_keep);
-        __syncthreads();
-    }
-#else
     finalize_block(P, blockIdx.x, gathered, G, lay, Smat, unom, ufilt, state, outv, tick_ptr, flags, tick_set, host_out, host_seq,
                    seq, smem_raw, wait, goal, tc, base, pk, state_src, goal_keep);
-#endif
 }
 #endif
 
