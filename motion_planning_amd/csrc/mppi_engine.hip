@@ -641,7 +641,7 @@ struct mppi_engine {
         const int n8 = (cfg.samples + ch8 - 1) / ch8, n16 = (cfg.samples + 2 * ch8 - 1) / (2 * ch8);
         upd_nv = upd_nv_opt ? upd_nv_opt : ((n8 > kDirectTuples && n16 <= kDirectTuples) ? 16 : 8);
         if (noise_pack) upd_nv = 8;   // (the other noise packings' re-draws are built into the streaming shape only)
-        CH = ch8 * (upd_nv / 8);
+        CH = ch8 * upd_nv / 8;
         NCH = (cfg.samples + CH - 1) / CH;
     }
     void launch_update(hipStream_t st, int ch0, int nch, const uint32_t* tick_ptr = nullptr, int dp_shift = 0) {

@@ -1325,7 +1325,7 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
     // block's vectors are dealt to the waves in 1-KB pieces, so the four queues fill evenly.)  A wave whose queue overflows
     // (sigma = 0, a flat cost: every sample carries weight) walks its own values again from L2 and re-draws each candidate
     // in place.
-    constexpr int kQueue = (sizeof(S) == 8 ? 1024 : 2048) * (NV / kUpdNV);   // (per sample of the chunk as before)
+    constexpr int kQueue = (sizeof(S) == 8 ? 1024 : 2048) * NV / kUpdNV;   // (per sample of the chunk as before)
     constexpr int kQW = kQueue / 4;   // per wave
     __shared__ uint32_t q_k[REGEN ? kQueue : 1];
     __shared__ R q_e[REGEN ? kQueue : 1];

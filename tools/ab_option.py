@@ -9,6 +9,9 @@ durations, and the outputs (which must not differ between the values of an optio
 import argparse, json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from motion_planning_amd import _capi
+if os.environ.get("MPPI_AB_LIB"):   # a measurement build (make VARIANT=name): lib/libmppi_hip_<name>.so instead of the product library
+    _capi.LIB_PATH = os.path.join(os.path.dirname(_capi.LIB_PATH), "libmppi_hip_%s.so" % os.environ["MPPI_AB_LIB"])
 from motion_planning_amd.mppi import Engine
 
 
