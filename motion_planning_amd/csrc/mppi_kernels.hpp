@@ -1278,11 +1278,53 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
     // pass 1: the chunk into registers, lane minimum
     S v[NV][VEC];
     R m = (R)INFINITY;
+    constexpr bool kNtRows = MPPI_UPD_LOAD_NT < 0 ? sizeof(S) == 8 : MPPI_UPD_LOAD_NT != 0;
+#ifdef MPPI_UPD_SERIAL_LOADS   // (measurement build: the general path for every chunk, as the kernel stood until round 5)
+    constexpr bool kWholeChunkPath = false;
+#else
+    constexpr bool kWholeChunkPath = true;
+#endif
+    if (kWholeChunkPath && k_end - k_begin == CH) {
+        // (uniform) a whole chunk -- every chunk of a row but its last: no per-lane bounds, so ALL of the chunk's row loads are in flight
+        // before the first is waited for.  (Round 5: behind the per-lane guard of the general path below each vector's two loads sit in
+        // their own basic block with their own s_waitcnt vmcnt(0) -- eight serial round trips per workgroup, one 16-byte load per lane
+        // in flight: that, not the DRAM, was what held this kernel at 5.4 TB/s in 4-byte rows and 4.8 in 8-byte ones.)
+        // In flight per lane: the HBM loads of up to eight vectors of the row (32 registers), and the per-sample totals (L2 hits) in
+        // groups of kSvGroup behind them -- sized so that the kernel keeps its eight workgroups per CU.
+        constexpr int kPvDepth = NV < 8 ? NV : 8;
+#ifndef MPPI_UPD_SV_GROUP
+#define MPPI_UPD_SV_GROUP 4
+#endif
+        constexpr int kSvGroup = MPPI_UPD_SV_GROUP < kPvDepth ? MPPI_UPD_SV_GROUP : kPvDepth;
+#pragma unroll
+        for (int h = 0; h < NV; h += kPvDepth) {
+            vec_t pv[kPvDepth];
+#pragma unroll
+            for (int j = 0; j < kPvDepth; ++j) {
+                const int k = k_begin + ((h + j) * 256 + tid) * VEC;
+                pv[j] = kNtRows ? __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(v_row + k)) : *reinterpret_cast<const vec_t*>(v_row + k);
+            }
+#pragma unroll
+            for (int g = 0; g < kPvDepth; g += kSvGroup) {
+                vec_t sv[kSvGroup];
+#pragma unroll
+                for (int j = 0; j < kSvGroup; ++j) sv[j] = *reinterpret_cast<const vec_t*>(s_row + k_begin + ((h + g + j) * 256 + tid) * VEC);
+                if (kSvGroup < kPvDepth) __builtin_amdgcn_sched_barrier(0);   // (the next group's loads stay behind this group's arithmetic)
+#pragma unroll
+                for (int j = 0; j < kSvGroup; ++j) {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) v[h + g + j][i] = sv[j][i] - pv[g + j][i];
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) m = fmin(m, v[h + g + j][i]);
+                }
+                if (kSvGroup < kPvDepth) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int k = k_begin + (j * 256 + tid) * VEC;
         if (k + VEC <= k_end) {  // rows are 256-byte aligned and k % VEC == 0: 16-byte aligned loads
-            constexpr bool kNtRows = MPPI_UPD_LOAD_NT < 0 ? sizeof(S) == 8 : MPPI_UPD_LOAD_NT != 0;
             const vec_t pv = kNtRows ? __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(v_row + k)) : *reinterpret_cast<const vec_t*>(v_row + k);
             const vec_t sv = *reinterpret_cast<const vec_t*>(s_row + k);
 #pragma unroll
