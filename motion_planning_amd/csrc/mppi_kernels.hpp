@@ -1512,9 +1512,35 @@ __global__ __launch_bounds__(256) void merge_kernel(DevParams P, const double* _
     const int t = blockIdx.x, a = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int nw = (int)blockDim.x >> 6;
     const double* src = part + ((size_t)a * P.T + t) * NCH * kTupleW;
+    // Up to kR tuples per thread are merged from registers: every one of them requested before anything is waited for (a clamped index
+    // instead of a per-lane guard around the loads -- a guard gives each load its own basic block and its own wait), one round trip to
+    // memory instead of three (count word -> minimum -> the rest).  More tuples than that: the two-pass loops.
+    constexpr int kR = 4;
+#ifdef MPPI_MERGE_LOOPS   // (measurement build: the two-pass loops for every launch, as the kernel stood)
+    const bool in_regs = false;
+#else
+    const bool in_regs = NCH <= kR * (int)blockDim.x;   // (uniform)
+#endif
+    double q[kR][7];
+    bool has[kR];
     double m = INFINITY;
-    for (int i = tid; i < NCH; i += (int)blockDim.x)
-        if (src[i * kTupleW + 6] > 0.0) m = fmin(m, src[i * kTupleW]);
+    if (in_regs) {
+#pragma unroll
+        for (int r = 0; r < kR; ++r) {
+            const int i = tid + r * (int)blockDim.x;
+            const double* p = src + (size_t)min(i, NCH - 1) * kTupleW;
+#pragma unroll
+            for (int c = 0; c < 7; ++c) q[r][c] = p[c];
+        }
+#pragma unroll
+        for (int r = 0; r < kR; ++r) {
+            has[r] = tid + r * (int)blockDim.x < NCH && q[r][6] > 0.0;
+            if (has[r]) m = fmin(m, q[r][0]);
+        }
+    } else {
+        for (int i = tid; i < NCH; i += (int)blockDim.x)
+            if (src[i * kTupleW + 6] > 0.0) m = fmin(m, src[i * kTupleW]);
+    }
     double M = wave_min(m);
     if (nw > 1) {
         if (lane == 0) sh[wid][0] = M;
@@ -1524,11 +1550,20 @@ __global__ __launch_bounds__(256) void merge_kernel(DevParams P, const double* _
         __syncthreads();
     }
     double d = 0, n0 = 0, n1 = 0, e0 = 0, e1 = 0, cnt = 0;
-    for (int i = tid; i < NCH; i += (int)blockDim.x) {
-        const double* q = src + i * kTupleW;
-        if (q[6] > 0.0) {
-            const double sc = exp((M - q[0]) * P.inv_lambda);
-            d += sc * q[1]; n0 += sc * q[2]; n1 += sc * q[3]; e0 += q[4]; e1 += q[5]; cnt += q[6];
+    if (in_regs) {
+#pragma unroll
+        for (int r = 0; r < kR; ++r)
+            if (has[r]) {
+                const double sc = exp((M - q[r][0]) * P.inv_lambda);
+                d += sc * q[r][1]; n0 += sc * q[r][2]; n1 += sc * q[r][3]; e0 += q[r][4]; e1 += q[r][5]; cnt += q[r][6];
+            }
+    } else {
+        for (int i = tid; i < NCH; i += (int)blockDim.x) {
+            const double* qq = src + i * kTupleW;
+            if (qq[6] > 0.0) {
+                const double sc = exp((M - qq[0]) * P.inv_lambda);
+                d += sc * qq[1]; n0 += sc * qq[2]; n1 += sc * qq[3]; e0 += qq[4]; e1 += qq[5]; cnt += qq[6];
+            }
         }
     }
     d = wave_sum(d); n0 = wave_sum(n0); n1 = wave_sum(n1);
