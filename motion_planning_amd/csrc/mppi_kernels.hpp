@@ -871,6 +871,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(S) =
     const int tid = threadIdx.x, a = blockIdx.y, T = P.T;
     ClockProbe probe(P);
     snapshot_inputs(P, state, goal, unom, a);
+    // the pose and the goal ONCE, in front of the prologue (they were read again behind its barrier: two more dependent round trips in
+    // every wave -- over PCIe when the tick's inputs are fresh and sit in the pinned slot); the prologue wave takes the same values
+    const double st_x = state[a * 3 + 0], st_y = state[a * 3 + 1], st_th = state[a * 3 + 2];
+    const double g_x = goal[a * 3 + 0], g_y = goal[a * 3 + 1], g_th = goal[a * 3 + 2];
     // LEAN: the node's own cost and model (rk4 diff-drive, Q = diag(q, q, 0) with q > 0, no obstacle grid).
     // Its step is written in scaled variables so that constants fold away (5 fp64 instructions fewer per step):
     //   wheel speeds times half_kd (the table holds half_kd * un, the clip bound is half_kd * u_max):
@@ -894,7 +898,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(S) =
         __shared__ double nom_sh[4];
         if (INLINE_NOM == 2 || tid < 64) {
             double row[5], base_t;
-            nominal_lanes<(INLINE_NOM == 2 ? 4 : 1)>(P, state, goal, unom, a, tid, row, base_t, nom_sh, head_sh);
+            nominal_lanes_v<(INLINE_NOM == 2 ? 4 : 1)>(P, st_x, st_y, st_th, g_x, g_y, g_th, tid < T ? unom[(a * 2 + 0) * T + tid] : 0.0,
+                                                      tid < T ? unom[(a * 2 + 1) * T + tid] : 0.0, tid, row, base_t, nom_sh, head_sh, nullptr);
             if (tid == 0) head_sh[2] = P.lean_inv_f;
             if (tid < T) {
 #pragma unroll
@@ -922,9 +927,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(S) =
     const int k = k_first + blockIdx.x * 256 + tid;  // this launch covers samples [k_first, k_last)
     const bool active = k < k_last;
     const size_t Ks = (size_t)P.Ks;
-    double gx = goal[a * 3 + 0], gy = goal[a * 3 + 1];
-    const double gth = goal[a * 3 + 2];
-    double x = state[a * 3 + 0], y = state[a * 3 + 1], th = state[a * 3 + 2];
+    double gx = g_x, gy = g_y;
+    const double gth = g_th;
+    double x = st_x, y = st_y, th = st_th;
     double c = head_sh[0], s = head_sh[1];
     if (LEAN) {
         const double f = P.lean_f, rho = P.lean_rho;
