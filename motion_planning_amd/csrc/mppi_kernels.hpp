@@ -875,6 +875,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(S) =
     // every wave -- over PCIe when the tick's inputs are fresh and sit in the pinned slot); the prologue wave takes the same values
     const double st_x = state[a * 3 + 0], st_y = state[a * 3 + 1], st_th = state[a * 3 + 2];
     const double g_x = goal[a * 3 + 0], g_y = goal[a * 3 + 1], g_th = goal[a * 3 + 2];
+    const uint32_t tick_in = PHILOX ? (tick_ptr ? *tick_ptr : tick_arg) : 0u;
     // LEAN: the node's own cost and model (rk4 diff-drive, Q = diag(q, q, 0) with q > 0, no obstacle grid).
     // Its step is written in scaled variables so that constants fold away (5 fp64 instructions fewer per step):
     //   wheel speeds times half_kd (the table holds half_kd * un, the clip bound is half_kd * u_max):
@@ -960,7 +961,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(S) =
     if (PHILOX) {
         key0 = (uint32_t)seed; key1 = (uint32_t)(seed >> 32);
         ctr0 = P.sample_offset + (uint32_t)k;
-        tick = tick_ptr ? *tick_ptr : tick_arg;
+        tick = tick_in;
         sigf = (float)P.sigma;
     }
 
@@ -1622,16 +1623,19 @@ __global__ __launch_bounds__(256) void scan_tick_kernel(DevParams P, const doubl
     const double gx = goal[a * 3 + 0], gy = goal[a * 3 + 1], gth = goal[a * 3 + 2];
     const double un0 = valid ? unom[(a * 2 + 0) * T + t] : 0.0;
     const double un1 = valid ? unom[(a * 2 + 1) * T + t] : 0.0;
+    const uint32_t tick = PHILOX ? (tick_ptr ? *tick_ptr : tick_arg) : 0u;   // (with the other inputs: one round trip, not one more behind the snapshot)
     if (first_block) {  // pre-tick snapshot: prev = {unom [A][2][T], state [A][3], goal [A][3]}
         double* pv_state = prev + (size_t)P.A * 2 * T;
         double* pv_goal = pv_state + (size_t)P.A * 3;
         if ((NWAVES == 4 || wid == 0) && valid) { prev[(a * 2 + 0) * T + t] = un0; prev[(a * 2 + 1) * T + t] = un1; }
         if (tid < 3) {
-            pv_state[a * 3 + tid] = state[a * 3 + tid]; pv_goal[a * 3 + tid] = goal[a * 3 + tid];
-            // `state` / `goal` may be the caller's pinned host slot (zero-copy input: no H2D copy in front of the
-            // tick); the device-resident copies the later kernels (finalize's plant step) read are refreshed here
-            if (state_keep != state) state_keep[a * 3 + tid] = state[a * 3 + tid];
-            if (goal_keep != goal) goal_keep[a * 3 + tid] = goal[a * 3 + tid];
+            // (from the values read above, not from memory again: `state` / `goal` may be the caller's pinned host slot -- zero-copy
+            // input: no H2D copy in front of the tick -- and every further load of it is another trip over PCIe in front of this block)
+            const double sv = tid == 0 ? x0 : (tid == 1 ? y0 : th0), gv = tid == 0 ? gx : (tid == 1 ? gy : gth);
+            pv_state[a * 3 + tid] = sv; pv_goal[a * 3 + tid] = gv;
+            // the device-resident copies the later kernels (finalize's plant step) read are refreshed here
+            if (state_keep != state) state_keep[a * 3 + tid] = sv;
+            if (goal_keep != goal) goal_keep[a * 3 + tid] = gv;
         }
     }
     const double half_uru = 0.5 * (P.r0 * un0 * un0 + P.r1 * un1 * un1 + (P.offdiag ? 2.0 * (P.r01 * un0 * un1) : 0.0));
@@ -1639,11 +1643,10 @@ __global__ __launch_bounds__(256) void scan_tick_kernel(DevParams P, const doubl
     cost_noise_weights(P, un0, un1, w0, w1);
     double sth0, cth0;
     sincos(th0, &sth0, &cth0);
-    uint32_t key0 = 0, key1 = 0, tick = 0;
+    uint32_t key0 = 0, key1 = 0;
     float sigf = 0.f;
     if (PHILOX) {
         key0 = (uint32_t)seed; key1 = (uint32_t)(seed >> 32);
-        tick = tick_ptr ? *tick_ptr : tick_arg;
         sigf = (float)P.sigma;
     }
     double m = INFINITY, D = 0.0, N0 = 0.0, N1 = 0.0, E0 = 0.0, E1 = 0.0, cnt = 0.0;
