@@ -404,11 +404,20 @@ __device__ __forceinline__ void merge_row16_vals(bool has, double m, double (&v)
 #pragma unroll
     for (int i = 0; i < 6; ++i) t[i + 1] = v[i];
 }
-__device__ __forceinline__ void merge_row16(const double* q, double inv_lambda, double (&t)[7]) {
-    const bool has = q != nullptr && q[6] > 0.0;
+// q = this lane's tuple or nullptr; safe = any readable tuple: the lanes without one read THAT, so that all seven words of every lane are
+// requested at once (behind a guard the count word was one round trip to memory and the rest a second one behind it)
+__device__ __forceinline__ void merge_row16_words(bool mine, const double (&w)[7], double inv_lambda, double (&t)[7]) {
+    const bool has = mine && w[6] > 0.0;
     double v[6] = {0, 0, 0, 0, 0, 0};
-    if (has) { v[0] = q[1]; v[1] = q[2]; v[2] = q[3]; v[3] = q[4]; v[4] = q[5]; v[5] = q[6]; }
-    merge_row16_vals(has, has ? q[0] : INFINITY, v, inv_lambda, t);
+    if (has) { v[0] = w[1]; v[1] = w[2]; v[2] = w[3]; v[3] = w[4]; v[4] = w[5]; v[5] = w[6]; }
+    merge_row16_vals(has, has ? w[0] : INFINITY, v, inv_lambda, t);
+}
+__device__ __forceinline__ void merge_row16(const double* q, const double* safe, double inv_lambda, double (&t)[7]) {
+    const double* p = q != nullptr ? q : safe;
+    double w[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) w[i] = p[i];
+    merge_row16_words(q != nullptr, w, inv_lambda, t);
 }
 // 64-lane sum with DPP adds only (no LDS traffic): after the four row steps every lane of a
 // 16-lane row holds its row sum, row_bcast15 / row_bcast31 chain the rows; LANE 63 holds the total.
@@ -1811,7 +1820,15 @@ constexpr int kFlagStride = 16;  // uint32 per flag line
 struct P2PPeers { double* data[8]; uint32_t* flag[8]; };  // slot `rank` of each peer's mailbox, for one parity
 __global__ __launch_bounds__(256) void p2p_publish_kernel(const double* __restrict__ src, int n, P2PPeers peers, uint32_t epoch) {
     double* dst = peers.data[blockIdx.x];
-    for (int i = threadIdx.x; i < n; i += 256) __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const int nt = (int)blockDim.x;
+    for (int i0 = threadIdx.x; i0 < n; i0 += 4 * nt) {   // four words per thread requested before the first is stored (clamped index, no guard)
+        double w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = src[min(i0 + j * nt, n - 1)];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i0 + j * nt < n) __hip_atomic_store(dst + i0 + j * nt, w[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope: every store of this wave has left for the peer
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1826,13 +1843,32 @@ __global__ __launch_bounds__(256) void p2p_publish_merge_kernel(DevParams P, con
                                                                P2PPeers peers, uint32_t epoch) {
     double* dst = peers.data[blockIdx.x];
     const int r = threadIdx.x >> 4, g = threadIdx.x & 15;   // 16 lanes per row, 16 rows per pass
-    for (int r0 = 0; r0 < n_rows; r0 += 16) {               // (uniform trip count)
-        const int row = r0 + r;
-        const double* q = (row < n_rows && g < NCH) ? part + ((size_t)row * NCH + g) * kTupleW : nullptr;
-        double t[7];
-        merge_row16(q, P.inv_lambda, t);
-        if (row < n_rows && g < kTupleW)   // lanes 0..7 of the row store the eight words of its tuple
-            __hip_atomic_store(dst + (size_t)row * kTupleW + g, g < 7 ? t[g] : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // Four passes' tuples (64 rows: the node's [T = 50][8] block whole) are requested before the first is merged: every round trip to
+    // the tuples -- they come from the update kernel's write-through stores, i.e. from memory -- is a microsecond in front of the
+    // peers' finalize kernels.  (Until round 5: a pass at a time, and within a pass the count word first and the rest behind it: eight
+    // dependent round trips for T = 50.  A 1024-thread workgroup does the same in one pass but has to find a whole free CU: measured
+    // slower next to another process's kernels.)
+    constexpr int kB = 4;
+    for (int r0 = 0; r0 < n_rows; r0 += 16 * kB) {          // (uniform trip count)
+        double w[kB][7];
+        bool mine[kB];
+#pragma unroll
+        for (int b = 0; b < kB; ++b) {
+            const int row = r0 + b * 16 + r;
+            mine[b] = row < n_rows && g < NCH;
+            const double* p = mine[b] ? part + ((size_t)row * NCH + g) * kTupleW : part;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) w[b][i] = p[i];
+        }
+#pragma unroll
+        for (int b = 0; b < kB; ++b) {
+            const int row = r0 + b * 16 + r;
+            if (r0 + b * 16 >= n_rows) break;               // (uniform)
+            double t[7];
+            merge_row16_words(mine[b], w[b], P.inv_lambda, t);
+            if (row < n_rows && g < kTupleW)   // lanes 0..7 of the row store the eight words of its tuple
+                __hip_atomic_store(dst + (size_t)row * kTupleW + g, g < 7 ? t[g] : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1931,7 +1967,7 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
             const int t = t0 + r;
             const double* q = (t < T && g < G) ? gathered + (size_t)a * lay.as + (size_t)t * lay.ts + (size_t)g * lay.gs : nullptr;
             double m[7];
-            merge_row16(q, P.inv_lambda, m);
+            merge_row16(q, gathered + (size_t)a * lay.as, P.inv_lambda, m);
             if (g == 0 && t < T) apply(t, m[1], m[2], m[3], m[4], m[5], m[6]);
         }
     } else {
