@@ -391,6 +391,16 @@ def test_python_shell_fast_paths_still_see_every_change():
     for _ in range(200):                                              # across several doublings of the buffers
         m.get_path(m.start, m.goal)
     assert m.path.shape == (212, 3) and np.array_equal(m.path[:12], old) and old.shape == (12, 3)
-    m.path = np.zeros((1, 3)); m.uvec = [[1.0, 2.0]]
+    src = np.zeros((1, 3))
+    m.path = src; m.uvec = [[1.0, 2.0]]
     m.get_path(m.start, m.goal)
     assert m.path.shape == (2, 3) and m.uvec.shape == (2, 2) and np.all(m.uvec[0] == [1.0, 2.0])
+    # the documented view semantics: assignment copies (the caller's array is never appended to); a held view writes
+    # through to the log until the buffer is next re-allocated, and keeps its own rows afterwards
+    assert src.shape == (1, 3) and not np.shares_memory(m.path, src)
+    held = m.path
+    held[0, 0] = 7.0
+    assert m.path[0, 0] == 7.0
+    for _ in range(100):
+        m.get_path(m.start, m.goal)
+    assert held.shape == (2, 3) and held[0, 0] == 7.0 and m.path[0, 0] == 7.0 and not np.shares_memory(held, m.path)
