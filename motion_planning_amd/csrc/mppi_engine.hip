@@ -644,50 +644,23 @@ struct mppi_engine {
         CH = ch8 * upd_nv / 8;
         NCH = (cfg.samples + CH - 1) / CH;
     }
-    // Chunks one update workgroup walks (update_kernel GROUPS) in an un-pieced tick: with ceil(chunks / 16) of them a row is left with at
-    // most kDirectTuples tuples and no merge launch follows.  Option "upd_group": 0 the engine's rule, -1 one chunk per workgroup, n > 0.
-    int upd_group_opt = 0;
-    int upd_per_group() const {
-        if (upd_group_opt < 0 || NCH <= 1 || upd_nv != 8 || noise_pack) return 1;   // (the grouped instance: eight vectors per lane, the default noise stream)
-        if (upd_group_opt > 0) return std::min(upd_group_opt, NCH);
-        if (NCH <= kDirectTuples) return 1;
-        // groups per row: <= kDirectTuples, and -- the grouped kernel keeps four workgroups per CU -- so that the launch is ONE round of
-        // the chip's 1024 resident ones where that is possible (config 4: 50 rows x 16 groups = 800)
-        const long rows = (long)cfg.n_agents * cfg.horizon;
-        int ng = kDirectTuples;
-        if (rows * ng > 1024 && rows * 8 <= 1024) ng = (int)(1024 / rows);
-        return (NCH + ng - 1) / ng;
-    }
-    // per_group > 1 (ch0 = 0, nch = NCH only): the launch writes ceil(NCH / per_group) tuples per row into d_part
-    void launch_update(hipStream_t st, int ch0, int nch, const uint32_t* tick_ptr = nullptr, int dp_shift = 0, int per_group = 1) {
+    void launch_update(hipStream_t st, int ch0, int nch, const uint32_t* tick_ptr = nullptr, int dp_shift = 0) {
         ensure_epart(st);
         const char* dP_at = static_cast<const char*>(d_dP) - (size_t)dp_shift * esz();
         Scope sc(this, MPPI_KERNEL_UPDATE, st);
-        const int n_chunks = NCH;
-        int NCH = n_chunks;   // (what the kernel counts its columns in: chunks, or groups of them)
-        if (per_group > 1) { NCH = (n_chunks + per_group - 1) / per_group; ch0 = 0; nch = NCH; }
         dim3 grid(8 * cfg.horizon, (cfg.n_agents * nch + 7) / 8);  // XCD-aware decode inside the kernel
 #define LAUNCH_UPD(TYPE, REGEN)                                                                                  \
     hipLaunchKernelGGL((mppi::update_kernel<TYPE, REGEN>), grid, dim3(256), 0, st, P, static_cast<const TYPE*>(d_eps), \
                        reinterpret_cast<const TYPE*>(dP_at), static_cast<const TYPE*>(d_stot), d_part, NCH, ch0, nch,    \
-                       static_cast<const TYPE*>(d_epart), lazy_seed, lazy_tick, tick_ptr, upd_skip_light, per_group, n_chunks)
+                       static_cast<const TYPE*>(d_epart), lazy_seed, lazy_tick, tick_ptr, upd_skip_light)
 #define LAUNCH_UPD_PACK(PK)                                                                                               \
     hipLaunchKernelGGL((mppi::update_kernel<float, true, PK>), grid, dim3(256), 0, st, P, static_cast<const float*>(d_eps), \
                        reinterpret_cast<const float*>(dP_at), static_cast<const float*>(d_stot), d_part, NCH, ch0, nch,           \
-                       static_cast<const float*>(d_epart), lazy_seed, lazy_tick, tick_ptr, upd_skip_light, per_group, n_chunks)
+                       static_cast<const float*>(d_epart), lazy_seed, lazy_tick, tick_ptr, upd_skip_light)
 #define LAUNCH_UPD16(TYPE, REGEN)                                                                                  \
     hipLaunchKernelGGL((mppi::update_kernel<TYPE, REGEN, 0, 16>), grid, dim3(256), 0, st, P, static_cast<const TYPE*>(d_eps), \
                        reinterpret_cast<const TYPE*>(dP_at), static_cast<const TYPE*>(d_stot), d_part, NCH, ch0, nch,    \
-                       static_cast<const TYPE*>(d_epart), lazy_seed, lazy_tick, tick_ptr, upd_skip_light, per_group, n_chunks)
-#define LAUNCH_UPDG(TYPE, REGEN)                                                                                  \
-    hipLaunchKernelGGL((mppi::update_kernel<TYPE, REGEN, 0, 8, true>), grid, dim3(256), 0, st, P, static_cast<const TYPE*>(d_eps), \
-                       reinterpret_cast<const TYPE*>(dP_at), static_cast<const TYPE*>(d_stot), d_part, NCH, ch0, nch,    \
-                       static_cast<const TYPE*>(d_epart), lazy_seed, lazy_tick, tick_ptr, upd_skip_light, per_group, n_chunks)
-        if (per_group > 1) {
-            if (f64()) { if (eps_lazy) LAUNCH_UPDG(double, true); else LAUNCH_UPDG(double, false); }
-            else { if (eps_lazy) LAUNCH_UPDG(float, true); else LAUNCH_UPDG(float, false); }
-        } else
-#undef LAUNCH_UPDG
+                       static_cast<const TYPE*>(d_epart), lazy_seed, lazy_tick, tick_ptr, upd_skip_light)
         if (upd_nv == 16) {
             if (f64()) { if (eps_lazy) LAUNCH_UPD16(double, true); else LAUNCH_UPD16(double, false); }
             else { if (eps_lazy) LAUNCH_UPD16(float, true); else LAUNCH_UPD16(float, false); }
@@ -773,10 +746,9 @@ struct mppi_engine {
             noise_ready = true; value_ready = false; value_lazy = true; partials_ready = true; epart_ready = false;
             return;
         }
+        merge_skipped = (skip_small_merge || (p2p_connected && !p2p_internal)) && NCH <= kDirectTuples;
+        direct_n = NCH;
         const int pieces = tick_pieces(ph, store);
-        const int pg = pieces > 1 ? 1 : upd_per_group(), ng = (NCH + pg - 1) / pg;   // tuples per row the update leaves
-        merge_skipped = (skip_small_merge || (p2p_connected && !p2p_internal)) && ng <= kDirectTuples;
-        direct_n = ng;
         if (pieces > 1) {
             // Infinity-Cache-sized pieces: rollout + update per piece, every piece's cost prefix in the same columns of d_dP -- what the
             // rollout wrote is read back before anything evicts it, and the next piece overwrites it in place (nothing of it ever has
@@ -804,8 +776,8 @@ struct mppi_engine {
             P.snap = snap_was;
             if (in_slot >= 0) inputs_consumed();
         }
-        launch_update(stream, 0, NCH, tick_ptr, 0, pg);
-        if (!merge_skipped) launch_merge(ng);
+        launch_update(stream, 0, NCH, tick_ptr);
+        if (!merge_skipped) launch_merge(NCH);
         noise_ready = true; value_ready = true; value_lazy = false; partials_ready = true; epart_ready = true;
     }
     // How many pieces a lane-per-sample tick runs its samples in (option "k_pieces"; include/mppi_hip_diag.h)
@@ -1199,7 +1171,7 @@ void mppi_engine::co_build() {
             e->sync_timeout_ms = sync_timeout_ms;
             e->store_eps_always = store_eps_always; e->use_pk = use_pk; e->upd_skip_light = upd_skip_light; e->pk_waves = pk_waves;
             e->pk_min_set = pk_min_set; e->pk_min_samples = pk_min_samples; e->noise_pack = noise_pack;
-            e->fin_threads_opt = fin_threads_opt; e->upd_group_opt = upd_group_opt; e->k_pieces_opt = k_pieces_opt; e->hoist_opt = hoist_on() ? 1 : 0;
+            e->fin_threads_opt = fin_threads_opt; e->k_pieces_opt = k_pieces_opt; e->hoist_opt = hoist_on() ? 1 : 0;
             if (upd_nv_opt) { e->upd_nv_opt = upd_nv_opt; e->pick_update_shape(); }
             for (int i = 0; i < 7; ++i) e->w_off[i] = w_off[i];
             e->refresh_weights();
@@ -1241,7 +1213,7 @@ void mppi_engine::co_build() {
             e->sync_timeout_ms = sync_timeout_ms;
             e->store_eps_always = store_eps_always; e->use_pk = use_pk; e->upd_skip_light = upd_skip_light; e->pk_waves = pk_waves;
             e->pk_min_set = pk_min_set; e->pk_min_samples = pk_min_samples; e->noise_pack = noise_pack;
-            e->fin_threads_opt = fin_threads_opt; e->upd_group_opt = upd_group_opt; e->k_pieces_opt = k_pieces_opt; e->hoist_opt = hoist_on() ? 1 : 0;
+            e->fin_threads_opt = fin_threads_opt; e->k_pieces_opt = k_pieces_opt; e->hoist_opt = hoist_on() ? 1 : 0;
             if (upd_nv_opt) { e->upd_nv_opt = upd_nv_opt; e->pick_update_shape(); }
             for (int i = 0; i < 7; ++i) e->w_off[i] = w_off[i];
             e->refresh_weights();
@@ -2161,10 +2133,6 @@ int mppi_set_option(mppi_engine* h, const char* key, int64_t value) {
         h->invalidate_table();
     }
     else if (k == "lanes_zero_copy") h->lanes_zero_copy = value != 0;
-    else if (k == "upd_group") {
-        if (value < -1 || value > 4096) fail(MPPI_E_INVALID, "upd_group: 0 (the engine's rule), -1 (one chunk per workgroup + the merge launch) or n chunks per workgroup");
-        h->upd_group_opt = (int)value; h->partials_ready = false; h->destroy_graph();
-    }
     else if (k == "upd_nv") {
         if (value != 0 && value != 8 && value != 16) fail(MPPI_E_INVALID, "upd_nv: 0 (by size), 8 or 16");
         if (h->co_active()) fail(MPPI_E_STATE, "upd_nv: set it before the handle builds its co-scheduled shards (their cuts follow the chunk length)");
@@ -2190,7 +2158,7 @@ int mppi_set_option(mppi_engine* h, const char* key, int64_t value) {
                 e->store_eps_always = h->store_eps_always; e->use_pk = h->use_pk; e->upd_skip_light = h->upd_skip_light; e->pk_waves = h->pk_waves;
                 e->pk_min_set = h->pk_min_set; e->pk_min_samples = h->pk_min_samples; e->sync_timeout_ms = h->sync_timeout_ms;
                 e->noise_pack = h->noise_pack;
-                e->fin_threads_opt = h->fin_threads_opt; e->upd_group_opt = h->upd_group_opt; e->k_pieces_opt = h->k_pieces_opt; e->hoist_opt = h->hoist_on() ? 1 : 0;
+                e->fin_threads_opt = h->fin_threads_opt; e->k_pieces_opt = h->k_pieces_opt; e->hoist_opt = h->hoist_on() ? 1 : 0;
             }
         }
     }
@@ -2209,7 +2177,6 @@ int mppi_get_option(mppi_engine* h, const char* key, int64_t* value) {
     else if (k == "pk_waves") *value = h->pk_waves;
     else if (k == "upd_nv") *value = h->upd_nv;
     else if (k == "lanes_zero_copy") *value = h->lanes_zero_copy;
-    else if (k == "upd_group") *value = h->upd_group_opt;
     else if (k == "fin_threads") *value = h->fin_threads_opt;
     else if (k == "k_pieces") *value = h->k_pieces_opt;
     else if (k == "table_hoist") *value = h->hoist_opt;
@@ -2323,7 +2290,7 @@ int mppi_engine_info(mppi_engine* h, size_t* hbm_bytes, int32_t* rollout_blocks,
     // what a tick launches: the scan kernel alone (no update kernel), or rollout + update
     const bool scan = h->small_nb > 0;
     if (rollout_blocks) *rollout_blocks = (scan ? h->small_nb : h->roll_blocks) * h->cfg.n_agents;
-    if (update_blocks) *update_blocks = scan ? 0 : ((h->NCH + h->upd_per_group() - 1) / h->upd_per_group()) * h->cfg.horizon * h->cfg.n_agents;
+    if (update_blocks) *update_blocks = scan ? 0 : h->NCH * h->cfg.horizon * h->cfg.n_agents;
     API_END(h)
 }
 

@@ -1249,33 +1249,16 @@ __device__ __forceinline__ double uniform_value(double v) {
 constexpr int kUpdNV = 8;
 template <typename S, int NV = kUpdNV> struct UpdCfg { static constexpr int VEC = 16 / (int)sizeof(S); static constexpr int CH = 256 * NV * VEC; };
 
-template <typename S, bool REGEN, int PACK = 0, int NV = kUpdNV, bool GRP = false>
+template <typename S, bool REGEN, int PACK = 0, int NV = kUpdNV>
 // (fp64 storage: 64 VGPRs, eight blocks per CU -- since the eps sums are read behind the loops and the block minimum sits in scalar
 // registers; 70 before, and FORCING 64 then spilled five registers and measured slower on the same box, update 110-117 us against
 // 95-103.  Without spills the eighth block changes nothing: 99-100 us for its 400 MB either way.)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GRP ? 4 : 1, 8))) void update_kernel(DevParams P, const S* __restrict__ eps,
+__global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __restrict__ eps,
                                                     const S* __restrict__ dP, const S* __restrict__ Stot,
                                                     double* __restrict__ part, int NCH, int ch_first, int n_local,
                                                     const S* __restrict__ epart, uint64_t seed, uint32_t tick_arg,
-                                                    const uint32_t* __restrict__ tick_ptr, int skip_light, int per_group, int n_chunks) {
-    // GROUPS.  per_group = 1: a workgroup owns ONE chunk of its row; `NCH`, `ch_first`, `n_local` count chunks.  per_group > 1: it owns a
-    // group of per_group consecutive chunks (of the row's n_chunks), walks them from the highest down and folds every chunk's tuple into
-    // its running one -- the exact tuple merge, fp64, in LDS -- and `NCH`, `ch_first`, `n_local` count GROUPS: part[a][t][group].  With
-    // ceil(chunks / 16) chunks per group a row is left with <= 16 tuples, which the finalize / publish kernels merge themselves: no merge
-    // launch in the tick.  (Round 4 built this and lost 4 us to it: each chunk's loads were eight dependent round trips then, and 800
-    // long-lived workgroups kept 3 MB in flight.  With a chunk's loads in flight together -- 32 KB per workgroup -- they keep 25 MB.)
+                                                    const uint32_t* __restrict__ tick_ptr, int skip_light) {
     using R = S;
-    // workgroup barrier.  GRP: ordering LDS only -- __syncthreads() also waits for every global load in flight (s_waitcnt vmcnt(0) in
-    // front of s_barrier), which would be the end of the next chunk's prefetch at the first barrier behind it
-    auto bsync = [&]() __attribute__((always_inline)) {
-        if constexpr (GRP) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-        } else {
-            __syncthreads();
-        }
-    };
     constexpr int VEC = UpdCfg<S, NV>::VEC, CH = UpdCfg<S, NV>::CH;
     typedef S vec_t __attribute__((ext_vector_type(VEC)));
     // XCD-aware block -> (t, chunk) map.  Workgroups go to the 8 XCDs round-robin by linear id, and
@@ -1291,93 +1274,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GRP ? 4 : 1
     UpdProbe uprobe(P, id == (int)(gridDim.x * gridDim.y) / 2);   // (diagnostic builds only)
     if (col >= P.A * n_local) return;
     const int a = col / n_local, local = col % n_local;
-    const int grp_id = ch_first + n_local - 1 - local;   // the chunk (per_group 1) or the group of chunks this workgroup owns
+    const int ch = ch_first + n_local - 1 - local;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const size_t Ks = (size_t)P.Ks;
     const S* v_row = dP + ((size_t)a * P.T + t) * Ks;   // exclusive cost prefix of row t
     const S* s_row = Stot + (size_t)a * Ks;               // per-sample totals (L2-resident, re-read per t)
     const S* e0_row = eps + (((size_t)a * P.T + t) * 2 + 0) * Ks;
     const S* e1_row = e0_row + Ks;
-    double* o = part + (((size_t)a * P.T + t) * NCH + grp_id) * kTupleW;
-    __shared__ R red[4][6];
-    __shared__ double redN[4][2];
-    __shared__ double run[kTupleW];   // the group's running tuple {M, D, N0, N1, E0, E1, count, 0}
-    constexpr bool grouped = GRP;   // (the grouped instance is its own kernel: the plain one keeps its registers and its eight workgroups per CU)
-    static_assert(!GRP || NV == 8, "groups walk chunks of eight vectors per lane");
-    const int ch_lo = grouped ? grp_id * per_group : grp_id, ch_hi = grouped ? min(n_chunks, ch_lo + per_group) : grp_id + 1;
-    if (grouped && tid < kTupleW) run[tid] = tid == 0 ? (double)INFINITY : 0.0;
-    // GRP: the NEXT chunk's row vectors are requested as soon as this chunk's are consumed, so that the workgroup's HBM loads are in
-    // flight through its reduce / weight / re-draw phases (a few hundred long-lived workgroups have nobody else to cover those phases)
-    constexpr bool kNtRows = MPPI_UPD_LOAD_NT < 0 ? sizeof(S) == 8 : MPPI_UPD_LOAD_NT != 0;
-    vec_t pf[GRP ? 8 : 1];
-    bool have_pf = false;   // (uniform) pf holds the chunk about to be processed
-    // (the row as a raw buffer: one lane offset in a VGPR, the chunk / vector offsets scalar -- eight 64-bit addresses would cost sixteen
-    // registers that the prefetch holds through the whole chunk)
-    typedef unsigned u4v __attribute__((ext_vector_type(4)));
-    const __amdgpu_buffer_rsrc_t row_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<S*>(v_row), 0, (int)min((size_t)0x7FFFFFFF, Ks * sizeof(S)), 0x00020000);
-    auto row_fetch = [&](int kb, vec_t (&dst)[GRP ? 8 : 1]) __attribute__((always_inline)) {
-        if constexpr (GRP) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const u4v w = __builtin_amdgcn_raw_buffer_load_b128(row_rsrc, (unsigned)tid * 16u, (unsigned)(kb + j * 256 * VEC) * (unsigned)sizeof(S), kNtRows ? 2 : 0);
-                dst[j] = __builtin_bit_cast(vec_t, w);
-            }
-        }
-    };
-    R Eg0 = 0, Eg1 = 0;     // GRP: the chunk's eps sums, read in front of the prefetch (vmcnt completes in order)
-#pragma unroll 1
-    for (int ch = ch_hi - 1; ch >= ch_lo; --ch) {
     const int k_begin = ch * CH;
     const int k_end = min(P.K, k_begin + CH);
+    double* o = part + (((size_t)a * P.T + t) * NCH + ch) * kTupleW;
     if (k_end <= k_begin) {  // empty chunk (uniform)
-        if (grouped) continue;
         if (tid == 0) { o[0] = INFINITY; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = 0; o[7] = 0; }
         return;
     }
-    if (grouped) bsync();   // (the LDS scratch of the chunk before this one has been read)
+    __shared__ R red[4][6];
 
     // pass 1: the chunk into registers, lane minimum
     S v[NV][VEC];
     R m = (R)INFINITY;
+    constexpr bool kNtRows = MPPI_UPD_LOAD_NT < 0 ? sizeof(S) == 8 : MPPI_UPD_LOAD_NT != 0;
 #ifdef MPPI_UPD_SERIAL_LOADS   // (measurement build: the general path for every chunk, as the kernel stood until round 5)
     constexpr bool kWholeChunkPath = false;
 #else
     constexpr bool kWholeChunkPath = true;
 #endif
-    if (GRP && k_end - k_begin == CH) {
-        if constexpr (GRP) {
-            if (!have_pf) row_fetch(k_begin, pf);
-#pragma unroll
-            for (int g = 0; g < 8; g += 4) {
-                vec_t sv[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) sv[j] = *reinterpret_cast<const vec_t*>(s_row + k_begin + ((g + j) * 256 + tid) * VEC);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) v[g + j][i] = sv[j][i] - pf[g + j][i];
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) m = fmin(m, v[g + j][i]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            {   // this chunk's eps sums now: a load issued behind the prefetch could only be waited for together with it
-                const size_t NW = Ks >> 6;
-                const S* ep = epart + (((size_t)a * P.T + t) * 2) * NW;
-                const int w_begin = k_begin >> 6, w_end = (k_end + 63) >> 6;
-                Eg0 = 0; Eg1 = 0;
-                for (int w = w_begin + tid; w < w_end; w += 256) { Eg0 += ep[w]; Eg1 += ep[NW + w]; }
-            }
-            // (the lane minimum pinned HERE: left to itself the compiler sinks the subtract / min chain below the prefetch, and its waits
-            // -- vmcnt completes in order -- then wait for the prefetch as well)
-            asm volatile("" : "+v"(m) :: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            have_pf = ch - 1 >= ch_lo;   // (every chunk below the row's last is whole)
-            if (have_pf) row_fetch((ch - 1) * CH, pf);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    } else if (kWholeChunkPath && k_end - k_begin == CH) {
+    if (kWholeChunkPath && k_end - k_begin == CH) {
         // (uniform) a whole chunk -- every chunk of a row but its last: no per-lane bounds, so ALL of the chunk's row loads are in flight
         // before the first is waited for.  (Round 5: behind the per-lane guard of the general path below each vector's two loads sit in
         // their own basic block with their own s_waitcnt vmcnt(0) -- eight serial round trips per workgroup, one 16-byte load per lane
@@ -1432,12 +1354,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GRP ? 4 : 1
     uprobe.mark(0);   // the chunk is in registers (every load waited for)
     m = wave_min(m);
     if (lane == 0) red[wid][0] = m;
-    bsync();
+    __syncthreads();
     uprobe.mark(1);
     // (the block minimum is uniform: kept in scalar registers -- in the fp64 mode the two vector registers it would hold are what
     // stands between seven and eight blocks per CU)
     const R M = uniform_value(fmin(fmin(red[0][0], red[1][0]), fmin(red[2][0], red[3][0])));
-    bsync();
+    __syncthreads();
 
     // pass 2: weights relative to the block minimum; eps only where the weight is representable
     const R scale = (R)(P.inv_lambda * 1.4426950408889634);  // log2(e) / lambda
@@ -1534,51 +1456,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GRP ? 4 : 1
     // E = sum_k eps of this chunk from the per-wave sums (CH/64 entries per wheel, a few hundred bytes) -- formed here, behind the loops,
     // so that it does not hold registers through them
     R E0 = 0, E1 = 0;
-    if (GRP && k_end - k_begin == CH) {
-        E0 = Eg0; E1 = Eg1;
-    } else {
+    {
         const size_t NW = Ks >> 6;
         const S* ep = epart + (((size_t)a * P.T + t) * 2) * NW;
         const int w_begin = k_begin >> 6, w_end = (k_end + 63) >> 6;
         for (int w = w_begin + tid; w < w_end; w += 256) { E0 += ep[w]; E1 += ep[NW + w]; }
     }
     uprobe.mark(3);   // re-draws done, eps sums read
+    __shared__ double redN[4][2];
     const double N0d = wave_sum((double)N0 + Na0), N1d = wave_sum((double)N1 + Na1);
     D = wave_sum(D); E0 = wave_sum(E0); E1 = wave_sum(E1);
     if (lane == 0) { red[wid][1] = D; redN[wid][0] = N0d; redN[wid][1] = N1d; red[wid][4] = E0; red[wid][5] = E1; }
-    bsync();
-    if (!grouped) {
-        if (tid < 5) {
-            const int c = tid + 1;
-            o[c] = (c == 2 || c == 3) ? redN[0][c - 2] + redN[1][c - 2] + redN[2][c - 2] + redN[3][c - 2]
-                                      : (double)red[0][c] + (double)red[1][c] + (double)red[2][c] + (double)red[3][c];
-        } else if (tid == 5) {
-            o[0] = (double)M; o[6] = (double)(k_end - k_begin); o[7] = 0.0;
-        }
-    } else {
-        // fold this chunk's tuple into the group's (M = min; D, N rescaled by exp(-(m - M) / lam); E, count add): lanes 1..6 of wave 0 own
-        // one component each, all of them form the two rescaling factors (one wave: no extra time)
-        if (tid >= 1 && tid <= 6) {
-            const int c = tid;
-            const double mine = c == 6 ? (double)(k_end - k_begin)
-                              : (c == 2 || c == 3) ? redN[0][c - 2] + redN[1][c - 2] + redN[2][c - 2] + redN[3][c - 2]
-                                                   : (double)red[0][c] + (double)red[1][c] + (double)red[2][c] + (double)red[3][c];
-            const double Mr = run[0], Mc = (double)M, Mn = fmin(Mr, Mc);
-            if (c <= 3) {
-                const double sr = Mr == Mn ? 1.0 : (Mr == INFINITY ? 0.0 : exp((Mn - Mr) * P.inv_lambda));
-                const double sc = Mc == Mn ? 1.0 : exp((Mn - Mc) * P.inv_lambda);
-                run[c] = run[c] * sr + mine * sc;
-            } else {
-                run[c] += mine;
-            }
-        }
-        bsync();
-        if (tid == 0) run[0] = fmin(run[0], (double)M);
-    }
-    }   // chunks of the group
-    if (grouped) {
-        bsync();
-        if (tid < kTupleW) o[tid] = run[tid];
+    __syncthreads();
+    if (tid < 5) {
+        const int c = tid + 1;
+        o[c] = (c == 2 || c == 3) ? redN[0][c - 2] + redN[1][c - 2] + redN[2][c - 2] + redN[3][c - 2]
+                                  : (double)red[0][c] + (double)red[1][c] + (double)red[2][c] + (double)red[3][c];
+    } else if (tid == 5) {
+        o[0] = (double)M; o[6] = (double)(k_end - k_begin); o[7] = 0.0;
     }
     uprobe.mark(4);
 }
