@@ -299,6 +299,7 @@ struct mppi_engine {
     bool p2p_internal = false;  // the mailboxes belong to the co-scheduled group, not to a caller's cross-GPU exchange
     std::string co_fallback = "";   // why this handle runs unsplit although co-scheduling was possible (mppi_co_note)
     bool is_co_sub = false;     // this engine is a co-scheduled shard inside another handle
+    mppi_engine* alias_parent = nullptr; int alias_k0 = 0;   // (set before init) a co-scheduled K-shard: rows = columns of the parent's buffers
     // this engine's view of its own shard while a co-scheduled tick is enqueued: K, chunk count and launch geometry of shard 0
     struct ShardView {
         mppi_engine* e; int K, samples, NCH, roll_blocks; double* snap;
@@ -942,6 +943,7 @@ struct mppi_engine {
 
         const int A = cfg.n_agents, K = cfg.samples, T = cfg.horizon;
         P.A = A; P.K = K; P.T = T; P.Ks = (K + 63) / 64 * 64;
+        if (alias_parent) P.Ks = alias_parent->P.Ks;   // (a co-scheduled shard: its rows are columns of the handle's own)
         P.sample_offset = cfg.sample_offset;
         if (cfg.agent_offset < 0) fail(MPPI_E_INVALID, "agent_offset must be >= 0");
         P.agent_offset = (uint32_t)cfg.agent_offset;
@@ -964,7 +966,21 @@ struct mppi_engine {
         // update geometry: each block keeps one chunk of a row in registers
         pick_update_shape();
         const size_t Ks = (size_t)P.Ks;
-        {
+        if (alias_parent) {
+            // A co-scheduled K-shard fills COLUMNS [alias_k0, alias_k0 + K) of the handle's own rows (same row stride; the cut is a
+            // multiple of the update kernel's chunk): ONE layout in memory whatever the number of engines that fill it -- the same
+            // DRAM pages as the one-engine tick -- and nothing to allocate.
+            const size_t es = esz(), k0 = (size_t)alias_k0;
+            d_eps = static_cast<char*>(alias_parent->d_eps) + k0 * es;
+            d_dP = static_cast<char*>(alias_parent->d_dP) + k0 * es;
+            d_stot = static_cast<char*>(alias_parent->d_stot) + k0 * es;
+            // (the per-wave eps sums stay the shard's own: their rows are not multiples of a cache line long, so the cut falls INSIDE a
+            // line of every row -- two engines writing words of one line through different XCDs)
+            void* p = nullptr;
+            const size_t bytes = (size_t)A * T * 2 * (Ks / 64) * esz();
+            HIPCHK(hipMalloc(&p, bytes)); hbm_bytes += bytes; d_epart = p;
+            HIPCHK(hipMemsetAsync(d_epart, 0, bytes, stream));
+        } else {
             void* p = nullptr;
             size_t bytes = (size_t)A * T * 2 * Ks * esz();
             HIPCHK(hipMalloc(&p, bytes)); hbm_bytes += bytes; d_eps = p;
@@ -1028,9 +1044,11 @@ struct mppi_engine {
         HIPCHK(hipMemsetAsync(d_ufilt, 0, (size_t)A * 2 * T * sizeof(double), stream));
         HIPCHK(hipMemsetAsync(d_out, 0, (size_t)A * 8 * sizeof(double), stream));
         HIPCHK(hipMemsetAsync(d_tick, 0, sizeof(uint32_t), stream));
-        HIPCHK(hipMemsetAsync(d_eps, 0, (size_t)A * T * 2 * Ks * esz(), stream));
-        HIPCHK(hipMemsetAsync(d_dP, 0, (size_t)A * T * Ks * esz(), stream));
-        HIPCHK(hipMemsetAsync(d_stot, 0, (size_t)A * Ks * esz(), stream));
+        if (!alias_parent) {
+            HIPCHK(hipMemsetAsync(d_eps, 0, (size_t)A * T * 2 * Ks * esz(), stream));
+            HIPCHK(hipMemsetAsync(d_dP, 0, (size_t)A * T * Ks * esz(), stream));
+            HIPCHK(hipMemsetAsync(d_stot, 0, (size_t)A * Ks * esz(), stream));
+        }
 
         std::vector<double> S;
         if (!mppi::savgol_basis(T, S)) fail(MPPI_E_INVALID, "cannot build the Savitzky-Golay operator for horizon %d", T);
@@ -1076,6 +1094,7 @@ struct mppi_engine {
         if (h_stage) hipHostFree(h_stage);
         if (h_out) hipHostFree(h_out);
         if (h_seq) hipHostFree(h_seq);
+        if (alias_parent) d_eps = d_dP = d_stot = nullptr;   // (the handle's)
         void* bufs[] = {d_eps, d_dP, d_stot, d_epart, tcb[0], tcb[1], baseb[0], baseb[1], pkb[0], pkb[1], d_unom, d_ufilt, d_state, d_goal, d_part, d_merged, d_S, d_out, d_tick, d_tmp, d_grid, d_prev, d_clk, d_fill};
         for (void* b : bufs) if (b) hipFree(b);
         if (own_stream) hipStreamDestroy(own_stream);
@@ -1201,6 +1220,9 @@ void mppi_engine::co_build() {
             mppi_engine* e = new mppi_engine();
             subs.push_back(e);
             e->is_co_sub = true;
+#ifndef MPPI_CO_OWN_BUFFERS   // (measurement build: every shard allocates its own rows, as until round 5)
+            e->alias_parent = this; e->alias_k0 = cuts[g];
+#endif
             e->init(c);
             // what the handle was told since its creation (the shards may be built long after): the cost's sig matrix, the obstacle grid
             // (shared: same device; a later mppi_set_obstacle_grid reaches the shards first and gives them their own copy), the shift
