@@ -92,7 +92,8 @@ extern "C" {
 
 /* Co-scheduled shards (mppi_config.co_shards).  A fused mppi_tick with device noise may split its samples over G
  * engines inside this one handle -- same GPU, one stream each, coupled only by device-side mailbox flags -- so that one
- * shard's HBM-bound update kernel runs under another's VALU-bound rollout (config 4: +7-9 % rollouts/s).  Results equal
+ * shard's HBM-bound update kernel runs under another's VALU-bound rollout (config 4: +3-5 % rollouts/s; a K-shard's rows are
+ * columns of the handle's own buffers: it allocates its small arrays only).  Results equal
  * the unsplit tick to rounding (sample ids are global, the tuple merge is exact); every other call of this ABI keeps
  * working: after such a tick mppi_download_value / _noise / mppi_update re-run the rollout over all samples from a
  * snapshot of the tick's inputs, bit for bit what the shards computed.  AUTO = 2 shards for n_agents * samples >= 500000
@@ -105,7 +106,7 @@ extern "C" {
  * second engine's results of the last tick (nominal / filtered controls, state, outputs, V) into the handle's own arrays, and the
  * next split tick hands over what changed.  Else none.  An AUTO handle builds its shards with its FIRST fused device-noise
  * mppi_tick -- a handle that only runs the caller's own exchange (the ranks of an N > 1 run), graph replays or injected-noise
- * ticks never pays for the second set of buffers; mppi_co_info reports the split from the start, mppi_co_note why a handle
+ * ticks never pays for the second engine (an agent split: a second set of buffers; a K split: a few megabytes); mppi_co_info reports the split from the start, mppi_co_note why a handle
  * that should have split did not.  mppi_tick_begin / _finish (the caller's own exchange), mppi_tick_graph and
  * injected-noise ticks always run unsplit; mppi_p2p_create on such a handle dissolves the group. */
 
