@@ -103,10 +103,10 @@ extern "C" {
  * half still holds >= 400 000 sample-agents: config 5's 64 x 16 384, 2 x 500 000 ...): two complete engines, agents [0, ceil(A / 2)) and the rest,
  * NOTHING exchanged (agents are independent controllers) -- per agent bit for bit the one engine's results (the noise streams are
  * keyed by the global agent index), config 5 +8-10 % rollouts/s.  Only the fused tick runs split; any other call first copies the
- * second engine's results of the last tick (nominal / filtered controls, state, outputs, V) into the handle's own arrays, and the
+ * second engine's small results of the last tick (nominal / filtered controls, state, outputs) into the handle's own arrays -- its V already is there --, and the
  * next split tick hands over what changed.  Else none.  An AUTO handle builds its shards with its FIRST fused device-noise
  * mppi_tick -- a handle that only runs the caller's own exchange (the ranks of an N > 1 run), graph replays or injected-noise
- * ticks never pays for the second engine (an agent split: a second set of buffers; a K split: a few megabytes); mppi_co_info reports the split from the start, mppi_co_note why a handle
+ * ticks never pays for the second engine (a few megabytes: both kinds of shard live in the handle's own big arrays); mppi_co_info reports the split from the start, mppi_co_note why a handle
  * that should have split did not.  mppi_tick_begin / _finish (the caller's own exchange), mppi_tick_graph and
  * injected-noise ticks always run unsplit; mppi_p2p_create on such a handle dissolves the group. */
 

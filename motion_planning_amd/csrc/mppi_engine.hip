@@ -299,7 +299,8 @@ struct mppi_engine {
     bool p2p_internal = false;  // the mailboxes belong to the co-scheduled group, not to a caller's cross-GPU exchange
     std::string co_fallback = "";   // why this handle runs unsplit although co-scheduling was possible (mppi_co_note)
     bool is_co_sub = false;     // this engine is a co-scheduled shard inside another handle
-    mppi_engine* alias_parent = nullptr; int alias_k0 = 0;   // (set before init) a co-scheduled K-shard: rows = columns of the parent's buffers
+    bool epart_aliased = false;
+    mppi_engine* alias_parent = nullptr; int alias_k0 = 0, alias_a0 = 0;   // (set before init) a co-scheduled shard lives in the parent's big arrays: from column k0 (K split) / from agent a0 (agent split)
     // this engine's view of its own shard while a co-scheduled tick is enqueued: K, chunk count and launch geometry of shard 0
     struct ShardView {
         mppi_engine* e; int K, samples, NCH, roll_blocks; double* snap;
@@ -970,16 +971,22 @@ struct mppi_engine {
             // A co-scheduled K-shard fills COLUMNS [alias_k0, alias_k0 + K) of the handle's own rows (same row stride; the cut is a
             // multiple of the update kernel's chunk): ONE layout in memory whatever the number of engines that fill it -- the same
             // DRAM pages as the one-engine tick -- and nothing to allocate.
-            const size_t es = esz(), k0 = (size_t)alias_k0;
-            d_eps = static_cast<char*>(alias_parent->d_eps) + k0 * es;
-            d_dP = static_cast<char*>(alias_parent->d_dP) + k0 * es;
-            d_stot = static_cast<char*>(alias_parent->d_stot) + k0 * es;
+            // (An agent-split shard: the handle's arrays from agent alias_a0 on -- whole rows, every array line-aligned per agent.)
+            const size_t es = esz(), k0 = (size_t)alias_k0, a0 = (size_t)alias_a0;
+            d_eps = static_cast<char*>(alias_parent->d_eps) + (a0 * T * 2 * Ks + k0) * es;
+            d_dP = static_cast<char*>(alias_parent->d_dP) + (a0 * T * Ks + k0) * es;
+            d_stot = static_cast<char*>(alias_parent->d_stot) + (a0 * Ks + k0) * es;
             // (the per-wave eps sums stay the shard's own: their rows are not multiples of a cache line long, so the cut falls INSIDE a
             // line of every row -- two engines writing words of one line through different XCDs)
-            void* p = nullptr;
-            const size_t bytes = (size_t)A * T * 2 * (Ks / 64) * esz();
-            HIPCHK(hipMalloc(&p, bytes)); hbm_bytes += bytes; d_epart = p;
-            HIPCHK(hipMemsetAsync(d_epart, 0, bytes, stream));
+            if (alias_k0 == 0) {   // agent split: the sums' rows of whole agents (T * 2 * Ks / 64 elements each: a multiple of a line)
+                d_epart = static_cast<char*>(alias_parent->d_epart) + a0 * T * 2 * (Ks / 64) * es;
+                epart_aliased = true;
+            } else {
+                void* p = nullptr;
+                const size_t bytes = (size_t)A * T * 2 * (Ks / 64) * esz();
+                HIPCHK(hipMalloc(&p, bytes)); hbm_bytes += bytes; d_epart = p;
+                HIPCHK(hipMemsetAsync(d_epart, 0, bytes, stream));
+            }
         } else {
             void* p = nullptr;
             size_t bytes = (size_t)A * T * 2 * Ks * esz();
@@ -1095,6 +1102,7 @@ struct mppi_engine {
         if (h_out) hipHostFree(h_out);
         if (h_seq) hipHostFree(h_seq);
         if (alias_parent) d_eps = d_dP = d_stot = nullptr;   // (the handle's)
+        if (epart_aliased) d_epart = nullptr;
         void* bufs[] = {d_eps, d_dP, d_stot, d_epart, tcb[0], tcb[1], baseb[0], baseb[1], pkb[0], pkb[1], d_unom, d_ufilt, d_state, d_goal, d_part, d_merged, d_S, d_out, d_tick, d_tmp, d_grid, d_prev, d_clk, d_fill};
         for (void* b : bufs) if (b) hipFree(b);
         if (own_stream) hipStreamDestroy(own_stream);
@@ -1183,6 +1191,11 @@ void mppi_engine::co_build() {
             mppi_engine* e = new mppi_engine();
             subs.push_back(e);
             e->is_co_sub = true;
+#ifndef MPPI_CO_OWN_BUFFERS
+            // the second engine's agents are agents [co_a0, A) of the handle's own big arrays (whole rows; per-agent sizes are line multiples
+            // only when T * Ks / 64 elements are: asked for below) -- its V is where every other call of the ABI looks for it, nothing to pull
+            if (((size_t)cfg.horizon * 2 * (P.Ks / 64) * esz()) % 128 == 0) { e->alias_parent = this; e->alias_a0 = co_a0; }
+#endif
             e->init(c);
             if (sig_is_matrix) { for (int i = 0; i < 4; ++i) e->sig_cost[i] = sig_cost[i]; e->sig_is_matrix = true; e->refresh_params(); }
             e->P.grid = P.grid; e->P.grid_w = P.grid_w; e->P.grid_h = P.grid_h; e->P.grid_res = P.grid_res; e->P.grid_ox = P.grid_ox;
@@ -1318,12 +1331,14 @@ void mppi_engine::co_pull_value() {
     auto pull = [&](void* dst, const void* src, size_t per_agent_bytes) {
         HIPCHK(hipMemcpyAsync(static_cast<char*>(dst) + a0 * per_agent_bytes, src, A1 * per_agent_bytes, hipMemcpyDeviceToDevice, stream));
     };
-    pull(d_dP, e->d_dP, T_ * Ks * es);
-    pull(d_stot, e->d_stot, Ks * es);
+    if (!e->alias_parent) {   // (a second engine with arrays of its own; else its V set already is where this handle keeps it)
+        pull(d_dP, e->d_dP, T_ * Ks * es);
+        pull(d_stot, e->d_stot, Ks * es);
+        pull(d_epart, e->d_epart, T_ * 2 * NW * es);
+        if (!eps_lazy && injected_ready) pull(d_eps, e->d_eps, T_ * 2 * Ks * es);   // (option store_eps: the tick's noise is resident, not re-drawn on demand)
+    }
     pull(d_base, e->d_base, T_ * sizeof(double));
     pull(d_tc, e->d_tc, T_ * mppi::kTcW * sizeof(double));
-    pull(d_epart, e->d_epart, T_ * 2 * NW * es);
-    if (!eps_lazy && injected_ready) pull(d_eps, e->d_eps, T_ * 2 * Ks * es);   // (option store_eps: the tick's noise is resident, not re-drawn on demand)
     wait_stream("co-scheduled agents: V pulled");
 }
 
