@@ -977,7 +977,8 @@ struct mppi_engine {
             d_dP = static_cast<char*>(alias_parent->d_dP) + (a0 * T * Ks + k0) * es;
             d_stot = static_cast<char*>(alias_parent->d_stot) + (a0 * Ks + k0) * es;
             // (the per-wave eps sums stay the shard's own: their rows are not multiples of a cache line long, so the cut falls INSIDE a
-            // line of every row -- two engines writing words of one line through different XCDs)
+            // line of every row -- two engines' concurrent kernels writing and reading words of one line through different XCDs: with
+            // those lines shared the controls came out wrong by 1e-7, EXPERIMENTS.md 56)
             if (alias_k0 == 0) {   // agent split: the sums' rows of whole agents (T * 2 * Ks / 64 elements each: a multiple of a line)
                 d_epart = static_cast<char*>(alias_parent->d_epart) + a0 * T * 2 * (Ks / 64) * es;
                 epart_aliased = true;
