@@ -979,8 +979,12 @@ struct mppi_engine {
             // (the per-wave eps sums stay the shard's own: their rows are not multiples of a cache line long, so the cut falls INSIDE a
             // line of every row -- two engines' concurrent kernels writing and reading words of one line through different XCDs: with
             // those lines shared the controls came out wrong by 1e-7, EXPERIMENTS.md 56)
+#ifdef MPPI_ALIAS_EPART_TOO   // (measurement build for EXPERIMENTS.md 56: the K-shard's sums as columns of the handle's as well)
+            if (true) {
+#else
             if (alias_k0 == 0) {   // agent split: the sums' rows of whole agents (T * 2 * Ks / 64 elements each: a multiple of a line)
-                d_epart = static_cast<char*>(alias_parent->d_epart) + a0 * T * 2 * (Ks / 64) * es;
+#endif
+                d_epart = static_cast<char*>(alias_parent->d_epart) + (a0 * T * 2 * (Ks / 64) + k0 / 64) * es;
                 epart_aliased = true;
             } else {
                 void* p = nullptr;
