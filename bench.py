@@ -179,7 +179,8 @@ def compact_line(line, full_path):
                 # N > 1: what every rank ran (its share, its big kernels, the exchange it came up on)
                 "per_rank": [{"rank": r.get("rank"), "samples": r.get("samples"), "rollout_us": (r.get("kernels_us") or {}).get("rollout"),
                               "update_us": (r.get("kernels_us") or {}).get("update"), "exchange_us": r.get("exchange_us"),
-                              "exchange_ran": (r.get("exchange") or {}).get("ran")} for r in (line.get("per_rank") or [])] or None,
+                              "exchange_ran": (r.get("exchange") or {}).get("ran"), "rccl_ranks": r.get("rccl_ranks")}
+                             for r in (line.get("per_rank") or [])] or None,
                 "one_engine_ms": one.get("ms_per_step"), "f64_ms": f64.get("ms_per_step"),
                 "final_state": line.get("final_state"), "final_u": line.get("final_u"),
                 "dtype_detail": (line.get("dtype_detail") or "")[:160], "full_record": full_path})
@@ -269,6 +270,47 @@ def run_pentagon(args, K, T, local_rank):
                                      "goal": [float(x) for x in m.goal]}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` started as a PLAIN process (no launcher, WORLD_SIZE unset): this process becomes the launcher --
+    N children of this same command line, one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment (what
+    torch.distributed.run would set; rendezvous on 127.0.0.1, a free port) -- and rank 0's child prints the one JSON line on the
+    stdout it inherits.  A rank that fails takes the others down with it (exact pids, never a pattern); the exit code is the
+    first non-zero one."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MPPI_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL, the p2p mailboxes)
+        env.setdefault("OMP_NUM_THREADS", "1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        live = list(procs)
+        while live:
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in live:       # one rank down: the others would wait in a collective until its timeout
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -290,10 +332,21 @@ def main():
     ap.add_argument("--no-co-line", action="store_true", help="(kept for old command lines; the co-scheduled tick is the headline handle's own now)")
     ap.add_argument("--co-shards", type=int, default=None, help="mppi_config.co_shards of the measured engine (default: the engine's own rule)")
     ap.add_argument("--full-out", default="", help="where the full nested record goes (default: gpurun_out/ on a gpurun box, else profiles/)")
+    ap.add_argument("--group-of-one", action="store_true",
+                    help="TEST ONLY: with one rank, still initialise the process group and tick through tick_begin -> all-gather -> "
+                         "tick_finish (RCCL as a world of one); the default `--gpus 1` never does, launcher or not")
     ap.add_argument("--all-ranks-on-gpu0", action="store_true",
                     help="TEST ONLY: every rank drives cuda:0 and the process group is gloo (RCCL refuses two ranks on one "
                          "device) -- runs the N > 1 code path of this script on a one-GPU box; use with --exchange p2p")
     args = ap.parse_args()
+
+    # However this script is started, `--gpus N` runs N ranks, one process per GPU:
+    #   under a launcher (torch.distributed.run, the driver's N > 1 command line): WORLD_SIZE / RANK / LOCAL_RANK are in the environment;
+    #   as a plain process with N > 1: it launches the N ranks itself (self_launch) and returns their exit code.
+    # `--gpus 1` is the SAME measurement whether or not a launcher wrapped it: one process, no process group, the handle's own
+    # (co-scheduled) fused tick -- a world of one has nothing to exchange.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -302,14 +355,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
-        args.gpus = world
+    args.gpus = world        # (a launcher's world size is what runs)
     if args.all_ranks_on_gpu0:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    in_group = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ  # launched by torch.distributed.run
+    in_group = world > 1 or (args.group_of_one and "MASTER_PORT" in os.environ)
     coll_dev = "cpu" if args.all_ranks_on_gpu0 else "cuda"       # where the few control collectives of this script live
     if in_group:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -531,6 +581,8 @@ def main():
         objs = [None] * world
         dist.all_gather_object(objs, {"rank": rank, "device": local_rank, "kernels_us": kernels_us, "exchange_us": exchange_us,
                                       "samples": int(eng.K), "exchange": getattr(ticker, "exchange_report", None),
+                                      # ranks of the RCCL communicator this rank is in (0: the group is gloo -- the one-GPU test mode)
+                                      "rccl_ranks": world if dist.get_backend() == "nccl" else 0,
                                       "shader_clock_mhz": clock_mhz, "co_shards": info.get("co_shards", 1)})
         per_rank = objs
 

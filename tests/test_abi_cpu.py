@@ -404,3 +404,33 @@ def test_python_shell_fast_paths_still_see_every_change():
     for _ in range(100):
         m.get_path(m.start, m.goal)
     assert held.shape == (2, 3) and held[0, 0] == 7.0 and m.path[0, 0] == 7.0 and not np.shares_memory(held, m.path)
+
+
+def test_bench_started_plain_with_several_gpus_launches_its_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it must start two ranks itself (it used to exit with
+    "launch N>1 with torch.distributed.run").  Without a GPU the ranks cannot get further than selecting their device -- what is
+    checked here is the launcher: two children of the same command line with RANK 0 / 1, WORLD_SIZE 2 and a 127.0.0.1 rendezvous in
+    their environment, a failing rank's exit code handed back, nothing left running.  (The GPU suite runs the real thing.)"""
+    import subprocess
+    import sys
+    import textwrap
+    # a stand-in for the interpreter's `torch` that records what each rank saw and fails the way a GPU-less box does
+    fake = tmp_path / "torch"
+    fake.mkdir()
+    (fake / "__init__.py").write_text(textwrap.dedent('''
+        import os, sys
+        open(os.path.join(os.environ["MPPI_TEST_DIR"], "rank%s" % os.environ.get("RANK", "x")), "w").write(
+            " ".join(os.environ.get(k, "-") for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")) + " " + " ".join(sys.argv[1:]))
+        raise SystemExit(7 if os.environ.get("RANK") == "1" else 0)
+    '''))
+    env = dict(os.environ, PYTHONPATH=str(tmp_path), MPPI_TEST_DIR=str(tmp_path))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3"], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 7, (out.returncode, out.stderr[-500:])
+    seen = [open(tmp_path / ("rank%d" % r)).read().split() for r in (0, 1)]
+    assert [s[0] for s in seen] == ["0", "1"] and [s[1] for s in seen] == ["0", "1"] and all(s[2] == "2" and s[3] == "127.0.0.1" for s in seen)
+    assert seen[0][4] == seen[1][4] and int(seen[0][4]) > 0 and all(s[5:] == ["--gpus", "2", "--steps", "3"] for s in seen)
+    # --gpus 1 never launches anything: the process itself is the one rank
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], env=dict(env, RANK="x"), capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and open(tmp_path / "rankx").read().split()[2] == "-"

@@ -1521,30 +1521,57 @@ def test_controller_state_machine_golden(golden, name, waypoints):
         plant = rk4(plant.reshape(3, 1), u.reshape(2, 1), c.mppi.dt)[:, 0]
 
 
-def test_bench_under_torchrun_uses_the_rccl_path():
-    """bench.py launched exactly like the driver launches N > 1 (torch.distributed.run, backend nccl =
-    RCCL), with the one GPU this box has: the tick goes tick_begin -> all_gather_into_tensor on the
-    aliased partials buffer -> tick_finish(gathered), and must agree with the plain single-process run."""
+def _bench_line(cmd, timeout=300):
+    """Run one bench.py command line in a fresh process (~25 s of torch import); no retry: a process that does not come back is a failure."""
     import json
     import os
-    import socket
     import subprocess
-    import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    common = ["bench.py", "--gpus", "1", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--samples", "50000"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    def run(cmd):  # a fresh process takes ~25 s (torch import); no retry: a process that does not come back is a failure
-        return subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=240)
-    out = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
-               "--master-addr", "127.0.0.1", "--master-port", str(port)] + common)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
     assert out.returncode == 0, out.stderr[-2000:]
-    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def _torchrun(n):
+    import socket
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(port)]
+
+
+def test_bench_group_of_one_uses_the_rccl_path():
+    """bench.py under torch.distributed.run with --group-of-one (backend nccl = RCCL, a world of one on the one GPU this box
+    has): the tick goes tick_begin -> all_gather_into_tensor on the aliased partials buffer -> tick_finish(gathered), and must
+    agree with the plain single-process run."""
+    import sys
+    common = ["bench.py", "--gpus", "1", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--samples", "50000"]
+    line = _bench_line(_torchrun(1) + common + ["--group-of-one"])
     assert line["n_gpus"] == 1 and line["value"] > 1e6 and line["config"]["samples_total"] == 50000
-    plain = run([sys.executable] + common)
-    assert plain.returncode == 0, plain.stderr[-2000:]
-    ref = json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["config"]["parallelism"] == "K-sharded x1, exchange: rccl"
+    ref = _bench_line([sys.executable] + common)
+    assert ref["config"]["parallelism"] == "K-sharded x1, exchange: none"
     assert line["final_state"] == ref["final_state"] and line["final_u"] == ref["final_u"]
+
+
+def test_bench_one_gpu_is_the_same_measurement_under_any_launcher():
+    """`bench.py --gpus 1` is BENCH's own path however it is started: under torch.distributed.run -- the way
+    the driver's scaling run may start every N -- it forms no process group and ticks the handle's own co-scheduled fused tick,
+    exactly like the plain process: same split, same kernels, bit-identical final state, and the same speed (the robust statistic
+    -- the median tick -- within 3 %, the 40-tick mean within 6 %: two handles on one box differ by 1-3 %, EXPERIMENTS.md 54)."""
+    import sys
+    common = ["bench.py", "--gpus", "1", "--steps", "40", "--warmup", "5", "--no-cpu-baseline", "--no-f64-line"]
+    wrapped = _bench_line(_torchrun(1) + common)
+    plain = _bench_line([sys.executable] + common)
+    for line in (wrapped, plain):
+        assert line["n_gpus"] == 1 and line["config"]["parallelism"] == "K-sharded x1, exchange: none"
+        assert line["config"]["co_shards"] == 2 and line["config"]["samples_total"] == 1000000 and line["per_rank"] is None
+    assert wrapped["final_state"] == plain["final_state"] and wrapped["final_u"] == plain["final_u"]
+    assert abs(wrapped["tick_us_median"] / plain["tick_us_median"] - 1.0) < 0.03, (wrapped["tick_us_median"], plain["tick_us_median"])
+    assert abs(wrapped["value"] / plain["value"] - 1.0) < 0.06, (wrapped["value"], plain["value"])
 
 
 @pytest.mark.gpu

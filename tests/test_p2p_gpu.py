@@ -462,6 +462,42 @@ def test_bench_with_all_ranks_on_the_one_gpu(exchange, n):
     assert np.abs(np.array(line["final_u"]) - np.array(ref["final_u"])).max() < tol
 
 
+def test_bench_launches_its_own_ranks_when_started_as_a_plain_process():
+    """`python bench.py --gpus 2` with NO launcher around it (the way the driver starts --gpus 1: VERDICT r5 item 1): the script
+    starts its two ranks itself -- rendezvous on 127.0.0.1, a free port -- and rank 0 prints the one line: n_gpus 2, two per_rank
+    entries that say which exchange each rank ran and how many ranks its RCCL communicator has (0 here: --all-ranks-on-gpu0 puts
+    both ranks on this box's one GPU, where the group is gloo), a flat roofline of ONE rank's share of the samples."""
+    import json
+    import subprocess
+    total = 50000
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--all-ranks-on-gpu0", "--steps", "6", "--warmup", "2", "--no-cpu-baseline",
+                          "--samples", str(total), "--min-warmup-s", "0.05"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1          # rank 0 alone prints
+    short = json.loads(lines[0])
+    assert short["n_gpus"] == 2 and short["config"]["samples_per_gpu"] == total // 2 and short["scaling"] == "strong"
+    assert [r["rank"] for r in short["per_rank"]] == [0, 1]
+    assert all(r["exchange_ran"] == "p2p" and r["rccl_ranks"] == 0 and r["samples"] == total // 2 and r["rollout_us"] > 0 for r in short["per_rank"])
+    assert short["roofline"]["samples_per_launch"] == total // 2 and all(not isinstance(v, (dict, list)) for v in short["roofline"].values())
+    assert short["value"] == pytest.approx(total / (short["ms_per_step"] * 1e-3))
+
+
+def test_bench_plain_process_reports_a_failing_rank():
+    """A rank that cannot start (an unknown flag) takes the self-launched job down: non-zero exit, no JSON line, no process left behind."""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--workload", "c3", "--all-ranks-on-gpu0", "--steps", "2", "--no-cpu-baseline"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "single-GPU configuration" in out.stderr
+
+
 @pytest.mark.parametrize("n_shards,K_total", [(2, 6000), (3, 50000), (2, 300000)])
 def test_co_scheduled_shards_equal_the_single_engine(n_shards, K_total):
     """sharded.make_co_scheduled_ticker: the K-split with all shards on this one GPU, every engine on its own stream,
