@@ -24,27 +24,16 @@ extern "C" {
 #define MPPI_KERNEL_COUNT 6
 
 /*
- * Per-handle switches for measurements and tests (none changes results beyond rounding); a co-scheduled handle passes them
- * on to its shards.  Keys of mppi_set_option (value) / mppi_get_option:
+ * Per-handle switches for tests and same-box A/B runs (none changes results beyond rounding); a co-scheduled handle passes them
+ * on to its shards.  SEVEN keys -- every one a code path the engine's own rules also take at some size or call pattern, so that a
+ * test can force either side; switches that lost everywhere they were measured are gone (EXPERIMENTS.md lists them with their numbers:
+ * k_pieces, upd_nv, fin_threads, upd_skip, pk_waves).  Keys of mppi_set_option (value) / mppi_get_option:
  *   "rollout_pk"      0: fp32-storage ticks stay on the all-fp64 rollout (same-box A/B against the mixed-precision one)
  *   "pk_min_samples"  >= 0: a plain size rule for the mixed-precision rollout; -1 (default): chosen by rounds of waves
- *   "pk_waves"        4 | 5: the mixed-precision rollout's 5-waves-per-SIMD build
- *   "upd_skip"        0: the update forms exp() for every sample (default 1: wave-vectors without a weight above the cut are skipped)
  *   "store_eps"       1: the tick path stores its noise like mppi_rollout does
  *   "co_cut_pct"      share of shard 0 of a two-shard co-scheduled handle in per cent (default 58); re-cuts the group
  *   "lanes_zero_copy" 1 (default) | 0: a fused lane-per-sample tick with fresh inputs lets its rollout read them from the pinned slot
  *                     (0: one small fetch launch in front of it, as mppi_rollout / mppi_tick_begin do)
- *   "upd_nv"          0 (default: by size) | 8 | 16: 16-byte vectors per lane of the update kernel = its chunk length (8: 8192 samples in
- *                     fp32 storage; 16: twice that -- AUTO takes it where it brings a row to <= 16 chunk tuples, which the finalize kernel
- *                     merges itself: no merge launch for 131 073 ... 262 144 samples).  Before the co-scheduled shards are built
- *   "fin_threads"     0 (default: the engine's rule) | 256 | 512 | 1024: threads of the finalize kernel's one block per agent
- *   "k_pieces"        0 (default: the engine's rule, below) | 1..16: a lane-per-sample tick that does not store its noise runs its
- *                     samples in that many pieces, rollout + update per piece, every piece's cost prefix in the SAME region of the
- *                     buffer -- sized so that what the rollout writes is still in the 256 MB Infinity Cache when the update reads it
- *                     (fp64 storage at config 4: 400 MB per tick as one piece, 133 MB as three).  AUTO: one piece -- measured, the
- *                     update's read rate recovers (100 MB pieces: 4.3 TB/s against 4.0) but every piece pays its rollout's ramp again:
- *                     config 4 in fp64 220 us as one piece, 218 as two, 234 as three (profiles/r5_ab_k_pieces.jsonl).  The tick's V then exists piece by piece only: mppi_download_value / mppi_update re-run the rollout
- *                     from the tick's input snapshot (as after a small-K tick).  1: never
  *   "table_hoist"     -1 (default: by size) | 0 | 1: the nominal trajectory's per-step table of a tick whose inputs are the previous
  *                     tick's own outputs is computed by that tick's finalize kernel instead of by every rollout workgroup's prologue
  *                     (AUTO: handles of >= 786 432 sample-agents at T <= 64, where the prologue costs a launch 4-5 us)

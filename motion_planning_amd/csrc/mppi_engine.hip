@@ -93,8 +93,7 @@ struct mppi_engine {
     // launch geometry
     int roll_bs = 256, roll_blocks = 0, nterm = 4;
     int NCH = 1, CH = 1024;
-    int upd_nv = mppi::kUpdNV;   // the update kernel's vectors per lane (8 | 16: mppi::UpdCfg)
-    int upd_nv_opt = 0;          // option "upd_nv": 0 by size, 8, 16
+    int upd_nv = mppi::kUpdNV;   // the update kernel's vectors per lane (8 | 16: mppi::UpdCfg), by size (pick_update_shape)
     // small-K tick: ONE scan_tick_kernel (lanes = timesteps) instead of rollout + update
     int small_nb = 0, small_spw = 1, small_nw = 1;  // blocks (0 = path not used), samples per unit, waves per unit
     double* d_prev = nullptr;                        // pre-tick {unom [A][2][T], state [A][3], goal [A][3]}
@@ -112,15 +111,12 @@ struct mppi_engine {
     uint64_t lazy_seed = 0;
     uint32_t lazy_tick = 0;
     bool store_eps_always = false;  // option "store_eps": the tick path writes eps like mppi_rollout does
-    int pk_waves = 4;
     long pk_min_samples = 400000;   // the size rule of co-scheduled shards (and of every engine whose option "pk_min_samples" is set)
     bool pk_min_set = false;
-    int force_pk = -1;             // >= 0: the size rule is overridden (the re-run of a co-scheduled tick takes the shards' kernel)
+    int force_pk = -1;             // >= 0: the size rule is overridden (every shard of a co-scheduled tick takes shard 0's kernel)
     bool last_rollout_pk = false;  // which kernel the last rollout launch was
     int last_rollout_kind = MPPI_ROLLOUT_NONE;   // ... as mppi_rollout_kernel reports it
-    bool co_shards_pk = false;     // ... and the one the shards of the last co-scheduled tick ran
     int noise_pack = 0;             // option "noise_packing": how a Philox call's bits become normals (mppi::NoisePack): 0 three steps per call, 1 four, 2 hipRAND's normals (two)
-    int upd_skip_light = 1;         // option "upd_skip" = 0: the update kernel forms exp() for every sample (same-box A/B)
     bool use_pk = true;             // option "rollout_pk" = 0: keep the all-fp64 rollout kernel on the tick path (same-box A/B measurements)
     double* d_tc = nullptr;  // [A][T][8]   the nominal trajectory's table the LAST rollout used (= tcb[tab])
     double* d_base = nullptr;   //             (= baseb[tab])
@@ -138,13 +134,12 @@ struct mppi_engine {
     // config 5 149.2 -> 146.7; config 4 on one engine 146.4 -> 146.0) and under 1 us of an under-filled one (the other workgroups'
     // waves fill the SIMD while one wave runs the prologue), while the finalize kernel's one wave per agent takes 1.9 us for it at
     // T = 50 and 5.7 at T = 100: 125 000 samples 39.7 -> 40.4, 250 000 54.6 -> 55.7, 500 000 84.4 -> 85.0, config 3 57.9 -> 62.2.
-    // AUTO: handles of >= 786 432 sample-agents with T <= 64 (a co-scheduled group decides for its shards).
-    bool hoist_on() const {
-        if (hoist_opt >= 0) return hoist_opt != 0;
-        return cfg.horizon <= 64 && (long)cfg.n_agents * cfg.samples >= 786432;
-    }
-    int fin_threads_opt = 0;    // option "fin_threads"
-    int k_pieces_opt = 0;       // option "k_pieces"
+    // AUTO: handles of >= 786 432 sample-agents with T <= 64 -- decided ONCE from the handle's full size (hoist_auto, set by init): the
+    // views a co-scheduled tick puts over cfg (ShardView, AgentView) shrink cfg.samples / cfg.n_agents for the duration of shard 0's
+    // launches, and its finalize launch runs outside them -- both must take the same decision.  A co-scheduled group
+    // decides for its shards (hoist_opt of a sub is the handle's decision).
+    bool hoist_auto = false;
+    bool hoist_on() const { return hoist_opt >= 0 ? hoist_opt != 0 : hoist_auto; }
     int graph_tab = 0;
     bool table_taken = false;   // this tick's rollout launches already switched to the set they load
     void use_table_set(int t) { tab = t; d_tc = tcb[t]; d_base = baseb[t]; }
@@ -287,28 +282,54 @@ struct mppi_engine {
     int co_k0 = 0;             // samples of shard 0
     int co_cut_pct = 58;       // two shards: shard 0's share in per cent (option "co_cut_pct" rebuilds the group)
     bool co_synced = false;    // the subs hold this engine's nominal controls / state / goal
-    bool co_last = false;      // the last tick ran co-scheduled: its V / noise exist only as "re-run from the snapshot"
     hipEvent_t ev_co = nullptr;
+    // Stream ordering between this engine's stream and the subs' (the subs' big arrays are regions of this engine's own).
+    // Back-to-back split ticks need none (every engine's launches follow its own earlier ones).  Anything ELSE this handle is asked
+    // to do runs on this engine's stream over the whole arrays, so
+    //   co_subs_inflight  the subs have launches enqueued that this engine's stream has not waited for: the next call that is not a
+    //                     split tick first makes this stream wait for them (co_join_subs: it may read or rewrite their regions);
+    //   co_parent_dirty   this engine's stream has been given such other work since: the next split tick makes every sub's stream
+    //                     wait for it before the sub's first launch (co_fence_subs: a re-draw or re-run still writing the sub's
+    //                     columns must not meet the sub's next rollout there).
+    bool co_subs_inflight = false, co_parent_dirty = false;
+    void co_join_subs() {
+        if (!co_subs_inflight) return;
+        for (auto* e : subs) {
+            HIPCHK(hipEventRecord(ev_co, e->stream));
+            HIPCHK(hipStreamWaitEvent(stream, ev_co, 0));
+        }
+        co_subs_inflight = false;
+    }
+    void co_fence_subs() {
+        if (!co_parent_dirty) return;
+        HIPCHK(hipEventRecord(ev_co, stream));
+        for (auto* e : subs) HIPCHK(hipStreamWaitEvent(e->stream, ev_co, 0));
+        co_parent_dirty = false;
+    }
+    void co_other_call() {   // every ABI call but the split tick itself, the outputs' read-back and the read-only queries (API_BEGIN)
+        if (subs.empty()) return;
+        co_join_subs();
+        co_parent_dirty = true;
+    }
     bool co_active() const { return !subs.empty(); }
     void co_release() {
         for (auto* e : subs) delete e;
         subs.clear();
         if (p2p_internal) { p2p_release(); p2p_internal = false; }
-        co_agents = false; co_dirty = false; co_value_dirty = false;
+        co_agents = false; co_dirty = false; co_value_dirty = false; co_subs_inflight = false; co_parent_dirty = false;
     }
     bool p2p_internal = false;  // the mailboxes belong to the co-scheduled group, not to a caller's cross-GPU exchange
     std::string co_fallback = "";   // why this handle runs unsplit although co-scheduling was possible (mppi_co_note)
     bool is_co_sub = false;     // this engine is a co-scheduled shard inside another handle
-    bool epart_aliased = false;
     mppi_engine* alias_parent = nullptr; int alias_k0 = 0, alias_a0 = 0;   // (set before init) a co-scheduled shard lives in the parent's big arrays: from column k0 (K split) / from agent a0 (agent split)
     // this engine's view of its own shard while a co-scheduled tick is enqueued: K, chunk count and launch geometry of shard 0
     struct ShardView {
-        mppi_engine* e; int K, samples, NCH, roll_blocks; double* snap;
-        explicit ShardView(mppi_engine* e_) : e(e_), K(e_->P.K), samples(e_->cfg.samples), NCH(e_->NCH), roll_blocks(e_->roll_blocks), snap(e_->P.snap) {
+        mppi_engine* e; int K, samples, NCH, roll_blocks;
+        explicit ShardView(mppi_engine* e_) : e(e_), K(e_->P.K), samples(e_->cfg.samples), NCH(e_->NCH), roll_blocks(e_->roll_blocks) {
             e->P.K = e->co_k0; e->cfg.samples = e->co_k0; e->NCH = (e->co_k0 + e->CH - 1) / e->CH;
-            e->roll_blocks = (e->co_k0 + e->roll_bs - 1) / e->roll_bs; e->P.snap = e->d_prev;
+            e->roll_blocks = (e->co_k0 + e->roll_bs - 1) / e->roll_bs;
         }
-        ~ShardView() { e->P.K = K; e->cfg.samples = samples; e->NCH = NCH; e->roll_blocks = roll_blocks; e->P.snap = snap; }
+        ~ShardView() { e->P.K = K; e->cfg.samples = samples; e->NCH = NCH; e->roll_blocks = roll_blocks; }
     };
     void co_sync_subs() {   // (rare) something other than a co-scheduled tick changed this engine's nominal controls / state / goal
         if (co_synced) return;
@@ -350,6 +371,13 @@ struct mppi_engine {
     bool co_pending = false;   // co_shards AUTO decided to split: the shards are built with the first fused device-noise tick
     int co_plan(bool& wanted, bool* by_agents = nullptr) const;
     void co_cuts(int G, std::vector<int>& cuts) const;
+    void co_check_regions(const mppi_engine* sub) const;
+    void co_hand_switches(mppi_engine* e) const {   // what the handle was told since its creation: the deadline and the option switches
+        e->sync_timeout_ms = sync_timeout_ms;
+        e->store_eps_always = store_eps_always; e->use_pk = use_pk;
+        e->pk_min_set = pk_min_set; e->pk_min_samples = pk_min_samples; e->noise_pack = noise_pack;
+        e->lanes_zero_copy = lanes_zero_copy; e->hoist_opt = hoist_on() ? 1 : 0;
+    }
     void co_build();   // creates the subs
     void co_tick(const double* state, const double* goal, uint64_t seed, uint32_t tick);
 
@@ -491,9 +519,7 @@ struct mppi_engine {
         }
     }
 
-    // dp_shift: this launch's cost prefix goes to columns [k0 - dp_shift, k1 - dp_shift) of the rows of d_dP (k_pieces: every piece of a
-    // tick in the same region of the buffer)
-    void launch_rollout(hipStream_t st, int k0, int k1, bool ph, bool store, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr, int dp_shift = 0) {
+    void launch_rollout(hipStream_t st, int k0, int k1, bool ph, bool store, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
         mppi::RolloutArgs a{};
         // timing: the launch carries its own start / stop events (no marker packets in the stream)
         if ((time_mask & (1u << MPPI_KERNEL_ROLLOUT)) && (time_seen[MPPI_KERNEL_ROLLOUT]++ % time_period) == 0) {
@@ -511,7 +537,7 @@ struct mppi_engine {
         a.seed = seed; a.tick = tick; a.tick_ptr = tick_ptr;
         a.state = ro_state ? ro_state : (in_state ? in_state : d_state); a.goal = ro_goal ? ro_goal : (in_goal ? in_goal : d_goal);
         a.unom = ro_unom ? ro_unom : d_unom; a.tc = d_tc; a.base = d_base;
-        a.eps = d_eps; a.dP = static_cast<char*>(d_dP) - (size_t)dp_shift * esz(); a.stot = d_stot; a.epart = d_epart;
+        a.eps = d_eps; a.dP = d_dP; a.stot = d_stot; a.epart = d_epart;
         hipError_t e;
         // the tick path of an fp32-storage engine with the node's own cost and model: the mixed-precision kernel, two
         // samples per lane on the packed-fp32 pipe (rollout_pk.hpp); its heading series need the noise's reach bounded
@@ -541,7 +567,7 @@ struct mppi_engine {
             b.dP = static_cast<float*>(d_dP); b.stot = static_cast<float*>(d_stot); b.epart = static_cast<float*>(d_epart);
             b.al_guard = mppi::rollout_pk_guard(P.kth, P.dt, P.sigma, noise_pack);
             b.pkrows = pkb[tab];
-            b.waves = pk_waves; b.noise_pack = noise_pack;
+            b.noise_pack = noise_pack;
             b.ev_start = a.ev_start; b.ev_stop = a.ev_stop;
             e = mppi::launch_rollout_pk(b);
         } else
@@ -575,7 +601,8 @@ struct mppi_engine {
     // The small-K tick keeps V in registers.  When a caller asks for it afterwards (mppi_download_value,
     // mppi_update), the lane-per-sample rollout kernel re-runs the tick's rollout from the pre-tick
     // snapshot the scan kernel left behind, with the same noise (re-drawn bit-identically, or the
-    // injected buffer), and leaves dP / Stot / base / epart as any rollout does.
+    // injected buffer), and leaves dP / Stot / base / epart as any rollout does.  (The scan tick only: a co-scheduled
+    // tick's V is complete in this handle's own arrays -- its shards fill columns of them -- and is read in place.)
     void materialise_value() {
         if (!value_lazy) return;
         const bool ph = eps_lazy;
@@ -585,18 +612,13 @@ struct mppi_engine {
         ro_goal = ro_state + (size_t)cfg.n_agents * 3;
         const int kind_of_the_tick = last_rollout_kind;   // (the re-run is not what mppi_rollout_kernel reports)
         try {
-            // a co-scheduled tick's shards ran the tick-path kernel (noise not stored): the re-run takes the same kernel over
-            // all samples -- per sample bit-identical to what the shards computed -- and the noise is re-drawn next to it
-            if (co_last) force_pk = co_shards_pk ? 1 : 0;
-            launch_rollout(stream, 0, cfg.samples, ph, !(co_last && ph), lazy_seed, tick, nullptr);
-            if (co_last && ph) launch_regen(stream, lazy_seed, tick, nullptr);
+            launch_rollout(stream, 0, cfg.samples, ph, true, lazy_seed, tick, nullptr);
         } catch (...) {
-            ro_unom = ro_state = ro_goal = nullptr; force_pk = -1;
+            ro_unom = ro_state = ro_goal = nullptr;
             throw;
         }
-        ro_unom = ro_state = ro_goal = nullptr; force_pk = -1;
+        ro_unom = ro_state = ro_goal = nullptr;
         last_rollout_kind = kind_of_the_tick;
-        co_last = false;
         if (ph) { eps_lazy = false; injected_ready = true; }
         value_lazy = false; value_ready = true; epart_ready = true;
     }
@@ -641,28 +663,27 @@ struct mppi_engine {
     void pick_update_shape() {
         const int ch8 = f64() ? mppi::UpdCfg<double, 8>::CH : mppi::UpdCfg<float, 8>::CH;
         const int n8 = (cfg.samples + ch8 - 1) / ch8, n16 = (cfg.samples + 2 * ch8 - 1) / (2 * ch8);
-        upd_nv = upd_nv_opt ? upd_nv_opt : ((n8 > kDirectTuples && n16 <= kDirectTuples) ? 16 : 8);
+        upd_nv = (n8 > kDirectTuples && n16 <= kDirectTuples) ? 16 : 8;
         if (noise_pack) upd_nv = 8;   // (the other noise packings' re-draws are built into the streaming shape only)
         CH = ch8 * upd_nv / 8;
         NCH = (cfg.samples + CH - 1) / CH;
     }
-    void launch_update(hipStream_t st, int ch0, int nch, const uint32_t* tick_ptr = nullptr, int dp_shift = 0) {
+    void launch_update(hipStream_t st, int ch0, int nch, const uint32_t* tick_ptr = nullptr) {
         ensure_epart(st);
-        const char* dP_at = static_cast<const char*>(d_dP) - (size_t)dp_shift * esz();
         Scope sc(this, MPPI_KERNEL_UPDATE, st);
         dim3 grid(8 * cfg.horizon, (cfg.n_agents * nch + 7) / 8);  // XCD-aware decode inside the kernel
 #define LAUNCH_UPD(TYPE, REGEN)                                                                                  \
     hipLaunchKernelGGL((mppi::update_kernel<TYPE, REGEN>), grid, dim3(256), 0, st, P, static_cast<const TYPE*>(d_eps), \
-                       reinterpret_cast<const TYPE*>(dP_at), static_cast<const TYPE*>(d_stot), d_part, NCH, ch0, nch,    \
-                       static_cast<const TYPE*>(d_epart), lazy_seed, lazy_tick, tick_ptr, upd_skip_light)
+                       static_cast<const TYPE*>(d_dP), static_cast<const TYPE*>(d_stot), d_part, NCH, ch0, nch,    \
+                       static_cast<const TYPE*>(d_epart), lazy_seed, lazy_tick, tick_ptr)
 #define LAUNCH_UPD_PACK(PK)                                                                                               \
     hipLaunchKernelGGL((mppi::update_kernel<float, true, PK>), grid, dim3(256), 0, st, P, static_cast<const float*>(d_eps), \
-                       reinterpret_cast<const float*>(dP_at), static_cast<const float*>(d_stot), d_part, NCH, ch0, nch,           \
-                       static_cast<const float*>(d_epart), lazy_seed, lazy_tick, tick_ptr, upd_skip_light)
+                       static_cast<const float*>(d_dP), static_cast<const float*>(d_stot), d_part, NCH, ch0, nch,           \
+                       static_cast<const float*>(d_epart), lazy_seed, lazy_tick, tick_ptr)
 #define LAUNCH_UPD16(TYPE, REGEN)                                                                                  \
     hipLaunchKernelGGL((mppi::update_kernel<TYPE, REGEN, 0, 16>), grid, dim3(256), 0, st, P, static_cast<const TYPE*>(d_eps), \
-                       reinterpret_cast<const TYPE*>(dP_at), static_cast<const TYPE*>(d_stot), d_part, NCH, ch0, nch,    \
-                       static_cast<const TYPE*>(d_epart), lazy_seed, lazy_tick, tick_ptr, upd_skip_light)
+                       static_cast<const TYPE*>(d_dP), static_cast<const TYPE*>(d_stot), d_part, NCH, ch0, nch,    \
+                       static_cast<const TYPE*>(d_epart), lazy_seed, lazy_tick, tick_ptr)
         if (upd_nv == 16) {
             if (f64()) { if (eps_lazy) LAUNCH_UPD16(double, true); else LAUNCH_UPD16(double, false); }
             else { if (eps_lazy) LAUNCH_UPD16(float, true); else LAUNCH_UPD16(float, false); }
@@ -750,27 +771,6 @@ struct mppi_engine {
         }
         merge_skipped = (skip_small_merge || (p2p_connected && !p2p_internal)) && NCH <= kDirectTuples;
         direct_n = NCH;
-        const int pieces = tick_pieces(ph, store);
-        if (pieces > 1) {
-            // Infinity-Cache-sized pieces: rollout + update per piece, every piece's cost prefix in the same columns of d_dP -- what the
-            // rollout wrote is read back before anything evicts it, and the next piece overwrites it in place (nothing of it ever has
-            // to reach HBM).  The tick's V exists piece by piece only: re-run from the snapshot on demand (materialise_value).
-            double* const snap_was = P.snap;
-            P.snap = d_prev;
-            const int per = (NCH + pieces - 1) / pieces;   // chunks per piece
-            try {
-                for (int c0 = 0; c0 < NCH; c0 += per) {
-                    const int c1 = std::min(NCH, c0 + per), k0 = c0 * CH, k1 = std::min(cfg.samples, c1 * CH);
-                    launch_rollout(stream, k0, k1, ph, store, seed, tick, tick_ptr, k0);
-                    launch_update(stream, c0, c1 - c0, tick_ptr, k0);
-                }
-            } catch (...) { P.snap = snap_was; throw; }
-            P.snap = snap_was;
-            if (in_slot >= 0) inputs_consumed();
-            if (!merge_skipped) launch_merge(NCH);
-            noise_ready = true; value_ready = false; value_lazy = true; partials_ready = true; epart_ready = true;
-            return;
-        }
         {
             double* const snap_was = P.snap;
             if (lanes_fresh_state || lanes_fresh_goal) P.snap = d_prev;   // (workgroup 0 keeps the inputs it read from the pinned slot)
@@ -781,13 +781,6 @@ struct mppi_engine {
         launch_update(stream, 0, NCH, tick_ptr);
         if (!merge_skipped) launch_merge(NCH);
         noise_ready = true; value_ready = true; value_lazy = false; partials_ready = true; epart_ready = true;
-    }
-    // How many pieces a lane-per-sample tick runs its samples in (option "k_pieces"; include/mppi_hip_diag.h)
-    int tick_pieces(bool ph, bool store) const {
-        if (!ph || store || small_nb > 0 || NCH < 2 || noise_pack) return 1;
-        int n = k_pieces_opt;
-        if (n == 0) n = 1;   // AUTO: one piece (measured: see include/mppi_hip_diag.h "k_pieces")
-        return std::max(1, std::min(n, NCH));
     }
     // T <= 256: the nominal rollout runs inside every rollout block (lanes = timesteps)
     bool inline_nominal() const { return cfg.horizon <= 256 && cfg.model == MPPI_MODEL_DIFFDRIVE_RK4; }
@@ -846,8 +839,7 @@ struct mppi_engine {
         // co-scheduled engines (shards, or the two halves of an agent split): a 1024-thread workgroup needs four free waves on EVERY SIMD
         // of a CU at once and waits for the other engine's rollout waves to drain; 512 threads start in the gaps (config 5 on its two
         // engines 134.5 -> 129.5 us per tick; one engine alone prefers 1024: 145.8 against 147.1, profiles/r5_ab_fin_threads.jsonl)
-        if (fin_threads_opt) fin_threads = fin_threads_opt;
-        else if ((co_active() || is_co_sub) && fin_threads > 512) fin_threads = 512;
+        if ((co_active() || is_co_sub) && fin_threads > 512) fin_threads = 512;
         // the next tick's nominal table on the way out (lane-per-sample ticks that run the plant step and the shift; a graph replay
         // keeps its prologue: its launches are frozen)
         if ((flags & 3) == 3 && !(flags & 4) && hoist_on() && inline_nominal() && small_nb == 0 && !capturing) flags |= 32;
@@ -918,8 +910,8 @@ struct mppi_engine {
         if ((size_t)cfg.samples * (cfg.storage == MPPI_STORE_F64 ? 8 : 4) >= ((size_t)1 << 31))
             fail(MPPI_E_INVALID, "samples %d: a row of %d-byte elements must stay below 2 GiB", cfg.samples,
                  cfg.storage == MPPI_STORE_F64 ? 8 : 4);
-        // the per-wave eps sums [A][T][2][Ks/64] are written through ONE 32-bit buffer descriptor (2 GiB of records)
-        if ((size_t)cfg.n_agents * cfg.horizon * 2 * (((size_t)cfg.samples + 63) / 64) * (cfg.storage == MPPI_STORE_F64 ? 8 : 4) >= ((size_t)1 << 31))
+        // the per-wave eps sums [A][T][2][NWp] (NWp: Ks / 64 rounded up to 32) are written through ONE 32-bit buffer descriptor (2 GiB of records)
+        if ((size_t)cfg.n_agents * cfg.horizon * 2 * ((((size_t)cfg.samples + 63) / 64 + 31) / 32 * 32) * (cfg.storage == MPPI_STORE_F64 ? 8 : 4) >= ((size_t)1 << 31))
             fail(MPPI_E_INVALID, "n_agents * horizon * samples = %d * %d * %d: the per-wave noise sums must stay below 2 GiB", cfg.n_agents,
                  cfg.horizon, cfg.samples);
         if (cfg.model != MPPI_MODEL_DIFFDRIVE_RK4 && cfg.model != MPPI_MODEL_UNICYCLE_EULER)
@@ -944,7 +936,9 @@ struct mppi_engine {
 
         const int A = cfg.n_agents, K = cfg.samples, T = cfg.horizon;
         P.A = A; P.K = K; P.T = T; P.Ks = (K + 63) / 64 * 64;
-        if (alias_parent) P.Ks = alias_parent->P.Ks;   // (a co-scheduled shard: its rows are columns of the handle's own)
+        P.NWp = (P.Ks / 64 + 31) / 32 * 32;   // rows of the per-wave eps sums: whole 128-byte lines (in either storage type)
+        if (alias_parent) { P.Ks = alias_parent->P.Ks; P.NWp = alias_parent->P.NWp; }   // (a co-scheduled shard: its rows are columns of the handle's own)
+        hoist_auto = T <= 64 && (long)A * K >= 786432;
         P.sample_offset = cfg.sample_offset;
         if (cfg.agent_offset < 0) fail(MPPI_E_INVALID, "agent_offset must be >= 0");
         P.agent_offset = (uint32_t)cfg.agent_offset;
@@ -972,26 +966,13 @@ struct mppi_engine {
             // multiple of the update kernel's chunk): ONE layout in memory whatever the number of engines that fill it -- the same
             // DRAM pages as the one-engine tick -- and nothing to allocate.
             // (An agent-split shard: the handle's arrays from agent alias_a0 on -- whole rows, every array line-aligned per agent.)
+            // The per-wave eps sums too: their rows are padded to whole lines (P.NWp) and the cut is a multiple of 2048 samples, so the
+            // shard's slots of a row start on a line of their own (co_check_regions verifies every array before the group is used).
             const size_t es = esz(), k0 = (size_t)alias_k0, a0 = (size_t)alias_a0;
             d_eps = static_cast<char*>(alias_parent->d_eps) + (a0 * T * 2 * Ks + k0) * es;
             d_dP = static_cast<char*>(alias_parent->d_dP) + (a0 * T * Ks + k0) * es;
             d_stot = static_cast<char*>(alias_parent->d_stot) + (a0 * Ks + k0) * es;
-            // (the per-wave eps sums stay the shard's own: their rows are not multiples of a cache line long, so the cut falls INSIDE a
-            // line of every row -- two engines' concurrent kernels writing and reading words of one line through different XCDs: with
-            // those lines shared the controls came out wrong by 1e-7, EXPERIMENTS.md 56)
-#ifdef MPPI_ALIAS_EPART_TOO   // (measurement build for EXPERIMENTS.md 56: the K-shard's sums as columns of the handle's as well)
-            if (true) {
-#else
-            if (alias_k0 == 0) {   // agent split: the sums' rows of whole agents (T * 2 * Ks / 64 elements each: a multiple of a line)
-#endif
-                d_epart = static_cast<char*>(alias_parent->d_epart) + (a0 * T * 2 * (Ks / 64) + k0 / 64) * es;
-                epart_aliased = true;
-            } else {
-                void* p = nullptr;
-                const size_t bytes = (size_t)A * T * 2 * (Ks / 64) * esz();
-                HIPCHK(hipMalloc(&p, bytes)); hbm_bytes += bytes; d_epart = p;
-                HIPCHK(hipMemsetAsync(d_epart, 0, bytes, stream));
-            }
+            d_epart = static_cast<char*>(alias_parent->d_epart) + (a0 * T * 2 * (size_t)P.NWp + k0 / 64) * es;
         } else {
             void* p = nullptr;
             size_t bytes = (size_t)A * T * 2 * Ks * esz();
@@ -1000,7 +981,7 @@ struct mppi_engine {
             HIPCHK(hipMalloc(&p, bytes)); hbm_bytes += bytes; d_dP = p;
             bytes = (size_t)A * Ks * esz();
             HIPCHK(hipMalloc(&p, bytes)); hbm_bytes += bytes; d_stot = p;
-            bytes = (size_t)A * T * 2 * (Ks / 64) * esz();
+            bytes = (size_t)A * T * 2 * (size_t)P.NWp * esz();
             HIPCHK(hipMalloc(&p, bytes)); hbm_bytes += bytes; d_epart = p;
             HIPCHK(hipMemsetAsync(d_epart, 0, bytes, stream));
         }
@@ -1106,8 +1087,7 @@ struct mppi_engine {
         if (h_stage) hipHostFree(h_stage);
         if (h_out) hipHostFree(h_out);
         if (h_seq) hipHostFree(h_seq);
-        if (alias_parent) d_eps = d_dP = d_stot = nullptr;   // (the handle's)
-        if (epart_aliased) d_epart = nullptr;
+        if (alias_parent) d_eps = d_dP = d_stot = d_epart = nullptr;   // (the handle's)
         void* bufs[] = {d_eps, d_dP, d_stot, d_epart, tcb[0], tcb[1], baseb[0], baseb[1], pkb[0], pkb[1], d_unom, d_ufilt, d_state, d_goal, d_part, d_merged, d_S, d_out, d_tick, d_tmp, d_grid, d_prev, d_clk, d_fill};
         for (void* b : bufs) if (b) hipFree(b);
         if (own_stream) hipStreamDestroy(own_stream);
@@ -1124,6 +1104,7 @@ struct mppi_engine {
 // every call but the split tick itself, the outputs' read-back and the read-only queries first makes this engine's arrays whole again
 #define API_BEGIN(h)                                   \
     API_BEGIN_FAST(h)                                  \
+        (h)->co_other_call();                          \
         if ((h)->co_dirty) (h)->co_pull();
 #define API_END(h)                                                                  \
         return MPPI_OK;                                                             \
@@ -1177,6 +1158,36 @@ void mppi_engine::co_cuts(int G, std::vector<int>& cuts) const {
     for (int g = 0; g < G; ++g) if (cuts[g + 1] <= cuts[g]) fail(MPPI_E_INVALID, "co_shards = %d: %d samples do not split", G, cfg.samples);
 }
 
+// A co-scheduled engine fills REGIONS of this handle's own big arrays while this engine's kernels fill and read the rest, the two
+// streams unordered: no 128-byte line may hold words of both regions (kernels of two streams writing and reading words of one line
+// through the eight XCDs' separate L2s is not something this layout leans on), and no write of one engine may land in the other's
+// region at all.  Verified here for every array, for whatever (K, A, cut) the group was built with -- a violated invariant refuses
+// the group (AUTO: the one engine serves every call) instead of computing on.
+//   K split at column k0:  rows of dP / eps / Stot: pitch Ks * es, the shard's columns from k0 * es;  eps sums: pitch NWp * es, from (k0 / 64) * es
+//   agent split at a0:     every array from agent a0: per-agent sizes T Ks es, 2 T Ks es, Ks es, 2 T NWp es
+void mppi_engine::co_check_regions(const mppi_engine* sub) const {
+    constexpr size_t kLine = 128;
+    const size_t es = esz(), T_ = (size_t)cfg.horizon, Ks = (size_t)P.Ks, NWp = (size_t)P.NWp;
+    auto on_line = [&](const void* p, const char* what) {
+        if (reinterpret_cast<uintptr_t>(p) % kLine != 0) fail(MPPI_E_INTERNAL, "co-scheduled shard: its region of %s does not start on a %zu-byte line", what, kLine);
+    };
+    auto pitch_ok = [&](size_t bytes, const char* what) {
+        if (bytes % kLine != 0) fail(MPPI_E_INTERNAL, "co-scheduled shard: %s (%zu bytes) is not a whole number of %zu-byte lines", what, bytes, kLine);
+    };
+    if (sub->alias_parent != this || sub->P.Ks != P.Ks || sub->P.NWp != P.NWp) fail(MPPI_E_INTERNAL, "co-scheduled shard: not a region of this handle's arrays");
+    on_line(d_dP, "dP (base)"); on_line(d_eps, "eps (base)"); on_line(d_stot, "Stot (base)"); on_line(d_epart, "the eps sums (base)");
+    on_line(sub->d_dP, "dP"); on_line(sub->d_eps, "eps"); on_line(sub->d_stot, "Stot"); on_line(sub->d_epart, "the eps sums");
+    pitch_ok(Ks * es, "a row of dP / eps / Stot"); pitch_ok(NWp * es, "a row of the eps sums");
+    if (sub->alias_k0 > 0) {
+        // the shard's slots of an eps-sum row are [k0 / 64, k0 / 64 + ceil(K_sub / 64)): inside the row, behind shard 0's
+        if (sub->alias_k0 % 64 != 0 || (size_t)sub->alias_k0 / 64 + ((size_t)sub->cfg.samples + 63) / 64 > NWp || (size_t)sub->alias_k0 + (size_t)sub->cfg.samples > Ks)
+            fail(MPPI_E_INTERNAL, "co-scheduled shard: columns [%d, %d) do not fit the handle's rows", sub->alias_k0, sub->alias_k0 + sub->cfg.samples);
+    } else {
+        pitch_ok(T_ * Ks * es, "an agent's dP"); pitch_ok(Ks * es, "an agent's Stot"); pitch_ok(T_ * 2 * NWp * es, "an agent's eps sums");
+        if (sub->alias_a0 < 1 || sub->alias_a0 + sub->cfg.n_agents > cfg.n_agents) fail(MPPI_E_INTERNAL, "co-scheduled shard: agents out of range");
+    }
+}
+
 // Builds the shards.  Asked for by name (co_shards >= 2): at mppi_create, errors reported there.  AUTO: with the first fused
 // device-noise mppi_tick (co_pending) -- a handle that only ever runs the caller's own exchange (mppi_tick_begin / _finish: the
 // ranks of an N > 1 run), graph replays or injected-noise ticks never pays for the second set of buffers.
@@ -1196,20 +1207,16 @@ void mppi_engine::co_build() {
             mppi_engine* e = new mppi_engine();
             subs.push_back(e);
             e->is_co_sub = true;
-#ifndef MPPI_CO_OWN_BUFFERS
-            // the second engine's agents are agents [co_a0, A) of the handle's own big arrays (whole rows; per-agent sizes are line multiples
-            // only when T * Ks / 64 elements are: asked for below) -- its V is where every other call of the ABI looks for it, nothing to pull
-            if (((size_t)cfg.horizon * 2 * (P.Ks / 64) * esz()) % 128 == 0) { e->alias_parent = this; e->alias_a0 = co_a0; }
-#endif
+            // the second engine's agents are agents [co_a0, A) of the handle's own big arrays (whole rows, every array's per-agent size
+            // a multiple of a line) -- its V is where every other call of the ABI looks for it, nothing to pull
+            e->alias_parent = this; e->alias_a0 = co_a0;
             e->init(c);
+            co_check_regions(e);
             if (sig_is_matrix) { for (int i = 0; i < 4; ++i) e->sig_cost[i] = sig_cost[i]; e->sig_is_matrix = true; e->refresh_params(); }
             e->P.grid = P.grid; e->P.grid_w = P.grid_w; e->P.grid_h = P.grid_h; e->P.grid_res = P.grid_res; e->P.grid_ox = P.grid_ox;
             e->P.grid_oy = P.grid_oy; e->P.grid_weight = P.grid_weight;
             e->sync_timeout_ms = sync_timeout_ms;
-            e->store_eps_always = store_eps_always; e->use_pk = use_pk; e->upd_skip_light = upd_skip_light; e->pk_waves = pk_waves;
-            e->pk_min_set = pk_min_set; e->pk_min_samples = pk_min_samples; e->noise_pack = noise_pack;
-            e->fin_threads_opt = fin_threads_opt; e->k_pieces_opt = k_pieces_opt; e->hoist_opt = hoist_on() ? 1 : 0;
-            if (upd_nv_opt) { e->upd_nv_opt = upd_nv_opt; e->pick_update_shape(); }
+            co_hand_switches(e);
             for (int i = 0; i < 7; ++i) e->w_off[i] = w_off[i];
             e->refresh_weights();
             e->out_view_ext = d_out_view + (size_t)co_a0 * 8;
@@ -1238,10 +1245,9 @@ void mppi_engine::co_build() {
             mppi_engine* e = new mppi_engine();
             subs.push_back(e);
             e->is_co_sub = true;
-#ifndef MPPI_CO_OWN_BUFFERS   // (measurement build: every shard allocates its own rows, as until round 5)
             e->alias_parent = this; e->alias_k0 = cuts[g];
-#endif
             e->init(c);
+            co_check_regions(e);
             // what the handle was told since its creation (the shards may be built long after): the cost's sig matrix, the obstacle grid
             // (shared: same device; a later mppi_set_obstacle_grid reaches the shards first and gives them their own copy), the shift
             // fill, the deadline and the measurement switches.  Nominal controls / state / goal follow with the first tick (co_sync_subs).
@@ -1250,11 +1256,7 @@ void mppi_engine::co_build() {
             e->P.grid_oy = P.grid_oy; e->P.grid_weight = P.grid_weight;
             HIPCHK(hipMemcpyAsync(e->d_fill, d_fill, (size_t)cfg.n_agents * 2 * sizeof(double), hipMemcpyDeviceToDevice, stream));
             wait_stream("co-scheduled shard set-up");
-            e->sync_timeout_ms = sync_timeout_ms;
-            e->store_eps_always = store_eps_always; e->use_pk = use_pk; e->upd_skip_light = upd_skip_light; e->pk_waves = pk_waves;
-            e->pk_min_set = pk_min_set; e->pk_min_samples = pk_min_samples; e->noise_pack = noise_pack;
-            e->fin_threads_opt = fin_threads_opt; e->k_pieces_opt = k_pieces_opt; e->hoist_opt = hoist_on() ? 1 : 0;
-            if (upd_nv_opt) { e->upd_nv_opt = upd_nv_opt; e->pick_update_shape(); }
+            co_hand_switches(e);
             for (int i = 0; i < 7; ++i) e->w_off[i] = w_off[i];
             e->refresh_weights();
         }
@@ -1329,19 +1331,14 @@ void mppi_engine::co_pull_value() {
     if (!co_value_dirty) return;
     co_value_dirty = false;
     mppi_engine* e = subs[0];
-    const size_t A1 = e->cfg.n_agents, T_ = cfg.horizon, a0 = (size_t)co_a0, Ks = (size_t)P.Ks, NW = Ks >> 6;
-    const size_t es = f64() ? sizeof(double) : sizeof(float);
+    const size_t A1 = e->cfg.n_agents, T_ = cfg.horizon, a0 = (size_t)co_a0;
     HIPCHK(hipEventRecord(ev_co, e->stream));
     HIPCHK(hipStreamWaitEvent(stream, ev_co, 0));
     auto pull = [&](void* dst, const void* src, size_t per_agent_bytes) {
         HIPCHK(hipMemcpyAsync(static_cast<char*>(dst) + a0 * per_agent_bytes, src, A1 * per_agent_bytes, hipMemcpyDeviceToDevice, stream));
     };
-    if (!e->alias_parent) {   // (a second engine with arrays of its own; else its V set already is where this handle keeps it)
-        pull(d_dP, e->d_dP, T_ * Ks * es);
-        pull(d_stot, e->d_stot, Ks * es);
-        pull(d_epart, e->d_epart, T_ * 2 * NW * es);
-        if (!eps_lazy && injected_ready) pull(d_eps, e->d_eps, T_ * 2 * Ks * es);   // (option store_eps: the tick's noise is resident, not re-drawn on demand)
-    }
+    // (the second engine's cost prefix, totals, eps sums and stored noise already are where this handle keeps them: its big arrays
+    // are agents [co_a0, A) of this engine's own; what it computed into arrays of its own are the two small per-step tables)
     pull(d_base, e->d_base, T_ * sizeof(double));
     pull(d_tc, e->d_tc, T_ * mppi::kTcW * sizeof(double));
     wait_stream("co-scheduled agents: V pulled");
@@ -1352,6 +1349,7 @@ void mppi_engine::co_tick_agents(const double* state, const double* goal, uint64
     mppi_engine* e = subs[0];
     co_push_agents();
     set_inputs(state, goal);
+    co_fence_subs();   // (whatever else this handle was asked to do since the last split tick ran on this engine's stream, over all agents' rows)
     e->set_inputs(state ? state + (size_t)3 * co_a0 : nullptr, goal ? goal + (size_t)3 * co_a0 : nullptr);
     {
         AgentView view(this);
@@ -1364,22 +1362,24 @@ void mppi_engine::co_tick_agents(const double* state, const double* goal, uint64
     e->run_pipeline(MPPI_NOISE_PHILOX, seed, tick, nullptr, /*skip_small_merge=*/true);
     e->run_finalize(nullptr, 1, 1 | 2);
     co_dirty = true; co_value_dirty = true;
-    co_last = false;
+    co_subs_inflight = true;
 }
 
 void mppi_engine::co_tick(const double* state, const double* goal, uint64_t seed, uint32_t tick) {
     if (co_agents) { co_tick_agents(state, goal, seed, tick); return; }
     co_sync_subs();
     set_inputs(state, goal);
+    co_fence_subs();   // (whatever else this handle was asked to do since the last split tick ran on this engine's stream, over all columns)
     for (auto* e : subs) e->set_inputs(state, goal);
+    bool shards_pk;
     {
         ShardView view(this);
         run_nominal();
         run_pipeline(MPPI_NOISE_PHILOX, seed, tick, nullptr, /*skip_small_merge=*/true);   // the publish kernel merges a handful of tuples itself
-        co_shards_pk = last_rollout_pk;
+        shards_pk = last_rollout_pk;
     }
-    for (auto* e : subs) {   // every shard takes shard 0's kernel (sizes differ by a chunk at most; the re-run must match them all)
-        e->force_pk = co_shards_pk ? 1 : 0;
+    for (auto* e : subs) {   // every shard takes shard 0's kernel (sizes differ by a chunk at most): one kernel's arithmetic for every column of V
+        e->force_pk = shards_pk ? 1 : 0;
         e->run_nominal();
         e->run_pipeline(MPPI_NOISE_PHILOX, seed, tick, nullptr, /*skip_small_merge=*/true);
     }
@@ -1389,10 +1389,14 @@ void mppi_engine::co_tick(const double* state, const double* goal, uint64_t seed
     const int par = (int)(p2p_epoch & 1u);
     run_finalize(p2p_data(p2p_mbox, par, 0), p2p_n, 1 | 2, p2p_wait, p2p_slot / sizeof(double));
     for (auto* e : subs) e->run_finalize(e->p2p_data(e->p2p_mbox, par, 0), e->p2p_n, 1 | 2, e->p2p_wait, e->p2p_slot / sizeof(double));
-    // the tick's V and noise exist shard by shard only: this handle re-runs them from the snapshot when asked (materialise_value)
-    noise_ready = true; value_ready = false; value_lazy = true; eps_lazy = true; injected_ready = false; epart_ready = false;
+    // The tick's V is complete in this handle's own arrays: the shards' cost prefixes, totals and eps sums are columns of this engine's
+    // rows, base / tc are shard 0's (every shard derives the same table bit for bit).  mppi_download_value / mppi_update read them IN
+    // PLACE -- the bytes the shards' update kernels consumed -- once this engine's stream has waited for the shards' (co_join_subs, made
+    // by whatever is called next).  The noise is a function of (seed, tick, global sample): re-drawn on demand as after any tick.
+    noise_ready = true; value_ready = true; value_lazy = false; epart_ready = true;
+    eps_lazy = !store_eps_always; injected_ready = store_eps_always;   // (option store_eps: the shards stored their columns of it)
     lazy_seed = seed; lazy_tick = tick; lazy_from_counter = false; lazy_counter_bumped = false;
-    co_last = true;
+    co_subs_inflight = true;
 }
 
 extern "C" {
@@ -2074,7 +2078,7 @@ static int tick_co(mppi_engine* h, const double* state, const double* goal, uint
             h->out_via_host = false;   // (a deleted sub will never raise its agents' sequence words)
             h->co_release();
         } catch (...) {}
-        h->co_synced = false; h->co_last = false;
+        h->co_synced = false;
         h->invalidate_table();
         h->co_fallback = lost ? "a co-scheduled tick failed and the second engine's results could not be fetched: the group was dissolved, the agents it "
                                 "carried were reset (zero nominal controls; pass every agent's state with the next call)"
@@ -2138,7 +2142,7 @@ int mppi_tick_graph(mppi_engine* h, uint64_t seed) {
     h->use_table_set(h->graph_tab);   // (eager ticks in between may have switched sets: the replay's rollout rewrites the captured one)
     HIPCHK(hipGraphLaunch(h->graph_exec, h->stream));
     h->out_via_host = false;
-    const bool small = h->small_nb > 0 || h->tick_pieces(true, h->store_eps_always) > 1;   // (V not resident: re-run from the snapshot on demand)
+    const bool small = h->small_nb > 0;   // (the scan kernel: V not resident, re-run from the snapshot on demand)
     h->noise_ready = true; h->value_ready = !small; h->value_lazy = small; h->partials_ready = false; h->epart_ready = !small;
     h->eps_lazy = small || !h->store_eps_always; h->lazy_seed = seed; h->lazy_from_counter = true; h->lazy_counter_bumped = true;
     h->injected_ready = !h->eps_lazy; h->last_tick_eager = false;
@@ -2154,20 +2158,11 @@ int mppi_set_option(mppi_engine* h, const char* key, int64_t value) {
         if (k != "co_cut_pct" && k != "table_hoist") if (int rc__ = mppi_set_option(sub__, key, value)) fail(rc__, "co-scheduled shard: %s", sub__->err.c_str());
     if (k == "store_eps") { h->settle_lazy_state(); h->store_eps_always = value != 0; h->destroy_graph(); }
     else if (k == "rollout_pk") { h->settle_lazy_state(); h->use_pk = value != 0; h->destroy_graph(); }
-    else if (k == "upd_skip") h->upd_skip_light = value != 0;
     else if (k == "noise_packing") {
         if (value < 0 || value > 2) fail(MPPI_E_INVALID, "noise_packing: 0 (three steps per Philox call, the default stream), 1 (four) or 2 (hipRAND's normals: two)");
         if (value && (h->f64() || h->small_nb > 0 || !h->inline_nominal()))
             fail(MPPI_E_INVALID, "noise_packing 1 / 2 is drawn by the mixed-precision rollout only: fp32 storage, the lane kernels (tick_path lanes), rk4 / diff drive, T <= 256");
         h->settle_lazy_state(); h->wait_stream(__func__); h->noise_pack = (int)value; h->pick_update_shape(); h->partials_ready = false; h->destroy_graph();
-    }
-    else if (k == "fin_threads") {
-        if (value != 0 && value != 256 && value != 512 && value != 1024) fail(MPPI_E_INVALID, "fin_threads: 0 (the engine's rule), 256, 512 or 1024");
-        h->fin_threads_opt = (int)value; h->destroy_graph();
-    }
-    else if (k == "k_pieces") {
-        if (value < 0 || value > 16) fail(MPPI_E_INVALID, "k_pieces: 0 (the engine's rule) or 1..16");
-        h->settle_lazy_state(); h->k_pieces_opt = (int)value; h->destroy_graph();
     }
     else if (k == "table_hoist") {
         if (value < -1 || value > 1) fail(MPPI_E_INVALID, "table_hoist: -1 (by size), 0 or 1");
@@ -2175,13 +2170,6 @@ int mppi_set_option(mppi_engine* h, const char* key, int64_t value) {
         h->invalidate_table();
     }
     else if (k == "lanes_zero_copy") h->lanes_zero_copy = value != 0;
-    else if (k == "upd_nv") {
-        if (value != 0 && value != 8 && value != 16) fail(MPPI_E_INVALID, "upd_nv: 0 (by size), 8 or 16");
-        if (h->co_active()) fail(MPPI_E_STATE, "upd_nv: set it before the handle builds its co-scheduled shards (their cuts follow the chunk length)");
-        if (value == 16 && h->noise_pack) fail(MPPI_E_INVALID, "upd_nv 16 is built for the default noise stream");
-        h->settle_lazy_state(); h->wait_stream(__func__); h->upd_nv_opt = (int)value; h->pick_update_shape(); h->partials_ready = false; h->destroy_graph();
-    }
-    else if (k == "pk_waves") { if (value != 4 && value != 5) fail(MPPI_E_INVALID, "pk_waves: 4 or 5"); h->pk_waves = (int)value; }
     else if (k == "pk_min_samples") { h->settle_lazy_state(); h->pk_min_set = value >= 0; h->pk_min_samples = value >= 0 ? (long)value : 400000; h->destroy_graph(); }
     else if (k == "co_cut_pct") {
         if (value < 1 || value > 99) fail(MPPI_E_INVALID, "co_cut_pct: 1..99");
@@ -2196,12 +2184,7 @@ int mppi_set_option(mppi_engine* h, const char* key, int64_t value) {
             h->cfg.co_shards = G;
             try { h->co_build(); } catch (...) { h->cfg.co_shards = asked; throw; }
             h->cfg.co_shards = asked;
-            for (auto* e : h->subs) {   // the new shards take over this handle's switches
-                e->store_eps_always = h->store_eps_always; e->use_pk = h->use_pk; e->upd_skip_light = h->upd_skip_light; e->pk_waves = h->pk_waves;
-                e->pk_min_set = h->pk_min_set; e->pk_min_samples = h->pk_min_samples; e->sync_timeout_ms = h->sync_timeout_ms;
-                e->noise_pack = h->noise_pack;
-                e->fin_threads_opt = h->fin_threads_opt; e->k_pieces_opt = h->k_pieces_opt; e->hoist_opt = h->hoist_on() ? 1 : 0;
-            }
+            // (co_build hands the new shards this handle's switches)
         }
     }
     else fail(MPPI_E_INVALID, "unknown option '%s'", key);
@@ -2214,13 +2197,8 @@ int mppi_get_option(mppi_engine* h, const char* key, int64_t* value) {
     const std::string k(key);
     if (k == "store_eps") *value = h->store_eps_always;
     else if (k == "rollout_pk") *value = h->use_pk;
-    else if (k == "upd_skip") *value = h->upd_skip_light;
     else if (k == "noise_packing") *value = h->noise_pack;
-    else if (k == "pk_waves") *value = h->pk_waves;
-    else if (k == "upd_nv") *value = h->upd_nv;
     else if (k == "lanes_zero_copy") *value = h->lanes_zero_copy;
-    else if (k == "fin_threads") *value = h->fin_threads_opt;
-    else if (k == "k_pieces") *value = h->k_pieces_opt;
     else if (k == "table_hoist") *value = h->hoist_opt;
     else if (k == "pk_min_samples") *value = h->pk_min_set ? h->pk_min_samples : -1;
     else if (k == "co_cut_pct") *value = h->co_cut_pct;

@@ -45,28 +45,18 @@ constexpr int kTupleW = 8;  // {min, D, N0, N1, E0, E1, count, pad}
 // write-back when it ends -- 4-5 us of an under-filled launch (25 MB dirty at 125 000 samples: rollout 24.0 -> 19.4 us, tick 39.7 ->
 // 34.9; config 3 57.7 -> 53.9), nothing of a launch whose rows leave the L2 on their own (config 4 144.7 / 145.1, config 5 128.2 /
 // 128.0); `nt` keeps the rollout's gain and slows the update that reads the rows back (profiles/r5_ab_store_policy.jsonl).
-// A measurement build overrides it (make VARIANT=plain EXTRA=-DMPPI_DP_STORE_AUX=0; tools/ab_lib.py).
-#ifndef MPPI_DP_STORE_AUX
-#define MPPI_DP_STORE_AUX 16
-#endif
-constexpr int kDpStoreAux = MPPI_DP_STORE_AUX;
-// ... of the 8-byte rows of fp64 storage (400 MB per tick at config 4: more than the 256 MB Infinity Cache holds), and whether the
-// update kernel reads its rows with non-temporal loads -- measurement switches of the same kind
-#ifndef MPPI_DP_STORE_AUX_F64
-#define MPPI_DP_STORE_AUX_F64 MPPI_DP_STORE_AUX
-#endif
-// (-1: by storage type -- non-temporal for the 8-byte rows: the update of fp64 storage reads 400 MB per tick at config 4 next to a
-// per-sample total it re-reads for every row; with rows that do not stay in the L2 behind them, that total does: update 90.7 -> 80.0 us,
-// tick 213 -> 200 (same box; 4-byte rows: 144.3 / 145.0 on one engine, 135.2 -> 139.1 co-scheduled -- they keep plain loads;
-// profiles/r5_ab_f64_memory_policy.jsonl))
-#ifndef MPPI_UPD_LOAD_NT
-#define MPPI_UPD_LOAD_NT -1
-#endif
-constexpr int kDpStoreAuxF64 = MPPI_DP_STORE_AUX_F64;
+constexpr int kDpStoreAux = 16;
+constexpr int kDpStoreAuxF64 = kDpStoreAux;   // ... of the 8-byte rows of fp64 storage (400 MB per tick at config 4: more than the 256 MB Infinity Cache holds)
+// The update kernel reads 8-byte rows with non-temporal loads, 4-byte rows with plain ones: the update of fp64 storage reads 400 MB per
+// tick at config 4 next to a per-sample total it re-reads for every row; with rows that do not stay in the L2 behind them, that total
+// does: update 90.7 -> 80.0 us, tick 213 -> 200 (same box; 4-byte rows: 144.3 / 145.0 on one engine, 135.2 -> 139.1 co-scheduled;
+// profiles/r5_ab_f64_memory_policy.jsonl)
 constexpr int kTcW = 8;     // {un0, un1, w0, w1, cb, 0, 0, 0}
 
 struct DevParams {
     int A, K, Ks, T;          // Ks: padded row pitch (elements) of eps / dP rows
+    int NWp;                  // row pitch (elements) of the per-wave eps sums [A][T][2][NWp]: ceil(Ks / 64) rounded up to a whole number of
+                              // 128-byte lines -- every row starts on a line, so a co-scheduled shard's columns of it share no line with its neighbour's
     uint32_t sample_offset;
     uint32_t agent_offset;    // global index of local agent 0: the device-noise streams are keyed by the GLOBAL agent index
     double dt, sigma, lambda, inv_lambda;
@@ -959,7 +949,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(S) =
     const double sixth_rd = P.dt * P.rhalf * (1.0 / 6.0);  // Simpson weight of (u0 + u1)
     const double hq0 = 0.5 * P.q0, hq1 = 0.5 * P.q1, hq2 = 0.5 * P.q2;
     const double p_max = half_kd * P.u_max;                 // LEAN: clip bound of the scaled wheel speeds
-    const size_t NW = Ks >> 6;  // waves per agent row (Ks is a multiple of 64)
+    const size_t NW = (size_t)P.NWp;  // row pitch of the eps sums
+    const size_t nw_own = ((size_t)P.K + 63) >> 6;   // ... and the slots of a row that are THIS engine's (a co-scheduled shard's row continues with its neighbour's)
     // raw buffer view of epart (byte-addressed, bounds-checked by the hardware); < 4 GB by construction
     const __amdgpu_buffer_rsrc_t ep_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         epart, 0, (int)min((size_t)0x7FFFFFFF, (size_t)P.A * T * 2 * NW * sizeof(S)), 0x00020000);
@@ -1023,7 +1014,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(S) =
             for (int j = 2 * U; j < 16; ++j) ev[j] = !EXTRA ? 0.f : ((FULL || active) ? (float)tl[(j - 2 * U) >> 1][j & 1] : 0.f);
             const float tot = wave_sum16<EXTRA>(ev, tid & 63);
             const int idx = sum16_index(tid & 63), te = t0 + (idx >> 1);
-            const bool mine = (tid & 63) < 16 && idx < (EXTRA ? 16 : 2 * U) && te < T && (size_t)(k >> 6) < NW;
+            const bool mine = (tid & 63) < 16 && idx < (EXTRA ? 16 : 2 * U) && te < T && (size_t)(k >> 6) < nw_own;
             const size_t at = (((size_t)a * T + te) * 2 + (idx & 1)) * NW + (k >> 6);
             if (sizeof(S) == 4) {
                 // predication by address instead of by branch: a buffer store whose offset lies beyond
@@ -1257,7 +1248,7 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
                                                     const S* __restrict__ dP, const S* __restrict__ Stot,
                                                     double* __restrict__ part, int NCH, int ch_first, int n_local,
                                                     const S* __restrict__ epart, uint64_t seed, uint32_t tick_arg,
-                                                    const uint32_t* __restrict__ tick_ptr, int skip_light) {
+                                                    const uint32_t* __restrict__ tick_ptr) {
     using R = S;
     constexpr int VEC = UpdCfg<S, NV>::VEC, CH = UpdCfg<S, NV>::CH;
     typedef S vec_t __attribute__((ext_vector_type(VEC)));
@@ -1293,13 +1284,8 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
     // pass 1: the chunk into registers, lane minimum
     S v[NV][VEC];
     R m = (R)INFINITY;
-    constexpr bool kNtRows = MPPI_UPD_LOAD_NT < 0 ? sizeof(S) == 8 : MPPI_UPD_LOAD_NT != 0;
-#ifdef MPPI_UPD_SERIAL_LOADS   // (measurement build: the general path for every chunk, as the kernel stood until round 5)
-    constexpr bool kWholeChunkPath = false;
-#else
-    constexpr bool kWholeChunkPath = true;
-#endif
-    if (kWholeChunkPath && k_end - k_begin == CH) {
+    constexpr bool kNtRows = sizeof(S) == 8;
+    if (k_end - k_begin == CH) {
         // (uniform) a whole chunk -- every chunk of a row but its last: no per-lane bounds, so ALL of the chunk's row loads are in flight
         // before the first is waited for.  (Round 5: behind the per-lane guard of the general path below each vector's two loads sit in
         // their own basic block with their own s_waitcnt vmcnt(0) -- eight serial round trips per workgroup, one 16-byte load per lane
@@ -1307,10 +1293,7 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
         // In flight per lane: the HBM loads of up to eight vectors of the row (32 registers), and the per-sample totals (L2 hits) in
         // groups of kSvGroup behind them -- sized so that the kernel keeps its eight workgroups per CU.
         constexpr int kPvDepth = NV < 8 ? NV : 8;
-#ifndef MPPI_UPD_SV_GROUP
-#define MPPI_UPD_SV_GROUP 4
-#endif
-        constexpr int kSvGroup = MPPI_UPD_SV_GROUP < kPvDepth ? MPPI_UPD_SV_GROUP : kPvDepth;
+        constexpr int kSvGroup = 4 < kPvDepth ? 4 : kPvDepth;
 #pragma unroll
         for (int h = 0; h < NV; h += kPvDepth) {
             vec_t pv[kPvDepth];
@@ -1409,7 +1392,7 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
         int n_here = 0;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) { bal[i] = __ballot(xs[i] > cand); n_here += (int)__popcll(bal[i]); }
-        if (skip_light && n_here == 0) continue;   // (uniform)
+        if (n_here == 0) continue;   // (uniform)
 #pragma unroll
         for (int i = 0; i < VEC; ++i) { es[i] = Exp2<R>::f(xs[i]); D += es[i]; }
         if (REGEN) {
@@ -1457,7 +1440,7 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
     // so that it does not hold registers through them
     R E0 = 0, E1 = 0;
     {
-        const size_t NW = Ks >> 6;
+        const size_t NW = (size_t)P.NWp;
         const S* ep = epart + (((size_t)a * P.T + t) * 2) * NW;
         const int w_begin = k_begin >> 6, w_end = (k_end + 63) >> 6;
         for (int w = w_begin + tid; w < w_end; w += 256) { E0 += ep[w]; E1 += ep[NW + w]; }
@@ -1483,10 +1466,10 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
 template <typename S>
 __global__ __launch_bounds__(256) void eps_wavesum_kernel(DevParams P, const S* __restrict__ eps, S* __restrict__ epart) {
     const int k = blockIdx.x * 256 + threadIdx.x;
-    const size_t row = (size_t)blockIdx.z * P.T * 2 + blockIdx.y, Ks = (size_t)P.Ks, NW = Ks >> 6;
+    const size_t row = (size_t)blockIdx.z * P.T * 2 + blockIdx.y, Ks = (size_t)P.Ks, NW = (size_t)P.NWp;
     const S val = (k < P.K) ? eps[row * Ks + k] : (S)0;
     const S sum = wave_sum_lane63(val);
-    if ((threadIdx.x & 63) == 63 && (size_t)(k >> 6) < NW) epart[row * NW + (k >> 6)] = sum;
+    if ((threadIdx.x & 63) == 63 && (k >> 6) < ((P.K + 63) >> 6)) epart[row * NW + (k >> 6)] = sum;
 }
 
 // The device noise as a kernel of its own, one lane per (sample, step pair): materialises the
@@ -1531,11 +1514,7 @@ __global__ __launch_bounds__(256) void merge_kernel(DevParams P, const double* _
     // instead of a per-lane guard around the loads -- a guard gives each load its own basic block and its own wait), one round trip to
     // memory instead of three (count word -> minimum -> the rest).  More tuples than that: the two-pass loops.
     constexpr int kR = 4;
-#ifdef MPPI_MERGE_LOOPS   // (measurement build: the two-pass loops for every launch, as the kernel stood)
-    const bool in_regs = false;
-#else
     const bool in_regs = NCH <= kR * (int)blockDim.x;   // (uniform)
-#endif
     double q[kR][7];
     bool has[kR];
     double m = INFINITY;

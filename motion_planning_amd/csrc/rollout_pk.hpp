@@ -60,7 +60,6 @@ struct RolloutPkArgs {
     float *dP, *stot, *epart;
     float al_guard;
     const PkRow* pkrows;  // inline_nominal 0: the table the previous tick's finalize kernel left ([A][T])
-    int waves;            // 4: the compiler's own allocation (no spills); 5: one more wave per SIMD at the price of a few spills
     int noise_pack;       // option "noise_packing": 0 three steps per Philox call (the default stream), 1 four, 2 hipRAND's normals, two (NoisePack, mppi_kernels.hpp)
     hipEvent_t ev_start, ev_stop;
 };
@@ -105,7 +104,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
     const int kA = kwave + 2 * lane;                             // this lane's two: kA, kA + 1
     const bool actA = kA < P.K, actB = kA + 1 < P.K;
     const bool block_full = ((int)blockIdx.x + 1) * 512 <= P.K;  // (uniform)
-    const size_t Ks = (size_t)P.Ks, NW = Ks >> 6;
+    const size_t Ks = (size_t)P.Ks, NW = (size_t)P.NWp;
+    // the slots of an eps-sum row that are THIS engine's: ceil(K / 64).  (Until round 6 the bound was the row's pitch: a co-scheduled
+    // shard whose last wave holds 64 samples wrote the 0 of that wave's second slot one past its own -- harmless in a buffer of
+    // its own, but with the shard's sums as columns of the handle's rows that slot is slot 0 of the NEXT row, i.e. the first wave
+    // sum of the other shard: the "shared cache line" error of EXPERIMENTS.md 56, root-caused in 57.)
+    const size_t nw_own = ((size_t)P.K + 63) >> 6;
     const uint64_t dP_a64 = reinterpret_cast<uint64_t>(dP + (size_t)a * T * Ks);
     float* const dP_a = reinterpret_cast<float*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(dP_a64 >> 32)) << 32) |
                                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)dP_a64));
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
         const float tot = wave_sum16<(EXTRA || U == 8)>(ev, lane);   // (an 8-step chunk fills all sixteen slots)
         const int idx = sum16_index(lane), te = t0 + (idx >> 1), half = lane >> 4;
         const size_t slot = (size_t)(kwave >> 6) + half;
-        const bool mine = lane < 32 && idx < (EXTRA ? 16 : 2 * U) && te < T && slot < NW;
+        const bool mine = lane < 32 && idx < (EXTRA ? 16 : 2 * U) && te < T && slot < nw_own;
         const size_t at = (((size_t)a * T + te) * 2 + (idx & 1)) * NW + slot;
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(half ? 0.f : tot), ep_rsrc, mine ? (unsigned)(at * 4) : 0xFFFFFFFFu, 0, kDpStoreAux);
     };
@@ -417,8 +421,8 @@ hipError_t launch_rollout_pk(const RolloutPkArgs& a) {
                                a.seed, a.tick, a.tick_ptr, a.epart, a.unom, a.base, a.al_guard, a.pkrows);                    \
     } while (0)
 #define MPPI_PK_GO(IN, W) do { if (a.noise_pack == 2) MPPI_PK_GO_(IN, W, 2); else if (a.noise_pack == 1) MPPI_PK_GO_(IN, W, 1); else MPPI_PK_GO_(IN, W, 0); } while (0)
-    if (a.waves == 5) { if (a.inline_nominal == 2) MPPI_PK_GO(2, 5); else if (a.inline_nominal == 1) MPPI_PK_GO(1, 5); else MPPI_PK_GO(0, 5); }
-    else { if (a.inline_nominal == 2) MPPI_PK_GO(2, 4); else if (a.inline_nominal == 1) MPPI_PK_GO(1, 4); else MPPI_PK_GO(0, 4); }
+    // (WAVES = 4: the compiler's own allocation, no spills; a fifth wave per SIMD cost spills and measured slower -- EXPERIMENTS.md)
+    if (a.inline_nominal == 2) MPPI_PK_GO(2, 4); else if (a.inline_nominal == 1) MPPI_PK_GO(1, 4); else MPPI_PK_GO(0, 4);
 #undef MPPI_PK_GO
 #undef MPPI_PK_GO_
     return hipGetLastError();

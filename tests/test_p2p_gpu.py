@@ -370,10 +370,12 @@ def test_options_are_per_handle_and_checked():
     from motion_planning_amd._capi import MppiError
     with Engine(4096, T, tick_path="lanes") as a, Engine(4096, T, tick_path="lanes") as b:
         assert a.get_option("rollout_pk") == 1 and a.get_option("pk_min_samples") == -1 and a.get_option("co_cut_pct") == 58
-        a.set_option("rollout_pk", 0); a.set_option("pk_min_samples", 1); a.set_option("upd_skip", 0); a.set_option("pk_waves", 5)
-        assert (a.get_option("rollout_pk"), a.get_option("pk_min_samples"), a.get_option("upd_skip"), a.get_option("pk_waves")) == (0, 1, 0, 5)
-        assert (b.get_option("rollout_pk"), b.get_option("pk_min_samples"), b.get_option("upd_skip"), b.get_option("pk_waves")) == (1, -1, 1, 4)
-        for key, val in (("no_such_switch", 1), ("pk_waves", 6), ("co_cut_pct", 0), ("co_cut_pct", 100)):
+        a.set_option("rollout_pk", 0); a.set_option("pk_min_samples", 1); a.set_option("lanes_zero_copy", 0); a.set_option("table_hoist", 1)
+        assert (a.get_option("rollout_pk"), a.get_option("pk_min_samples"), a.get_option("lanes_zero_copy"), a.get_option("table_hoist")) == (0, 1, 0, 1)
+        assert (b.get_option("rollout_pk"), b.get_option("pk_min_samples"), b.get_option("lanes_zero_copy"), b.get_option("table_hoist")) == (1, -1, 1, -1)
+        # the switches that lost everywhere they were measured are gone (round 6): unknown keys now
+        for key, val in (("no_such_switch", 1), ("k_pieces", 2), ("upd_nv", 16), ("fin_threads", 512), ("upd_skip", 0), ("pk_waves", 5),
+                         ("table_hoist", 2), ("co_cut_pct", 0), ("co_cut_pct", 100)):
             with pytest.raises(MppiError) as err:
                 a.set_option(key, val)
             assert err.value.code == -1, (key, val)
@@ -555,8 +557,8 @@ def test_large_k_single_engine_equals_four_small_ones(log2_k):
 def test_co_scheduled_shards_behind_one_handle(K, shards, monkeypatch):
     """mppi_config.co_shards: the SAME calls on ONE handle (mppi_tick, then the two-stage calls) with the fused tick split
     over co-scheduled engines inside it.  Closed loop of six device-noise ticks equals the unsplit engine to 1e-10 (sample
-    ids are global, the tuple merge is exact); V and the noise downloaded after such a tick -- re-run from the tick's
-    snapshot over all samples -- are bit for bit the unsplit engine's; calls that bypass the group (mppi_update on the
+    ids are global, the tuple merge is exact); V (read in place: the shards' rows are columns of the handle's arrays) and the
+    noise (re-drawn) downloaded after such a tick are bit for bit the unsplit engine's; calls that bypass the group (mppi_update on the
     resident V, a split tick_begin / tick_finish) leave the shards behind and the next fused tick brings them back."""
     from motion_planning_amd.mppi import Engine
     # one rollout kernel on both sides: left alone the unsplit engine picks it by rounds of waves (820 000 samples: the all-fp64
@@ -576,7 +578,7 @@ def test_co_scheduled_shards_behind_one_handle(K, shards, monkeypatch):
             for i in range(6):
                 st, ua = e.tick(st if i % 2 == 0 else None, goal if i == 0 else None, noise="philox", seed=5, tick_id=i)
                 traj.append(np.concatenate([st[0], ua[0]]))
-            V, eps = e.download_value()[0], e.download_noise()[0]   # after a co-scheduled tick: re-run from the snapshot
+            V, eps = e.download_value()[0], e.download_noise()[0]   # after a co-scheduled tick: V in place, the noise re-drawn
             lat = e.get_nominal()
             # a call that bypasses the group, then the group again
             u_upd = e.update()[0]                                    # update_action on the resident V / noise of tick 5
@@ -663,8 +665,9 @@ def test_auto_co_shards_are_built_lazily_and_inherit_the_handles_settings():
                 traj.append(np.concatenate([st[0], ua[0]]))
             after = e.info()
             assert after["co_shards"] == (2 if co is None else 1) and after["co_note"] == ""
-            # the second engine exists now: its small arrays and its per-wave noise sums -- its rows are columns of the handle's own buffers
-            assert (after["hbm_bytes"] > hbm0 + (1 << 20)) == (co is None) and after["hbm_bytes"] < 1.1 * hbm0
+            # the second engine exists now: its small arrays and its mailbox only -- its rows, totals and per-wave noise sums are columns
+            # of the handle's own buffers
+            assert (after["hbm_bytes"] > hbm0) == (co is None) and after["hbm_bytes"] < hbm0 + (4 << 20)
             outs[co] = (np.array(traj), e.get_nominal())
     assert np.abs(outs[None][0] - outs[1][0]).max() < 1e-10 and np.abs(outs[None][1] - outs[1][1]).max() < 1e-10
     assert outs[1][1][0, -1] == 0.25 and outs[1][1][1, -1] == -0.5
@@ -672,8 +675,8 @@ def test_auto_co_shards_are_built_lazily_and_inherit_the_handles_settings():
 
 @pytest.mark.gpu
 def test_co_scheduled_value_is_bit_identical_to_the_unsplit_engine(monkeypatch):
-    """First tick from identical inputs: the V a co-scheduled handle hands back (re-run over all samples from the tick's
-    snapshot, with the kernel the shards ran) equals the unsplit engine's bit for bit, on both rollout kernels (820 000
+    """First tick from identical inputs: the V a co-scheduled handle hands back (read in place: every shard's columns, all from
+    the kernel shard 0 picked) equals the unsplit engine's bit for bit, on both rollout kernels (820 000
     samples: shards of >= 400 000, the mixed-precision one), and the AUTO rule splits config 4 in two."""
     from motion_planning_amd.mppi import Engine
     T = 50
@@ -712,6 +715,74 @@ def test_co_scheduled_value_is_bit_identical_to_the_unsplit_engine(monkeypatch):
             got.append((nxt, ua, np.array([e.get_nominal(agent=a) for a in range(3)])))
     for x, y in zip(got[0], got[1]):
         assert np.abs(x - y).max() < 1e-10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [500001, 655361, 999999, 1000000, 1 << 20])
+def test_co_scheduled_cut_sweep_equals_one_engine(K):
+    """VERDICT r5 item 3.  Two co-scheduled engines fill ONE set of rows (cost prefix, totals, per-wave noise sums) from two unordered
+    streams; the engine refuses a group whose regions share a 128-byte line (co_check_regions) and no write of one shard may land in
+    the other's columns.  Swept here over sample counts whose rows are NOT multiples of a line, of a wave pair or of a chunk (500 001,
+    655 361, 999 999, config 4's 10^6 -- the size the round-5 build with shared noise-sum rows got wrong by 1.9e-7: its last wave's zero
+    fill ran one slot past the shard, EXPERIMENTS.md 57) and one that is (2^20), times three cuts: after two ticks V is BIT-equal to the
+    one engine's on every sample, the stand-alone update (which reads every shard's noise sums in place) to 1e-12, the controls and
+    the state to the exact merge's rounding."""
+    from motion_planning_amd.mppi import Engine
+    u0, st0, goal = _u0(), [[0.0, 0.0, 0.0]], [[0.0, -1.0, 0.0]]
+    opts = {"pk_min_samples": 100000}      # one rollout kernel for every shard size of the sweep and for the one engine
+
+    def run(co, cut):
+        with Engine(K, T, storage="f32", tick_path="lanes", co_shards=co, options=dict(opts, **({"co_cut_pct": cut} if cut else {}))) as e:
+            e.set_nominal(u0)
+            e.tick(st0, goal, noise="philox", seed=11, tick_id=0)
+            nxt, ua = e.tick(None, None, noise="philox", seed=11, tick_id=1)
+            info = e.info()
+            assert info["co_shards"] == co and info["rollout_kernel"] == "mixed" and sum(info["co_samples"]) == K
+            V = e.download_value()[0]
+            return V, e.update()[0], nxt[0], ua[0], e.get_nominal(), info["co_samples"]
+    ref = run(1, None)
+    seen = set()
+    for cut in (30, 58, 77):
+        got = run(2, cut)
+        seen.add(got[5][0])
+        assert got[5][0] % 8192 == 0                                  # the cut: a multiple of the update chunk (and so of 2048 samples = a line of sums)
+        assert np.array_equal(got[0], ref[0]), (K, cut, float(np.abs(got[0] - ref[0]).max()))
+        assert np.abs(got[1] - ref[1]).max() < 1e-12, (K, cut, float(np.abs(got[1] - ref[1]).max()))
+        assert np.abs(got[2] - ref[2]).max() < 1e-12 and np.abs(got[3] - ref[3]).max() < 1e-10 and np.abs(got[4] - ref[4]).max() < 1e-10, (K, cut)
+    assert len(seen) == 3
+
+
+@pytest.mark.gpu
+def test_co_scheduled_ticks_are_ordered_behind_whatever_else_the_handle_was_asked():
+    """ADVICE r5 (high).  The shards' rows are columns of the handle's own arrays, so work this handle runs on its OWN stream over
+    the whole arrays between two split ticks -- the re-draw of the last tick's noise that a parameter change settles first, a download,
+    a stand-alone update -- must be finished before the other shard's next rollout writes its columns (and must not start before
+    that shard's last kernels are done).  co tick -> set_sigma_lambda -> co tick (and the same around download_noise / update /
+    set_weights), several rounds at config 4's size, against one engine: every round's controls to 1e-10, the final V bit for bit."""
+    from motion_planning_amd.mppi import Engine
+    K = 1000000
+    u0 = _u0()
+    outs = {}
+    for co in (2, 1):
+        with Engine(K, T, storage="f32", tick_path="lanes", co_shards=co, options={"pk_min_samples": 200000}) as e:
+            e.set_nominal(u0)
+            rows = []
+            nxt, ua = e.tick([[0, 0, 0]], [[0, -1, 0]], noise="philox", seed=6, tick_id=0)
+            for r in range(4):
+                e.set_sigma_lambda(0.9 - 0.05 * r, 0.001 + 0.0005 * r)      # settles the lazy noise: a full-K re-draw on the handle's stream
+                nxt, ua = e.tick(None, None, noise="philox", seed=6, tick_id=10 * r + 1)
+                rows.append(np.concatenate([nxt[0], ua[0]]))
+                eps = e.download_noise()[0]                                 # full-K re-draw, then straight into the next split tick
+                nxt, ua = e.tick(None, None, noise="philox", seed=6, tick_id=10 * r + 2)
+                rows.append(np.concatenate([nxt[0], ua[0], [float(eps[7, 1, K - 5]), float(eps[3, 0, 11])]]))
+                e.set_weights(q=[1e3 - 10 * r, 1e3 - 10 * r, 0.0], r=[1.0, 1.0], p1=[1e3, 1e3, 1e3 + r])
+                nxt, ua = e.tick(None, None, noise="philox", seed=6, tick_id=10 * r + 3)
+                rows.append(np.concatenate([nxt[0], ua[0]]))
+            V = e.download_value()[0]
+            outs[co] = (rows, V)
+    for i, (x, y) in enumerate(zip(outs[1][0], outs[2][0])):
+        assert np.abs(x - y).max() < 1e-10, (i, float(np.abs(x - y).max()))
+    assert np.abs(outs[1][1] - outs[2][1]).max() <= 1e-5      # V of the last tick: its inputs (the nominal controls) agree to 1e-10 only
 
 
 @pytest.mark.gpu

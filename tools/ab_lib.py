@@ -27,7 +27,7 @@ if __name__ == "__main__":
             p.add_argument(name, type=typ, default=dflt)
         b = p.parse_args(rest)
         b.fixed_options = dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in b.fixed.split(",") if kv)
-        r = ab.run("upd_skip", 1, b)     # (an option at its default value: the protocol needs one)
+        r = ab.run("lanes_zero_copy", 1, b)     # (an option at its default value: the protocol needs one)
         r.update({"lib": a.child, "option": None, "value": None})
         print(json.dumps(r), flush=True)
     else:

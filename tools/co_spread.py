@@ -1,6 +1,6 @@
 """Run ON THE GPU BOX: the co-scheduled config-4 tick from handle instance to handle instance.  Five handles are created one after the other in ONE
 process (each: 0.4 s of warm-up ticks, then 3 x 300 back-to-back ticks on the host clock), the same with co_shards = 1 next to each.
-MPPI_AB_LIB=name runs a measurement build (lib/libmppi_hip_<name>.so), e.g. one made with -DMPPI_CO_OWN_BUFFERS.  (EXPERIMENTS.md 54, 56)"""
+MPPI_AB_LIB=name runs a measurement build (lib/libmppi_hip_<name>.so: make VARIANT=name EXTRA=...).  (EXPERIMENTS.md 54, 56)"""
 import sys, time, os, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from motion_planning_amd import _capi

@@ -33,7 +33,6 @@ timeout 60 ./tools/depbench > $O/depbench.txt 2>&1
 timeout 120 ./tools/rampbench > $O/rampbench.txt 2>&1
 timeout 200 python tools/probe_timeline.py --samples 125000,250000,1000000 > $O/probe_timeline.jsonl 2>/dev/null
 timeout 120 python tools/probe_timeline.py --samples 100000 --horizon 100 >> $O/probe_timeline.jsonl 2>/dev/null
-[ -f motion_planning_amd/lib/libmppi_hip_plain.so ] && timeout 300 python tools/ab_lib.py --libs default,plain --rounds 2 --samples 125000 > $O/ab_store_policy_final.jsonl 2>/dev/null   # (make VARIANT=plain EXTRA=-DMPPI_DP_STORE_AUX=0 first)
 cp $R/gpurun_out/bench_full_*.json $O/ 2>/dev/null
 g++ -O2 -std=c++17 -Iinclude tools/node_tail.cpp -o tools/node_tail -Lmotion_planning_amd/lib -lmppi_hip -Wl,-rpath,$R/motion_planning_amd/lib && ( ./tools/node_tail 10 100 5000 0; ./tools/node_tail 10 100 3000 500; ./tools/node_tail 1000 50 3000 0; ./tools/node_tail 10000 50 3000 0 ) > $O/node_tail.txt 2>&1
 ( ./tools/node_tail 100000 100 2000 0; ./tools/node_tail 125000 50 2000 0; ./tools/node_tail 1000000 50 1000 0 ) > $O/node_tail_large_k.txt 2>&1
