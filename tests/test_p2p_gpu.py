@@ -667,7 +667,8 @@ def test_auto_co_shards_are_built_lazily_and_inherit_the_handles_settings():
             assert after["co_shards"] == (2 if co is None else 1) and after["co_note"] == ""
             # the second engine exists now: its small arrays and its mailbox only -- its rows, totals and per-wave noise sums are columns
             # of the handle's own buffers
-            assert (after["hbm_bytes"] > hbm0) == (co is None) and after["hbm_bytes"] < hbm0 + (4 << 20)
+            # (the 1600-byte obstacle grid is the one engine's only growth)
+            assert (after["hbm_bytes"] > hbm0 + (32 << 10)) == (co is None) and after["hbm_bytes"] < hbm0 + (4 << 20)
             outs[co] = (np.array(traj), e.get_nominal())
     assert np.abs(outs[None][0] - outs[1][0]).max() < 1e-10 and np.abs(outs[None][1] - outs[1][1]).max() < 1e-10
     assert outs[1][1][0, -1] == 0.25 and outs[1][1][1, -1] == -0.5
