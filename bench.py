@@ -166,7 +166,7 @@ def compact_line(line, full_path):
         for thr, v in (cpu.get("by_threads") or {}).items():
             c["threads_%s_value" % thr] = v
     cfg = {k: line["config"].get(k) for k in ("workload", "agents", "samples_total", "horizon", "samples_per_gpu", "state_steps_per_tick", "storage", "noise",
-                                              "parallelism", "graph", "tick_kernels", "co_shards", "co_samples")}
+                                              "parallelism", "graph", "tick_kernels", "co_shards", "co_samples", "kernels_pinned_by_samples_total")}
     sync, tick = line.get("sync_tick_us") or {}, line.get("tick_us") or {}
     out = {k: line.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                                     "dtype", "data")}
@@ -321,6 +321,12 @@ def main():
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--storage", default="f32", choices=["f32", "f64"])
     ap.add_argument("--samples", type=int, default=0, help="override K_total")
+    ap.add_argument("--samples-total", type=int, default=0,
+                    help="with --samples K on ONE GPU: measure a rank's SHARE of a controller of this many samples (mppi_config.samples_total: the "
+                         "kernels the whole controller's size picks, as every rank of `--gpus N` runs them; no exchange partner)")
+    ap.add_argument("--rank-kernels", action="store_true",
+                    help="N > 1: let every rank pick its kernels by its OWN share (samples_total = 0: faster small shares, "
+                         "results no longer equal across N beyond 1e-6)")
     ap.add_argument("--horizon", type=int, default=0, help="override T (sweeps; not a BASELINE config)")
     ap.add_argument("--tick-path", default="auto", choices=["auto", "lanes", "scan"],
                     help="which kernels a tick runs (include/mppi_hip.h MPPI_TICK_*; sweeps)")
@@ -411,8 +417,12 @@ def main():
             goals = np.array([[0.05 * a, -1.0, 0.0] for a in range(lo, hi)])
             K_local, units_total = K_total, A_total * K_total
         else:
+            # every rank (N = 1 included) is told the whole controller's size: all N run the same arithmetic
+            pinned = 0 if args.rank_kernels else (args.samples_total or K_total)
             ticker, eng = sharded.make_hip_ticker(K_total, T, n_agents=1, storage=args.storage, local_rank=local_rank,
-                                                  exchange=args.exchange, tick_path=args.tick_path, co_shards=args.co_shards)
+                                                  exchange=args.exchange, tick_path=args.tick_path, co_shards=args.co_shards,
+                                                  pinned_total=pinned)
+            extra["samples_total_pinned"] = pinned
             A = 1
             states, goals = np.zeros((1, 3)), np.array([goal])
             K_local, units_total = eng.K, K_total
@@ -905,6 +915,9 @@ def main():
                        "parallelism": ("K-sharded x%d, exchange: %s" % (world, exch_kind)) if args.workload != "c5" else "agent replicas",
                        "graph": bool(args.graph), "tick_kernels": info.get("tick_kernels", "lanes"),
                        "co_shards": info.get("co_shards", 1), "co_samples": info.get("co_samples"),
+                       # what every rank's size rules were given (mppi_config.samples_total): the whole controller's samples, so that
+                       # N = 1 / 2 / 4 / 8 run the same kernels and end every tick with the same controls to rounding; 0: each rank's own share
+                       "kernels_pinned_by_samples_total": extra.get("samples_total_pinned", 0),
                        "min_warmup_s": args.min_warmup_s},
             "state_steps_per_s": value * T,
             "tick_us": tick_us,

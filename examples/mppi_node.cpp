@@ -112,6 +112,9 @@ public:
             c.samples = base + (g < rem ? 1 : 0);
             c.sample_offset = cfg_.sample_offset + (uint32_t)(g * base + (g < rem ? g : rem));
             c.co_shards = G > 1 ? 1 : cfg_.co_shards;
+            // every shard is told the whole controller's size: all of them pick the kernels the unsplit controller runs, and any number
+            // of handles / ranks ends every tick with the same controls to rounding (mppi_config.samples_total)
+            if (G > 1) c.samples_total = (int64_t)cfg_.sample_offset + cfg_.samples;
             mppi_engine* e = nullptr;
             if (handles > 1 || n_ranks > 1) c.device = cfg_.device + g;            // one GPU per handle / rank where the node has them ...
             int rc = mppi_create(&c, &e);

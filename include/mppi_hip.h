@@ -38,7 +38,8 @@
  *     current device before returning.
  *   - K is the number of samples owned by THIS handle (one GPU's shard); sample_offset is
  *     the global index of its first sample (device-RNG streams are keyed by global index,
- *     so results do not depend on the shard count).
+ *     so the NOISE does not depend on the shard count; with mppi_config.samples_total the
+ *     arithmetic does not either).
  *
  * Environment: MPPI_SYNC_TIMEOUT_MS (default deadline of the blocking waits) is the only variable the library reads.
  * Measurement and test switches are per-handle options: mppi_set_option / mppi_get_option in include/mppi_hip_diag.h,
@@ -139,6 +140,14 @@ typedef struct mppi_config {
     double wheel_radius;   /* WHEEL_RADIUS   (control/src/mppi:19)                            */
     double wheel_base;     /* WHEEL_BASE     (control/src/mppi:20)                            */
     double floor_w;        /* weight floor 1e-8 (control/src/mppi:193)                        */
+    /* -- appended in round 6 (struct_size 176; callers compiled against the 168-byte struct get the default 0) -- */
+    int64_t samples_total; /* 0: this handle is the whole controller.  > 0: the controller's samples per agent over ALL handles / ranks
+                              it is sharded over (this one owns [sample_offset, sample_offset + samples) of them): every choice the
+                              engine makes by SIZE -- which rollout kernel (all-fp64 | mixed precision), lane kernels or scan kernel --
+                              is then made from this number, so every rank of an N-way split runs the arithmetic the unsplit
+                              controller would and N = 1 / 2 / 4 / 8 end every tick with the same controls to rounding (1e-10;
+                              SURVEY 8d-4).  bench.py --gpus N and sharded.make_hip_ticker set it.  The price: a small share runs
+                              the kernel sized for the whole (125 000 samples on the mixed rollout: +3-4 us per tick)           */
 } mppi_config;
 /* the struct as ABI version 5 introduced it: the shortest struct_size mppi_create accepts (fields are only ever appended) */
 #define MPPI_CONFIG_SIZE_V5 168u

@@ -25,7 +25,7 @@ class MppiConfig(C.Structure):
                 ("reserved0", C.c_int32), ("dt", C.c_double), ("sigma", C.c_double), ("lambda_", C.c_double),
                 ("q", C.c_double * 3), ("r", C.c_double * 2), ("p1", C.c_double * 3),
                 ("u_max", C.c_double), ("wheel_radius", C.c_double), ("wheel_base", C.c_double),
-                ("floor_w", C.c_double)]
+                ("floor_w", C.c_double), ("samples_total", C.c_int64)]
 
 
 class MppiError(RuntimeError):

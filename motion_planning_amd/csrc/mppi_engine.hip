@@ -732,6 +732,8 @@ struct mppi_engine {
         bool pk_size;
         if (noise_pack) pk_size = true;   // (the only kernel that draws that stream)
         else if (force_pk >= 0) pk_size = force_pk != 0;
+        // a shard of a controller split over handles / ranks (mppi_config.samples_total): the size that decides is the WHOLE controller's
+        else if (cfg.samples_total > 0) pk_size = (long)cfg.n_agents * cfg.samples_total >= pk_min_samples;
         else if (pk_min_set || co_active() || is_co_sub) pk_size = (long)cfg.n_agents * cfg.samples >= pk_min_samples;
         else {
             const long r_pk = ((long)cfg.n_agents * ((cfg.samples + 511) / 512) + 255) / 256;
@@ -941,6 +943,9 @@ struct mppi_engine {
         hoist_auto = T <= 64 && (long)A * K >= 786432;
         P.sample_offset = cfg.sample_offset;
         if (cfg.agent_offset < 0) fail(MPPI_E_INVALID, "agent_offset must be >= 0");
+        if (cfg.samples_total != 0 && (cfg.samples_total < (int64_t)cfg.sample_offset + cfg.samples || cfg.samples_total > 0xFFFFFFFFll))
+            fail(MPPI_E_INVALID, "samples_total = %lld: 0 (this handle is the whole controller) or >= sample_offset + samples = %lld (global sample ids are 32-bit)",
+                 (long long)cfg.samples_total, (long long)cfg.sample_offset + cfg.samples);
         P.agent_offset = (uint32_t)cfg.agent_offset;
         P.dt = cfg.dt;
         P.u_max = cfg.u_max;
@@ -1005,7 +1010,8 @@ struct mppi_engine {
             // r5_blocking_tick_scan_vs_lanes.txt), T = 50: 12000 26.2 vs 26.8 | 34.7 vs 38.2, 14000 27.9 vs 26.8 | 36.5 vs 37.8, 16000 30.5 vs 27.1 |
             // 39.1 vs 38.4; T = 100: 4000 32.0 vs 35.0 | 40.3 vs 43.2, 5000 35.0 vs 35.2 | 43.2 vs 43.3, 6000 38.1 vs 35.5 | 46.1 vs 43.8  ->  14336 / 5120
             const bool applies = T <= 256 && cfg.model == MPPI_MODEL_DIFFDRIVE_RK4;
-            const bool want = cfg.tick_path == MPPI_TICK_SCAN || (cfg.tick_path == MPPI_TICK_AUTO && (long)A * K <= (T <= 64 ? 14336 : 5120));
+            const long k_rule = cfg.samples_total > 0 ? (long)cfg.samples_total : (long)K;   // (a shard decides by the whole controller's size)
+            const bool want = cfg.tick_path == MPPI_TICK_SCAN || (cfg.tick_path == MPPI_TICK_AUTO && (long)A * k_rule <= (T <= 64 ? 14336 : 5120));
             if (applies && want) {
                 small_nw = T <= 64 ? 1 : 4;
                 // units the chip keeps resident at once (152 VGPRs: 3 waves per SIMD x 1024 SIMDs): the kernel is
@@ -1240,6 +1246,7 @@ void mppi_engine::co_build() {
             mppi_config c = cfg;
             c.samples = cuts[g + 1] - cuts[g];
             c.sample_offset = cfg.sample_offset + (uint32_t)cuts[g];
+            c.samples_total = 0;   // (a co-scheduled shard takes shard 0's kernel: force_pk)
             c.co_shards = 1;
             c.tick_path = MPPI_TICK_LANES;
             mppi_engine* e = new mppi_engine();
@@ -1426,6 +1433,7 @@ int mppi_default_config(mppi_config* cfg) {
     cfg->wheel_radius = 0.033;  // :19
     cfg->wheel_base = 0.16;     // :20
     cfg->floor_w = 1e-8;        // :193
+    cfg->samples_total = 0;     // this handle is the whole controller
     return MPPI_OK;
 }
 

@@ -1353,8 +1353,19 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
     // a few 1e-10 in u -- the cut is relative to the CHUNK's minimum -- which the split-invariance tests see; round 2 cut at
     // 2^-80 and fetched twice as many); fp64 mode keeps everything down to 2^-100.
     const R cand = (R)(sizeof(S) == 4 ? -40.0 : -100.0);
-    R D = 0, N0 = 0, N1 = 0;
+    R D = 0;
     double Na0 = 0.0, Na1 = 0.0;
+    // fp32 storage: the weights of the CANDIDATES -- the only samples that carry weight at all -- are formed in fp64,
+    //     e = exp2(((double)M - (double)v) log2e / lambda)        (M - v is exact in fp64: two fp32 values)
+    // and summed in fp64 (Dc; their noise products Na0 / Na1 were fp64 sums already): v_exp_f32 gives every weight its own ~1e-7 of
+    // relative error, and M is the CHUNK's minimum -- another way of cutting the samples into chunks, shards or ranks moves M, and
+    // with it every weight's error: controls of N = 1 and N = 8 agreed to 1e-8, not to the 1e-10 SURVEY 8d-4 asks for.  In fp64 the
+    // weight is the same function of (M - v) to 1e-16 whatever M is, and the tuple merge's rescaling is exact: shard-count-invariant
+    // to rounding.  The fp32 sum D keeps the non-candidates of the vectors that were not skipped (< 2^-40 of the chunk's best each).
+    // Far from the goal a row has a handful of candidates; parked at it a few per cent: one fp64 exp2 next to each one's Philox re-draw.
+    constexpr bool kWideCand = sizeof(S) == 4;
+    const double scale64 = P.inv_lambda * 1.4426950408889634, M64 = (double)M;
+    double Dc = 0.0;
     // REGEN (eps was never stored): a sample that carries weight needs its noise re-drawn -- one Philox call.  Far from the
     // goal a row has a handful of such samples; parked AT the goal a few per cent of a row carry weight.  The loop only
     // NOTES them -- (index, weight) appended to a queue in LDS -- and the re-draws happen afterwards, spread evenly over the
@@ -1371,12 +1382,18 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
     __shared__ R q_e[REGEN ? kQueue : 1];
     int n_w = 0;   // (wave-uniform) candidates this wave has noted
     const uint32_t tick_now = REGEN ? (tick_ptr ? *tick_ptr : tick_arg) : 0u;
-    auto redraw = [&](uint32_t kk, R e) {
+    // a candidate's weight from what the queue holds for it: its value v (fp32 storage) or the weight itself (fp64 storage)
+    auto cand_weight = [&](R q) -> double {
+        if constexpr (kWideCand) { const double e = exp2((M64 - (double)q) * scale64); Dc += e; return e; }
+        else return (double)q;
+    };
+    auto redraw = [&](uint32_t kk, R q) {
         float f0, f1;  // the same Philox counter the rollout used for this (sample, step)
         philox_normal_pair<PACK>(P.sample_offset + kk, (uint32_t)t, tick_now, P.agent_offset + (uint32_t)a, (uint32_t)seed, (uint32_t)(seed >> 32),
                            (float)P.sigma, f0, f1);
-        Na0 = fma((double)e, (double)(S)f0, Na0);   // exact products, fp64 sums: independent of how the queue orders them
-        Na1 = fma((double)e, (double)(S)f1, Na1);
+        const double e = cand_weight(q);
+        Na0 = fma(e, (double)(S)f0, Na0);   // exact products (fp64 storage) / fp64 products, fp64 sums: independent of how the queue orders them
+        Na1 = fma(e, (double)(S)f1, Na1);
     };
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -1394,13 +1411,13 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
         for (int i = 0; i < VEC; ++i) { bal[i] = __ballot(xs[i] > cand); n_here += (int)__popcll(bal[i]); }
         if (n_here == 0) continue;   // (uniform)
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) { es[i] = Exp2<R>::f(xs[i]); D += es[i]; }
+        for (int i = 0; i < VEC; ++i) { es[i] = Exp2<R>::f(xs[i]); D += (kWideCand && xs[i] > cand) ? (R)0 : es[i]; }
         if (REGEN) {
             if (n_here) {  // (uniform) skipped for almost every vector while the robot is far from its goal
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
                     const int pos = n_w + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal[i] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal[i], 0u));
-                    if (xs[i] > cand && pos < kQW) { q_k[wid * kQW + pos] = (uint32_t)(k + i); q_e[wid * kQW + pos] = es[i]; }
+                    if (xs[i] > cand && pos < kQW) { q_k[wid * kQW + pos] = (uint32_t)(k + i); q_e[wid * kQW + pos] = kWideCand ? (R)v[j][i] : es[i]; }
                     n_w += (int)__popcll(bal[i]);
                 }
             }
@@ -1408,8 +1425,9 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
 #pragma unroll
             for (int i = 0; i < VEC; ++i)
                 if (xs[i] > cand) {
-                    N0 = fma(es[i], (R)e0_row[k + i], N0);
-                    N1 = fma(es[i], (R)e1_row[k + i], N1);
+                    const double e = cand_weight(kWideCand ? (R)v[j][i] : es[i]);
+                    Na0 = fma(e, (double)e0_row[k + i], Na0);
+                    Na1 = fma(e, (double)e1_row[k + i], Na1);
                 }
         }
     }
@@ -1427,8 +1445,9 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
             for (int idx = 0; idx < NV * VEC; ++idx) {
                 const int k = k_begin + ((idx / VEC) * 256 + tid) * VEC + idx % VEC;
                 if (k < k_end) {
-                    const R x = (M - (s_row[k] - v_row[k])) * scale;
-                    if (x > cand) redraw((uint32_t)k, Exp2<R>::f(x));
+                    const R vk = s_row[k] - v_row[k];
+                    const R x = (M - vk) * scale;
+                    if (x > cand) redraw((uint32_t)k, kWideCand ? vk : Exp2<R>::f(x));
                 }
             }
         }
@@ -1446,15 +1465,17 @@ __global__ __launch_bounds__(256) void update_kernel(DevParams P, const S* __res
         for (int w = w_begin + tid; w < w_end; w += 256) { E0 += ep[w]; E1 += ep[NW + w]; }
     }
     uprobe.mark(3);   // re-draws done, eps sums read
-    __shared__ double redN[4][2];
-    const double N0d = wave_sum((double)N0 + Na0), N1d = wave_sum((double)N1 + Na1);
-    D = wave_sum(D); E0 = wave_sum(E0); E1 = wave_sum(E1);
-    if (lane == 0) { red[wid][1] = D; redN[wid][0] = N0d; redN[wid][1] = N1d; red[wid][4] = E0; red[wid][5] = E1; }
+    __shared__ double redN[4][3];
+    const double N0d = wave_sum(Na0), N1d = wave_sum(Na1);
+    const double Dd = wave_sum((double)D + Dc);     // (the lane's fp32 sum of non-candidates + its candidates' fp64 weights)
+    E0 = wave_sum(E0); E1 = wave_sum(E1);
+    if (lane == 0) { redN[wid][2] = Dd; redN[wid][0] = N0d; redN[wid][1] = N1d; red[wid][4] = E0; red[wid][5] = E1; }
     __syncthreads();
     if (tid < 5) {
         const int c = tid + 1;
-        o[c] = (c == 2 || c == 3) ? redN[0][c - 2] + redN[1][c - 2] + redN[2][c - 2] + redN[3][c - 2]
-                                  : (double)red[0][c] + (double)red[1][c] + (double)red[2][c] + (double)red[3][c];
+        const int cn = c == 1 ? 2 : c - 2;
+        o[c] = (c <= 3) ? redN[0][cn] + redN[1][cn] + redN[2][cn] + redN[3][cn]
+                        : (double)red[0][c] + (double)red[1][c] + (double)red[2][c] + (double)red[3][c];
     } else if (tid == 5) {
         o[0] = (double)M; o[6] = (double)(k_end - k_begin); o[7] = 0.0;
     }

@@ -109,7 +109,8 @@ class Engine(object):
     default_options = {}
 
     def __init__(self, samples, horizon, n_agents=1, storage="f32", device=0, sample_offset=0,
-                 dt=None, sigma=0.9, lam=0.001, model="rk4", tick_path=None, co_shards=None, options=None, agent_offset=0, **overrides):
+                 dt=None, sigma=0.9, lam=0.001, model="rk4", tick_path=None, co_shards=None, options=None, agent_offset=0,
+                 samples_total=0, **overrides):
         self._lib = _capi.load()
         cfg = _capi.default_config()
         cfg.n_agents, cfg.samples, cfg.horizon = int(n_agents), int(samples), int(horizon)
@@ -117,6 +118,9 @@ class Engine(object):
         cfg.device = int(device)
         cfg.sample_offset = int(sample_offset)
         cfg.agent_offset = int(agent_offset)   # global index of local agent 0 (replica ranks: the noise streams are keyed by the global index)
+        # the whole controller's samples per agent when this engine is one shard of it (0: it is the whole): size rules follow IT, so
+        # every shard runs the unsplit controller's arithmetic (include/mppi_hip.h mppi_config.samples_total)
+        cfg.samples_total = int(samples_total or 0)
         cfg.model = _MODELS[model]
         cfg.tick_path = _TICK_PATHS[tick_path if tick_path is not None else self.default_tick_path]
         # co-scheduled shards of the fused tick (include/mppi_hip.h): None = the engine's own rule, 1 = off, 2..8

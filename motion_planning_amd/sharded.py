@@ -154,8 +154,12 @@ class ShardedTicker(object):
 
 
 def make_hip_ticker(samples_total, horizon, n_agents=1, storage="f32", local_rank=0, group=None, exchange="auto",
-                    **engine_kw):
-    """Engine for this rank's slice of the samples + the ticker around it."""
+                    pinned_total=None, **engine_kw):
+    """Engine for this rank's slice of the samples + the ticker around it.
+    pinned_total: what the engine's size rules are given as the whole controller's sample count (mppi_config.samples_total).  None
+    (default) = samples_total: every rank picks its kernels by the WHOLE controller's size -- N = 1 / 2 / 4 / 8 then end every tick
+    with the same controls to rounding; 0: every rank chooses by its own share (faster small shares, results equal to ~1e-6 only);
+    another number: this group is itself one share of a larger controller."""
     import torch
     import torch.distributed as dist
     from .mppi import Engine
@@ -164,8 +168,8 @@ def make_hip_ticker(samples_total, horizon, n_agents=1, storage="f32", local_ran
     rank = dist.get_rank(group) if in_group else 0
     lo, hi = shard_range(samples_total, world, rank)
     torch.cuda.set_device(local_rank)
-    eng = Engine(hi - lo, horizon, n_agents=n_agents, storage=storage, device=local_rank,
-                 sample_offset=lo, **engine_kw)
+    eng = Engine(hi - lo, horizon, n_agents=n_agents, storage=storage, device=local_rank, sample_offset=lo,
+                 samples_total=samples_total if pinned_total is None else pinned_total, **engine_kw)
     kind = "none" if not in_group else "rccl"
     report = {"requested": exchange}
     if in_group and world > 1 and exchange in ("auto", "p2p"):
@@ -202,13 +206,14 @@ class P2PTicker(object):
 
 
 def make_p2p_ticker(samples_total, horizon, rank, world, rendezvous_prefix, n_agents=1, storage="f32", device=0,
-                    timeout_ms=60000, selftest_rounds=2, **engine_kw):
+                    timeout_ms=60000, selftest_rounds=2, pinned_total=None, **engine_kw):
     """This rank's slice of the samples (global sample offsets) + the exchange, no torch and no process group: every rank calls this
     with the same `rendezvous_prefix` (a path inside a directory the launcher made for THIS run; the files `<prefix>.<rank>` are left
     for the launcher to remove).  Returns (ticker, engine)."""
     from .mppi import Engine
     lo, hi = shard_range(samples_total, world, rank)
-    eng = Engine(hi - lo, horizon, n_agents=n_agents, storage=storage, device=device, sample_offset=lo, co_shards=1, **engine_kw)
+    eng = Engine(hi - lo, horizon, n_agents=n_agents, storage=storage, device=device, sample_offset=lo, co_shards=1,
+                 samples_total=samples_total if pinned_total is None else pinned_total, **engine_kw)   # (size rules: see make_hip_ticker)
     try:
         eng.p2p_rendezvous(rendezvous_prefix, world, rank, timeout_ms)
         if selftest_rounds:

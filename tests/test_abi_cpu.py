@@ -142,15 +142,24 @@ def test_config_struct_size_is_checked_before_anything_else():
     from motion_planning_amd import _capi
     lib = _capi.load()
     cfg = _capi.default_config()
-    assert cfg.struct_size == C.sizeof(_capi.MppiConfig) == 168 and _capi.MppiConfig.struct_size.offset == 0
+    # 168 bytes as ABI 5 introduced it + the int64 samples_total appended in round 6
+    assert cfg.struct_size == C.sizeof(_capi.MppiConfig) == 176 and _capi.MppiConfig.struct_size.offset == 0
+    assert _capi.MppiConfig.samples_total.offset == 168 and cfg.samples_total == 0
     h = C.c_void_p()
     for bad in (0, 167, C.sizeof(_capi.MppiConfig) + 8):
         cfg.struct_size = bad
         assert lib.mppi_create(C.byref(cfg), C.byref(h)) == -1 and h.value is None
         assert b"struct_size" in lib.mppi_last_error(None)
+    # a caller compiled against the 168-byte struct: accepted (the appended field takes its default) -- without a GPU the call then
+    # fails for the device, not for the struct
+    cfg.struct_size = 168
+    rc = lib.mppi_create(C.byref(cfg), C.byref(h))
+    assert rc in (0, -2) and (rc == 0 or b"struct_size" not in lib.mppi_last_error(None))
+    if rc == 0:
+        lib.mppi_destroy(h)
     with tempfile.TemporaryDirectory() as d:     # both headers are plain C; the product header does not need the diagnostic one
         src = os.path.join(d, "h.c")
-        open(src, "w").write('#include "mppi_hip_diag.h"\nint main(void){ return MPPI_CONFIG_SIZE_V5 == sizeof(mppi_config) && MPPI_PROBE_MARKS == 30 ? 0 : 1; }\n')
+        open(src, "w").write('#include "mppi_hip_diag.h"\nint main(void){ return MPPI_CONFIG_SIZE_V5 + 8 == sizeof(mppi_config) && MPPI_PROBE_MARKS == 30 ? 0 : 1; }\n')
         exe = os.path.join(d, "h")
         subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
         assert subprocess.call([exe]) == 0

@@ -103,11 +103,12 @@ def _run_ranks(world, devices=None):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(r[0] for r in res) == list(range(world))
-    # fp32 storage: a chunk's sum of weights is an fp32 sum, and the shards' 16-byte vectors group the samples differently from the
-    # unsharded engine's (750-sample shards do not start on a vector boundary): a row where two samples share the weight differs by
-    # a few 1e-8 of its increment, and six closed-loop ticks carry that along -- measured 8e-10 (controls) / 3e-9 (nominal) at eight
-    # ranks, below 1e-10 at two.  A lost or doubled shard would show at 1e-3.
-    tol = 1e-10 if world <= 2 else 1e-8
+    # Shard-count invariance: every rank picks its kernels by the whole controller's size (mppi_config.samples_total,
+    # set by make_hip_ticker) and the weights of the samples that carry any are formed and summed in fp64 -- the same function of
+    # (chunk minimum - V) whatever the chunk -- so 2, 4 and 8 ranks reproduce the unsharded engine to the exact merge's rounding.
+    # (Until round 6 the weights were fp32 exp2 relative to a chunk minimum that moves with the split: 8e-10 (controls) / 3e-9
+    # (nominal) at eight ranks, stated 1e-8.)  A lost or doubled shard would show at 1e-3.
+    tol = 1e-10
     for rank, outs, lat in res:
         assert np.abs(outs - ref).max() < tol, (rank, np.abs(outs - ref).max(axis=1), np.abs(lat - ref_lat).max())
         assert np.abs(lat - ref_lat).max() < tol, (rank, np.abs(lat - ref_lat).max())
@@ -159,10 +160,10 @@ def test_config4_as_stated_eight_ranks_against_the_oracle(orc, tmp_path):
     sharded result is held to THAT line, not to another engine -- rank 0's applied controls, predicted state and nominal controls
     against the oracle's replay of ALL 10^6 samples on the noise the eight devices-side shards drew (V of every sample against the stated
     V tolerance, the controls against the stated u bound at the measured V error; asserted caps = config 4's on one engine,
-    FULL_CAPS in test_gpu_parity.py).  Then against the N = 1 handle (one process, co-scheduled, the mixed-precision rollout where
-    the eight shards run the all-fp64 one): STATED cross-kernel tolerance 1e-8 on the controls / 1e-10 on the state -- both sides
-    sit within 1e-9 of the oracle on this scene (its rows are decided, gap / lambda ~ 100); every rank ends with bit-identical
-    nominal controls."""
+    FULL_CAPS in test_gpu_parity.py).  Then against the N = 1 handle (one process, co-scheduled): the ranks were created with
+    mppi_config.samples_total = 10^6, so each runs the kernels the unsplit controller runs (the mixed-precision rollout, although a
+    share of 125 000 would pick the all-fp64 one) -- SHARD-COUNT INVARIANCE, SURVEY 8d-4: controls and nominal sequence equal to
+    1e-10, the state to 1e-12, tick after tick; every rank ends with bit-identical nominal controls."""
     import multiprocessing as mp
     from test_gpu_parity import _replay_full
     from motion_planning_amd.mppi import Engine
@@ -182,7 +183,7 @@ def test_config4_as_stated_eight_ranks_against_the_oracle(orc, tmp_path):
     for i in range(n_ticks):                                                      # every rank finishes every tick identically
         for r in res[1:]:
             assert np.array_equal(r[3][i][2], res[0][3][i][2]) and np.array_equal(r[3][i][0], res[0][3][i][0])
-    assert all(o[3] == "fp64" for r in res for o in r[3])                        # 125 000 samples: the all-fp64 rollout
+    assert all(o[3] == "mixed" for r in res for o in r[3])                       # 125 000 samples each, but shards of a 10^6-sample controller
     state, u0 = np.zeros(3), _u0()
     for i in range(n_ticks):
         eps = np.concatenate([np.load(os.path.join(str(tmp_path), "eps_%d_%d.npy" % (i, r))) for r in range(world)], axis=2).astype(np.float64)
@@ -201,9 +202,10 @@ def test_config4_as_stated_eight_ranks_against_the_oracle(orc, tmp_path):
         e.set_nominal(_u0())
         for i in range(n_ticks):
             nxt1, ua1 = e.tick([0, 0, 0] if i == 0 else None, [0, -1, 0] if i == 0 else None, noise="philox", seed=SEED, tick_id=i)
-            assert np.abs(ua1[0] - res[0][3][i][1]).max() <= 1e-8 and np.abs(nxt1[0] - res[0][3][i][0]).max() <= 1e-10, i
-        assert e.info()["rollout_kernel"] == "mixed"
-        assert np.abs(e.get_nominal() - res[0][3][-1][2]).max() <= 1e-8
+            assert np.abs(ua1[0] - res[0][3][i][1]).max() <= 1e-10 and np.abs(nxt1[0] - res[0][3][i][0]).max() <= 1e-12, \
+                (i, float(np.abs(ua1[0] - res[0][3][i][1]).max()), float(np.abs(nxt1[0] - res[0][3][i][0]).max()))
+        assert e.info()["rollout_kernel"] == "mixed" and e.info()["co_shards"] == 2
+        assert np.abs(e.get_nominal() - res[0][3][-1][2]).max() <= 1e-10, float(np.abs(e.get_nominal() - res[0][3][-1][2]).max())
 
 
 def _c5_worker(rank, world, q):
@@ -295,7 +297,7 @@ def test_p2p_ranks_without_torch(world, tmp_path):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    tol = 1e-10 if world <= 2 else 1e-8      # (fp32 chunk sums group the samples differently for every split, see _run_ranks)
+    tol = 1e-10      # (shard-count invariance, see _run_ranks)
     for rank, outs, lat, torch_loaded in res:
         assert not torch_loaded
         assert np.abs(outs - ref).max() < tol and np.abs(lat - ref_lat).max() < tol, (rank, np.abs(outs - ref).max())
@@ -459,7 +461,7 @@ def test_bench_with_all_ranks_on_the_one_gpu(exchange, n):
     plain = run([sys.executable] + common + ["--gpus", "1"])
     assert plain.returncode == 0, plain.stderr[-3000:]
     ref = json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][-1])
-    tol = 1e-10 if n == 2 else 1e-8   # (fp32 chunk sums group the samples differently for every split, see _run_ranks)
+    tol = 1e-10      # (shard-count invariance, see _run_ranks)
     assert np.abs(np.array(line["final_state"]) - np.array(ref["final_state"])).max() < tol
     assert np.abs(np.array(line["final_u"]) - np.array(ref["final_u"])).max() < tol
 
