@@ -33,7 +33,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.
 CLOCK_PEAK_HZ = 2.4e9  # max shader clock, same guide
 N_SIMD = 1024          # 256 CUs x 4 SIMDs
 BYTES_PER_STEP_PER_KERNEL = 12  # eps 2 x fp32 + V 1 x fp32, written once (rollout) / read once (update): SURVEY 8(d)
-PROFILE_ROUND = "r5"
+PROFILE_ROUND = "r6"
+PYTHON_REFERENCE_ROLLOUTS_PER_S = 3825.0   # MPPI.get_path, K = 1000, T = 50, one core of the survey container (quoted)
 HBM_ACHIEVABLE_GBS = 6300.0  # what a streaming read reaches on this part (MI355X_MICROARCH.md, HBM section)
 
 WORKLOADS = {
@@ -165,6 +166,10 @@ def compact_line(line, full_path):
         c["sample"] = (cpu.get("sample") or "")[:200]
         for thr, v in (cpu.get("by_threads") or {}).items():
             c["threads_%s_value" % thr] = v
+        # the reference's OWN Python loop (control/src/mppi:85-102 imported with ROS stubbed), 1 core, K = 1000 / 10 000, T = 50: quoted from
+        # BASELINE.md section 2 (measured in the survey container; the reference does not travel to the GPU box), never re-measured here
+        c["python_reference_value"] = PYTHON_REFERENCE_ROLLOUTS_PER_S
+        c["python_reference_source"] = "BASELINE.md 2 (quoted: reference's numpy loop, 1 core, K=1000 T=50)"
     cfg = {k: line["config"].get(k) for k in ("workload", "agents", "samples_total", "horizon", "samples_per_gpu", "state_steps_per_tick", "storage", "noise",
                                               "parallelism", "graph", "tick_kernels", "co_shards", "co_samples", "kernels_pinned_by_samples_total")}
     sync, tick = line.get("sync_tick_us") or {}, line.get("tick_us") or {}
@@ -562,7 +567,9 @@ def main():
         sync_tick_us, btimes = None, None
         if not in_group:
             n_lat = min(args.steps, 200)
-            eng.kernel_timing(("rollout",), period=1)
+            # NOTHING bracketed while the call is timed (the event pair around every rollout launch cost the blocking call
+            # 30 us at config 4); the rollout launch of this call pattern is timed in a short pass of its own behind it
+            eng.kernel_timing(())
             st, lat = nxt, []
             # the interpreter's cyclic garbage collector is held off for these calls: with torch and numpy imported a full
             # collection takes 30-45 ms and lands on a fixed call of this loop (call 11 at --steps 200, call 24 at 100:
@@ -574,11 +581,15 @@ def main():
                 t0 = time.perf_counter()
                 st, _ = eng.tick(st, goals, noise="philox", seed=seed, tick_id=10_000_000 + i)
                 lat.append(1e6 * (time.perf_counter() - t0))
+            eng.kernel_timing(("rollout",), period=1)
+            for i in range(min(n_lat, 20)):
+                st, _ = eng.tick(st, goals, noise="philox", seed=seed, tick_id=11_000_000 + i)
             if gc_was_on:
                 gc.enable()
             btimes = eng.kernel_times()
             eng.kernel_timing(())
             sync_tick_us = dist_stats(lat)
+            sync_tick_us["instrumented"] = False
             sync_tick_us["max"] = float(max(lat))
             sync_tick_us["max_at_call"] = int(np.argmax(lat))
             sync_tick_us["first_calls"] = [float(x) for x in lat[:4]]
@@ -737,11 +748,11 @@ def main():
 
     if rank == 0:
         lanes = info.get("tick_kernels", "lanes") == "lanes"
-        mixes = load_profile(PROFILE_ROUND + "_valu_mix.json") or load_profile("r4_valu_mix.json") or {}
+        mixes = load_profile(PROFILE_ROUND + "_valu_mix.json") or load_profile("r5_valu_mix.json") or load_profile("r4_valu_mix.json") or {}
 
         pmc_name = PROFILE_ROUND + "_pmc_summary_bench_c4.json"
         pm = load_profile(pmc_name)
-        for older in ("r4", "r3", "r1"):
+        for older in ("r5", "r4", "r3", "r1"):
             if pm is None:
                 pmc_name = older + "_pmc_summary_bench_c4.json"
                 pm = load_profile(pmc_name)

@@ -192,7 +192,7 @@ def test_config4_as_stated_eight_ranks_against_the_oracle(orc, tmp_path):
             os.remove(os.path.join(str(tmp_path), "eps_%d_%d.npy" % (i, r)))
             os.remove(os.path.join(str(tmp_path), "V_%d_%d.npy" % (i, r)))
         nxt, ua, lat, _ = res[0][3][i]
-        m = _replay_full(orc, V, eps, nxt, ua, lat, state, [0.0, -1.0, 0.0], u0, T, "f32", v_abs=0.0)
+        m = _replay_full(orc, V, eps, nxt, ua, lat, state, [0.0, -1.0, 0.0], u0, T, "f32")   # (the mixed rollout's stated V tolerance)
         print("config 4 as stated (8 x 125 000, p2p), tick %d: %s" % (i, m))
         assert m["eV_max"] <= 2e-4 and m["du_max"] <= 1e-9, m
         state, u0 = nxt, lat                                                      # closed loop: the next tick's inputs
