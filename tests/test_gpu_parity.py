@@ -1228,7 +1228,7 @@ def test_the_mixed_rollout_hands_over_where_it_does_not_apply(monkeypatch, tick_
             assert e.info()["rollout_kernel"] == "none"
             e.tick([0.0, 0.0, 0.0], [0.3, 0.2, 0.0], noise="philox", seed=1, tick_id=0)
             assert e.info()["rollout_kernel"] == want, (kw, e.info())
-    # without the switch the two lane kernels are chosen by rounds of waves (launch_rollout in mppi_engine.hip): the mixed one where
+    # without the switch the two lane kernels are chosen by rounds of waves (mppi_engine::pick_pk in mppi_engine.hip): the mixed one where
     # 1.9 x its rounds undercut the all-fp64 kernel's, from three rounds on; shards of a co-scheduled handle by size alone
     monkeypatch.setattr(Engine, "default_options", {})
     for K, A, co, want in [(393216, 1, 1, "mixed"), (400000, 1, 1, "fp64"), (460000, 1, 1, "mixed"), (560000, 1, 1, "fp64"), (250000, 1, 1, "fp64"),
