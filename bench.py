@@ -156,7 +156,8 @@ def compact_line(line, full_path):
          "tick_valu_frac": tl.get("valu_frac"), "tick_floor_us": roof.get("tick_floor_us"), "tick_frac": roof.get("tick_frac"),
          "measured_in": "one_engine leg (co_shards = 1) of this command" if roof.get("measured_in") else "the timed region of this command",
          "one_engine_ms": one.get("ms_per_step"), "one_engine_rollout_us": one.get("rollout_us"),
-         "f64_ms": f64.get("ms_per_step"), "f64_rollout_us": f64.get("rollout_us"), "f64_update_us": f64.get("update_us")}
+         "f64_ms": f64.get("ms_per_step"), "f64_rollout_us": f64.get("rollout_us"), "f64_update_us": f64.get("update_us"),
+         "f64_kernel": f64.get("rollout_kernel"), "f64_parked_ms": (f64.get("parked_at_goal") or {}).get("ms_per_step")}
     co = roof.get("co_scheduled_launch") or {}
     if co:
         r.update({"co_launch_samples": co.get("samples_per_launch"), "co_launch_us": co.get("avg_launch_us"), "co_launches": co.get("concurrent_launches")})
@@ -634,11 +635,27 @@ def main():
         e64.synchronize()
         el64 = time.perf_counter() - t0
         k64 = e64.kernel_times()
+        kind64 = e64.info().get("rollout_kernel")
+        # the other regime: parked at the goal (the engine goes back to the two-kernel tick there: rollout + update)
+        e64.kernel_timing(())
+        e64.set_nominal(np.zeros((2, T)))
+        t64.tick_async(np.array([goal]), np.array([goal]), "philox", 0, 5_000_000)
+        for j in range(30):
+            t64.tick_async(None, None, "philox", 0, 5_000_001 + j)
+        e64.synchronize()
+        t0 = time.perf_counter()
+        for j in range(50):
+            t64.tick_async(None, None, "philox", 0, 5_000_100 + j)
+        e64.synchronize()
+        elp64 = time.perf_counter() - t0
         f64_line = {"storage": "f64", "dtype": "f64", "ms_per_step": 1e3 * el64 / n64, "value": K_total / (el64 / n64), "steps": n64,
                     "protocol": "as the headline: own engine, warm-up, controller back at the start, --steps timed ticks",
+                    "rollout_kernel": kind64,
                     "rollout_us": k64["rollout"][0] * 1e3 / max(k64["rollout"][1], 1),
-                    "update_us": k64["update"][0] * 1e3 / max(k64["update"][1], 1),
-                    "note": "eps / V stored as fp64, softmax in fp64 (exp2 in fp64): the reference's own precision end to end"}
+                    "update_us": k64["update"][0] * 1e3 / max(k64["update"][1], 1) if k64["update"][1] else None,
+                    "parked_at_goal": {"ms_per_step": 1e3 * elp64 / 50, "rollout_kernel": e64.info().get("rollout_kernel")},
+                    "note": "V and the softmax in fp64: the reference's own precision end to end.  `fused`: rollout + cost-to-go + softmax "
+                            "partials in ONE kernel, V never stored (under way); parked at the goal the engine runs rollout + update"}
         e64.close()
 
     # One engine next to the headline: N = 1, config 4 only.  The headline handle splits its fused tick over co-scheduled

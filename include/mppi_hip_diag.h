@@ -93,6 +93,7 @@ const char *mppi_co_note(const mppi_engine *h);
 #define MPPI_ROLLOUT_FP64 1
 #define MPPI_ROLLOUT_MIXED 2
 #define MPPI_ROLLOUT_SCAN 3
+#define MPPI_ROLLOUT_FUSED 4 /* fp64 storage, device noise: rollout + cost-to-go + softmax partials in one kernel, V never stored (rollout_fused.hpp) */
 int mppi_rollout_kernel(mppi_engine *h, int32_t *kind);
 
 /* Bytes of HBM held by the engine, and the launch geometry (blocks) of a tick's kernels: rollout +

@@ -5,6 +5,7 @@
 #include "mppi_engine.hpp"
 #include "rollout_launch.hpp"
 #include "rollout_pk.hpp"
+#include "rollout_fused.hpp"
 
 // publish this rank's tuples for the next epoch and return the wait descriptor for the consumer.
 // src = merged tuples [A][T][8]; src == nullptr: merge d_part's direct_n tuples per row on the way (merge_skipped)
@@ -274,6 +275,38 @@ bool mppi_engine::pick_pk(bool ph, bool store, int k0, int k1) const {
            mppi::rollout_pk_applies(P.kth, P.dt, P.sigma, cfg.horizon, noise_pack);
 }
 
+// whether a device-noise tick of this engine runs the fused fp64 kernel (rollout_fused.hpp; rules: mppi_engine.hpp fused_nb)
+bool mppi_engine::pick_fused(bool ph, bool store) const {
+    if (fused_nb == 0 || !ph || store || !use_pk || capturing || noise_pack || general_cost() || ro_state || ro_goal || ro_unom) return false;
+    const long k_rule = cfg.samples_total > 0 ? (long)cfg.samples_total : (long)cfg.samples;
+    if (pk_min_set) return (long)cfg.n_agents * k_rule >= pk_min_samples;
+    return (long)cfg.n_agents * k_rule >= kFusedMinSamples && regime_weight() < kFusedRegimeCut;
+}
+void mppi_engine::launch_fused(uint64_t seed, uint32_t tick, const uint32_t* tick_ptr) {
+    // the nominal trajectory's per-step table: the set the previous tick's finalize kernel left for exactly these inputs, else nominal_kernel now
+    if (table_valid) {
+        if (!table_taken) { use_table_set(tab ^ 1); table_taken = true; }
+    } else {
+        Scope sc(this, MPPI_KERNEL_NOMINAL);
+        hipLaunchKernelGGL(mppi::nominal_kernel, dim3(cfg.n_agents), dim3(mppi::kNomThreads), (size_t)cfg.horizon * sizeof(double), stream, P,
+                           in_state ? in_state : (const double*)d_state, in_goal ? in_goal : (const double*)d_goal, d_unom, d_tc, d_base);
+        HIPCHK(hipGetLastError());
+    }
+    mppi::RolloutFusedArgs a{};
+    a.P = P; a.P.snap = d_prev;   // (V is never stored: mppi_download_value / mppi_update re-run the tick from this snapshot)
+    a.stream = stream; a.seed = seed; a.tick = tick; a.tick_ptr = tick_ptr;
+    a.state = in_state ? in_state : d_state; a.goal = in_goal ? in_goal : d_goal; a.unom = d_unom;
+    a.tc = d_tc; a.part = d_part; a.NB = fused_nb; a.nterm = nterm;
+    {
+        Scope sc(this, MPPI_KERNEL_ROLLOUT);
+        const hipError_t e = mppi::launch_rollout_fused(a);
+        if (e != hipSuccess) fail(MPPI_E_HIP, "fused rollout launch failed: %s", hipGetErrorString(e));
+    }
+    last_rollout_pk = false;
+    last_rollout_kind = MPPI_ROLLOUT_FUSED;
+    if (in_slot >= 0) inputs_consumed();
+}
+
 void mppi_engine::run_pipeline(int noise_mode, uint64_t seed, uint32_t tick, const uint32_t* tick_ptr, bool skip_small_merge) {
     check_noise_mode(noise_mode);
     if (!in_agent_view) co_value_dirty = false;   // (V of EVERY agent is about to be this engine's own: nothing of a sub's is wanted any more)
@@ -291,6 +324,14 @@ void mppi_engine::run_pipeline(int noise_mode, uint64_t seed, uint32_t tick, con
         merge_skipped = (skip_small_merge || (p2p_connected && !p2p_internal)) && small_nb <= kDirectTuples;
         direct_n = small_nb;
         if (!merge_skipped) launch_merge(small_nb);
+        noise_ready = true; value_ready = false; value_lazy = true; partials_ready = true; epart_ready = false;
+        return;
+    }
+    if (pick_fused(ph, store)) {   // fp64 storage, under way: rollout + cost-to-go + partials in one kernel, V stays on the chip
+        eps_lazy = true; injected_ready = false;
+        launch_fused(seed, tick, tick_ptr);
+        merge_skipped = false; direct_n = fused_nb;
+        launch_merge(fused_nb);
         noise_ready = true; value_ready = false; value_lazy = true; partials_ready = true; epart_ready = false;
         return;
     }
@@ -369,7 +410,8 @@ void mppi_engine::run_finalize(const double* gathered, int G, int flags, mppi::P
     if ((co_active() || is_co_sub) && fin_threads > 512) fin_threads = 512;
     // the next tick's nominal table on the way out (lane-per-sample ticks that run the plant step and the shift; a graph replay
     // keeps its prologue: its launches are frozen)
-    if ((flags & 3) == 3 && !(flags & 4) && hoist_on() && inline_nominal() && small_nb == 0 && !capturing) flags |= 32;
+    // (a fused fp64 tick always wants it: that kernel only ever LOADS its table)
+    if ((flags & 3) == 3 && !(flags & 4) && (hoist_on() || last_rollout_kind == MPPI_ROLLOUT_FUSED) && inline_nominal() && small_nb == 0 && !capturing) flags |= 32;
     uint32_t tick_set = 0;
     if ((flags & 1) && !(flags & 4) && last_tick_eager) { flags |= 16; tick_set = last_tick_id + 1u; }
     // eager ticks also drop their outputs into the pinned host buffer (a graph replay cannot: its sequence number
@@ -524,9 +566,17 @@ void mppi_engine::init(const mppi_config& c) {
             small_nb = small_nw == 1 ? (units + 3) / 4 : units;
         }
     }
+    // the fused fp64 tick: one wave per SIMD of the chip (four to a workgroup, a workgroup per CU: its LDS), split over the agents
+    if (f64() && small_nb == 0 && inline_nominal() && T <= 64 && nterm != 0 && !is_co_sub) {
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+        const int groups = (K + 63) / 64;
+        fused_nb = std::max(4, std::min((groups + 3) / 4 * 4, std::max(1, cus / A) * 4));
+        if (mppi::rollout_fused_lds(T) > (size_t)160 * 1024) fused_nb = 0;
+    }
     {
         const int ch8 = f64() ? mppi::UpdCfg<double, 8>::CH : mppi::UpdCfg<float, 8>::CH;
-        d_part = dev_alloc<double>((size_t)A * T * std::max((K + ch8 - 1) / ch8, small_nb) * mppi::kTupleW, hbm_bytes);
+        d_part = dev_alloc<double>((size_t)A * T * std::max(std::max((K + ch8 - 1) / ch8, small_nb), fused_nb) * mppi::kTupleW, hbm_bytes);
     }
     d_prev = dev_alloc<double>((size_t)A * (2 * T + 6), hbm_bytes);
     d_merged = dev_alloc<double>((size_t)A * T * mppi::kTupleW, hbm_bytes);

@@ -127,6 +127,27 @@ struct mppi_engine {
     int last_rollout_kind = MPPI_ROLLOUT_NONE;   // ... as mppi_rollout_kernel reports it
     int noise_pack = 0;             // option "noise_packing": how a Philox call's bits become normals (mppi::NoisePack): 0 three steps per call, 1 four, 2 hipRAND's normals (two)
     bool use_pk = true;             // option "rollout_pk" = 0: keep the all-fp64 rollout kernel on the tick path (same-box A/B measurements)
+    // The fused tick of fp64 storage (rollout_fused.hpp): rollout + cost-to-go + softmax partials in one kernel, V never stored.
+    // fused_nb: its waves per agent (0: this engine can never run it -- storage, model, cost, horizon).  It serves the regime of the
+    // closed loop in which a row has a handful of samples with weight; parked at the goal (every sample of a row within a few lambda)
+    // each of them would cost it a Philox call, so the engine looks at the largest row sum of weights the last finished tick reported
+    // (finalize writes it next to the outputs in pinned memory: a host read, no synchronisation, stale by a tick at most) and keeps the
+    // two-kernel tick above kFusedRegimeCut.  Option "pk_min_samples" >= 0 replaces both rules by a plain size rule (tests, A/B).
+    int fused_nb = 0;
+    static constexpr double kFusedRegimeCut = 64.0;
+    static constexpr long kFusedMinSamples = 131072;
+    double regime_weight() const {   // the largest row sum of softmax weights the last finished tick reported (0 before the first)
+        double d = 0.0;
+        for (int a = 0; a < cfg.n_agents; ++a) {
+            const uint64_t bits = __atomic_load_n(reinterpret_cast<const uint64_t*>(h_out) + (size_t)a * 8 + 5, __ATOMIC_RELAXED);
+            double v;
+            std::memcpy(&v, &bits, sizeof(v));
+            d = std::max(d, v);
+        }
+        return d;
+    }
+    bool pick_fused(bool ph, bool store) const;
+    void launch_fused(uint64_t seed, uint32_t tick, const uint32_t* tick_ptr);
     double* d_tc = nullptr;  // [A][T][8]   the nominal trajectory's table the LAST rollout used (= tcb[tab])
     double* d_base = nullptr;   //             (= baseb[tab])
     // The table exists twice: a tick's finalize kernel writes the NEXT tick's table (nominal_table_lanes) into the other set while
@@ -451,7 +472,9 @@ struct mppi_engine {
     // nominal_kernel reading d_state in front of it) and the launch is not so big that thousands of workgroups would queue on PCIe
     bool lanes_zero_copy = true;   // option "lanes_zero_copy" (0: the fetch launch in front of the rollout, as every other call takes it)
     bool lanes_zero_copy_ok() const {
-        return lanes_zero_copy && small_nb == 0 && inline_nominal() && (long)cfg.n_agents * roll_blocks <= 4096 && !capturing;
+        // (the fused fp64 tick loads its table: its inputs go through the fetch launch)
+        return lanes_zero_copy && small_nb == 0 && inline_nominal() && (long)cfg.n_agents * roll_blocks <= 4096 && !capturing &&
+               !pick_fused(true, store_eps_always);
     }
     void inputs_consumed() {  // the kernel that reads the pinned slot has been enqueued: the slot is free once it has run
         if (in_slot >= 0) { slot_unclaimed = in_slot; in_slot = -1; }

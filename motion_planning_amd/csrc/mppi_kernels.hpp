@@ -1945,7 +1945,13 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
     __shared__ double trig[3][2];
     __shared__ double nx_sh[3];     // the pose the plant step predicts (flags bit5: the next tick's table starts from it)
     __shared__ double tab_sh[16];   // scan scratch of nominal_table_lanes
+    // the largest merged sum of weights of this agent's rows, as its bit pattern (non-negative doubles order like integers): what the
+    // engine reads from the pinned outputs to tell the regimes of the closed loop apart -- under way a row's sum is 1 ... 3 (the best
+    // sample and a neighbour or two), parked at the goal it is in the thousands (out[5]; the fused fp64 tick keeps to the first regime)
+    __shared__ unsigned long long dmax_sh;
     const int tid = threadIdx.x, T = P.T;
+    if (tid == 0) dmax_sh = 0ull;
+    double d_seen = 0.0;
     // the filter operator does not depend on anything this kernel waits for: fetch it now, all loads in
     // flight at once, and read it from LDS when the updated controls are ready
     const bool staged = (flags & 8) != 0;
@@ -1955,6 +1961,7 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
     // omg = exp(-V/lam) + 1e-8, normalised; uvec += eps . omg   (control/src/mppi:193-196), then clip (:198-199)
     auto apply = [&](int t, double d, double n0, double n1, double e0, double e1, double cnt) {
         const double den = d + P.floor_w * cnt;
+        d_seen = fmax(d_seen, d);
         const double du0 = (n0 + P.floor_w * e0) / den, du1 = (n1 + P.floor_w * e1) / den;
         un[t] = clampd(unom[((size_t)a * 2 + 0) * T + t] + du0, P.u_max);
         un[T + t] = clampd(unom[((size_t)a * 2 + 1) * T + t] + du1, P.u_max);
@@ -1991,6 +1998,7 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
     }
     fprobe.mark(1);   // tuples merged, controls updated (this thread's share)
     __syncthreads();
+    if (d_seen > 0.0) atomicMax(&dmax_sh, (unsigned long long)__double_as_longlong(d_seen));   // (read behind the barriers below)
     fprobe.mark(2);
     {   // savgol_filter (:202) as u @ S, clip (:205-206).  With window T-1 the operator has rank 8 (savgol.hpp):
         //   (u @ S)[j] = sum_d p_d(e_j) c_d[shift_j],   c_d[s] = sum_i p_d(i) u[i + s]
@@ -2070,6 +2078,7 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
             }
             double* o = outv + (size_t)a * 8;
             o[0] = xn[0]; o[1] = xn[1]; o[2] = xn[2]; o[3] = uf[0]; o[4] = uf[T];
+            o[5] = __longlong_as_double((long long)dmax_sh);
             state[a * 3 + 0] = xn[0]; state[a * 3 + 1] = xn[1]; state[a * 3 + 2] = xn[2];
             nx_sh[0] = xn[0]; nx_sh[1] = xn[1]; nx_sh[2] = xn[2];
             if (host_out) {
@@ -2077,7 +2086,7 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
                 // sequence word (system-scope release) -- mppi_get_outputs polls that word instead of issuing a D2H copy
                 double* ho = host_out + (size_t)a * 8;
 #pragma unroll
-                for (int i = 0; i < 5; ++i) __hip_atomic_store(ho + i, o[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                for (int i = 0; i < 6; ++i) __hip_atomic_store(ho + i, o[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 __hip_atomic_store(host_seq + a, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }

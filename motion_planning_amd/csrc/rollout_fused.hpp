@@ -1,0 +1,251 @@
+// rollout_fused.hpp -- rollout_fused_kernel: rollout + cost-to-go + softmax partials of a lane-per-sample tick in ONE kernel, for
+// the reference's own precision (MPPI_STORE_F64: the reference is float64 end to end, control/src/mppi:127-208).  The two-kernel
+// tick of that mode is memory-bound twice over -- the rollout writes 8 B per sample-step (400 MB per tick at config 4, more than
+// the 256 MB Infinity Cache holds), the update reads them back -- and its two big launches run one after the other (110 + 70 us).
+// Here V never leaves the chip (EXPERIMENTS.md 46, built in round 6):
+//
+//   one WAVE (four to a workgroup: one per SIMD of its CU, each on its own) walks groups of 64 samples (lane = sample), T sequential steps each -- the all-fp64 lean step of
+//   rollout_kernel, operation for operation -- and drops the running cost prefix of every step into LDS, pf[t][lane];
+//   behind the loop the wave turns round: lane = ROW t, and folds its 64 samples into the row's softmax tuple
+//       v_k = Stot_k - pf[t][k]        (V[t][k] = base[t] + v_k: total minus exclusive prefix, control/src/mppi:175)
+//       m = min_k v_k;   e_k = exp2((m - v_k) log2e / lambda);   D = sum e_k,   N = sum e_k eps_k[t]       (:189-196)
+//   (two passes over the wave's own LDS: minimum, then weights) with the noise of the few samples that carry
+//   weight re-drawn from its Philox counter (lane t draws (sample k, step t): one call serves every row that needs it);
+//   the group's tuple is merged into the wave's running one (exact rescaling), and the wave leaves ONE tuple per row:
+//   part[a][t][wave] -- 1024 waves' tuples per row for the merge launch, whatever K is.
+//
+// LDS per wave: the prefix [T][65] doubles (pitch 65: lanes = rows read conflict-free), 64 totals, the eps sums -- 27 KB at T = 50;
+// a workgroup = four waves + the per-step table = 110 KB: one workgroup per CU, one wave per SIMD, 1024 waves on the chip, each
+// walking ceil(K / 65536) groups (static, strided: the same wave folds the same samples in the same order every run).  The per-step table of the nominal trajectory is LOADED (the previous
+// tick's finalize kernel or nominal_kernel computed it): no prologue per wave.
+// Serves: fp64 storage, device noise not stored, rk4 + dd_dynamics, Q = diag(q, q, 0), no obstacle grid, T <= 64, the default
+// noise stream.  Far from the goal a group has a handful of (row, sample) pairs with weight (the block's best sample of each
+// row); parked AT the goal a few per cent of all pairs carry weight and every one costs a Philox call here -- the engine keeps the
+// two-kernel tick for that regime (it reads the last tick's largest row sum of weights from the pinned outputs).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mppi_kernels.hpp"
+
+namespace mppi {
+
+constexpr int kFusedPitch = 65;   // doubles per prefix row in LDS (64 samples + 1: rows land in distinct banks)
+// LDS bytes of one wave (prefix [T][65] f64, totals [64] f64, eps sums [T][2] f32, rounded to 16) and of a workgroup (table [T][5] f64 + four waves)
+inline size_t rollout_fused_lds_wave(int T) { return ((size_t)T * kFusedPitch * 8 + 64 * 8 + (size_t)T * 2 * 4 + 15) / 16 * 16; }
+inline size_t rollout_fused_lds(int T) { return ((size_t)T * 5 * 8 + 15) / 16 * 16 + 4 * rollout_fused_lds_wave(T); }
+
+struct RolloutFusedArgs {
+    DevParams P;
+    hipStream_t stream;
+    uint64_t seed;
+    uint32_t tick;
+    const uint32_t* tick_ptr;
+    const double *state, *goal, *unom;
+    const double* tc;     // [A][T][8] the nominal trajectory's per-step table (rows {un0, un1, w0, w1, cb}; row 0 also (cos, sin) of the pose's heading)
+    double* part;         // [A][T][NB][8]
+    int NB;               // waves per agent (a multiple of 4: four to a workgroup)
+    int nterm;            // 4 | 7
+};
+hipError_t launch_rollout_fused(const RolloutFusedArgs& a);
+
+#ifdef MPPI_ROLLOUT_FUSED_TU
+template <int NTERM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void rollout_fused_kernel(
+    DevParams P, const double* __restrict__ state, const double* __restrict__ goal, const double* __restrict__ unom,
+    const double* __restrict__ tc, uint64_t seed, uint32_t tick_arg, const uint32_t* __restrict__ tick_ptr, double* __restrict__ part, int NB) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int T = P.T, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, a = blockIdx.y, wv = (int)blockIdx.x * 4 + wid;
+    double* lt = reinterpret_cast<double*>(smem_raw);          // [T][5]   (the workgroup's)
+    char* mine = smem_raw + ((size_t)T * 5 * 8 + 15) / 16 * 16 + (size_t)wid * (((size_t)T * kFusedPitch * 8 + 64 * 8 + (size_t)T * 2 * 4 + 15) / 16 * 16);
+    double* pf = reinterpret_cast<double*>(mine);              // [T][kFusedPitch]   (this wave's, like everything below)
+    double* st = pf + (size_t)T * kFusedPitch;                 // [64]
+    float* es = reinterpret_cast<float*>(st + 64);             // [T][2]
+    // this wave's own LDS traffic needs no workgroup barrier: a wave's LDS operations complete in order; the fences keep the compiler in line
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    snapshot_inputs(P, state, goal, unom, a);
+    const double st_x = state[a * 3 + 0], st_y = state[a * 3 + 1], st_th = state[a * 3 + 2];
+    const double g_x = goal[a * 3 + 0], g_y = goal[a * 3 + 1], g_th = goal[a * 3 + 2];
+    const uint32_t tick = tick_ptr ? *tick_ptr : tick_arg;
+    const double half_kd = 0.5 * P.kth * P.dt;
+    for (int i = tid; i < T * 5; i += 256) {
+        const double v = tc[((size_t)a * T + i / 5) * kTcW + i % 5];
+        lt[i] = (i % 5 < 2) ? v * half_kd : v;
+    }
+    const double head_c = tc[(size_t)a * T * kTcW + 5], head_s = tc[(size_t)a * T * kTcW + 6];
+    __syncthreads();
+    const double p_max = half_kd * P.u_max, f = P.lean_f, rho = P.lean_rho, inv_sq = P.lean_inv_f;
+    const uint32_t key0 = (uint32_t)seed, key1 = (uint32_t)(seed >> 32);
+    const float sigf = (float)P.sigma;
+    const double scale = P.inv_lambda * 1.4426950408889634;   // log2(e) / lambda
+    const double cut = -100.0;                                // log2 of the smallest weight that is kept (the update kernel's fp64 cut)
+    const int groups = (P.K + 63) >> 6;
+    const int trow = lane < T ? lane : T - 1;                 // this lane's ROW in the folding pass (lanes >= T shadow the last row)
+
+    // the wave's running tuple of row `lane`
+    double Mr = INFINITY, Dr = 0.0, N0r = 0.0, N1r = 0.0, E0r = 0.0, E1r = 0.0, Cr = 0.0;
+
+    for (int g = wv; g < groups; g += NB) {
+        const int k = g * 64 + lane;
+        const bool active = k < P.K;
+        const uint32_t ctr0 = P.sample_offset + (uint32_t)k;
+        double x = (st_x - g_x) * f, y = (st_y - g_y) * f, th = st_th;
+        double c = head_c * rho, s = head_s * rho;
+        double pre = 0.0;
+        constexpr int U = 6;
+        double cur[U][2], tl[kStepsPerDraw][2];
+        auto draw_chunk = [&](int t0, bool tail) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < U; j += kStepsPerDraw) {
+                if (!tail || t0 + j < T) {
+                    float e[6];
+                    philox_normals(ctr0, (uint32_t)((t0 + j) / kStepsPerDraw), tick, P.agent_offset + (uint32_t)a, key0, key1, sigf, e);
+#pragma unroll
+                    for (int i = 0; i < kStepsPerDraw; ++i) { cur[j + i][0] = (double)e[2 * i]; cur[j + i][1] = (double)e[2 * i + 1]; }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < kStepsPerDraw; ++i) { cur[j + i][0] = 0.0; cur[j + i][1] = 0.0; }
+                }
+            }
+        };
+        // per-wave sums of eps for the chunk's steps (the E of the softmax floor term, control/src/mppi:193): fp32, as rollout_kernel forms them
+        auto eps_sums = [&](int t0, auto extra_tag) __attribute__((always_inline)) {
+            constexpr bool EXTRA = decltype(extra_tag)::value;
+            float ev[16];
+#pragma unroll
+            for (int j = 0; j < U; ++j) { ev[2 * j] = active ? (float)cur[j][0] : 0.f; ev[2 * j + 1] = active ? (float)cur[j][1] : 0.f; }
+#pragma unroll
+            for (int j = 2 * U; j < 16; ++j) ev[j] = !EXTRA ? 0.f : (active ? (float)tl[(j - 2 * U) >> 1][j & 1] : 0.f);
+            const float tot = wave_sum16<EXTRA>(ev, lane);
+            const int idx = sum16_index(lane), te = t0 + (idx >> 1);
+            if (lane < 16 && idx < (EXTRA ? 16 : 2 * U) && te < T) es[te * 2 + (idx & 1)] = tot;
+        };
+        // one step: the prefix BEFORE the step goes to LDS, then explore + clip + rk4 + cost (rollout_kernel's lean step, operation for operation)
+        auto step = [&](int t, double e0, double e1) __attribute__((always_inline)) {
+            const double* tcp = lt + t * 5;
+            const double un0 = tcp[0], un1 = tcp[1], w0 = tcp[2], w1 = tcp[3], cb = tcp[4];
+            pf[t * kFusedPitch + lane] = pre;
+            const double p0 = clamp_sym(fma(e0, half_kd, un0), p_max), p1 = clamp_sym(fma(e1, half_kd, un1), p_max);
+            const double phi = p1 - p0;
+            double sp, cp;
+            small_sincos<NTERM>(phi, sp, cp);
+            const double c1 = c * cp - s * sp, s1 = s * cp + c * sp;
+            const double tcp2 = twice(cp);
+            const double c2 = fma(tcp2, c1, -c), s2 = fma(tcp2, s1, -s);
+            const double gg = (p0 + p1) * (tcp2 + 4.0);
+            x = fma(gg, c1, x);
+            y = fma(gg, s1, y);
+            th = fma(2.0, phi, th);
+            c = c2; s = s2;
+            double dc = fma(x, x, fma(y, y, cb));
+            dc = fma(w0, e0, dc);
+            dc = fma(w1, e1, dc);
+            pre += dc;
+        };
+        auto integrate = [&](int t0, bool guard) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < U; ++j)
+                if (!guard || t0 + j < T) step(t0 + j, cur[j][0], cur[j][1]);
+        };
+        const int T4 = T - T % U;
+        const bool ride = T4 >= U && (T - T4 == 1 || T - T4 == 2);   // (uniform) as rollout_kernel: the one or two steps behind the last full chunk
+        const int t_loop = ride ? T4 - U : T4;
+        for (int t0 = 0; t0 < t_loop; t0 += U) {
+            draw_chunk(t0, false);
+            eps_sums(t0, std::false_type{});
+            integrate(t0, false);
+        }
+        if (ride) {
+            const int t0 = T4 - U;
+            draw_chunk(t0, false);
+            {
+                float e[6];
+                philox_normals(ctr0, (uint32_t)(T4 / kStepsPerDraw), tick, P.agent_offset + (uint32_t)a, key0, key1, sigf, e);
+#pragma unroll
+                for (int i = 0; i < kStepsPerDraw; ++i) {
+                    tl[i][0] = T4 + i < T ? (double)e[2 * i] : 0.0;
+                    tl[i][1] = T4 + i < T ? (double)e[2 * i + 1] : 0.0;
+                }
+            }
+            eps_sums(t0, std::true_type{});
+            integrate(t0, false);
+#pragma unroll
+            for (int j = 0; j < U; ++j) { cur[j][0] = j < kStepsPerDraw ? tl[j][0] : 0.0; cur[j][1] = j < kStepsPerDraw ? tl[j][1] : 0.0; }
+            integrate(T4, true);
+        } else if (T4 < T) {
+            draw_chunk(T4, true);
+            eps_sums(T4, std::false_type{});
+            integrate(T4, true);
+        }
+        {   // terminal cost (control/src/mppi:165-173); the theta error is not wrapped beyond rk4's own wrap
+            const double thw = (th > M_PI || th <= -M_PI) ? wrap_theta(th) : th;
+            const double dx = x * inv_sq, dy = y * inv_sq, dth = thw - g_th;
+            pre += P.p0 * dx * dx + P.p1 * dy * dy + P.p2 * dth * dth;
+        }
+        st[lane] = active ? pre : INFINITY;
+        wave_sync();
+
+        // ---- lanes = rows: fold the group's 64 samples into row `trow`'s tuple ------------------------------------------------------
+        const double* prow = pf + (size_t)trow * kFusedPitch;
+        double m = INFINITY;
+#pragma unroll
+        for (int kk = 0; kk < 64; ++kk) m = fmin(m, st[kk] - prow[kk]);     // (+inf for the samples beyond K)
+        // Weights are formed relative to the minimum the wave's running tuple will have BEHIND this group, Mn = min(Mr, m): a group
+        // whose best sample of a row is already hopeless against what the wave has seen (more than 100 lambda ln 2 above it -- the rule
+        // after the first few groups: a group's best beats the running best of g groups with probability 1 / (g + 1)) has no
+        // candidate in that row at all, and nothing of it is drawn.  Exact to the 2^-100 every weight cut here is.
+        const double Mn = fmin(Mr, m);
+        const double so = (Mr == Mn) ? 1.0 : exp((Mn - Mr) * P.inv_lambda);   // (Mr = +inf in front of the first group: exp(-inf) = 0 times D = 0)
+        double Dg = 0.0, N0g = 0.0, N1g = 0.0;
+        const uint32_t gk0 = P.sample_offset + (uint32_t)(g * 64);
+        // weights: eight samples at a time are tested for ANY row giving them weight (almost every octet has none while the robot is
+        // under way: the group's best sample of a row is usually its only one); the octets that do are walked sample by sample
+#pragma unroll 1
+        for (int kk0 = 0; kk0 < 64; kk0 += 8) {
+            bool some = false;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) some |= (Mn - (st[kk0 + j] - prow[kk0 + j])) * scale > cut;
+            if (!__any(some && lane < T)) continue;   // (uniform)
+#pragma unroll 1
+            for (int kk = kk0; kk < kk0 + 8; ++kk) {
+                const double xs = (Mn - (st[kk] - prow[kk])) * scale;      // <= 0; -inf beyond K
+                const bool cand = xs > cut && lane < T;
+                if (__any(cand)) {   // (uniform) some row gives sample kk weight: its noise, re-drawn -- lane t draws (sample, step t)
+                    float f0, f1;
+                    philox_normal_pair<0>(gk0 + (uint32_t)kk, (uint32_t)trow, tick, P.agent_offset + (uint32_t)a, key0, key1, sigf, f0, f1);
+                    const double e = cand ? exp2(xs) : 0.0;
+                    Dg += e;
+                    N0g = fma(e, (double)f0, N0g);
+                    N1g = fma(e, (double)f1, N1g);
+                }
+            }
+        }
+        const double E0g = (double)es[trow * 2 + 0], E1g = (double)es[trow * 2 + 1];
+        const double Cg = (double)min(64, P.K - g * 64);
+        // merge into the running tuple (exact: M = min, the old D and N rescaled by exp(-(Mr - Mn) / lambda); E and the count add)
+        Dr = Dr * so + Dg; N0r = N0r * so + N0g; N1r = N1r * so + N1g;
+        E0r += E0g; E1r += E1g; Cr += Cg; Mr = Mn;
+        wave_sync();   // (the next group's prefix stores stay behind this group's reads)
+    }
+    if (lane < T) {
+        double* o = part + (((size_t)a * T + lane) * NB + wv) * kTupleW;
+        o[0] = Mr; o[1] = Dr; o[2] = N0r; o[3] = N1r; o[4] = E0r; o[5] = E1r; o[6] = Cr; o[7] = 0.0;
+    }
+}
+
+hipError_t launch_rollout_fused(const RolloutFusedArgs& a) {
+    const dim3 grid(a.NB / 4, a.P.A);
+    const unsigned lds = (unsigned)rollout_fused_lds(a.P.T);
+    if (a.nterm == 7)
+        hipLaunchKernelGGL(rollout_fused_kernel<7>, grid, dim3(256), lds, a.stream, a.P, a.state, a.goal, a.unom, a.tc, a.seed, a.tick, a.tick_ptr, a.part, a.NB);
+    else
+        hipLaunchKernelGGL(rollout_fused_kernel<4>, grid, dim3(256), lds, a.stream, a.P, a.state, a.goal, a.unom, a.tc, a.seed, a.tick, a.tick_ptr, a.part, a.NB);
+    return hipGetLastError();
+}
+#endif  // MPPI_ROLLOUT_FUSED_TU
+
+}  // namespace mppi

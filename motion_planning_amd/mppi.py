@@ -452,7 +452,7 @@ class Engine(object):
                 "co_shards": n.value, "co_samples": [per[g] for g in range(n.value)],
                 "co_note": (self._lib.mppi_co_note(self._h) or b"").decode(),
                 # which kernel the last rollout launch was (include/mppi_hip.h MPPI_ROLLOUT_*)
-                "rollout_kernel": ("none", "fp64", "mixed", "scan")[kind.value]}
+                "rollout_kernel": ("none", "fp64", "mixed", "scan", "fused")[kind.value]}
 
 
 class _NominalView(np.ndarray):

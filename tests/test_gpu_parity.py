@@ -1036,6 +1036,79 @@ def test_full_size_replay_of_the_mixed_rollout_at_a_long_horizon(orc, tick_path,
     assert m["du_max"] <= 1e-6, m      # empirical cap (the analytic bound of this scene is m["tol_max"])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,T", [(1, 50), (64, 50), (65, 49), (3000, 50), (5000, 26), (4097, 64), (70001, 51), (300000, 50)])
+def test_fused_fp64_tick_equals_the_two_kernel_tick_and_the_oracle(orc, tick_path, K, T):
+    """rollout_fused_kernel (fp64 storage, device noise: rollout + cost-to-go + softmax partials in ONE kernel, V never stored;
+    VERDICT r5 item 2 / EXPERIMENTS.md 46) against the two-kernel tick of the same engine and against the oracle: one sample, a
+    ragged last group of 64, every horizon class mod 6 up to its longest (64), sizes from one wave with work to several groups per
+    wave.  First tick (table from nominal_kernel) and resident ticks (table left by the previous tick's finalize kernel): applied
+    controls / state / nominal sequence equal to the merge's rounding; V and noise handed back after a fused tick (re-run from the
+    tick's snapshot, re-drawn) equal the two-kernel tick's; the first tick replayed on the oracle at the fp64 tolerances (V 1e-9 |V|,
+    u 1e-9, state 1e-12)."""
+    if tick_path == "scan":
+        pytest.skip("a lane-kernel test (the engines below name their tick path)")
+    from motion_planning_amd.mppi import Engine
+    u0 = np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
+    state, goal = [0.05, -0.02, 0.3], [0.0, -1.0, 0.0]
+    res = {}
+    for name, opts in (("fused", {"pk_min_samples": 1}), ("two", {"rollout_pk": 0})):
+        with Engine(K, T, storage="f64", tick_path="lanes", options=opts) as e:
+            e.set_nominal(u0)
+            nxt, ua = e.tick(state, goal, noise="philox", seed=3, tick_id=0)
+            kinds = [e.info()["rollout_kernel"]]
+            V0, eps0, lat0 = e.download_value()[0], e.download_noise()[0], e.get_nominal()
+            rows = [np.concatenate([nxt[0], ua[0]])]
+            for i in range(1, 4):                                   # resident ticks: the table the finalize kernel left
+                nxt, ua = e.tick(None, None, noise="philox", seed=3, tick_id=i)
+                rows.append(np.concatenate([nxt[0], ua[0]]))
+                kinds.append(e.info()["rollout_kernel"])
+            nxt, ua = e.tick([0.01, 0.0, 0.1], None, noise="philox", seed=3, tick_id=9)   # a fresh pose: nominal_kernel again
+            rows.append(np.concatenate([nxt[0], ua[0]]))
+            res[name] = (np.array(rows), V0, eps0, lat0, e.download_value()[0], e.get_nominal(), kinds)
+    f, t = res["fused"], res["two"]
+    assert set(f[6]) == {"fused"} and set(t[6]) == {"fp64"}, (f[6], t[6])
+    assert np.array_equal(f[2], t[2])                                                          # the same noise
+    assert np.abs(f[1] - t[1]).max() <= 1e-12 * np.abs(t[1]).max()                            # V of tick 0 (the fused tick's: re-run)
+    assert np.abs(f[0] - t[0]).max() < 1e-11, np.abs(f[0] - t[0]).max(axis=1)                 # five ticks of the closed loop
+    assert np.abs(f[3] - t[3]).max() < 1e-11 and np.abs(f[5] - t[5]).max() < 1e-10
+    assert np.abs(f[4] - t[4]).max() <= 1e-9 * np.abs(t[4]).max()
+    so, uo, _ = orc.get_path(state, goal, u0, f[2], LAM, SIG)
+    Vo = orc.get_cost2go(state, u0, goal, LAM, SIG, f[2])
+    assert np.abs(f[1] - Vo).max() <= 1e-9 * np.abs(Vo).max()
+    assert np.abs(f[0][0][3:] - uo).max() < 1e-9 and np.abs(f[0][0][:3] - so).max() < 1e-12
+
+
+@pytest.mark.gpu
+def test_fused_fp64_tick_keeps_to_its_regime(tick_path):
+    """The engine's own rule for the fused fp64 tick: under way (a row has a handful of samples with weight) it runs; parked at the
+    goal with zero nominal controls -- every sample of a row within a few lambda, each would cost it a Philox call -- the engine sees
+    the last tick's largest row sum of weights in the pinned outputs and goes back to the two-kernel tick; the closed loop does not
+    notice (both against an engine that never fuses, 1e-10)."""
+    if tick_path == "scan":
+        pytest.skip("a lane-kernel test")
+    from motion_planning_amd.mppi import Engine
+    K, T = 200000, 50
+    out = {}
+    for name, opts in (("auto", {}), ("never", {"rollout_pk": 0})):
+        with Engine(K, T, storage="f64", tick_path="lanes", options=opts) as e:
+            rows, kinds = [], []
+            e.set_nominal(np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)]))
+            nxt, ua = e.tick([0, 0, 0], [0, -1, 0], noise="philox", seed=5, tick_id=0)
+            for i in range(1, 4):
+                nxt, ua = e.tick(None, None, noise="philox", seed=5, tick_id=i)
+                rows.append(np.concatenate([nxt[0], ua[0]])); kinds.append(e.info()["rollout_kernel"])
+            e.set_nominal(np.zeros((2, T)))                      # parked: pose = goal, nothing to do
+            nxt, ua = e.tick([0, -1, 0], [0, -1, 0], noise="philox", seed=5, tick_id=10)
+            for i in range(11, 16):
+                nxt, ua = e.tick(None, None, noise="philox", seed=5, tick_id=i)
+                rows.append(np.concatenate([nxt[0], ua[0]])); kinds.append(e.info()["rollout_kernel"])
+            out[name] = (np.array(rows), kinds)
+    assert out["auto"][1][:3] == ["fused"] * 3 and out["auto"][1][-3:] == ["fp64"] * 3, out["auto"][1]
+    assert set(out["never"][1]) == {"fp64"}
+    assert np.abs(out["auto"][0] - out["never"][0]).max() < 1e-10
+
+
 PK_SMALL = [(1, 26), (2, 27), (511, 28), (513, 29), (1025, 30), (2049, 31), (777, 32), (1300, 49), (900, 50), (1100, 51), (640, 100),
             (515, 255), (300, 256)]
 
