@@ -135,7 +135,9 @@ struct mppi_engine {
     // two-kernel tick above kFusedRegimeCut.  Option "pk_min_samples" >= 0 replaces both rules by a plain size rule (tests, A/B).
     int fused_nb = 0;
     static constexpr double kFusedRegimeCut = 64.0;
-    static constexpr long kFusedMinSamples = 131072;
+    // (same box, fp64 storage, T = 50, tick us fused / two kernels: 10^6 samples 177.6 / 194.1, 500 000 101.2 / 116.4, 250 000 61.9 / 63.9,
+    // 125 000 42.4 / 39.8 -- profiles/r6_ab_fused_f64.txt)
+    static constexpr long kFusedMinSamples = 200000;
     double regime_weight() const {   // the largest row sum of softmax weights the last finished tick reported (0 before the first)
         double d = 0.0;
         for (int a = 0; a < cfg.n_agents; ++a) {

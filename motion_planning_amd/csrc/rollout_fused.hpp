@@ -30,10 +30,11 @@
 
 namespace mppi {
 
-constexpr int kFusedPitch = 65;   // doubles per prefix row in LDS (64 samples + 1: rows land in distinct banks)
+constexpr int kFusedPitch = 66;   // doubles per prefix row in LDS (64 samples + 2: rows stay 16-byte aligned and a row pair's 16-byte reads of one lane group land in distinct banks)
+constexpr int kFusedRow = 6;      // doubles per table row in LDS ({un0, un1, w0, w1, cb, -}: three 16-byte reads)
 // LDS bytes of one wave (prefix [T][65] f64, totals [64] f64, eps sums [T][2] f32, rounded to 16) and of a workgroup (table [T][5] f64 + four waves)
 inline size_t rollout_fused_lds_wave(int T) { return ((size_t)T * kFusedPitch * 8 + 64 * 8 + (size_t)T * 2 * 4 + 15) / 16 * 16; }
-inline size_t rollout_fused_lds(int T) { return ((size_t)T * 5 * 8 + 15) / 16 * 16 + 4 * rollout_fused_lds_wave(T); }
+inline size_t rollout_fused_lds(int T) { return ((size_t)T * kFusedRow * 8 + 15) / 16 * 16 + 4 * rollout_fused_lds_wave(T); }
 
 struct RolloutFusedArgs {
     DevParams P;
@@ -56,8 +57,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     const double* __restrict__ tc, uint64_t seed, uint32_t tick_arg, const uint32_t* __restrict__ tick_ptr, double* __restrict__ part, int NB) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int T = P.T, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, a = blockIdx.y, wv = (int)blockIdx.x * 4 + wid;
-    double* lt = reinterpret_cast<double*>(smem_raw);          // [T][5]   (the workgroup's)
-    char* mine = smem_raw + ((size_t)T * 5 * 8 + 15) / 16 * 16 + (size_t)wid * (((size_t)T * kFusedPitch * 8 + 64 * 8 + (size_t)T * 2 * 4 + 15) / 16 * 16);
+    double* lt = reinterpret_cast<double*>(smem_raw);          // [T][kFusedRow]   (the workgroup's)
+    char* mine = smem_raw + ((size_t)T * kFusedRow * 8 + 15) / 16 * 16 + (size_t)wid * (((size_t)T * kFusedPitch * 8 + 64 * 8 + (size_t)T * 2 * 4 + 15) / 16 * 16);
     double* pf = reinterpret_cast<double*>(mine);              // [T][kFusedPitch]   (this wave's, like everything below)
     double* st = pf + (size_t)T * kFusedPitch;                 // [64]
     float* es = reinterpret_cast<float*>(st + 64);             // [T][2]
@@ -67,14 +68,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
+    ClockProbe probe(P);
     snapshot_inputs(P, state, goal, unom, a);
     const double st_x = state[a * 3 + 0], st_y = state[a * 3 + 1], st_th = state[a * 3 + 2];
     const double g_x = goal[a * 3 + 0], g_y = goal[a * 3 + 1], g_th = goal[a * 3 + 2];
     const uint32_t tick = tick_ptr ? *tick_ptr : tick_arg;
     const double half_kd = 0.5 * P.kth * P.dt;
-    for (int i = tid; i < T * 5; i += 256) {
-        const double v = tc[((size_t)a * T + i / 5) * kTcW + i % 5];
-        lt[i] = (i % 5 < 2) ? v * half_kd : v;
+    for (int i = tid; i < T * kFusedRow; i += 256) {
+        const double v = tc[((size_t)a * T + i / kFusedRow) * kTcW + i % kFusedRow];   // (word 5 of a row: not used)
+        lt[i] = (i % kFusedRow < 2) ? v * half_kd : v;
     }
     const double head_c = tc[(size_t)a * T * kTcW + 5], head_s = tc[(size_t)a * T * kTcW + 6];
     __syncthreads();
@@ -125,9 +127,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             if (lane < 16 && idx < (EXTRA ? 16 : 2 * U) && te < T) es[te * 2 + (idx & 1)] = tot;
         };
         // one step: the prefix BEFORE the step goes to LDS, then explore + clip + rk4 + cost (rollout_kernel's lean step, operation for operation)
-        auto step = [&](int t, double e0, double e1) __attribute__((always_inline)) {
-            const double* tcp = lt + t * 5;
-            const double un0 = tcp[0], un1 = tcp[1], w0 = tcp[2], w1 = tcp[3], cb = tcp[4];
+        // the chunk's table rows, requested at the top of the chunk (in front of its Philox draws): a lone wave per SIMD has nobody to
+        // hide an LDS round trip per step behind
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        d2 tb[U][3];
+        auto load_rows = [&](int t0, int n) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < U; ++j)
+                if (j < n) {
+                    const d2* r = reinterpret_cast<const d2*>(lt + (t0 + j) * kFusedRow);
+                    tb[j][0] = r[0]; tb[j][1] = r[1]; tb[j][2] = r[2];
+                }
+        };
+        auto step = [&](int t, int j, double e0, double e1) __attribute__((always_inline)) {
+            const double un0 = tb[j][0].x, un1 = tb[j][0].y, w0 = tb[j][1].x, w1 = tb[j][1].y, cb = tb[j][2].x;
             pf[t * kFusedPitch + lane] = pre;
             const double p0 = clamp_sym(fma(e0, half_kd, un0), p_max), p1 = clamp_sym(fma(e1, half_kd, un1), p_max);
             const double phi = p1 - p0;
@@ -149,18 +162,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         auto integrate = [&](int t0, bool guard) __attribute__((always_inline)) {
 #pragma unroll
             for (int j = 0; j < U; ++j)
-                if (!guard || t0 + j < T) step(t0 + j, cur[j][0], cur[j][1]);
+                if (!guard || t0 + j < T) step(t0 + j, j, cur[j][0], cur[j][1]);
         };
         const int T4 = T - T % U;
         const bool ride = T4 >= U && (T - T4 == 1 || T - T4 == 2);   // (uniform) as rollout_kernel: the one or two steps behind the last full chunk
         const int t_loop = ride ? T4 - U : T4;
         for (int t0 = 0; t0 < t_loop; t0 += U) {
+            load_rows(t0, U);
             draw_chunk(t0, false);
             eps_sums(t0, std::false_type{});
             integrate(t0, false);
         }
         if (ride) {
             const int t0 = T4 - U;
+            load_rows(t0, U);
             draw_chunk(t0, false);
             {
                 float e[6];
@@ -175,8 +190,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             integrate(t0, false);
 #pragma unroll
             for (int j = 0; j < U; ++j) { cur[j][0] = j < kStepsPerDraw ? tl[j][0] : 0.0; cur[j][1] = j < kStepsPerDraw ? tl[j][1] : 0.0; }
+            load_rows(T4, 2);
             integrate(T4, true);
         } else if (T4 < T) {
+            load_rows(T4, T - T4);
             draw_chunk(T4, true);
             eps_sums(T4, std::false_type{});
             integrate(T4, true);
@@ -190,39 +207,68 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         wave_sync();
 
         // ---- lanes = rows: fold the group's 64 samples into row `trow`'s tuple ------------------------------------------------------
-        const double* prow = pf + (size_t)trow * kFusedPitch;
+        const d2* prow2 = reinterpret_cast<const d2*>(pf + (size_t)trow * kFusedPitch);
+        const d2* st2 = reinterpret_cast<const d2*>(st);
+        // ONE pass over the row's 64 values for both the group's minimum and the samples that can matter: a weight is formed relative to
+        // the minimum the wave's running tuple will have BEHIND this group, Mn = min(Mr, m) <= Mr, so a sample whose v is not below
+        // Mr + w (w = 100 lambda ln 2: the cut of every weight here) cannot carry any -- and against the running minimum of the groups
+        // behind it almost nothing passes (a group's best beats the best of g groups with probability 1 / (g + 1)).  Each lane notes the
+        // passing samples of ITS row as bits; the wave's OR of them is what gets visited.  The first group of a wave has no running
+        // minimum yet: it takes a second pass against its own.
+        const double w = -cut / scale;
         double m = INFINITY;
+        uint32_t hit_lo = 0, hit_hi = 0;
+        auto scan = [&](double thr, bool want_min) __attribute__((always_inline)) {
+            // seven samples' pairs at a time: fourteen 16-byte LDS reads requested together (the counter holds fifteen), one wait -- left
+            // to itself the compiler waits for every pair (a lone wave pays each of those round trips in full)
 #pragma unroll
-        for (int kk = 0; kk < 64; ++kk) m = fmin(m, st[kk] - prow[kk]);     // (+inf for the samples beyond K)
-        // Weights are formed relative to the minimum the wave's running tuple will have BEHIND this group, Mn = min(Mr, m): a group
-        // whose best sample of a row is already hopeless against what the wave has seen (more than 100 lambda ln 2 above it -- the rule
-        // after the first few groups: a group's best beats the running best of g groups with probability 1 / (g + 1)) has no
-        // candidate in that row at all, and nothing of it is drawn.  Exact to the 2^-100 every weight cut here is.
+            for (int q0 = 0; q0 < 32; q0 += 7) {
+                d2 sv[7], pv[7];
+#pragma unroll
+                for (int q = 0; q < 7; ++q)
+                    if (q0 + q < 32) { sv[q] = st2[q0 + q]; pv[q] = prow2[q0 + q]; }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 7; ++q)
+                    if (q0 + q < 32) {     // (+inf for the samples beyond K)
+                        const double va = sv[q].x - pv[q].x, vb = sv[q].y - pv[q].y;
+                        if (want_min) m = fmin(m, fmin(va, vb));
+                        const uint32_t bits = (va < thr ? 1u : 0u) | (vb < thr ? 2u : 0u);
+                        if (q0 + q < 16) hit_lo |= bits << (2 * (q0 + q)); else hit_hi |= bits << (2 * (q0 + q) - 32);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        scan(Mr + w, true);
+        if (Mr == INFINITY) { hit_lo = 0; hit_hi = 0; scan(m + w, false); }   // (Mr is +inf in every lane, or in none)
+        if (lane >= T) { hit_lo = 0; hit_hi = 0; }
         const double Mn = fmin(Mr, m);
         const double so = (Mr == Mn) ? 1.0 : exp((Mn - Mr) * P.inv_lambda);   // (Mr = +inf in front of the first group: exp(-inf) = 0 times D = 0)
         double Dg = 0.0, N0g = 0.0, N1g = 0.0;
         const uint32_t gk0 = P.sample_offset + (uint32_t)(g * 64);
-        // weights: eight samples at a time are tested for ANY row giving them weight (almost every octet has none while the robot is
-        // under way: the group's best sample of a row is usually its only one); the octets that do are walked sample by sample
-#pragma unroll 1
-        for (int kk0 = 0; kk0 < 64; kk0 += 8) {
-            bool some = false;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) some |= (Mn - (st[kk0 + j] - prow[kk0 + j])) * scale > cut;
-            if (!__any(some && lane < T)) continue;   // (uniform)
-#pragma unroll 1
-            for (int kk = kk0; kk < kk0 + 8; ++kk) {
-                const double xs = (Mn - (st[kk] - prow[kk])) * scale;      // <= 0; -inf beyond K
-                const bool cand = xs > cut && lane < T;
-                if (__any(cand)) {   // (uniform) some row gives sample kk weight: its noise, re-drawn -- lane t draws (sample, step t)
-                    float f0, f1;
-                    philox_normal_pair<0>(gk0 + (uint32_t)kk, (uint32_t)trow, tick, P.agent_offset + (uint32_t)a, key0, key1, sigf, f0, f1);
-                    const double e = cand ? exp2(xs) : 0.0;
-                    Dg += e;
-                    N0g = fma(e, (double)f0, N0g);
-                    N1g = fma(e, (double)f1, N1g);
-                }
-            }
+        // the wave's OR of the lanes' bits, through the DPP network (row steps, then the row results across the rows)
+        auto wave_or = [](uint32_t v) __attribute__((always_inline)) {
+            v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+            v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+            v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+            v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);   // row_mirror
+            return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) | (uint32_t)__builtin_amdgcn_readlane((int)v, 16) |
+                   (uint32_t)__builtin_amdgcn_readlane((int)v, 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+        };
+        uint64_t want = ((uint64_t)wave_or(hit_hi) << 32) | wave_or(hit_lo);   // (uniform) bit kk: sample kk may have weight in some row
+        while (want) {   // (uniform)
+            const int kk = __builtin_ctzll(want);
+            want &= want - 1;
+            const double xs = (Mn - (st[kk] - pf[(size_t)trow * kFusedPitch + kk])) * scale;      // <= 0; -inf beyond K
+            const bool cand = xs > cut && lane < T;
+            if (!__any(cand)) continue;   // (passed against the old minimum, not against the new one)
+            // some row gives sample kk weight: its noise, re-drawn -- lane t draws (sample, step t)
+            float f0, f1;
+            philox_normal_pair<0>(gk0 + (uint32_t)kk, (uint32_t)trow, tick, P.agent_offset + (uint32_t)a, key0, key1, sigf, f0, f1);
+            const double e = cand ? exp2(xs) : 0.0;
+            Dg += e;
+            N0g = fma(e, (double)f0, N0g);
+            N1g = fma(e, (double)f1, N1g);
         }
         const double E0g = (double)es[trow * 2 + 0], E1g = (double)es[trow * 2 + 1];
         const double Cg = (double)min(64, P.K - g * 64);
@@ -231,6 +277,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         E0r += E0g; E1r += E1g; Cr += Cg; Mr = Mn;
         wave_sync();   // (the next group's prefix stores stay behind this group's reads)
     }
+    probe.stop(P);
     if (lane < T) {
         double* o = part + (((size_t)a * T + lane) * NB + wv) * kTupleW;
         o[0] = Mr; o[1] = Dr; o[2] = N0r; o[3] = N1r; o[4] = E0r; o[5] = E1r; o[6] = Cr; o[7] = 0.0;
