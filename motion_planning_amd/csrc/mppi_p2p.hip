@@ -3,6 +3,8 @@
 // (publish, the self-test's consumer) are launched by the core (mppi_engine.hip: p2p_publish, launch_p2p_check).
 #include "mppi_engine.hpp"
 
+#include <sys/stat.h>
+
 extern "C" {
 
 int mppi_p2p_create(mppi_engine* h, int n_ranks, int rank, void* ipc_handle_out) {
@@ -88,8 +90,12 @@ int mppi_p2p_rendezvous(mppi_engine* h, const char* prefix, int n_ranks, int ran
     // file = {magic, n_ranks, rank, bytes of one mailbox, writer's pid} + the handle.  A reader refuses a file of another SHAPE (not
     // this group's) and keeps waiting over a file whose writer is no longer alive (a stale file of an earlier run of the same
     // shape -- the normal relaunch case: its handle would name a dead process's memory)
-    struct Head { char magic[8]; int32_t n_ranks, rank; uint64_t mbox_bytes; int64_t pid; };
-    auto head_of = [&](int r) { Head hd{}; std::memcpy(hd.magic, "MPPIMBX2", 8); hd.n_ranks = n_ranks; hd.rank = r; hd.mbox_bytes = h->p2p_bytes; hd.pid = (int64_t)getpid(); return hd; };
+    // (the pid only means something inside the writer's pid namespace -- ranks in separate containers see each other as pid 1, or not at
+    // all: the file carries the namespace's inode too, and a reader in ANOTHER namespace skips the liveness test -- ADVICE r5)
+    struct Head { char magic[8]; int32_t n_ranks, rank; uint64_t mbox_bytes; int64_t pid; uint64_t pid_ns; };
+    struct stat ns_st{};
+    const uint64_t my_ns = stat("/proc/self/ns/pid", &ns_st) == 0 ? (uint64_t)ns_st.st_ino : 0ull;
+    auto head_of = [&](int r) { Head hd{}; std::memcpy(hd.magic, "MPPIMBX3", 8); hd.n_ranks = n_ranks; hd.rank = r; hd.mbox_bytes = h->p2p_bytes; hd.pid = (int64_t)getpid(); hd.pid_ns = my_ns; return hd; };
     {
         const std::string tmp = name(rank) + ".tmp";
         FILE* f = std::fopen(tmp.c_str(), "wb");
@@ -109,10 +115,11 @@ int mppi_p2p_rendezvous(mppi_engine* h, const char* prefix, int n_ranks, int ran
                 Head hd{};
                 const size_t got = std::fread(&hd, 1, sizeof(hd), f) + std::fread(all.data() + (size_t)r * MPPI_IPC_HANDLE_BYTES, 1, MPPI_IPC_HANDLE_BYTES, f);
                 std::fclose(f);
-                const bool writer_alive = hd.pid > 0 && (kill((pid_t)hd.pid, 0) == 0 || errno == EPERM);
+                const bool same_ns = my_ns != 0 && hd.pid_ns == my_ns;
+                const bool writer_alive = !same_ns || (hd.pid > 0 && (kill((pid_t)hd.pid, 0) == 0 || errno == EPERM));
                 if (got == sizeof(hd) + MPPI_IPC_HANDLE_BYTES && writer_alive) {
                     Head want = head_of(r);
-                    want.pid = hd.pid;
+                    want.pid = hd.pid; want.pid_ns = hd.pid_ns;
                     if (std::memcmp(&hd, &want, sizeof(hd)) != 0)
                         fail(MPPI_E_INVALID, "p2p rendezvous: %s belongs to another group (ranks %d / rank %d / mailbox %llu bytes; this group: %d / %d / %llu): "
                              "a stale file of an earlier run, or engines of different shapes", name(r).c_str(), hd.n_ranks, hd.rank,

@@ -994,7 +994,10 @@ def test_full_size_oracle_replay(orc, tick_path, cfg, storage, record_property):
         # The V checked below is the tick's own: read IN PLACE from the rows the tick's update kernel(s) consumed -- no rollout launch
         # behind the download (config 4's headline tick runs on two co-scheduled engines whose rows are columns of
         # the handle's arrays; until round 6 its V came from a RE-RUN of the rollout over all samples)
-        assert e.kernel_times()["rollout"][1] == 1, e.kernel_times()
+        # (config 4 in fp64 storage runs the FUSED kernel: its V is never stored anywhere -- what is checked for it is the re-run from the
+        # tick's snapshot, one more rollout launch; its applied controls, below, are the fused tick's own)
+        fused = e.info()["rollout_kernel"] == "fused"
+        assert fused == ((cfg, storage) == ("c4", "f64")) and e.kernel_times()["rollout"][1] == (2 if fused else 1), e.kernel_times()
         assert e.info()["co_shards"] == (2 if (cfg, storage) == ("c4", "f32") else 1)
         e.kernel_timing(())
         eps = e.download_noise()[0]
@@ -1287,12 +1290,14 @@ def test_noise_packing_full_size_shards_and_refusals(orc, tick_path, packing):
 
 def test_the_mixed_rollout_hands_over_where_it_does_not_apply(monkeypatch, tick_path):
     """Beyond T = 256 (no inline nominal rollout), below T = 26 (steps too long for its series), in fp64 storage, with the heading weight or the euler model the tick runs
-    the all-fp64 kernel even when the size rule says mixed; the small-K path reports the scan kernel."""
+    the all-fp64 kernel even when the size rule says mixed; the small-K path reports the scan kernel.  fp64 storage has a specialised
+    tick of its own under the same switches -- the fused kernel (T <= 64, the node's cost and model) -- and hands over the same way."""
     if tick_path == "scan":
         pytest.skip("the engines below name their tick path")
     from motion_planning_amd.mppi import Engine
     monkeypatch.setattr(Engine, "default_options", {"pk_min_samples": 1})
-    for kw, want in [(dict(K=600, T=257), "fp64"), (dict(K=600, T=25), "fp64"), (dict(K=600, T=26), "mixed"), (dict(K=600, T=50, storage="f64"), "fp64"), (dict(K=600, T=50, model="euler"), "fp64"),
+    for kw, want in [(dict(K=600, T=257), "fp64"), (dict(K=600, T=25), "fp64"), (dict(K=600, T=26), "mixed"), (dict(K=600, T=50, storage="f64"), "fused"), (dict(K=600, T=65, storage="f64"), "fp64"), (dict(K=600, T=50, storage="f64", q=(1e3, 1e3, 5.0)), "fp64"),
+                     (dict(K=600, T=50, model="euler"), "fp64"),
                      (dict(K=600, T=50, q=(1e3, 1e3, 5.0)), "fp64"), (dict(K=600, T=50), "mixed"), (dict(K=600, T=50, tick_path="scan"), "scan")]:
         kw = dict(kw)
         K, T, storage = kw.pop("K"), kw.pop("T"), kw.pop("storage", "f32")
