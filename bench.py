@@ -567,7 +567,7 @@ def main():
         # (mppi_tick; what Controller.pos_cb pays per odometry message), N = 1 only.
         sync_tick_us, btimes = None, None
         if not in_group:
-            n_lat = min(args.steps, 200)
+            n_lat = 200     # (whatever --steps says: twenty calls are no statistic, and the first ones behind a change of call pattern run slow)
             # NOTHING bracketed while the call is timed (the event pair around every rollout launch cost the blocking call
             # 30 us at config 4); the rollout launch of this call pattern is timed in a short pass of its own behind it
             eng.kernel_timing(())
@@ -578,6 +578,8 @@ def main():
             gc_was_on = gc.isenabled()
             gc.collect()
             gc.disable()
+            for i in range(20):     # (the call pattern's own warm-up, not recorded)
+                st, _ = eng.tick(st, goals, noise="philox", seed=seed, tick_id=9_000_000 + i)
             for i in range(n_lat):
                 t0 = time.perf_counter()
                 st, _ = eng.tick(st, goals, noise="philox", seed=seed, tick_id=10_000_000 + i)
