@@ -238,6 +238,11 @@ int mppi_upload_value(mppi_engine *h, const double *V);
  * copied to uvec_out [A][2][T] when non-NULL.
  */
 int mppi_update(mppi_engine *h, double *uvec_out);
+/* What the last mppi_update left BEFORE its Savitzky-Golay step: uvec + the weighted noise, clipped -- [A][2][T].  The reference's
+ * update_action writes exactly this into its caller's `uvec` IN PLACE (control/src/mppi:196-199) and returns the filtered sequence
+ * as a new array (:202); a binding that wants the method's side effects as well as its result copies this into the caller's array
+ * (motion_planning_amd.MPPI.update_action does). */
+int mppi_get_unfiltered(mppi_engine *h, double *uvec);
 
 /* MPPI.perform_action, control/src/mppi:210-213: one rk4 step with the nominal u[:,0].
  * state [A][3] (NULL: resident), next_state [A][3]. */

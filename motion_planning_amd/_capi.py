@@ -84,6 +84,7 @@ SIGNATURES = {
     "mppi_tick": (C.c_int, [_H, _dp, _dp, C.c_int, C.c_uint64, C.c_uint32, _dp, _dp]),
     "mppi_tick_graph": (C.c_int, [_H, C.c_uint64]),
     "mppi_synchronize": (C.c_int, [_H]),
+    "mppi_get_unfiltered": (C.c_int, [_H, _dp]),
     "mppi_set_option": (C.c_int, [_H, C.c_char_p, C.c_int64]),
     "mppi_get_option": (C.c_int, [_H, C.c_char_p, C.POINTER(C.c_int64)]),
     "mppi_savgol_matrix": (C.c_int, [C.c_int, _dp]),

@@ -338,6 +338,15 @@ int mppi_update(mppi_engine* h, double* uvec_out) {
     API_END(h)
 }
 
+int mppi_get_unfiltered(mppi_engine* h, double* uvec) {
+    API_BEGIN(h)
+    if (!uvec) fail(MPPI_E_INVALID, "uvec is NULL");
+    const size_t n = (size_t)h->cfg.n_agents * 2 * h->cfg.horizon;
+    HIPCHK(hipMemcpyAsync(uvec, h->d_ufilt + n, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    h->wait_stream(__func__);
+    API_END(h)
+}
+
 int mppi_plant_step(mppi_engine* h, const double* state, double* next_state) {
     API_BEGIN(h)
     h->invalidate_table();

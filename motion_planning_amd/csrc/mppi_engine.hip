@@ -464,6 +464,9 @@ void mppi_engine::init(const mppi_config& c) {
     if (cfg.tick_path != MPPI_TICK_AUTO && cfg.tick_path != MPPI_TICK_LANES && cfg.tick_path != MPPI_TICK_SCAN)
         fail(MPPI_E_INVALID, "bad tick_path %d", cfg.tick_path);
     if (!(cfg.lambda > 0.0) || !(cfg.sigma >= 0.0)) fail(MPPI_E_INVALID, "lambda must be > 0 and sigma >= 0");
+    if (cfg.samples_total != 0 && (cfg.samples_total < (int64_t)cfg.sample_offset + cfg.samples || cfg.samples_total > 0xFFFFFFFFll))
+        fail(MPPI_E_INVALID, "samples_total = %lld: 0 (this handle is the whole controller) or >= sample_offset + samples = %lld (global sample ids are 32-bit)",
+             (long long)cfg.samples_total, (long long)cfg.sample_offset + cfg.samples);
     if (!(cfg.dt > 0.0)) cfg.dt = 1.0 / (double)cfg.horizon;  // control/src/mppi:67
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
@@ -485,10 +488,6 @@ void mppi_engine::init(const mppi_config& c) {
     hoist_auto = T <= 64 && (long)A * K >= 786432;
     P.sample_offset = cfg.sample_offset;
     if (cfg.agent_offset < 0) fail(MPPI_E_INVALID, "agent_offset must be >= 0");
-    if (cfg.samples_total != 0 && (cfg.samples_total < (int64_t)cfg.sample_offset + cfg.samples || cfg.samples_total > 0xFFFFFFFFll))
-        fail(MPPI_E_INVALID, "samples_total = %lld: 0 (this handle is the whole controller) or >= sample_offset + samples = %lld (global sample ids are 32-bit)",
-             (long long)cfg.samples_total, (long long)cfg.sample_offset + cfg.samples);
-    P.agent_offset = (uint32_t)cfg.agent_offset;
     P.dt = cfg.dt;
     P.u_max = cfg.u_max;
     P.kth = cfg.wheel_radius / cfg.wheel_base;
@@ -539,7 +538,7 @@ void mppi_engine::init(const mppi_config& c) {
     }
     use_table_set(0);
     d_unom = dev_alloc<double>((size_t)A * 2 * T, hbm_bytes);
-    d_ufilt = dev_alloc<double>((size_t)A * 2 * T, hbm_bytes);
+    d_ufilt = dev_alloc<double>((size_t)2 * A * 2 * T, hbm_bytes);   // [A][2][T] filtered | [A][2][T] updated + clipped, not filtered (mppi_update)
     d_state = dev_alloc<double>((size_t)A * 3, hbm_bytes);
     d_goal = dev_alloc<double>((size_t)A * 3, hbm_bytes);
     {   // small-K path: lanes = timesteps, one wave (T <= 64) or one block (T <= 256) per sample
@@ -590,7 +589,7 @@ void mppi_engine::init(const mppi_config& c) {
     HIPCHK(hipMemsetAsync(d_fill, 0, (size_t)A * 2 * sizeof(double), stream));
     P.shift_fill = d_fill;
     HIPCHK(hipMemsetAsync(d_unom, 0, (size_t)A * 2 * T * sizeof(double), stream));  // uvec_init, :65
-    HIPCHK(hipMemsetAsync(d_ufilt, 0, (size_t)A * 2 * T * sizeof(double), stream));
+    HIPCHK(hipMemsetAsync(d_ufilt, 0, (size_t)2 * A * 2 * T * sizeof(double), stream));
     HIPCHK(hipMemsetAsync(d_out, 0, (size_t)A * 8 * sizeof(double), stream));
     HIPCHK(hipMemsetAsync(d_tick, 0, sizeof(uint32_t), stream));
     if (!alias_parent) {

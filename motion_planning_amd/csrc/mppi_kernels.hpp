@@ -1998,6 +1998,11 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
     }
     fprobe.mark(1);   // tuples merged, controls updated (this thread's share)
     __syncthreads();
+    // the stand-alone update (mppi_update: no plant step): the updated, clipped controls BEFORE the filter -- what the reference's
+    // update_action leaves in its caller's uvec (control/src/mppi:196-199, in place; the filtered array it returns is a new one) --
+    // behind the filtered ones, ufilt[A][2][T] | unfiltered [A][2][T]  (mppi_get_unfiltered)
+    if (!(flags & 1))
+        for (int j = tid; j < 2 * T; j += blockDim.x) ufilt[(size_t)P.A * 2 * T + (size_t)a * 2 * T + j] = un[j];
     if (d_seen > 0.0) atomicMax(&dmax_sh, (unsigned long long)__double_as_longlong(d_seen));   // (read behind the barriers below)
     fprobe.mark(2);
     {   // savgol_filter (:202) as u @ S, clip (:205-206).  With window T-1 the operator has rank 8 (savgol.hpp):

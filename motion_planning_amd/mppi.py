@@ -309,6 +309,13 @@ class Engine(object):
         self._ck(self._lib.mppi_update(self._h, _capi.dptr(u)))
         return u
 
+    def get_unfiltered(self):
+        """[A][2][T]: the last update()'s controls before the filter (updated + clipped): what the reference's update_action leaves
+        in its caller's uvec (control/src/mppi:196-199)."""
+        out = np.empty((self.A, 2, self.T))
+        self._ck(self._lib.mppi_get_unfiltered(self._h, _capi.dptr(out)))
+        return out
+
     def plant_step(self, state=None):
         s, _ = self._sg(state, None)
         nxt = np.empty((self.A, 3))
@@ -494,7 +501,8 @@ class MPPI(object):
                "philox" -- device Philox4x32-10 keyed by (seed, tick, sample): nothing
                            crosses PCIe, the production mode.
       storage  "f32" (default) | "f64"  HBM storage of eps / V (arithmetic is fp64 either way).
-    Unlike the reference, get_cost2go / update_action do not mutate their arguments.
+    update_action mutates its arguments like the reference does (value_fcn rows minus their minimum, uvec plus the weighted noise,
+    clipped: control/src/mppi:189, :196-199) when they are writable numpy arrays.
     """
 
     def __init__(self, model=rk4, horizon=100, samples=10, thresh=0.05, rng="numpy", seed=0,
@@ -709,7 +717,14 @@ class MPPI(object):
         self._eng.set_nominal(uvec)
         self._eng.upload_noise(np.asarray(eps, dtype=np.float64))
         self._eng.upload_value(value_fcn)
-        return self._eng.update()[0]
+        out = self._eng.update()[0]
+        # the reference's side effects on its arguments (control/src/mppi:189, :196-199): every row of value_fcn has its minimum taken
+        # out IN PLACE, uvec receives the weighted noise and the first clip IN PLACE; the filtered sequence is returned as a new array
+        if isinstance(value_fcn, np.ndarray) and value_fcn.flags.writeable:
+            value_fcn -= value_fcn.min(axis=1, keepdims=True)
+        if isinstance(uvec, np.ndarray) and uvec.flags.writeable:
+            uvec[...] = self._eng.get_unfiltered()[0]
+        return out
 
     # control/src/mppi:210-213
     def perform_action(self, state, uvec):

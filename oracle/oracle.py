@@ -145,8 +145,9 @@ def savgol_matrix(T):
     return S
 
 
-def update_action(uvec, eps, V, lam, S=None, params=None):
-    """Returns the filtered controls [2,T]; like the reference, mutates copies only."""
+def update_action(uvec, eps, V, lam, S=None, params=None, want_inplace=False):
+    """Returns the filtered controls [2,T] (the arguments are copied first).  want_inplace: also what the reference leaves in its
+    caller's uvec and value_fcn (control/src/mppi:189, :196-199: it mutates both in place) -> (out, uvec_after, V_after)."""
     p = params or default_params()
     eps = _d(eps)
     T, _, K = eps.shape
@@ -155,7 +156,7 @@ def update_action(uvec, eps, V, lam, S=None, params=None):
     S = savgol_matrix(T) if S is None else _d(S)
     out = np.zeros((2, T))
     lib().orc_update_action(C.byref(p), K, T, _p(u), _p(eps), _p(Vc), C.c_double(lam), _p(S), _p(out))
-    return out
+    return (out, u, Vc) if want_inplace else out
 
 
 def get_path(state, goal, latest_uvec, eps, lam=0.001, sigma=0.9, dt=None, S=None, params=None):

@@ -160,9 +160,14 @@ def main():
         chk = np.random.RandomState(seed).normal(0.0, SIG, (T, 2, K))
         assert np.array_equal(eps, chk), name
         V_in = V.copy()
-        unew = mp.update_action(u0.copy(), list(eps), V.copy(), sig, LAM)
+        u_arg, V_arg = u0.copy(), V.copy()
+        unew = mp.update_action(u_arg, list(eps), V_arg, sig, LAM)
         out[name + "_V"] = V_in
         out[name + "_unew"] = unew
+        # (round 6) update_action's side effects on its ARGUMENTS (:189, :196-199): every row of value_fcn minus its minimum, uvec plus
+        # the weighted noise, clipped -- both in place; the filtered sequence it returns is a new array
+        out[name + "_V_inplace"] = V_arg
+        out[name + "_u_inplace"] = u_arg
         out[name + "_meta"] = np.array([K, T, seed], dtype=np.int64)
         out[name + "_state"] = np.array(state)
         out[name + "_goal"] = np.array(goal)

@@ -443,3 +443,24 @@ def test_bench_started_plain_with_several_gpus_launches_its_ranks(tmp_path):
     # --gpus 1 never launches anything: the process itself is the one rank
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], env=dict(env, RANK="x"), capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and open(tmp_path / "rankx").read().split()[2] == "-"
+
+
+def test_samples_total_is_checked_before_any_device_is_touched():
+    """mppi_config.samples_total (round 6): 0 = this handle is the whole controller; otherwise the whole controller's samples per
+    agent, which must cover this handle's own range [sample_offset, sample_offset + samples) and fit the 32-bit global sample ids.
+    Refused by mppi_create before it looks for a device -- so this runs without a GPU."""
+    import ctypes as C
+    from motion_planning_amd import _capi
+    lib = _capi.load()
+    h = C.c_void_p()
+    for total, offset, samples in ((5, 0, 10), (100, 95, 10), (1 << 33, 0, 10), (-1, 0, 10)):
+        cfg = _capi.default_config()
+        cfg.samples, cfg.horizon, cfg.sample_offset, cfg.samples_total = samples, 50, offset, total
+        assert lib.mppi_create(C.byref(cfg), C.byref(h)) == -1 and h.value is None, (total, offset, samples)
+        assert b"samples_total" in lib.mppi_last_error(None)
+    cfg = _capi.default_config()
+    cfg.samples, cfg.horizon, cfg.sample_offset, cfg.samples_total = 10, 50, 90, 100      # a valid share: past this check (fails for the device here)
+    rc = lib.mppi_create(C.byref(cfg), C.byref(h))
+    assert rc in (0, -2) and (rc == 0 or b"samples_total" not in lib.mppi_last_error(None))
+    if rc == 0:
+        lib.mppi_destroy(h)

@@ -93,6 +93,23 @@ def test_update_action_golden(orc, golden, name, storage):
     assert np.abs(Vback - V).max() <= rt
 
 
+@pytest.mark.parametrize("name", ["c2g_zero", "c2g_warm", "c2g_wrap", "c2g_clip", "c2g_tiny"])
+def test_update_action_mutates_its_arguments_like_the_reference(golden, name, tick_path):
+    """MPPI.update_action through the class (the seam of SURVEY 8b): the reference subtracts every row's minimum from the caller's
+    value_fcn and adds the weighted noise into the caller's uvec, clipped, IN PLACE (control/src/mppi:189, :196-199), and returns the
+    filtered sequence as a new array -- so does the shim (round 6: mppi_get_unfiltered), pinned to what the imported reference
+    left in the arrays it was handed."""
+    from motion_planning_amd import MPPI
+    K, T, seed = [int(x) for x in golden[name + "_meta"]]
+    m = MPPI(horizon=T, samples=K, storage="f64")
+    eps = np.random.RandomState(seed).normal(0.0, SIG, (T, 2, K))
+    uvec, V = golden[name + "_u0"].copy(), golden[name + "_V"].copy()
+    out = m.update_action(uvec, list(eps), V, np.array([[SIG, 0.0], [0.0, SIG]]), LAM)
+    assert out is not uvec and np.abs(out - golden[name + "_unew"]).max() <= 1e-9
+    assert np.abs(uvec - golden[name + "_u_inplace"]).max() <= 1e-9
+    assert np.array_equal(V, golden[name + "_V_inplace"])
+
+
 @pytest.mark.parametrize("storage", ["f64", "f32"])
 @pytest.mark.parametrize("name", ["seq_park", "seq_wp"])
 def test_closed_loop_ticks_golden(golden, name, storage):

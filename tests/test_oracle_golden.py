@@ -369,3 +369,16 @@ def test_device_noise_twins_use_the_philox_words_as_documented(orc, packing):
     assert abs(big.mean()) < 4 * sigma / np.sqrt(n)
     assert abs(big.var() / sigma**2 - 1.0) < 0.02
     assert abs(np.corrcoef(big[:, 0].ravel(), big[:, 1].ravel())[0, 1]) < 0.02
+
+
+@pytest.mark.parametrize("name", ["c2g_zero", "c2g_warm", "c2g_wrap", "c2g_clip", "c2g_tiny"])
+def test_update_action_side_effects_golden(orc, golden, name):
+    """update_action mutates its ARGUMENTS (control/src/mppi:189, :196-199): every row of value_fcn loses its minimum, uvec receives
+    the weighted noise and the first clip, both in place; what it returns (the filtered sequence) is a new array.  The oracle's C
+    restatement does the same to its buffers: pinned to what the imported reference left in the arrays it was given."""
+    K, T, seed = [int(x) for x in golden[name + "_meta"]]
+    eps = orc.reference_noise(seed, 0.9, T, K)
+    out, u_after, V_after = orc.update_action(golden[name + "_u0"], eps, golden[name + "_V"], 0.001, want_inplace=True)
+    assert np.abs(out - golden[name + "_unew"]).max() < 1e-12
+    assert np.abs(u_after - golden[name + "_u_inplace"]).max() < 1e-12
+    assert np.array_equal(V_after, golden[name + "_V_inplace"])
