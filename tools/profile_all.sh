@@ -27,7 +27,12 @@ timeout 300 python $R/bench.py --co-shards 1 --no-cpu-baseline --no-f64-line 2>/
 cd $R
 timeout 900 bash tools/pmc.sh final/pmc --co-shards 1 > $O/pmc.log 2>&1; tail -4 $O/pmc.log
 for w in c2 c3 c5; do timeout 300 python bench.py --workload $w --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_$w.json; done
-for k in 500000 250000 125000; do timeout 200 python bench.py --samples $k --co-shards 1 --no-cpu-baseline --no-f64-line --steps 100 2>/dev/null | tail -1 > $O/bench_shard_$k.json; done
+# one rank's share of config 4 at N = 2 / 4 / 8, as a rank of `bench.py --gpus N` runs it (kernels picked by the whole controller's size:
+# --samples-total) and with each share choosing for itself (--rank-kernels)
+for k in 500000 250000 125000; do
+  timeout 200 python bench.py --samples $k --samples-total 1000000 --co-shards 1 --no-cpu-baseline --no-f64-line --steps 100 2>/dev/null | tail -1 > $O/bench_shard_$k.json
+  timeout 200 python bench.py --samples $k --rank-kernels --co-shards 1 --no-cpu-baseline --no-f64-line --steps 100 2>/dev/null | tail -1 > $O/bench_shard_${k}_own_kernels.json
+done
 python tools/ab_rollout.py --rounds 2 > $O/ab_rollout_c4.jsonl 2>/dev/null
 timeout 60 ./tools/depbench > $O/depbench.txt 2>&1
 timeout 120 ./tools/rampbench > $O/rampbench.txt 2>&1
@@ -40,7 +45,19 @@ timeout 120 python tools/node_latency.py > $O/node_latency.txt 2>&1
 timeout 60 ./tools/ubench > $O/ubench.txt 2>&1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/bwbench.hip -o tools/bwbench 2>/dev/null && timeout 120 ./tools/bwbench > $O/bwbench.txt 2>&1
 timeout 200 python bench.py --storage f64 --no-cpu-baseline --steps 100 2>/dev/null | tail -1 > $O/bench_c4_f64.json
-timeout 200 python bench.py --samples 125000 --storage f64 --co-shards 1 --no-cpu-baseline --no-f64-line --steps 100 2>/dev/null | tail -1 > $O/bench_shard_125000_f64.json
+timeout 200 python bench.py --samples 125000 --samples-total 1000000 --storage f64 --co-shards 1 --no-cpu-baseline --no-f64-line --steps 100 2>/dev/null | tail -1 > $O/bench_shard_125000_f64.json
+timeout 300 python tools/ab_fused_f64.py 2>/dev/null | grep "^K" > $O/ab_fused_f64.txt
+timeout 120 ./tools/shared_line_repro 3000 200 > $O/shared_line_repro.txt 2>&1
+( for co in 0 1 0 1; do ./tools/node_tail 1000000 50 1500 0 $co | head -1; done ) > $O/node_tail_c4_blocking_co_ab.txt 2>&1
+# the fused fp64 tick under rocprofv3 and the counters
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_f64 -- python $R/bench.py --storage f64 --no-cpu-baseline --steps 100 > $O/stats_f64.log 2>&1
+cp $O/stats_f64/*/*kernel_stats.csv $O/kernel_stats_c4_f64.csv 2>/dev/null
+cd $R
+timeout 600 bash tools/pmc.sh final/pmc_f64 --storage f64 > $O/pmc_f64.log 2>&1; tail -3 $O/pmc_f64.log
+# the driver's N > 1 command line and the plain-process form of it, all ranks on this box's one GPU
+timeout 300 python bench.py --gpus 2 --all-ranks-on-gpu0 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_c4_two_ranks_one_gpu_self_launched.json
+timeout 300 python bench.py --gpus 8 --all-ranks-on-gpu0 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_c4_eight_ranks_one_gpu_self_launched.json
 [ -z "$RUN_HANG_HUNT" ] || timeout 300 bash tools/hang_hunt.sh 600 4 gpurun_out/final/hang 2>&1 | tail -5
 python3 - <<PY
 import csv, glob, json, collections
