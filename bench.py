@@ -803,7 +803,7 @@ def main():
             steps = A_l * k_launch * T
             share = (A_l * k_launch) / float(A_total * K_total)    # the PMC passes covered ALL samples of the workload: a shard's (or a rank's) launch moves its share
             # `kind`: what the engine says its last tick launched (mppi_rollout_kernel), not a copy of its rule
-            name = {"mixed": "rollout_pk_kernel", "fp64": "rollout_kernel", "scan": "scan_tick_kernel"}[kind]
+            name = {"mixed": "rollout_pk_kernel", "fp64": "rollout_kernel", "scan": "scan_tick_kernel", "fused": "rollout_fused_kernel"}[kind]
             gbs = BYTES_PER_STEP_PER_KERNEL * steps / avg_s / 1e9
             acc = {"bound": "hbm", "bytes_per_state_step_per_kernel": BYTES_PER_STEP_PER_KERNEL, "algorithmic_bytes_per_launch": BYTES_PER_STEP_PER_KERNEL * steps,
                    "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,

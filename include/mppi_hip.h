@@ -93,11 +93,13 @@ extern "C" {
 
 /* Co-scheduled shards (mppi_config.co_shards).  A fused mppi_tick with device noise may split its samples over G
  * engines inside this one handle -- same GPU, one stream each, coupled only by device-side mailbox flags -- so that one
- * shard's HBM-bound update kernel runs under another's VALU-bound rollout (config 4: +3-5 % rollouts/s; a K-shard's rows are
- * columns of the handle's own buffers: it allocates its small arrays only).  Results equal
+ * shard's HBM-bound update kernel runs under another's VALU-bound rollout (config 4: +3-5 % rollouts/s back to back, -7 us on the
+ * blocking call; a K-shard's cost prefix, totals and per-wave noise sums are columns of the handle's own rows -- it allocates its
+ * small arrays only, and no 128-byte line holds words of two shards: checked when the group is built).  Results equal
  * the unsplit tick to rounding (sample ids are global, the tuple merge is exact); every other call of this ABI keeps
- * working: after such a tick mppi_download_value / _noise / mppi_update re-run the rollout over all samples from a
- * snapshot of the tick's inputs, bit for bit what the shards computed.  AUTO = 2 shards for n_agents * samples >= 500000
+ * working: after such a tick the tick's V is complete IN PLACE in the handle's arrays -- mppi_download_value / mppi_update read the
+ * bytes the shards' update kernels consumed -- and the noise is re-drawn on demand as after any tick; whatever the handle is asked
+ * between two split ticks is ordered against the shards' streams both ways.  AUTO = 2 shards for n_agents * samples >= 500000
  * on the lane-per-sample path with at least 32768 samples per agent and n_agents * horizon <= 256 rows (beyond that the
  * shards' publish kernels cost more than the overlap gains), fp32 storage only (the all-fp64 mode's two big kernels are both
  * HBM-bound: split it measured slower).  A handle of SEVERAL agents splits its AGENTS instead (AUTO prefers this wherever each

@@ -488,6 +488,7 @@ void mppi_engine::init(const mppi_config& c) {
     hoist_auto = T <= 64 && (long)A * K >= 786432;
     P.sample_offset = cfg.sample_offset;
     if (cfg.agent_offset < 0) fail(MPPI_E_INVALID, "agent_offset must be >= 0");
+    P.agent_offset = (uint32_t)cfg.agent_offset;
     P.dt = cfg.dt;
     P.u_max = cfg.u_max;
     P.kth = cfg.wheel_radius / cfg.wheel_base;

@@ -206,9 +206,9 @@ def test_sig_matrix_golden(golden, tag, storage):
     m = MPPI(horizon=T, samples=K, storage=storage)
     np.random.seed(seed)
     V, eps = m.get_cost2go(state, u0, goal, lam, sm)
-    u = m.update_action(u0, eps, V, sm, lam)
     tv, tu = (1e-9, 1e-9) if storage == "f64" else (3e-3, 2e-5)   # f32: eps rounded to fp32 once
     assert np.abs(V - golden[tag + "_c2g_V"]).max() < tv
+    u = m.update_action(u0.copy(), eps, V, sm, lam)                # (mutates uvec and V in place, like the reference)
     assert np.abs(u - golden[tag + "_c2g_unew"]).max() < tu
     m.initialize()
     np.random.seed(seed + 1)

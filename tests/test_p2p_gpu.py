@@ -319,7 +319,11 @@ def test_rendezvous_refuses_stale_and_missing_files(tmp_path):
             e.p2p_rendezvous(prefix, 2, 0, timeout_ms=300)
         assert err.value.code == -5                                   # too short to be a complete file: treated as not there yet
         import os
-        head = lambda n, r, pid: b"MPPIMBX2" + n.to_bytes(4, "little") + r.to_bytes(4, "little") + (0).to_bytes(8, "little") + pid.to_bytes(8, "little")
+        # header: magic, ranks, rank, mailbox bytes, the writer's pid and the inode of its pid namespace (round 6: the pid only means
+        # something inside that namespace; a reader in another one skips the liveness test)
+        ns = os.stat("/proc/self/ns/pid").st_ino
+        head = lambda n, r, pid, ns=ns: (b"MPPIMBX3" + n.to_bytes(4, "little") + r.to_bytes(4, "little") + (0).to_bytes(8, "little") +
+                                         pid.to_bytes(8, "little") + ns.to_bytes(8, "little"))
         with open(prefix + ".1", "wb") as f:                         # complete, written by a live process, but of a group of three
             f.write(head(3, 1, os.getpid()) + b"\0" * 64)
         with pytest.raises(MppiError) as err:
@@ -334,12 +338,19 @@ def test_rendezvous_refuses_stale_and_missing_files(tmp_path):
         with pytest.raises(MppiError) as err:
             e.p2p_rendezvous(prefix, 2, 0, timeout_ms=300)
         assert err.value.code == -5 and "did not appear" in str(err.value)
+        # the same dead pid in a file written from ANOTHER pid namespace (a rank in its own container): no liveness test is possible --
+        # the file is read, and refused for what it says (its mailbox size is not this group's)
+        with open(prefix + ".1", "wb") as f:
+            f.write(head(2, 1, dead.pid, ns + 1) + b"\0" * 64)
+        with pytest.raises(MppiError) as err:
+            e.p2p_rendezvous(prefix, 2, 0, timeout_ms=300)
+        assert err.value.code == -1 and "another group" in str(err.value)
         # ... and this rank's own leftover is removed on entry (a fast peer must not read it before the new one is in place)
         with open(prefix + ".0", "wb") as f:
             f.write(b"stale")
         with pytest.raises(MppiError):
             e.p2p_rendezvous(prefix, 2, 0, timeout_ms=100)
-        assert open(prefix + ".0", "rb").read()[:8] == b"MPPIMBX2"
+        assert open(prefix + ".0", "rb").read()[:8] == b"MPPIMBX3"
         os.remove(prefix + ".1")
         nxt, ua = e.tick([0, 0, 0], [0, -1, 0], noise="philox", seed=1, tick_id=0)   # the handle still ticks (unconnected mailbox: plain tick)
         assert np.isfinite(ua).all()

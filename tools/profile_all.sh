@@ -15,7 +15,7 @@ cd /tmp && export TMPDIR=/tmp
 for i in 1 2 3; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats$i -- python $R/bench.py --co-shards 1 --no-cpu-baseline --no-f64-line > $O/stats$i.log 2>&1
   cp $O/stats$i/*/*kernel_stats.csv $O/kernel_stats_one_engine_run$i.csv 2>/dev/null
-  tail -1 $O/stats$i.log > $O/bench_under_rocprof_one_engine_run$i.json
+  grep '^{"metric"' $O/stats$i.log | tail -1 > $O/bench_under_rocprof_one_engine_run$i.json
 done
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_co -- python $R/bench.py --no-cpu-baseline --no-f64-line > $O/stats_co.log 2>&1
 cp $O/stats_co/*/*kernel_stats.csv $O/kernel_stats_co_headline.csv 2>/dev/null
