@@ -219,6 +219,7 @@ int mppi_reset(mppi_engine* h, int agent) {
     if (agent < 0) HIPCHK(hipMemsetAsync(h->d_unom, 0, row * h->cfg.n_agents, h->stream));
     else if (agent < h->cfg.n_agents) HIPCHK(hipMemsetAsync(h->d_unom + (size_t)agent * 2 * h->cfg.horizon, 0, row, h->stream));
     else fail(MPPI_E_INVALID, "agent %d out of range", agent);
+    h->regime_fresh_start();
     API_END(h)
 }
 
@@ -242,6 +243,7 @@ int mppi_set_nominal(mppi_engine* h, int agent, const double* uvec) {
     const size_t n = (size_t)2 * h->cfg.horizon;
     HIPCHK(hipMemcpyAsync(h->d_unom + agent * n, uvec, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
     h->wait_stream(__func__);
+    h->regime_fresh_start();
     API_END(h)
 }
 

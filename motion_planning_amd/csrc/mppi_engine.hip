@@ -276,7 +276,7 @@ bool mppi_engine::pick_pk(bool ph, bool store, int k0, int k1) const {
 }
 
 // whether a device-noise tick of this engine runs the fused fp64 kernel (rollout_fused.hpp; rules: mppi_engine.hpp fused_nb)
-bool mppi_engine::pick_fused(bool ph, bool store) const {
+bool mppi_engine::pick_fused(bool ph, bool store) {
     if (fused_nb == 0 || !ph || store || !use_pk || capturing || noise_pack || general_cost() || ro_state || ro_goal || ro_unom) return false;
     const long k_rule = cfg.samples_total > 0 ? (long)cfg.samples_total : (long)cfg.samples;
     if (pk_min_set) return (long)cfg.n_agents * k_rule >= pk_min_samples;

@@ -138,7 +138,18 @@ struct mppi_engine {
     // (same box, fp64 storage, T = 50, tick us fused / two kernels: 10^6 samples 177.6 / 194.1, 500 000 101.2 / 116.4, 250 000 61.9 / 63.9,
     // 125 000 42.4 / 39.8 -- profiles/r6_ab_fused_f64.txt)
     static constexpr long kFusedMinSamples = 200000;
-    double regime_weight() const {   // the largest row sum of softmax weights the last finished tick reported (0 before the first)
+    // A caller that enqueues ticks without waiting (mppi_tick with NULL outputs) runs ahead of the device: what it reads here is a tick
+    // that finished a while ago.  That lag is harmless while the regime drifts (the robot parks over hundreds of ticks), not when the
+    // caller starts something new: mppi_set_nominal / mppi_reset (a new plan) put the estimate back to "under way" until a tick
+    // enqueued behind them has finished and says otherwise (regime_fresh_start; sequence numbers of the finalize launches).
+    bool regime_reset = false;
+    uint32_t regime_reset_seq = 0;
+    void regime_fresh_start() { regime_reset = true; regime_reset_seq = out_seq + 1u; }
+    double regime_weight() {   // the largest row sum of softmax weights the last finished tick reported (0 before the first)
+        if (regime_reset) {
+            if ((int32_t)(__atomic_load_n(h_seq, __ATOMIC_ACQUIRE) - regime_reset_seq) < 0) return 0.0;
+            regime_reset = false;
+        }
         double d = 0.0;
         for (int a = 0; a < cfg.n_agents; ++a) {
             const uint64_t bits = __atomic_load_n(reinterpret_cast<const uint64_t*>(h_out) + (size_t)a * 8 + 5, __ATOMIC_RELAXED);
@@ -148,7 +159,7 @@ struct mppi_engine {
         }
         return d;
     }
-    bool pick_fused(bool ph, bool store) const;
+    bool pick_fused(bool ph, bool store);
     void launch_fused(uint64_t seed, uint32_t tick, const uint32_t* tick_ptr);
     double* d_tc = nullptr;  // [A][T][8]   the nominal trajectory's table the LAST rollout used (= tcb[tab])
     double* d_base = nullptr;   //             (= baseb[tab])
@@ -473,7 +484,7 @@ struct mppi_engine {
     // the lane kernels take fresh inputs from the pinned slot when the nominal trajectory is computed inside the rollout (no
     // nominal_kernel reading d_state in front of it) and the launch is not so big that thousands of workgroups would queue on PCIe
     bool lanes_zero_copy = true;   // option "lanes_zero_copy" (0: the fetch launch in front of the rollout, as every other call takes it)
-    bool lanes_zero_copy_ok() const {
+    bool lanes_zero_copy_ok() {
         // (the fused fp64 tick loads its table: its inputs go through the fetch launch)
         return lanes_zero_copy && small_nb == 0 && inline_nominal() && (long)cfg.n_agents * roll_blocks <= 4096 && !capturing &&
                !pick_fused(true, store_eps_always);

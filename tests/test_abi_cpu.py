@@ -339,6 +339,47 @@ def test_committed_round5_bench_line_is_flat_and_reproducible_from_itself():
     assert "protocol" in full["f64_storage"] and full["f64_storage"]["steps"] == line["steps"]
 
 
+def test_committed_round6_bench_line():
+    """profiles/r6_bench_c4.json = the line bench.py PRINTED on the GPU box with round 6's final build: the round-5 contract (flat,
+    every fraction recomputable from the scalars next to it) plus what round 6 added -- the fp64 leg says which kernel it ran
+    (`fused`) and carries its parked-at-goal figure, the blocking call is measured with nothing bracketed (within a few per cent of
+    the back-to-back tick + the host's enqueue), `cpu_baseline` carries the 1-thread figure and the quoted Python-reference figure,
+    the config says that every size rule was pinned to the whole controller's sample count."""
+    import json
+    path = os.path.join(ROOT, "profiles", "r6_bench_c4.json")
+    if not os.path.exists(path):
+        pytest.skip("the round's bench line is committed with the final profile refresh")
+    text = open(path).read().strip()
+    line = json.loads(text)
+    assert len(text) <= 4096
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["vs_baseline"] is None and line["unit"] == "rollouts/s" and line["dtype"] == "f32"
+    assert "K=1000000 T=50" in line["config"]["workload"] and "model" not in line["config"]
+    assert line["config"]["kernels_pinned_by_samples_total"] == 1000000 and line["config"]["co_shards"] == 2
+    assert abs(line["value"] - line["config"]["samples_total"] / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+    roof, cpu = line["roofline"], line["cpu_baseline"]
+    assert all(not isinstance(v, (dict, list)) for v in roof.values()) and all(not isinstance(v, (dict, list)) for v in cpu.values())
+    steps = line["config"]["state_steps_per_tick"]
+    launch_s, tick_s = roof["avg_launch_us"] * 1e-6, line["ms_per_step"] * 1e-3
+    rel = lambda a, b: abs(a - b) <= 2e-6 * abs(b)
+    assert roof["bound"] == "valu-issue" and roof["kernel"] == "rollout_pk_kernel"
+    t_min = roof["issue_cycles_per_step"] * (steps / 64.0) / 1024 / (roof["clock_mhz_under_load"] * 1e6)
+    assert rel(roof["frac"], t_min / launch_s) and rel(roof["frac"], roof["achieved"] / roof["peak"]) and 0.5 < roof["frac_at_peak_clock"] < 1.0
+    assert roof["traffic"] == roof["hbm_rollout_bytes"] and rel(roof["hbm_rollout_frac"], roof["hbm_rollout_bytes"] / launch_s / 8e12)
+    assert rel(roof["hbm_update_frac"], roof["hbm_update_bytes"] / (roof["hbm_update_us"] * 1e-6) / 8e12) and 0.5 < roof["hbm_update_frac"] < 0.8
+    assert roof["accounting_8d_bytes"] == 12 * steps and rel(roof["accounting_8d_frac"], 12 * steps / launch_s / 8e12)
+    assert 0.4 < roof["tick_frac"] < 1.0
+    # the reference's own precision: one fused kernel under way (faster than round 5's 0.195 ms), rollout + update parked at the goal
+    assert roof["f64_kernel"] == "fused" and roof["f64_ms"] == line["f64_ms"] and line["ms_per_step"] < line["f64_ms"] < 0.190
+    assert roof["f64_update_us"] is None and roof["f64_parked_ms"] > roof["f64_ms"]
+    # the node's blocking call, nothing bracketed: the back-to-back tick + the host's enqueue of the co-scheduled pair, not 30 us of events
+    assert 1e3 * line["ms_per_step"] < line["sync_tick_us_median"] < 1e3 * line["ms_per_step"] + 30.0
+    assert cpu["kind"] == "port" and "threads_1_value" in cpu and cpu["python_reference_value"] == 3825.0 and "BASELINE.md" in cpu["python_reference_source"]
+    assert cpu["threads_1_value"] < cpu["value"] and cpu["value"] / cpu["python_reference_value"] > 100
+
+
 def test_python_shell_fast_paths_still_see_every_change():
     """The reference reads Q, R, P1 and uvec_init[:, 0] on every get_path (control/src/mppi:69-73, :101) and grows path / uvec by
     np.concatenate (:97-98).  The shell keeps those semantics on fast paths (a byte comparison of the attributes, buffers that
