@@ -412,6 +412,7 @@ void mppi_engine::run_finalize(const double* gathered, int G, int flags, mppi::P
     // keeps its prologue: its launches are frozen)
     // (a fused fp64 tick always wants it: that kernel only ever LOADS its table)
     if ((flags & 3) == 3 && !(flags & 4) && (hoist_on() || last_rollout_kind == MPPI_ROLLOUT_FUSED) && inline_nominal() && small_nb == 0 && !capturing) flags |= 32;
+    if (fused_nb > 0) flags |= 64;   // (the regime report the fused fp64 tick's rule reads)
     uint32_t tick_set = 0;
     if ((flags & 1) && !(flags & 4) && last_tick_eager) { flags |= 16; tick_set = last_tick_id + 1u; }
     // eager ticks also drop their outputs into the pinned host buffer (a graph replay cannot: its sequence number

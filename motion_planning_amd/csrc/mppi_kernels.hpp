@@ -1945,13 +1945,12 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
     __shared__ double trig[3][2];
     __shared__ double nx_sh[3];     // the pose the plant step predicts (flags bit5: the next tick's table starts from it)
     __shared__ double tab_sh[16];   // scan scratch of nominal_table_lanes
-    // the largest merged sum of weights of this agent's rows, as its bit pattern (non-negative doubles order like integers): what the
-    // engine reads from the pinned outputs to tell the regimes of the closed loop apart -- under way a row's sum is 1 ... 3 (the best
-    // sample and a neighbour or two), parked at the goal it is in the thousands (out[5]; the fused fp64 tick keeps to the first regime)
-    __shared__ unsigned long long dmax_sh;
+    // flags bit 6 (engines that can run the fused fp64 tick, T <= 64): the largest merged sum of weights of this agent's rows goes out
+    // next to the outputs (out[5]) -- what the engine reads from pinned memory to tell the regimes of the closed loop apart: under way
+    // a row's sum is 1 ... 3 (the best sample and a neighbour or two), parked at the goal it is in the thousands
+    __shared__ double dsum_sh[64];
     const int tid = threadIdx.x, T = P.T;
-    if (tid == 0) dmax_sh = 0ull;
-    double d_seen = 0.0;
+    const bool report_regime = (flags & 64) != 0 && T <= 64;
     // the filter operator does not depend on anything this kernel waits for: fetch it now, all loads in
     // flight at once, and read it from LDS when the updated controls are ready
     const bool staged = (flags & 8) != 0;
@@ -1961,7 +1960,7 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
     // omg = exp(-V/lam) + 1e-8, normalised; uvec += eps . omg   (control/src/mppi:193-196), then clip (:198-199)
     auto apply = [&](int t, double d, double n0, double n1, double e0, double e1, double cnt) {
         const double den = d + P.floor_w * cnt;
-        d_seen = fmax(d_seen, d);
+        if (report_regime) dsum_sh[t] = d;
         const double du0 = (n0 + P.floor_w * e0) / den, du1 = (n1 + P.floor_w * e1) / den;
         un[t] = clampd(unom[((size_t)a * 2 + 0) * T + t] + du0, P.u_max);
         un[T + t] = clampd(unom[((size_t)a * 2 + 1) * T + t] + du1, P.u_max);
@@ -2003,7 +2002,10 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
     // behind the filtered ones, ufilt[A][2][T] | unfiltered [A][2][T]  (mppi_get_unfiltered)
     if (!(flags & 1))
         for (int j = tid; j < 2 * T; j += blockDim.x) ufilt[(size_t)P.A * 2 * T + (size_t)a * 2 * T + j] = un[j];
-    if (d_seen > 0.0) atomicMax(&dmax_sh, (unsigned long long)__double_as_longlong(d_seen));   // (read behind the barriers below)
+    if (report_regime && tid < 64) {   // (one wave; the sums were written in front of the barrier above)
+        const double dm = -wave_min(tid < T ? -dsum_sh[tid] : 0.0);
+        if (tid == 0) dsum_sh[0] = dm;   // (read by thread 0 behind the barriers below)
+    }
     fprobe.mark(2);
     {   // savgol_filter (:202) as u @ S, clip (:205-206).  With window T-1 the operator has rank 8 (savgol.hpp):
         //   (u @ S)[j] = sum_d p_d(e_j) c_d[shift_j],   c_d[s] = sum_i p_d(i) u[i + s]
@@ -2083,7 +2085,7 @@ __device__ __forceinline__ void finalize_block(const DevParams& P, int a, const 
             }
             double* o = outv + (size_t)a * 8;
             o[0] = xn[0]; o[1] = xn[1]; o[2] = xn[2]; o[3] = uf[0]; o[4] = uf[T];
-            o[5] = __longlong_as_double((long long)dmax_sh);
+            o[5] = report_regime ? dsum_sh[0] : 0.0;
             state[a * 3 + 0] = xn[0]; state[a * 3 + 1] = xn[1]; state[a * 3 + 2] = xn[2];
             nx_sh[0] = xn[0]; nx_sh[1] = xn[1]; nx_sh[2] = xn[2];
             if (host_out) {
