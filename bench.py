@@ -630,7 +630,7 @@ def main():
         t64.tick_async(np.zeros((1, 3)), np.array([goal]), "philox", 0, 1_000_000)
         e64.kernel_timing(("rollout", "update"), period=4)
         e64.synchronize()
-        n64 = args.steps
+        n64 = max(args.steps, 100)     # (an auxiliary leg: twenty ticks right behind the fp32 legs are 3.6 ms of a chip still settling -- its `steps` field says what was timed)
         t0 = time.perf_counter()
         for j in range(n64):
             t64.tick_async(None, None, "philox", 0, 1_000_001 + j)
