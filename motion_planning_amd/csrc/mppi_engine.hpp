@@ -135,8 +135,8 @@ struct mppi_engine {
     // two-kernel tick above kFusedRegimeCut.  Option "pk_min_samples" >= 0 replaces both rules by a plain size rule (tests, A/B).
     int fused_nb = 0;
     static constexpr double kFusedRegimeCut = 64.0;
-    // (same box, fp64 storage, T = 50, tick us fused / two kernels: 10^6 samples 177.6 / 194.1, 500 000 101.2 / 116.4, 250 000 61.9 / 63.9,
-    // 125 000 42.4 / 39.8 -- profiles/r6_ab_fused_f64.txt)
+    // (same box, fp64 storage, T = 50, tick us fused / two kernels: 10^6 samples 176.3 / 194-201, 500 000 99.9 / 113.0, 250 000 61.4 / 61.6,
+    // 125 000 40.9 / 40.1 -- profiles/r6_ab_fused_f64.txt)
     static constexpr long kFusedMinSamples = 200000;
     // A caller that enqueues ticks without waiting (mppi_tick with NULL outputs) runs ahead of the device: what it reads here is a tick
     // that finished a while ago.  That lag is harmless while the regime drifts (the robot parks over hundreds of ticks), not when the
