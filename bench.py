@@ -157,7 +157,8 @@ def compact_line(line, full_path):
          "measured_in": "one_engine leg (co_shards = 1) of this command" if roof.get("measured_in") else "the timed region of this command",
          "one_engine_ms": one.get("ms_per_step"), "one_engine_rollout_us": one.get("rollout_us"),
          "f64_ms": f64.get("ms_per_step"), "f64_rollout_us": f64.get("rollout_us"), "f64_update_us": f64.get("update_us"),
-         "f64_kernel": f64.get("rollout_kernel"), "f64_parked_ms": (f64.get("parked_at_goal") or {}).get("ms_per_step")}
+         "f64_kernel": f64.get("rollout_kernel"), "f64_parked_ms": (f64.get("parked_at_goal") or {}).get("ms_per_step"),
+         "f64_valu_issue_frac": f64.get("valu_issue_frac")}
     co = roof.get("co_scheduled_launch") or {}
     if co:
         r.update({"co_launch_samples": co.get("samples_per_launch"), "co_launch_us": co.get("avg_launch_us"), "co_launches": co.get("concurrent_launches")})
@@ -638,6 +639,7 @@ def main():
         el64 = time.perf_counter() - t0
         k64 = e64.kernel_times()
         kind64 = e64.info().get("rollout_kernel")
+        mhz64 = e64.shader_clock_mhz()
         # the other regime: parked at the goal (the engine goes back to the two-kernel tick there: rollout + update)
         e64.kernel_timing(())
         e64.set_nominal(np.zeros((2, T)))
@@ -655,6 +657,7 @@ def main():
                     "rollout_kernel": kind64,
                     "rollout_us": k64["rollout"][0] * 1e3 / max(k64["rollout"][1], 1),
                     "update_us": k64["update"][0] * 1e3 / max(k64["update"][1], 1) if k64["update"][1] else None,
+                    "shader_clock_mhz": mhz64,
                     "parked_at_goal": {"ms_per_step": 1e3 * elp64 / 50, "rollout_kernel": e64.info().get("rollout_kernel")},
                     "note": "V and the softmax in fp64: the reference's own precision end to end.  `fused`: rollout + cost-to-go + softmax "
                             "partials in ONE kernel, V never stored (under way); parked at the goal the engine runs rollout + update"}
@@ -813,7 +816,7 @@ def main():
             r = {"kernel": name, "bound": "valu-issue", "achieved": None, "peak": None, "unit": "G wave-inst/s", "frac": None, "traffic": None,
                  "samples_per_launch": A_l * k_launch, "avg_launch_us": avg_s * 1e6, "launches_timed": n_timed, "accounting_8d": acc}
             mix = mixes.get(name)
-            if mix and lanes and args.storage == "f32":
+            if mix and lanes and (args.storage == "f32" or name == "rollout_fused_kernel"):   # (the fused fp64 kernel: its rollout loop's issue time; the fold behind each group is not in it)
                 wave_steps = steps / 64.0          # sample-steps per 64 lanes (the pk kernel's waves carry 128 samples)
                 cyc = mix["issue_cycles_per_step"] * wave_steps / N_SIMD
                 clk = mhz * 1e6 if mhz and mhz > 0 else CLOCK_PEAK_HZ
@@ -855,6 +858,11 @@ def main():
                                                  "and finalize launches: the two big kernels fully overlapped, the small ones as they are"}
             return r
 
+        if f64_line and mixes.get("rollout_fused_kernel") and f64_line.get("rollout_kernel") == "fused" and f64_line.get("shader_clock_mhz"):
+            # the fused fp64 kernel against ITS roof: VALU issue of its rollout loop (the fold behind every group of 64 samples is not counted)
+            cyc64 = mixes["rollout_fused_kernel"]["issue_cycles_per_step"] * (K_total * T / 64.0) / N_SIMD
+            f64_line["valu_issue_frac"] = cyc64 / (f64_line["shader_clock_mhz"] * 1e6) / (f64_line["rollout_us"] * 1e-6)
+            f64_line["valu_issue_frac_at_peak_clock"] = cyc64 / CLOCK_PEAK_HZ / (f64_line["rollout_us"] * 1e-6)
         co_n = info.get("co_shards", 1)
         k_launch = info["co_samples"][0] if co_n > 1 else K_local    # the launches this handle's events time: its own shard
         # co_samples all equal to K: the handle splits its AGENTS (config 5), engine 0 carries the first ceil(A / 2) of them

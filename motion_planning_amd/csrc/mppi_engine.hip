@@ -330,8 +330,11 @@ void mppi_engine::run_pipeline(int noise_mode, uint64_t seed, uint32_t tick, con
     if (pick_fused(ph, store)) {   // fp64 storage, under way: rollout + cost-to-go + partials in one kernel, V stays on the chip
         eps_lazy = true; injected_ready = false;
         launch_fused(seed, tick, tick_ptr);
-        merge_skipped = false; direct_n = fused_nb;
-        launch_merge(fused_nb);
+        // (one tuple per row and workgroup of four waves; a handful of them -- small engines -- the consumer merges itself)
+        const int n_tuples = fused_nb / 4;
+        merge_skipped = (skip_small_merge || (p2p_connected && !p2p_internal)) && n_tuples <= kDirectTuples;
+        direct_n = n_tuples;
+        if (!merge_skipped) launch_merge(n_tuples);
         noise_ready = true; value_ready = false; value_lazy = true; partials_ready = true; epart_ready = false;
         return;
     }
@@ -428,7 +431,8 @@ void mppi_engine::run_finalize(const double* gathered, int G, int flags, mppi::P
                        stream, P, gathered, G, lay, d_S, d_unom, d_ufilt, d_state, d_out, d_tick, flags, tick_set,
                        ext ? out_view_ext : (host_out ? d_out_view : nullptr), ext ? seq_view_ext : d_seq_view, ext ? seq_ext : out_seq, wait,
                        lanes_fresh_goal ? (const double*)(d_prev + (size_t)cfg.n_agents * 2 * cfg.horizon + (size_t)cfg.n_agents * 3) : (const double*)d_goal,
-                       tcb[tab ^ 1], baseb[tab ^ 1], pkb[tab ^ 1],
+                       tcb[tab ^ 1], baseb[tab ^ 1], f64() ? nullptr : pkb[tab ^ 1],   // (the deviation-form rows are the mixed rollout's: fp32 storage only)
+                       
                        lanes_fresh_state ? (const double*)(d_prev + (size_t)cfg.n_agents * 2 * cfg.horizon) : (const double*)nullptr, d_goal);
     lanes_fresh_state = lanes_fresh_goal = false;
     if (flags & 1) out_via_host = host_out;

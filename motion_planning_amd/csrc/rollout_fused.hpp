@@ -11,8 +11,8 @@
 //       m = min_k v_k;   e_k = exp2((m - v_k) log2e / lambda);   D = sum e_k,   N = sum e_k eps_k[t]       (:189-196)
 //   (two passes over the wave's own LDS: minimum, then weights) with the noise of the few samples that carry
 //   weight re-drawn from its Philox counter (lane t draws (sample k, step t): one call serves every row that needs it);
-//   the group's tuple is merged into the wave's running one (exact rescaling), and the wave leaves ONE tuple per row:
-//   part[a][t][wave] -- 1024 waves' tuples per row for the merge launch, whatever K is.
+//   the group's tuple is merged into the wave's running one (exact rescaling), the four waves of a workgroup merge theirs, and
+//   the workgroup leaves ONE tuple per row: part[a][t][workgroup] -- 256 tuples per row for the merge launch, whatever K is.
 //
 // LDS per wave: the prefix [T][65] doubles (pitch 65: lanes = rows read conflict-free), 64 totals, the eps sums -- 27 KB at T = 50;
 // a workgroup = four waves + the per-step table = 110 KB: one workgroup per CU, one wave per SIMD, 1024 waves on the chip, each
@@ -44,7 +44,7 @@ struct RolloutFusedArgs {
     const uint32_t* tick_ptr;
     const double *state, *goal, *unom;
     const double* tc;     // [A][T][8] the nominal trajectory's per-step table (rows {un0, un1, w0, w1, cb}; row 0 also (cos, sin) of the pose's heading)
-    double* part;         // [A][T][NB][8]
+    double* part;         // [A][T][NB / 4][8]: one tuple per row and workgroup
     int NB;               // waves per agent (a multiple of 4: four to a workgroup)
     int nterm;            // 4 | 7
 };
@@ -52,7 +52,7 @@ hipError_t launch_rollout_fused(const RolloutFusedArgs& a);
 
 #ifdef MPPI_ROLLOUT_FUSED_TU
 template <int NTERM>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void rollout_fused_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rollout_fused_kernel(
     DevParams P, const double* __restrict__ state, const double* __restrict__ goal, const double* __restrict__ unom,
     const double* __restrict__ tc, uint64_t seed, uint32_t tick_arg, const uint32_t* __restrict__ tick_ptr, double* __restrict__ part, int NB) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -278,9 +278,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         wave_sync();   // (the next group's prefix stores stay behind this group's reads)
     }
     probe.stop(P);
-    if (lane < T) {
-        double* o = part + (((size_t)a * T + lane) * NB + wv) * kTupleW;
-        o[0] = Mr; o[1] = Dr; o[2] = N0r; o[3] = N1r; o[4] = E0r; o[5] = E1r; o[6] = Cr; o[7] = 0.0;
+    // the workgroup's four waves leave ONE tuple per row (256 per row for the merge launch): waves 1-3 hand theirs over through their
+    // own LDS regions (nothing else lives there any more), wave 0 merges (exact rescaling) and stores
+    double* hand = pf;   // [7][64] of this wave's region
+    if (wid != 0) {
+        hand[0 * 64 + lane] = Mr; hand[1 * 64 + lane] = Dr; hand[2 * 64 + lane] = N0r; hand[3 * 64 + lane] = N1r;
+        hand[4 * 64 + lane] = E0r; hand[5 * 64 + lane] = E1r; hand[6 * 64 + lane] = Cr;
+    }
+    __syncthreads();   // (every wave gets here exactly once, whatever its number of groups)
+    if (wid == 0 && lane < T) {
+        const size_t wave_bytes = ((size_t)T * kFusedPitch * 8 + 64 * 8 + (size_t)T * 2 * 4 + 15) / 16 * 16;
+        double Mo[3], Dn = Dr, N0n = N0r, N1n = N1r, Mn = Mr;
+#pragma unroll
+        for (int w2 = 1; w2 < 4; ++w2) {
+            const double* h2 = reinterpret_cast<const double*>(reinterpret_cast<const char*>(pf) + (size_t)w2 * wave_bytes);
+            Mo[w2 - 1] = h2[0 * 64 + lane];
+            Mn = fmin(Mn, Mo[w2 - 1]);
+        }
+        const double s0 = (Mr == Mn) ? 1.0 : exp((Mn - Mr) * P.inv_lambda);   // (a wave without groups: M = +inf, D = N = 0: exp(-inf) = 0)
+        Dn *= s0; N0n *= s0; N1n *= s0;
+#pragma unroll
+        for (int w2 = 1; w2 < 4; ++w2) {
+            const double* h2 = reinterpret_cast<const double*>(reinterpret_cast<const char*>(pf) + (size_t)w2 * wave_bytes);
+            const double sc = (Mo[w2 - 1] == Mn) ? 1.0 : exp((Mn - Mo[w2 - 1]) * P.inv_lambda);
+            Dn += sc * h2[1 * 64 + lane]; N0n += sc * h2[2 * 64 + lane]; N1n += sc * h2[3 * 64 + lane];
+            E0r += h2[4 * 64 + lane]; E1r += h2[5 * 64 + lane]; Cr += h2[6 * 64 + lane];
+        }
+        double* o = part + (((size_t)a * T + lane) * (NB / 4) + blockIdx.x) * kTupleW;
+        o[0] = Mn; o[1] = Dn; o[2] = N0n; o[3] = N1n; o[4] = E0r; o[5] = E1r; o[6] = Cr; o[7] = 0.0;
     }
 }
 
