@@ -2,26 +2,30 @@
 // the reference's own precision (MPPI_STORE_F64: the reference is float64 end to end, control/src/mppi:127-208).  The two-kernel
 // tick of that mode is memory-bound twice over -- the rollout writes 8 B per sample-step (400 MB per tick at config 4, more than
 // the 256 MB Infinity Cache holds), the update reads them back -- and its two big launches run one after the other (110 + 70 us).
-// Here V never leaves the chip (EXPERIMENTS.md 46, built in round 6):
+// Here V never leaves the chip (EXPERIMENTS.md 46: the estimate; 58: the build, round 6):
 //
-//   one WAVE (four to a workgroup: one per SIMD of its CU, each on its own) walks groups of 64 samples (lane = sample), T sequential steps each -- the all-fp64 lean step of
-//   rollout_kernel, operation for operation -- and drops the running cost prefix of every step into LDS, pf[t][lane];
+//   one WAVE (four to a workgroup: one per SIMD of its CU, each on its own) walks groups of 64 samples (lane = sample), T
+//   sequential steps each -- the all-fp64 lean step of rollout_kernel, operation for operation -- and drops the running cost
+//   prefix of every step into LDS, pf[t][lane];
 //   behind the loop the wave turns round: lane = ROW t, and folds its 64 samples into the row's softmax tuple
 //       v_k = Stot_k - pf[t][k]        (V[t][k] = base[t] + v_k: total minus exclusive prefix, control/src/mppi:175)
-//       m = min_k v_k;   e_k = exp2((m - v_k) log2e / lambda);   D = sum e_k,   N = sum e_k eps_k[t]       (:189-196)
-//   (two passes over the wave's own LDS: minimum, then weights) with the noise of the few samples that carry
-//   weight re-drawn from its Philox counter (lane t draws (sample k, step t): one call serves every row that needs it);
+//       m = min_k v_k;   e_k = exp2((M - v_k) log2e / lambda);   D = sum e_k,   N = sum e_k eps_k[t]       (:189-196)
+//   in ONE pass over the wave's own LDS: the group's minimum, and -- as bits per lane -- the samples that can still carry weight
+//   against the wave's RUNNING minimum M (almost none after the first groups); only those are visited: their weight in fp64, their
+//   noise re-drawn from its Philox counter (lane t draws (sample k, step t): one call serves every row that needs it);
 //   the group's tuple is merged into the wave's running one (exact rescaling), the four waves of a workgroup merge theirs, and
 //   the workgroup leaves ONE tuple per row: part[a][t][workgroup] -- 256 tuples per row for the merge launch, whatever K is.
 //
-// LDS per wave: the prefix [T][65] doubles (pitch 65: lanes = rows read conflict-free), 64 totals, the eps sums -- 27 KB at T = 50;
-// a workgroup = four waves + the per-step table = 110 KB: one workgroup per CU, one wave per SIMD, 1024 waves on the chip, each
-// walking ceil(K / 65536) groups (static, strided: the same wave folds the same samples in the same order every run).  The per-step table of the nominal trajectory is LOADED (the previous
-// tick's finalize kernel or nominal_kernel computed it): no prologue per wave.
+// LDS per wave: the prefix [T][66] doubles (rows 16-byte aligned: read as pairs; a lane group's reads land in distinct banks), 64
+// totals, the eps sums -- 27 KB at T = 50; a workgroup = four waves + the per-step table = 110 KB: one workgroup per CU, one wave
+// per SIMD, 1024 waves on the chip, each walking ceil(K / 65536) groups (static, strided: the same wave folds the same samples in
+// the same order every run).  The per-step table of the nominal trajectory is LOADED (the previous tick's finalize kernel or
+// nominal_kernel computed it): no prologue per wave; a chunk's rows are requested at its top, in front of its Philox draws (a lone
+// wave per SIMD has nobody to hide an LDS round trip behind).
 // Serves: fp64 storage, device noise not stored, rk4 + dd_dynamics, Q = diag(q, q, 0), no obstacle grid, T <= 64, the default
-// noise stream.  Far from the goal a group has a handful of (row, sample) pairs with weight (the block's best sample of each
-// row); parked AT the goal a few per cent of all pairs carry weight and every one costs a Philox call here -- the engine keeps the
-// two-kernel tick for that regime (it reads the last tick's largest row sum of weights from the pinned outputs).
+// noise stream.  Far from the goal a group has a handful of (row, sample) pairs with weight; parked AT the goal a few per cent of
+// all pairs carry weight and every one costs a Philox call here -- the engine keeps the two-kernel tick for that regime (it reads
+// the last tick's largest row sum of weights from the pinned outputs).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -32,7 +36,7 @@ namespace mppi {
 
 constexpr int kFusedPitch = 66;   // doubles per prefix row in LDS (64 samples + 2: rows stay 16-byte aligned and a row pair's 16-byte reads of one lane group land in distinct banks)
 constexpr int kFusedRow = 6;      // doubles per table row in LDS ({un0, un1, w0, w1, cb, -}: three 16-byte reads)
-// LDS bytes of one wave (prefix [T][65] f64, totals [64] f64, eps sums [T][2] f32, rounded to 16) and of a workgroup (table [T][5] f64 + four waves)
+// LDS bytes of one wave (prefix [T][66] f64, totals [64] f64, eps sums [T][2] f32, rounded to 16) and of a workgroup (table [T][6] f64 + four waves)
 inline size_t rollout_fused_lds_wave(int T) { return ((size_t)T * kFusedPitch * 8 + 64 * 8 + (size_t)T * 2 * 4 + 15) / 16 * 16; }
 inline size_t rollout_fused_lds(int T) { return ((size_t)T * kFusedRow * 8 + 15) / 16 * 16 + 4 * rollout_fused_lds_wave(T); }
 

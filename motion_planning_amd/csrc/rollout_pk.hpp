@@ -124,6 +124,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
     constexpr int SPD = NoisePack<PACK>::kSteps;   // steps per Philox draw: 3 (the default stream) | 4 (16-bit packing) | 2 (hipRAND's normals)
     constexpr int U = PACK ? 8 : 6;  // steps per chunk = two (hipRAND's normals: four) Philox draws per sample; wave_sum16 carries the chunk's 12 | 16 eps sums
     float nz[U][4];             // the chunk's noise: [step]{wheel 0 of kA, wheel 0 of kA + 1, wheel 1 of kA, wheel 1 of kA + 1}
+    // WAVES <= 2: the instance for UNDER-FILLED launches (at most two waves per SIMD: a rank's share of a sharded controller).  Same
+    // arithmetic, operation for operation; the chunk's table rows are requested from LDS at the chunk's top, in front of its Philox
+    // draws, and held in registers (120 of them: no room at four waves per SIMD) -- a wave that has the SIMD almost to itself pays
+    // every LDS round trip of the per-step reads in full (the fused fp64 kernel gained 18 % from the same move, EXPERIMENTS.md 58).
+    constexpr bool PRE = WAVES <= 2;
+    PkRow rows[PRE ? U : 1];
+    auto load_rows = [&](int t0, int n) __attribute__((always_inline)) {
+        if constexpr (PRE) {
+#pragma unroll
+            for (int j = 0; j < U; ++j)
+                if (j < n) rows[j] = lt[t0 + j];
+        }
+    };
     float tz[SPD][4];
     bool drawn0 = false;   // (wave-uniform) this wave drew its first chunk's noise before the barrier
     double dX[2] = {0.0, 0.0}, dY[2] = {0.0, 0.0}, pre[2] = {0.0, 0.0};
@@ -254,9 +267,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
         const size_t at = (((size_t)a * T + te) * 2 + (idx & 1)) * NW + slot;
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(half ? 0.f : tot), ep_rsrc, mine ? (unsigned)(at * 4) : 0xFFFFFFFFu, 0, kDpStoreAux);
     };
-    auto step = [&](int t, f2 n0, f2 n1, auto full_tag, bool robust) __attribute__((always_inline)) {
+    auto step = [&](int t, int j, f2 n0, f2 n1, auto full_tag, bool robust) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_tag)::value;
-        const PkRow& r = lt[t];
+        const PkRow& r = PRE ? rows[PRE ? j : 0] : lt[t];
         {   // dP[t] = the exclusive cost prefix (control/src/mppi:175 as total minus prefix)
             const __amdgpu_buffer_rsrc_t row = __builtin_amdgcn_make_buffer_rsrc(dP_a + (size_t)t * Ks, 0, (int)(Ks * sizeof(float)), 0x00020000);
             const float pa = (float)pre[0] + ncs.x, pb = (float)pre[1] + ncs.y;
@@ -325,7 +338,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
 #endif
 #pragma unroll
         for (int j = 0; j < U; ++j)
-            if (j < nsteps) step(t0 + j, f2{nz[j][0], nz[j][1]}, f2{nz[j][2], nz[j][3]}, full_tag, robust);
+            if (j < nsteps) step(t0 + j, j, f2{nz[j][0], nz[j][1]}, f2{nz[j][2], nz[j][3]}, full_tag, robust);
     };
     const int T4 = T - T % U;
     // T = 6 n + 1 or 6 n + 2 (the node's 50): the steps behind the last full chunk ride along with it (their draw is made
@@ -336,12 +349,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
         const int t_loop = ride ? T4 - U : T4;
         // (the first chunk stands in front of the loop: the waves that waited at the barrier have drawn its noise there)
         if (t_loop > 0) {
+            load_rows(0, U);
             if (!drawn0) draw(0, U);   // (uniform)
             eps_sums(0, full_tag, std::false_type{});
             chunk(0, U, full_tag);
             probe.mark(P, mk++);
         }
         for (int t0 = U; t0 < t_loop; t0 += U) {
+            load_rows(t0, U);
             draw(t0, U);
             eps_sums(t0, full_tag, std::false_type{});
             chunk(t0, U, full_tag);
@@ -349,6 +364,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
         }
         if (ride) {
             const int t0 = T4 - U;
+            load_rows(t0, U);
             draw(t0, U);
             {
                 f2 w0[SPD], w1[SPD];
@@ -366,8 +382,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
             for (int j = 0; j < SPD; ++j)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) nz[j][c] = tz[j][c];
+            load_rows(T4, T - T4);
             chunk(T4, T - T4, full_tag);
         } else if (T4 < T) {  // ragged tail: sums of steps at or beyond T are never stored, their noise is never integrated
+            load_rows(T4, T - T4);
             draw(T4, T - T4);
             eps_sums(T4, full_tag, std::false_type{});
             chunk(T4, T - T4, full_tag);
@@ -421,7 +439,12 @@ hipError_t launch_rollout_pk(const RolloutPkArgs& a) {
                                a.seed, a.tick, a.tick_ptr, a.epart, a.unom, a.base, a.al_guard, a.pkrows);                    \
     } while (0)
 #define MPPI_PK_GO(IN, W) do { if (a.noise_pack == 2) MPPI_PK_GO_(IN, W, 2); else if (a.noise_pack == 1) MPPI_PK_GO_(IN, W, 1); else MPPI_PK_GO_(IN, W, 0); } while (0)
-    // (WAVES = 4: the compiler's own allocation, no spills; a fifth wave per SIMD cost spills and measured slower -- EXPERIMENTS.md)
+    // (WAVES = 4: the compiler's own allocation, no spills; a fifth wave per SIMD cost spills and measured slower -- EXPERIMENTS.md.
+    //  WAVES = 2: the under-filled instance, table rows in registers -- launches of at most two waves per SIMD, the default noise stream)
+    const bool under_filled = (long)grid.x * grid.y <= 512 && a.noise_pack == 0;
+    if (under_filled) {
+        if (a.inline_nominal == 2) MPPI_PK_GO_(2, 2, 0); else if (a.inline_nominal == 1) MPPI_PK_GO_(1, 2, 0); else MPPI_PK_GO_(0, 2, 0);
+    } else
     if (a.inline_nominal == 2) MPPI_PK_GO(2, 4); else if (a.inline_nominal == 1) MPPI_PK_GO(1, 4); else MPPI_PK_GO(0, 4);
 #undef MPPI_PK_GO
 #undef MPPI_PK_GO_

@@ -732,6 +732,29 @@ def test_co_scheduled_value_is_bit_identical_to_the_unsplit_engine(monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("share", [125000, 250000, 77777])
+def test_a_rank_share_runs_the_unsplit_controllers_arithmetic_bit_for_bit(share):
+    """A rank's share of config 4 (mppi_config.samples_total = 10^6) is an UNDER-FILLED launch of the mixed-precision rollout: at most
+    512 workgroups, the instance that holds a chunk's table rows in registers (rollout_pk.hpp, WAVES = 2).  Same arithmetic,
+    operation for operation: its V and its noise equal the first `share` columns of the unsplit engine's (four waves per SIMD,
+    rows read from LDS per step) bit for bit -- sample k draws the stream of global sample k on both."""
+    from motion_planning_amd.mppi import Engine
+    T = 50
+    u0 = np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
+    with Engine(1000000, T, storage="f32", co_shards=1) as e:
+        e.set_nominal(u0)
+        e.tick([0, 0, 0], [0, -1, 0], noise="philox", seed=7, tick_id=5)
+        assert e.info()["rollout_kernel"] == "mixed"
+        V_all, eps_all = e.download_value()[0], e.download_noise()[0]
+    with Engine(share, T, storage="f32", co_shards=1, samples_total=1000000) as e:
+        e.set_nominal(u0)
+        e.tick([0, 0, 0], [0, -1, 0], noise="philox", seed=7, tick_id=5)
+        assert e.info()["rollout_kernel"] == "mixed"
+        V, eps = e.download_value()[0], e.download_noise()[0]
+    assert np.array_equal(V, V_all[:, :share]) and np.array_equal(eps, eps_all[..., :share])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("K", [500001, 655361, 999999, 1000000, 1 << 20])
 def test_co_scheduled_cut_sweep_equals_one_engine(K):
     """VERDICT r5 item 3.  Two co-scheduled engines fill ONE set of rows (cost prefix, totals, per-wave noise sums) from two unordered

@@ -23,7 +23,7 @@ if __name__ == "__main__":
         ab = importlib.util.module_from_spec(spec); spec.loader.exec_module(ab)
         p = argparse.ArgumentParser()
         for name, typ, dflt in (("--samples", int, 1000000), ("--horizon", int, 50), ("--agents", int, 1), ("--storage", str, "f32"), ("--tick-path", str, "auto"),
-                                ("--co-shards", int, 1), ("--ticks", int, 300), ("--fixed", str, "")):
+                                ("--co-shards", int, 1), ("--samples-total", int, 0), ("--ticks", int, 300), ("--fixed", str, "")):
             p.add_argument(name, type=typ, default=dflt)
         b = p.parse_args(rest)
         b.fixed_options = dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in b.fixed.split(",") if kv)

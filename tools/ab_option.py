@@ -17,7 +17,7 @@ from motion_planning_amd.mppi import Engine
 
 def run(opt, val, a):
     T, A = a.horizon, a.agents
-    with Engine(a.samples, T, n_agents=A, storage=a.storage, tick_path=a.tick_path, co_shards=a.co_shards,
+    with Engine(a.samples, T, n_agents=A, storage=a.storage, tick_path=a.tick_path, co_shards=a.co_shards, samples_total=getattr(a, "samples_total", 0),
                 options=dict(a.fixed_options, **{opt: int(val)})) as e:
         u0 = np.tile(np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)]), (A, 1, 1))
         goal = np.tile(np.array([[0.0, -1.0, 0.0]]), (A, 1))
@@ -58,6 +58,7 @@ if __name__ == "__main__":
     ap.add_argument("--storage", default="f32")
     ap.add_argument("--tick-path", default="auto")
     ap.add_argument("--co-shards", type=int, default=1)
+    ap.add_argument("--samples-total", type=int, default=0, help="the engine is one share of a controller of this many samples (mppi_config.samples_total)")
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--ticks", type=int, default=400)
     ap.add_argument("--fixed", default="", help="name=value,...: options every run gets next to the one under test")
