@@ -85,8 +85,14 @@ __device__ __forceinline__ f2 pk_med3(f2 v, float lo, float hi) {
     return f2{__builtin_amdgcn_fmed3f(v.x, lo, hi), __builtin_amdgcn_fmed3f(v.y, lo, hi)};
 }
 
-template <int INLINE_NOM, int WAVES, int PACK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void rollout_pk_kernel(DevParams P, const double* __restrict__ state,
+// SPLIT (under-filled launches, T <= 64, the default noise stream): a workgroup of EIGHT waves for the same 512 samples -- waves 0-3 walk
+// the dynamics as ever, waves 4-7 draw the noise (Philox + Box-Muller + the per-wave eps sums: 45 % of a chunk's instructions) one chunk
+// ahead and hand it over through LDS, a barrier per chunk.  A launch of <= 256 workgroups puts ONE wave of this kernel on a SIMD, and a
+// lone wave leaves a third of the SIMD's issue slots empty (1.91 us per chunk against 1.14 where two waves share a SIMD: EXPERIMENTS.md
+// 65, 66); the hardware deals a workgroup's waves to the SIMDs in turn (wave i + 4 lands next to wave i: tools/simd_map.hip), so every
+// SIMD hosts a drawing wave and the walking wave it feeds.  Same functions, same operands: bit-identical results.
+template <int INLINE_NOM, int WAVES, int PACK, bool SPLIT = false>
+__global__ __launch_bounds__(SPLIT ? 512 : 256) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void rollout_pk_kernel(DevParams P, const double* __restrict__ state,
                                                         const double* __restrict__ goal, double* __restrict__ tc,
                                                         float* __restrict__ dP, float* __restrict__ Stot, uint64_t seed,
                                                         uint32_t tick_arg, const uint32_t* __restrict__ tick_ptr,
@@ -95,12 +101,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     PkRow* lt = reinterpret_cast<PkRow*>(smem_raw);  // [T]
     __shared__ double fin_sh[1];                      // the nominal trajectory's final heading (unwrapped)
+    static_assert(!SPLIT || (INLINE_NOM != 2 && PACK == 0 && WAVES <= 2), "the split form: T <= 64, the default noise stream, the under-filled instance");
     const int tid = threadIdx.x, a = blockIdx.y, T = P.T;
+    const bool producer = SPLIT && __builtin_amdgcn_readfirstlane(tid >> 8) != 0;   // (wave-uniform) SPLIT: waves 4-7 draw, waves 0-3 walk
     ClockProbe probe(P);
     snapshot_inputs(P, state, goal, unom, a);
     const double gx = goal[a * 3 + 0], gy = goal[a * 3 + 1], gth = goal[a * 3 + 2];
     const int lane = tid & 63;
-    const int kwave = (int)blockIdx.x * 512 + (tid >> 6) * 128;  // this wave's 128 consecutive samples
+    const int kwave = (int)blockIdx.x * 512 + ((tid >> 6) & 3) * 128;  // this wave's 128 consecutive samples (SPLIT: the pair's)
     const int kA = kwave + 2 * lane;                             // this lane's two: kA, kA + 1
     const bool actA = kA < P.K, actB = kA + 1 < P.K;
     const bool block_full = ((int)blockIdx.x + 1) * 512 <= P.K;  // (uniform)
@@ -202,9 +210,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
         // the table from memory: the previous tick's finalize kernel computed it for this tick's inputs (nominal_table_lanes)
         const PkRow* src = pkrows + (size_t)a * T;
         typedef float f4 __attribute__((ext_vector_type(4)));
-        for (int i = tid; i < T * 5; i += 256) reinterpret_cast<f4*>(lt)[i] = reinterpret_cast<const f4*>(src)[i];
+        for (int i = tid; i < T * 5; i += (SPLIT ? 512 : 256)) reinterpret_cast<f4*>(lt)[i] = reinterpret_cast<const f4*>(src)[i];
         if (tid == 0) fin_sh[0] = tc[(size_t)a * T * kTcW + 7];
-        if constexpr (PACK == 0) {   // the first chunk's noise depends on nothing the table holds: drawn while the loads are in flight
+        if constexpr (PACK == 0 && !SPLIT) {   // the first chunk's noise depends on nothing the table holds: drawn while the loads are in flight
             draw(0, U);
             drawn0 = true;
         }
@@ -214,6 +222,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
         __shared__ double nom_sh[4];
         // (a scalar condition: the two sides are real branches, the noise registers of one are not live through the other)
         const bool prologue_wave = INLINE_NOM == 2 || __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
+        if (SPLIT && !prologue_wave) {
+            // (the drawing waves start on their first chunk at once, the other walking waves wait at the first chunk's barrier)
+        } else
         if (prologue_wave) {
             double row[5], base_t;
             NomExtra ex;
@@ -240,7 +251,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
             }
         }
     }
-    __syncthreads();
+    if constexpr (!SPLIT) __syncthreads();   // (SPLIT: the first chunk's hand-over barrier is this barrier)
     int mk = 0;   // (timeline marks of a diagnostic build; dead code in the product)
     probe.mark(P, mk++);
     // per-wave sums of eps (the E of the softmax floor term, control/src/mppi:193) for the chunk's steps x 2 wheels: the
@@ -391,8 +402,86 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
             chunk(T4, T - T4, full_tag);
         }
     };
-    if (block_full) run(std::true_type{});
-    else run(std::false_type{});
+    // SPLIT: the same schedule as a list of hand-overs -- (first step, steps drawn, whether the one or two steps behind the last full
+    // chunk ride along) -- that both kinds of wave walk, a barrier per entry: a drawing wave draws, sums, leaves the chunk's noise in
+    // one of two LDS buffers and arrives; a walking wave arrives, takes the noise into registers and integrates.  The chunk a
+    // walking wave integrates is the one its drawing wave finished before the barrier; meanwhile the next one is drawn.
+    typedef float f4n __attribute__((ext_vector_type(4)));
+    f4n* const nzb = reinterpret_cast<f4n*>(smem_raw + ((size_t)T * sizeof(PkRow) + 15) / 16 * 16) + (size_t)((tid >> 6) & 3) * (U + SPD) * 64 + lane;
+    constexpr int kBufStride = 4 * (U + SPD) * 64;   // float4s per buffer (four wave pairs)
+    // (the two kinds of wave are separate loops over the same list: neither carries the other's registers)
+    auto for_each_hand_over = [&](auto&& f) __attribute__((always_inline)) {
+        const int t_loop = ride ? T4 - U : T4;
+        if (t_loop > 0) f(0, U, std::false_type{});
+        for (int t0 = U; t0 < t_loop; t0 += U) f(t0, U, std::false_type{});
+        if (ride) f(T4 - U, U, std::true_type{});
+        else if (T4 < T) f(T4, T - T4, std::false_type{});
+    };
+    auto run_draw = [&](auto full_tag) __attribute__((always_inline)) {
+        int ev = 0;
+        for_each_hand_over([&](int t0, int n, auto extra_tag) __attribute__((always_inline)) {
+            constexpr bool EXTRA = decltype(extra_tag)::value;
+            f4n* const buf = nzb + (size_t)(ev & 1) * kBufStride;
+            ++ev;
+            draw(t0, n);
+            if constexpr (EXTRA) {
+                f2 w0[SPD], w1[SPD];
+                draw3((uint32_t)(T4 / SPD), w0, w1);
+#pragma unroll
+                for (int i = 0; i < SPD; ++i) {  // steps at or beyond T carry no noise (they are never integrated)
+                    const bool in = T4 + i < T;
+                    tz[i][0] = in ? w0[i].x : 0.f; tz[i][1] = in ? w0[i].y : 0.f;
+                    tz[i][2] = in ? w1[i].x : 0.f; tz[i][3] = in ? w1[i].y : 0.f;
+                }
+            }
+            eps_sums(t0, full_tag, extra_tag);
+#pragma unroll
+            for (int j = 0; j < U; ++j) buf[j * 64] = f4n{nz[j][0], nz[j][1], nz[j][2], nz[j][3]};
+            if constexpr (EXTRA) {
+#pragma unroll
+                for (int j = 0; j < SPD; ++j) buf[(U + j) * 64] = f4n{tz[j][0], tz[j][1], tz[j][2], tz[j][3]};
+            }
+            __syncthreads();
+        });
+    };
+    auto run_walk = [&](auto full_tag) __attribute__((always_inline)) {
+        int ev = 0;
+        for_each_hand_over([&](int t0, int n, auto extra_tag) __attribute__((always_inline)) {
+            constexpr bool EXTRA = decltype(extra_tag)::value;
+            const f4n* const buf = nzb + (size_t)(ev & 1) * kBufStride;
+            ++ev;
+            __syncthreads();
+            load_rows(t0, n);
+#pragma unroll
+            for (int j = 0; j < U; ++j) { const f4n v = buf[j * 64]; nz[j][0] = v.x; nz[j][1] = v.y; nz[j][2] = v.z; nz[j][3] = v.w; }
+            if constexpr (EXTRA) {
+#pragma unroll
+                for (int j = 0; j < SPD; ++j) { const f4n v = buf[(U + j) * 64]; tz[j][0] = v.x; tz[j][1] = v.y; tz[j][2] = v.z; tz[j][3] = v.w; }
+            }
+            chunk(t0, n, full_tag);
+            if constexpr (EXTRA) {
+#pragma unroll
+                for (int j = 0; j < SPD; ++j)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) nz[j][c] = tz[j][c];
+                load_rows(T4, T - T4);
+                chunk(T4, T - T4, full_tag);
+            }
+            probe.mark(P, mk++);
+        });
+    };
+    if constexpr (SPLIT) {
+        if (producer) {
+            if (block_full) run_draw(std::true_type{});
+            else run_draw(std::false_type{});
+            return;   // (behind its last barrier: the walking waves meet no other)
+        }
+        if (block_full) run_walk(std::true_type{});
+        else run_walk(std::false_type{});
+    } else {
+        if (block_full) run(std::true_type{});
+        else run(std::false_type{});
+    }
     // terminal cost (control/src/mppi:165-173) minus the nominal's; the theta error is not wrapped beyond rk4's own wrap
     const PkRow& rT = lt[T - 1];
     const double thn = fin_sh[0], inv_f2 = P.lean_inv_f * P.lean_inv_f;
@@ -442,6 +531,22 @@ hipError_t launch_rollout_pk(const RolloutPkArgs& a) {
     // (WAVES = 4: the compiler's own allocation, no spills; a fifth wave per SIMD cost spills and measured slower -- EXPERIMENTS.md.
     //  WAVES = 2: the under-filled instance, table rows in registers -- launches of at most two waves per SIMD, the default noise stream)
     const bool under_filled = (long)grid.x * grid.y <= 512 && a.noise_pack == 0;
+    // ... and at most ONE wave per SIMD (256 workgroups), T <= 64: the split form -- eight waves per workgroup, four of them drawing the noise
+    const bool split = under_filled && (long)grid.x * grid.y <= 256 && a.inline_nominal != 2;
+    if (split) {
+        const unsigned lds_split = (unsigned)(((size_t)a.P.T * sizeof(PkRow) + 15) / 16 * 16 + (size_t)2 * 4 * (6 + 3) * 64 * 16);
+#define MPPI_PK_SPLIT_(IN)                                                                                                       \
+        do {                                                                                                                  \
+            if (a.ev_start)                                                                                                   \
+                hipExtLaunchKernelGGL((rollout_pk_kernel<IN, 2, 0, true>), grid, dim3(512), lds_split, a.stream, a.ev_start, a.ev_stop, 0, a.P, a.state, \
+                                      a.goal, a.tc, a.dP, a.stot, a.seed, a.tick, a.tick_ptr, a.epart, a.unom, a.base, a.al_guard, a.pkrows); \
+            else                                                                                                              \
+                hipLaunchKernelGGL((rollout_pk_kernel<IN, 2, 0, true>), grid, dim3(512), lds_split, a.stream, a.P, a.state, a.goal, a.tc, a.dP, a.stot, \
+                                   a.seed, a.tick, a.tick_ptr, a.epart, a.unom, a.base, a.al_guard, a.pkrows);                \
+        } while (0)
+        if (a.inline_nominal == 1) MPPI_PK_SPLIT_(1); else MPPI_PK_SPLIT_(0);
+#undef MPPI_PK_SPLIT_
+    } else
     if (under_filled) {
         if (a.inline_nominal == 2) MPPI_PK_GO_(2, 2, 0); else if (a.inline_nominal == 1) MPPI_PK_GO_(1, 2, 0); else MPPI_PK_GO_(0, 2, 0);
     } else
