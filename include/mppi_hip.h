@@ -149,7 +149,7 @@ typedef struct mppi_config {
                               is then made from this number, so every rank of an N-way split runs the arithmetic the unsplit
                               controller would and N = 1 / 2 / 4 / 8 end every tick with the same controls to rounding (1e-10;
                               SURVEY 8d-4).  bench.py --gpus N and sharded.make_hip_ticker set it.  The price: a small share runs
-                              the kernel sized for the whole (125 000 samples on the mixed rollout: +3 us per tick)             */
+                              the kernel sized for the whole (125 000 samples on the mixed rollout: its under-filled forms, +0 us)  */
 } mppi_config;
 /* the struct as ABI version 5 introduced it: the shortest struct_size mppi_create accepts (fields are only ever appended) */
 #define MPPI_CONFIG_SIZE_V5 168u

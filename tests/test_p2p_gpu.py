@@ -735,9 +735,10 @@ def test_co_scheduled_value_is_bit_identical_to_the_unsplit_engine(monkeypatch):
 @pytest.mark.parametrize("share", [125000, 250000, 77777])
 def test_a_rank_share_runs_the_unsplit_controllers_arithmetic_bit_for_bit(share):
     """A rank's share of config 4 (mppi_config.samples_total = 10^6) is an UNDER-FILLED launch of the mixed-precision rollout: at most
-    512 workgroups, the instance that holds a chunk's table rows in registers (rollout_pk.hpp, WAVES = 2).  Same arithmetic,
-    operation for operation: its V and its noise equal the first `share` columns of the unsplit engine's (four waves per SIMD,
-    rows read from LDS per step) bit for bit -- sample k draws the stream of global sample k on both."""
+    512 workgroups (250 000), the instance that holds a chunk's table rows in registers (rollout_pk.hpp, WAVES = 2); at most 256
+    (125 000, 77 777), the split form -- four waves of a workgroup draw the noise and hand it over through LDS, four walk the
+    dynamics.  Same arithmetic, operation for operation: V and noise equal the first `share` columns of the unsplit engine's (four
+    waves per SIMD, rows read from LDS per step) bit for bit -- sample k draws the stream of global sample k on all of them."""
     from motion_planning_amd.mppi import Engine
     T = 50
     u0 = np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
