@@ -297,6 +297,7 @@ void mppi_engine::launch_fused(uint64_t seed, uint32_t tick, const uint32_t* tic
     a.stream = stream; a.seed = seed; a.tick = tick; a.tick_ptr = tick_ptr;
     a.state = in_state ? in_state : d_state; a.goal = in_goal ? in_goal : d_goal; a.unom = d_unom;
     a.tc = d_tc; a.part = d_part; a.NB = fused_nb; a.nterm = nterm;
+    a.split = mppi::rollout_fused_lds(cfg.horizon, true) <= (size_t)160 * 1024;   // (T <= 56: the pairs' noise buffers fit next to the prefix rows)
     {
         Scope sc(this, MPPI_KERNEL_ROLLOUT);
         const hipError_t e = mppi::launch_rollout_fused(a);

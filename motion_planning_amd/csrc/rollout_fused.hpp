@@ -22,6 +22,11 @@
 // the same order every run).  The per-step table of the nominal trajectory is LOADED (the previous tick's finalize kernel or
 // nominal_kernel computed it): no prologue per wave; a chunk's rows are requested at its top, in front of its Philox draws (a lone
 // wave per SIMD has nobody to hide an LDS round trip behind).
+// SPLIT (T <= 56: what the CU's LDS holds next to the prefix rows): a workgroup of EIGHT waves -- every walking wave gets a DRAWING wave
+// on its SIMD (the hardware deals a workgroup's waves to the four SIMDs in turn) that makes its noise (Philox, Box-Muller, the eps sums: a
+// third of a chunk's issue cycles) up to two chunks ahead and hands it over through two LDS buffers and a pair of counters: a lone
+// wave leaves a third of its SIMD's issue slots empty, and the drawing wave lives in them -- config 4 176 -> 162 us per tick
+// (EXPERIMENTS.md 67).  Same functions, same operands, the same groups in the same order: bit-identical tuples.
 // Serves: fp64 storage, device noise not stored, rk4 + dd_dynamics, Q = diag(q, q, 0), no obstacle grid, T <= 64, the default
 // noise stream.  Far from the goal a group has a handful of (row, sample) pairs with weight; parked AT the goal a few per cent of
 // all pairs carry weight and every one costs a Philox call here -- the engine keeps the two-kernel tick for that regime (it reads
@@ -37,8 +42,13 @@ namespace mppi {
 constexpr int kFusedPitch = 66;   // doubles per prefix row in LDS (64 samples + 2: rows stay 16-byte aligned and a row pair's 16-byte reads of one lane group land in distinct banks)
 constexpr int kFusedRow = 6;      // doubles per table row in LDS ({un0, un1, w0, w1, cb, -}: three 16-byte reads)
 // LDS bytes of one wave (prefix [T][66] f64, totals [64] f64, eps sums [T][2] f32, rounded to 16) and of a workgroup (table [T][6] f64 + four waves)
-inline size_t rollout_fused_lds_wave(int T) { return ((size_t)T * kFusedPitch * 8 + 64 * 8 + (size_t)T * 2 * 4 + 15) / 16 * 16; }
-inline size_t rollout_fused_lds(int T) { return ((size_t)T * kFusedRow * 8 + 15) / 16 * 16 + 4 * rollout_fused_lds_wave(T); }
+// (split form: two sets of eps sums per wave -- the drawing wave is a group ahead of the fold -- and the pairs' noise buffers)
+constexpr int kFusedNBuf = 2;     // split form: noise buffers per wave pair (the drawing wave runs up to two chunks ahead)
+constexpr int kFusedBufSteps = 6 + 3;   // steps a buffer holds: a chunk + the steps that ride along with the last one
+inline size_t rollout_fused_lds_wave(int T, bool split = false) { return ((size_t)T * kFusedPitch * 8 + 64 * 8 + (size_t)T * 2 * 4 * (split ? 2 : 1) + 15) / 16 * 16; }
+inline size_t rollout_fused_lds(int T, bool split = false) {
+    return ((size_t)T * kFusedRow * 8 + 15) / 16 * 16 + 4 * rollout_fused_lds_wave(T, split) + (split ? (size_t)4 * kFusedNBuf * kFusedBufSteps * 64 * 8 : 0);
+}
 
 struct RolloutFusedArgs {
     DevParams P;
@@ -51,21 +61,35 @@ struct RolloutFusedArgs {
     double* part;         // [A][T][NB / 4][8]: one tuple per row and workgroup
     int NB;               // waves per agent (a multiple of 4: four to a workgroup)
     int nterm;            // 4 | 7
+    bool split;           // eight waves per workgroup: waves 4-7 draw the noise for waves 0-3 (rollout_fused_kernel, SPLIT)
 };
 hipError_t launch_rollout_fused(const RolloutFusedArgs& a);
 
 #ifdef MPPI_ROLLOUT_FUSED_TU
-template <int NTERM>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rollout_fused_kernel(
+// SPLIT: a workgroup of EIGHT waves -- waves 4-7 draw the noise (Philox, Box-Muller, the per-wave eps sums: a third of a chunk's
+// issue cycles) for waves 0-3, up to two chunks ahead, through LDS buffers and a pair of counters per wave pair; waves 0-3 walk the
+// dynamics and fold as ever.  The hardware deals a workgroup's waves to the SIMDs in turn (wave i + 4 next to wave i:
+// tools/simd_map.hip): every SIMD hosts a walking wave and, in the issue slots that lone wave leaves empty, the drawing wave that
+// feeds it (EXPERIMENTS.md 66, 67).  Same functions, same operands, the same groups in the same order: bit-identical tuples.
+template <int NTERM, bool SPLIT>
+__global__ __launch_bounds__(SPLIT ? 512 : 256) __attribute__((amdgpu_waves_per_eu(SPLIT ? 2 : 1, SPLIT ? 2 : 1))) void rollout_fused_kernel(
     DevParams P, const double* __restrict__ state, const double* __restrict__ goal, const double* __restrict__ unom,
     const double* __restrict__ tc, uint64_t seed, uint32_t tick_arg, const uint32_t* __restrict__ tick_ptr, double* __restrict__ part, int NB) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int T = P.T, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, a = blockIdx.y, wv = (int)blockIdx.x * 4 + wid;
+    const int T = P.T, tid = threadIdx.x, lane = tid & 63, wid = (tid >> 6) & 3, a = blockIdx.y, wv = (int)blockIdx.x * 4 + wid;
+    const bool drawer = SPLIT && __builtin_amdgcn_readfirstlane(tid >> 8) != 0;   // (wave-uniform)
+    const size_t wave_bytes = ((size_t)T * kFusedPitch * 8 + 64 * 8 + (size_t)T * 2 * 4 * (SPLIT ? 2 : 1) + 15) / 16 * 16;
     double* lt = reinterpret_cast<double*>(smem_raw);          // [T][kFusedRow]   (the workgroup's)
-    char* mine = smem_raw + ((size_t)T * kFusedRow * 8 + 15) / 16 * 16 + (size_t)wid * (((size_t)T * kFusedPitch * 8 + 64 * 8 + (size_t)T * 2 * 4 + 15) / 16 * 16);
-    double* pf = reinterpret_cast<double*>(mine);              // [T][kFusedPitch]   (this wave's, like everything below)
+    char* mine = smem_raw + ((size_t)T * kFusedRow * 8 + 15) / 16 * 16 + (size_t)wid * wave_bytes;
+    double* pf = reinterpret_cast<double*>(mine);              // [T][kFusedPitch]   (this wave's -- SPLIT: this wave pair's --, like everything below)
     double* st = pf + (size_t)T * kFusedPitch;                 // [64]
-    float* es = reinterpret_cast<float*>(st + 64);             // [T][2]
+    float* es0 = reinterpret_cast<float*>(st + 64);            // [T][2]  (SPLIT: [2][T][2], by the parity of the pair's group count)
+    // SPLIT: the pair's noise buffers [kFusedNBuf][kFusedBufSteps][64] of {wheel 0, wheel 1}, and its hand-over words: chunks drawn (the
+    // drawing wave's word), chunks taken (the walking wave's) -- each set to 0 by its writer in front of the first barrier
+    typedef float f2n __attribute__((ext_vector_type(2)));
+    f2n* const nzb = reinterpret_cast<f2n*>(smem_raw + ((size_t)T * kFusedRow * 8 + 15) / 16 * 16 + 4 * wave_bytes) + (size_t)wid * kFusedNBuf * kFusedBufSteps * 64 + lane;
+    __shared__ int ho_drawn[SPLIT ? 4 : 1], ho_taken[SPLIT ? 4 : 1];
+    if (SPLIT && lane == 0) { if (drawer) ho_drawn[wid] = 0; else ho_taken[wid] = 0; }
     // this wave's own LDS traffic needs no workgroup barrier: a wave's LDS operations complete in order; the fences keep the compiler in line
     auto wave_sync = [] {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -78,7 +102,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const double g_x = goal[a * 3 + 0], g_y = goal[a * 3 + 1], g_th = goal[a * 3 + 2];
     const uint32_t tick = tick_ptr ? *tick_ptr : tick_arg;
     const double half_kd = 0.5 * P.kth * P.dt;
-    for (int i = tid; i < T * kFusedRow; i += 256) {
+    for (int i = tid; i < T * kFusedRow; i += (SPLIT ? 512 : 256)) {
         const double v = tc[((size_t)a * T + i / kFusedRow) * kTcW + i % kFusedRow];   // (word 5 of a row: not used)
         lt[i] = (i % kFusedRow < 2) ? v * half_kd : v;
     }
@@ -92,17 +116,87 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int groups = (P.K + 63) >> 6;
     const int trow = lane < T ? lane : T - 1;                 // this lane's ROW in the folding pass (lanes >= T shadow the last row)
 
+    constexpr int U = 6;
+    const int T4 = T - T % U;
+    const bool ride = T4 >= U && (T - T4 == 1 || T - T4 == 2);   // (uniform) as rollout_kernel: the one or two steps behind the last full chunk
+    // a group's chunks as a list of (first step, whether a tail, whether the steps behind the last full chunk ride along): what a
+    // walking wave integrates and -- SPLIT -- what its drawing wave hands over, one entry at a time
+    auto for_each_chunk = [&](auto&& fn) __attribute__((always_inline)) {
+        const int t_loop = ride ? T4 - U : T4;
+        for (int t0 = 0; t0 < t_loop; t0 += U) fn(t0, false, std::false_type{});
+        if (ride) fn(T4 - U, false, std::true_type{});
+        else if (T4 < T) fn(T4, true, std::false_type{});
+    };
+    if constexpr (SPLIT) {
+        if (drawer) {
+            int ev = 0, gi = 0;
+            for (int g = wv; g < groups; g += NB, ++gi) {
+                const int k = g * 64 + lane;
+                const bool active = k < P.K;
+                const uint32_t ctr0 = P.sample_offset + (uint32_t)k;
+                float* const es = es0 + (size_t)(gi & 1) * T * 2;
+                for_each_chunk([&](int t0, bool tail, auto extra_tag) __attribute__((always_inline)) {
+                    constexpr bool EXTRA = decltype(extra_tag)::value;
+                    float nz[U][2], tz[kStepsPerDraw][2];
+#pragma unroll
+                    for (int j = 0; j < U; j += kStepsPerDraw) {
+                        if (!tail || t0 + j < T) {
+                            float e[6];
+                            philox_normals(ctr0, (uint32_t)((t0 + j) / kStepsPerDraw), tick, P.agent_offset + (uint32_t)a, key0, key1, sigf, e);
+#pragma unroll
+                            for (int i = 0; i < kStepsPerDraw; ++i) { nz[j + i][0] = e[2 * i]; nz[j + i][1] = e[2 * i + 1]; }
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < kStepsPerDraw; ++i) { nz[j + i][0] = 0.f; nz[j + i][1] = 0.f; }
+                        }
+                    }
+                    if constexpr (EXTRA) {
+                        float e[6];
+                        philox_normals(ctr0, (uint32_t)(T4 / kStepsPerDraw), tick, P.agent_offset + (uint32_t)a, key0, key1, sigf, e);
+#pragma unroll
+                        for (int i = 0; i < kStepsPerDraw; ++i) { tz[i][0] = T4 + i < T ? e[2 * i] : 0.f; tz[i][1] = T4 + i < T ? e[2 * i + 1] : 0.f; }
+                    }
+                    {   // per-wave sums of eps (the walking wave's eps_sums, on the floats it would convert back)
+                        float sv[16];
+#pragma unroll
+                        for (int j = 0; j < U; ++j) { sv[2 * j] = active ? nz[j][0] : 0.f; sv[2 * j + 1] = active ? nz[j][1] : 0.f; }
+#pragma unroll
+                        for (int j = 2 * U; j < 16; ++j) sv[j] = !EXTRA ? 0.f : (active ? tz[(j - 2 * U) >> 1][j & 1] : 0.f);
+                        const float tot = wave_sum16<EXTRA>(sv, lane);
+                        const int idx = sum16_index(lane), te = t0 + (idx >> 1);
+                        if (lane < 16 && idx < (EXTRA ? 16 : 2 * U) && te < T) es[te * 2 + (idx & 1)] = tot;
+                    }
+                    // the buffer is free once the chunk drawn into it kFusedNBuf hand-overs ago has been taken
+                    if (ev >= kFusedNBuf)
+                        while (__hip_atomic_load(&ho_taken[wid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < ev - kFusedNBuf + 1) __builtin_amdgcn_s_sleep(1);
+                    f2n* const buf = nzb + (size_t)(ev % kFusedNBuf) * kFusedBufSteps * 64;
+#pragma unroll
+                    for (int j = 0; j < U; ++j) buf[j * 64] = f2n{nz[j][0], nz[j][1]};
+                    if constexpr (EXTRA) {
+#pragma unroll
+                        for (int j = 0; j < kStepsPerDraw; ++j) buf[(U + j) * 64] = f2n{tz[j][0], tz[j][1]};
+                    }
+                    ++ev;
+                    __hip_atomic_store(&ho_drawn[wid], ev, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // (every lane stores the same count)
+                });
+            }
+            __syncthreads();   // (the barrier in front of the walking waves' merge)
+            return;
+        }
+    }
+    int ev = 0, gi = 0;   // (SPLIT) chunks taken, groups begun
+
     // the wave's running tuple of row `lane`
     double Mr = INFINITY, Dr = 0.0, N0r = 0.0, N1r = 0.0, E0r = 0.0, E1r = 0.0, Cr = 0.0;
 
-    for (int g = wv; g < groups; g += NB) {
+    for (int g = wv; g < groups; g += NB, ++gi) {
         const int k = g * 64 + lane;
         const bool active = k < P.K;
         const uint32_t ctr0 = P.sample_offset + (uint32_t)k;
+        float* const es = es0 + (SPLIT ? (size_t)(gi & 1) * T * 2 : 0);
         double x = (st_x - g_x) * f, y = (st_y - g_y) * f, th = st_th;
         double c = head_c * rho, s = head_s * rho;
         double pre = 0.0;
-        constexpr int U = 6;
         double cur[U][2], tl[kStepsPerDraw][2];
         auto draw_chunk = [&](int t0, bool tail) __attribute__((always_inline)) {
 #pragma unroll
@@ -168,40 +262,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int j = 0; j < U; ++j)
                 if (!guard || t0 + j < T) step(t0 + j, j, cur[j][0], cur[j][1]);
         };
-        const int T4 = T - T % U;
-        const bool ride = T4 >= U && (T - T4 == 1 || T - T4 == 2);   // (uniform) as rollout_kernel: the one or two steps behind the last full chunk
-        const int t_loop = ride ? T4 - U : T4;
-        for (int t0 = 0; t0 < t_loop; t0 += U) {
-            load_rows(t0, U);
-            draw_chunk(t0, false);
-            eps_sums(t0, std::false_type{});
-            integrate(t0, false);
-        }
-        if (ride) {
-            const int t0 = T4 - U;
-            load_rows(t0, U);
-            draw_chunk(t0, false);
-            {
-                float e[6];
-                philox_normals(ctr0, (uint32_t)(T4 / kStepsPerDraw), tick, P.agent_offset + (uint32_t)a, key0, key1, sigf, e);
+        // SPLIT: the chunk's noise from the pair's buffer (the floats the drawing wave left; widened here as draw_chunk widens them)
+        auto take_chunk = [&](auto extra_tag) __attribute__((always_inline)) {
+            constexpr bool EXTRA = decltype(extra_tag)::value;
+            const f2n* const buf = nzb + (size_t)(ev % kFusedNBuf) * kFusedBufSteps * 64;
+            ++ev;
+            while (__hip_atomic_load(&ho_drawn[wid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < ev) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
-                for (int i = 0; i < kStepsPerDraw; ++i) {
-                    tl[i][0] = T4 + i < T ? (double)e[2 * i] : 0.0;
-                    tl[i][1] = T4 + i < T ? (double)e[2 * i + 1] : 0.0;
-                }
+            for (int j = 0; j < U; ++j) { const f2n v = buf[j * 64]; cur[j][0] = (double)v.x; cur[j][1] = (double)v.y; }
+            if constexpr (EXTRA) {
+#pragma unroll
+                for (int j = 0; j < kStepsPerDraw; ++j) { const f2n v = buf[(U + j) * 64]; tl[j][0] = (double)v.x; tl[j][1] = (double)v.y; }
             }
-            eps_sums(t0, std::true_type{});
-            integrate(t0, false);
+            // (release: the reads above are complete before the count that frees the buffer is visible)
+            __hip_atomic_store(&ho_taken[wid], ev, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        for_each_chunk([&](int t0, bool tail, auto extra_tag) __attribute__((always_inline)) {
+            constexpr bool EXTRA = decltype(extra_tag)::value;
+            load_rows(t0, tail ? T - T4 : U);
+            if constexpr (SPLIT) take_chunk(extra_tag);
+            else {
+                draw_chunk(t0, tail);
+                if constexpr (EXTRA) {
+                    float e[6];
+                    philox_normals(ctr0, (uint32_t)(T4 / kStepsPerDraw), tick, P.agent_offset + (uint32_t)a, key0, key1, sigf, e);
 #pragma unroll
-            for (int j = 0; j < U; ++j) { cur[j][0] = j < kStepsPerDraw ? tl[j][0] : 0.0; cur[j][1] = j < kStepsPerDraw ? tl[j][1] : 0.0; }
-            load_rows(T4, 2);
-            integrate(T4, true);
-        } else if (T4 < T) {
-            load_rows(T4, T - T4);
-            draw_chunk(T4, true);
-            eps_sums(T4, std::false_type{});
-            integrate(T4, true);
-        }
+                    for (int i = 0; i < kStepsPerDraw; ++i) {
+                        tl[i][0] = T4 + i < T ? (double)e[2 * i] : 0.0;
+                        tl[i][1] = T4 + i < T ? (double)e[2 * i + 1] : 0.0;
+                    }
+                }
+                eps_sums(t0, extra_tag);
+            }
+            integrate(t0, tail);
+            if constexpr (EXTRA) {
+#pragma unroll
+                for (int j = 0; j < U; ++j) { cur[j][0] = j < kStepsPerDraw ? tl[j][0] : 0.0; cur[j][1] = j < kStepsPerDraw ? tl[j][1] : 0.0; }
+                load_rows(T4, 2);
+                integrate(T4, true);
+            }
+        });
         {   // terminal cost (control/src/mppi:165-173); the theta error is not wrapped beyond rk4's own wrap
             const double thw = (th > M_PI || th <= -M_PI) ? wrap_theta(th) : th;
             const double dx = x * inv_sq, dy = y * inv_sq, dth = thw - g_th;
@@ -291,7 +391,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     __syncthreads();   // (every wave gets here exactly once, whatever its number of groups)
     if (wid == 0 && lane < T) {
-        const size_t wave_bytes = ((size_t)T * kFusedPitch * 8 + 64 * 8 + (size_t)T * 2 * 4 + 15) / 16 * 16;
         double Mo[3], Dn = Dr, N0n = N0r, N1n = N1r, Mn = Mr;
 #pragma unroll
         for (int w2 = 1; w2 < 4; ++w2) {
@@ -315,11 +414,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 hipError_t launch_rollout_fused(const RolloutFusedArgs& a) {
     const dim3 grid(a.NB / 4, a.P.A);
-    const unsigned lds = (unsigned)rollout_fused_lds(a.P.T);
-    if (a.nterm == 7)
-        hipLaunchKernelGGL(rollout_fused_kernel<7>, grid, dim3(256), lds, a.stream, a.P, a.state, a.goal, a.unom, a.tc, a.seed, a.tick, a.tick_ptr, a.part, a.NB);
-    else
-        hipLaunchKernelGGL(rollout_fused_kernel<4>, grid, dim3(256), lds, a.stream, a.P, a.state, a.goal, a.unom, a.tc, a.seed, a.tick, a.tick_ptr, a.part, a.NB);
+    const unsigned lds = (unsigned)rollout_fused_lds(a.P.T, a.split);
+#define MPPI_FUSED_GO(NT, SP) hipLaunchKernelGGL((rollout_fused_kernel<NT, SP>), grid, dim3(SP ? 512 : 256), lds, a.stream, a.P, a.state, a.goal, a.unom, a.tc, a.seed, a.tick, a.tick_ptr, a.part, a.NB)
+    if (a.split) { if (a.nterm == 7) MPPI_FUSED_GO(7, true); else MPPI_FUSED_GO(4, true); }
+    else { if (a.nterm == 7) MPPI_FUSED_GO(7, false); else MPPI_FUSED_GO(4, false); }
+#undef MPPI_FUSED_GO
     return hipGetLastError();
 }
 #endif  // MPPI_ROLLOUT_FUSED_TU

@@ -1057,12 +1057,13 @@ def test_full_size_replay_of_the_mixed_rollout_at_a_long_horizon(orc, tick_path,
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("K,T", [(1, 50), (64, 50), (65, 49), (3000, 50), (5000, 26), (4097, 64), (70001, 51), (300000, 50)])
+@pytest.mark.parametrize("K,T", [(1, 50), (64, 50), (65, 49), (3000, 50), (5000, 26), (4097, 64), (70001, 51), (300000, 50), (2000, 56), (2000, 57)])
 def test_fused_fp64_tick_equals_the_two_kernel_tick_and_the_oracle(orc, tick_path, K, T):
     """rollout_fused_kernel (fp64 storage, device noise: rollout + cost-to-go + softmax partials in ONE kernel, V never stored;
     VERDICT r5 item 2 / EXPERIMENTS.md 46) against the two-kernel tick of the same engine and against the oracle: one sample, a
     ragged last group of 64, every horizon class mod 6 up to its longest (64), sizes from one wave with work to several groups per
-    wave.  First tick (table from nominal_kernel) and resident ticks (table left by the previous tick's finalize kernel): applied
+    wave; both forms of the kernel -- T <= 56 the split one (eight waves per workgroup, four of them drawing the noise), 57 ... 64 a
+    wave on its own.  First tick (table from nominal_kernel) and resident ticks (table left by the previous tick's finalize kernel): applied
     controls / state / nominal sequence equal to the merge's rounding; V and noise handed back after a fused tick (re-run from the
     tick's snapshot, re-drawn) equal the two-kernel tick's; the first tick replayed on the oracle at the fp64 tolerances (V 1e-9 |V|,
     u 1e-9, state 1e-12)."""
