@@ -1804,6 +1804,36 @@ def test_cpp_node_rccl_exchange_and_fallback(tmp_path, tick_path):
     assert np.abs(a[:, 7:11] - d[:, 7:11]).max() < 1e-9
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [100000, 200000, 300000])
+def test_under_filled_forms_of_the_mixed_rollout_with_and_without_the_hoisted_table(K, tick_path):
+    """The mixed rollout's three forms by launch size -- <= 256 workgroups the split form (four waves of a workgroup draw the noise for
+    the four that walk), <= 512 the instance with a chunk's table rows in registers, above that the four-waves-per-SIMD kernel -- each
+    with its nominal table computed by its own prologue (`table_hoist` 0: the small sizes' default) and loaded from what the previous
+    tick's finalize kernel left (`table_hoist` 1): the closed loop and the last tick's V, bit for bit."""
+    from motion_planning_amd.mppi import Engine
+    if tick_path == "scan":
+        pytest.skip("the engines below name their tick path")
+    T = 50
+    u0 = np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
+
+    def run(hoist):
+        out = []
+        with Engine(K, T, storage="f32", tick_path="lanes", co_shards=1, options={"pk_min_samples": 0, "table_hoist": hoist}) as e:
+            e.set_nominal(u0)
+            nxt, ua = e.tick([0.02, -0.01, 0.1], [0.0, -1.0, 0.0], seed=11, tick_id=0); out.append(np.hstack([nxt, ua]))
+            for i in range(3):                                   # resident ticks: the hoisted table's case
+                nxt, ua = e.tick(seed=11, tick_id=1 + i); out.append(np.hstack([nxt, ua]))
+            assert e.info()["rollout_kernel"] == "mixed"
+            out.append(e.download_value()[0, ::7, ::997])
+            nxt, ua = e.tick(nxt + 0.01, None, seed=11, tick_id=5); out.append(np.hstack([nxt, ua]))   # a fresh pose: the prologue again
+            out.append(e.get_nominal())
+        return out
+    ref, got = run(0), run(1)
+    for i, (x, y) in enumerate(zip(ref, got)):
+        assert np.array_equal(x, y), (i, float(np.abs(np.asarray(x) - np.asarray(y)).max()))
+
+
 @pytest.mark.parametrize("K,T,A", [(20000, 50, 1), (140000, 50, 1), (9000, 100, 2)])
 def test_schedule_options_do_not_change_results(K, T, A, tick_path):
     """How a tick is SCHEDULED must not change what it computes: the next tick's nominal table from the finalize kernel
