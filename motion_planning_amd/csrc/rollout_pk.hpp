@@ -88,7 +88,7 @@ __device__ __forceinline__ f2 pk_med3(f2 v, float lo, float hi) {
 // SPLIT (under-filled launches, T <= 64, the default noise stream): a workgroup of EIGHT waves for the same 512 samples -- waves 0-3 walk
 // the dynamics as ever, waves 4-7 draw the noise (Philox + Box-Muller + the per-wave eps sums: 45 % of a chunk's instructions) one chunk
 // ahead and hand it over through LDS, a barrier per chunk.  A launch of <= 256 workgroups puts ONE wave of this kernel on a SIMD, and a
-// lone wave leaves a third of the SIMD's issue slots empty (1.91 us per chunk against 1.14 where two waves share a SIMD: EXPERIMENTS.md
+// lone wave leaves a third of the SIMD's issue slots empty (4116 cycles per chunk for 2749 cycles of issue; the pair: 3600 -- EXPERIMENTS.md
 // 65, 66); the hardware deals a workgroup's waves to the SIMDs in turn (wave i + 4 lands next to wave i: tools/simd_map.hip), so every
 // SIMD hosts a drawing wave and the walking wave it feeds.  Same functions, same operands: bit-identical results.
 template <int INLINE_NOM, int WAVES, int PACK, bool SPLIT = false>
