@@ -1101,6 +1101,33 @@ def test_fused_fp64_tick_equals_the_two_kernel_tick_and_the_oracle(orc, tick_pat
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("A,K", [(3, 70000), (5, 4000), (300, 200)])
+def test_fused_fp64_tick_with_several_agents(tick_path, A, K):
+    """The fused fp64 kernel's grid is (workgroups, agents): a few agents share the chip's CUs between them, 300 agents are more
+    workgroups than CUs (one workgroup's LDS per CU: rounds of them).  Four closed-loop ticks of every agent against the two-kernel
+    tick of the same engine, 1e-10."""
+    if tick_path == "scan":
+        pytest.skip("a lane-kernel test (the engines below name their tick path)")
+    from motion_planning_amd.mppi import Engine
+    T = 50
+    u0 = np.array([np.linspace(-2, 1, T), np.linspace(1.5, -1, T)])
+    st = np.tile(np.array([[0.05, -0.02, 0.3]]), (A, 1)) + 0.001 * np.arange(A)[:, None]
+    goal = np.tile(np.array([[0.0, -1.0, 0.0]]), (A, 1))
+    res = {}
+    for name, opts in (("fused", {"pk_min_samples": 1}), ("two", {"rollout_pk": 0})):
+        with Engine(K, T, n_agents=A, storage="f64", tick_path="lanes", co_shards=1, options=opts) as e:
+            for a in range(A):
+                e.set_nominal(u0 * (1.0 - 0.002 * a), agent=a)
+            rows = []
+            for i in range(4):
+                nxt, ua = e.tick(st if i == 0 else None, goal if i == 0 else None, noise="philox", seed=3, tick_id=i)
+                rows.append(np.hstack([nxt, ua]))
+            res[name] = (np.array(rows), e.info()["rollout_kernel"])
+    assert res["fused"][1] == "fused" and res["two"][1] == "fp64"
+    assert np.abs(res["fused"][0] - res["two"][0]).max() < 1e-10
+
+
+@pytest.mark.gpu
 def test_fused_fp64_tick_keeps_to_its_regime(tick_path):
     """The engine's own rule for the fused fp64 tick: under way (a row has a handful of samples with weight) it runs; parked at the
     goal with zero nominal controls -- every sample of a row within a few lambda, each would cost it a Philox call -- the engine sees
